@@ -1,0 +1,186 @@
+/*
+ * pgmi.h -- C ABI of libpgmi.so, the MI355X (gfx950) masked-LM scorer behind ProteinGym's
+ * ESM zero-shot path.
+ *
+ * The reference (OATML-Markslab/ProteinGym, /root/reference) has no FFI: a "baseline" plugs in
+ * through (1) the per-baseline CLI + per-assay CSV and (2) the in-process seam
+ *     model, alphabet = pretrained.load_model_and_alphabet(path)
+ *                         (proteingym/baselines/esm/compute_fitness.py:349, esm/pretrained.py:24-28)
+ *     model(tokens_int64[B,T])["logits"] -> f32 [B,T,33]
+ *                         (compute_fitness.py:502; esm/model/esm1.py:116,177; esm/model/esm2.py:76,130)
+ * Every entry point below names the reference code it replaces.  The Python host
+ * (proteingym_amd/) binds these with ctypes; INTEGRATION.md shows the stub a ProteinGym
+ * maintainer would add.
+ *
+ * Conventions: plain C types only; return 0 on success, negative PGMI_E* otherwise (never
+ * throws); the caller owns every host buffer; the library owns device memory and one HIP
+ * stream per model handle.  A handle is not thread-safe; distinct handles are independent.
+ * pgmi_last_error() returns a thread-local message for the last failing call.
+ */
+#ifndef PGMI_H
+#define PGMI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGMI_ABI_VERSION 1
+
+/* error codes */
+#define PGMI_OK 0
+#define PGMI_EINVAL (-1)   /* bad argument / unsupported shape */
+#define PGMI_ENOMEM (-2)   /* device allocation failed */
+#define PGMI_EHIP (-3)     /* HIP runtime error (message in pgmi_last_error) */
+#define PGMI_ENODEV (-4)   /* no usable GPU */
+#define PGMI_EPARSE (-5)   /* malformed mutant string / wild-type mismatch */
+
+/* architectures: esm/model/esm1.py (arch "roberta_large": ESM-1b, ESM-1v) and esm/model/esm2.py */
+#define PGMI_ARCH_ESM1B 1
+#define PGMI_ARCH_ESM2 2
+
+/* GEMM operand precision.  Residual stream, LayerNorm statistics, softmax and every
+ * accumulator are fp32 in all modes. */
+#define PGMI_PREC_FP32 0  /* v_mfma_f32_32x32x2_f32: exact fp32 products (parity-gated mode) */
+#define PGMI_PREC_BF16 1  /* bf16 operands, fp32 accumulate (throughput mode; error is measured, not assumed) */
+#define PGMI_PREC_F16X3 2 /* split-fp16 3-pass error-compensated GEMM (fp32-class accuracy on the f16 MFMA pipe) */
+
+/* token ids of the 33-symbol ESM alphabet (esm/data.py:151-157, esm/constants.py:8) */
+#define PGMI_TOK_CLS 0
+#define PGMI_TOK_PAD 1
+#define PGMI_TOK_EOS 2
+#define PGMI_TOK_UNK 3
+#define PGMI_TOK_MASK 32
+#define PGMI_VOCAB 33
+
+typedef struct pgmi_config {
+    int32_t abi_version;          /* = PGMI_ABI_VERSION */
+    int32_t arch;                 /* PGMI_ARCH_* */
+    int32_t layers;               /* encoder_layers */
+    int32_t embed_dim;            /* D  (encoder_embed_dim) */
+    int32_t heads;                /* H  (encoder_attention_heads); D/H must be 64 */
+    int32_t ffn_dim;              /* F  (encoder_ffn_embed_dim; 4*D for ESM2, esm2.py:52) */
+    int32_t vocab;                /* = 33 */
+    int32_t max_positions;        /* ESM-1b learned positions (table has max_positions+2 rows, modules.py:246-251); 0 for ESM2 */
+    int32_t token_dropout;        /* esm1.py:125-131 / esm2.py:85-91 */
+    int32_t emb_layer_norm_before;/* pretrained.py:80-82,98 */
+    int32_t precision;            /* PGMI_PREC_* */
+    int32_t max_rows;             /* workspace rows (B*T per internal chunk); 0 = default */
+} pgmi_config;
+
+typedef struct pgmi_model pgmi_model;
+typedef struct pgmi_assay pgmi_assay;
+
+/* ---- library ---------------------------------------------------------------------------- */
+int pgmi_abi_version(void);
+int pgmi_device_count(void);
+const char* pgmi_last_error(void);
+
+/* Number of fp32 elements of the flat weight blob for cfg, in this order (all row-major,
+ * nn.Linear layout y = x W^T + b, esm/modules.py; names as in SURVEY.md Appendix A):
+ *   embed_tokens[V,D]; (ESM1B) embed_positions[max_positions+2,D];
+ *   (emb_layer_norm_before) w[D],b[D];
+ *   per layer: self_attn_layer_norm w,b; q_proj W[D,D],b; k_proj W,b; v_proj W,b; out_proj W,b;
+ *              final_layer_norm w,b; fc1 W[F,D],b[F]; fc2 W[D,F],b[D];
+ *   emb_layer_norm_after w,b; lm_head.dense W[D,D],b; lm_head.layer_norm w,b; lm_head.bias[V].
+ * (lm_head.weight is tied to embed_tokens, esm1.py:101-105.)  Returns <0 on a bad cfg. */
+int64_t pgmi_weight_count(const pgmi_config* cfg);
+
+/* Replaces pretrained.load_model_and_alphabet + model.cuda() (compute_fitness.py:349-353):
+ * uploads the blob to `device`, packs it for the selected precision, allocates workspace.
+ * The <mask> embedding row is zeroed here as pretrained.py:97 does for v1 checkpoints
+ * (harmless for ESM2: the forward zeroes masked rows whenever token_dropout is set). */
+int pgmi_model_create(const pgmi_config* cfg, const float* weights, int64_t n_weights,
+                      int device, pgmi_model** out);
+void pgmi_model_destroy(pgmi_model* m);
+int pgmi_model_device(const pgmi_model* m);
+
+/* ---- forward ---------------------------------------------------------------------------- */
+/* Replaces `torch.log_softmax(model(tokens)["logits"], -1)` (compute_fitness.py:476,502):
+ * tokens int32 [B,T] row-major (host), out f32 [B,T,V] (host).  <pad> tokens are honoured as
+ * the reference does (embedding rows zeroed, keys masked).  Chunked internally. */
+int pgmi_token_logprobs(pgmi_model* m, const int32_t* tokens, int B, int T, float* out);
+
+/* The masked-marginals inner loop (compute_fitness.py:489-503) for B ready-made rows:
+ * row b is forwarded with tokens[b, mask_pos[b]] replaced by <mask>; out[b,:] =
+ * log_softmax(logits[b, mask_pos[b], :]).  tokens/mask_pos host int32, out host f32 [B,V]. */
+int pgmi_masked_logprobs(pgmi_model* m, const int32_t* tokens, const int32_t* mask_pos,
+                         int B, int T, float* out);
+
+/* ---- per-assay pipeline, inputs resident in HBM --------------------------------------------
+ * pgmi_assay_create uploads everything one DMS assay needs:
+ *   wt_tokens  int32 [n_tok]   cls + residues + eos   (BatchConverter, esm/data.py:262-297)
+ *   positions  int32 [P]       token positions to mask (any subset of [0,n_tok); the reference
+ *                              runs all n_tok, compute_fitness.py:489 -- rows no mutant reads
+ *                              may be skipped without changing any output)
+ *   window                     model window (1024): for n_tok > window each position gets
+ *                              get_optimal_window(i, n_tok, window) (utils/scoring_utils.py:43-52,
+ *                              compute_fitness.py:492-495)
+ *   sub_pos/sub_wt/sub_mt int32 [n_sub], mut_off int64 [n_mut+1]
+ *                              flattened substitutions of every mutant: token position (1+idx),
+ *                              wild-type and mutant token ids (label_row, compute_fitness.py:240-250)
+ * pgmi_assay_run then executes the whole hot path on the device: masked windows -> forward ->
+ * head on masked rows -> log-softmax table [n_tok,V] (NaN rows where not computed) ->
+ * per-mutant score = sum_subs (f32(lp[mt]-lp[wt])) accumulated in double.
+ * scores_host / table_host may be NULL; scores_dev (device pointer, double[n_mut]) may be NULL. */
+int pgmi_assay_create(pgmi_model* m, const int32_t* wt_tokens, int n_tok,
+                      const int32_t* positions, int P, int window,
+                      const int32_t* sub_pos, const int32_t* sub_wt, const int32_t* sub_mt,
+                      const int64_t* mut_off, int64_t n_mut, pgmi_assay** out);
+int pgmi_assay_run(pgmi_model* m, pgmi_assay* a, double* scores_host, float* table_host,
+                   double* scores_dev);
+void pgmi_assay_destroy(pgmi_assay* a);
+
+/* ---- host-side mutant parsing (label_row's string handling, compute_fitness.py:240-250) -----
+ * text: n_mut NUL-free mutant strings ("A25G:L30P") concatenated, str_off int64 [n_mut+1].
+ * sequence: wild type (len seq_len); offset_idx as --offset-idx.  Two-pass: call with
+ * sub_* == NULL to get the substitution count in *n_sub, then with buffers of that size.
+ * Fails with PGMI_EPARSE on a wild-type mismatch ("The listed wildtype does not match the
+ * provided sequence") or a malformed token.  Letters map through the ESM alphabet
+ * (unknown -> <unk>, esm/data.py:125-128). */
+int pgmi_parse_mutants(const char* text, const int64_t* str_off, int64_t n_mut,
+                       const char* sequence, int seq_len, int offset_idx,
+                       int32_t* sub_pos, int32_t* sub_wt, int32_t* sub_mt,
+                       int64_t* mut_off, int64_t* n_sub);
+
+/* get_optimal_window (proteingym/utils/scoring_utils.py:43-52) */
+void pgmi_optimal_window(int position, int seq_len_with_special, int model_window,
+                         int* start, int* end);
+
+/* ---- profiling (HIP events on the model's stream) ----------------------------------------- */
+#define PGMI_K_EMBED 0
+#define PGMI_K_LAYERNORM 1
+#define PGMI_K_GEMM_QKV 2
+#define PGMI_K_ATTENTION 3
+#define PGMI_K_GEMM_OUT 4
+#define PGMI_K_GEMM_FC1 5
+#define PGMI_K_GEMM_FC2 6
+#define PGMI_K_HEAD 7
+#define PGMI_K_SCORE 8
+#define PGMI_K_COUNT 9
+/* on != 0: every launch of the classes above is bracketed by hipEventRecord on the stream. */
+int pgmi_profile_enable(pgmi_model* m, int on);
+/* Sum of event-measured milliseconds, launch count and algorithmic FLOPs / bytes for a class
+ * since the last reset. */
+int pgmi_profile_get(pgmi_model* m, int kernel_class, double* ms, int64_t* launches,
+                     double* flops, double* bytes);
+int pgmi_profile_reset(pgmi_model* m);
+int pgmi_synchronize(pgmi_model* m);
+
+/* ---- single ops (numerics tests compare each against the torch op it replaces) -------------
+ * All pointers are host; each call uploads, runs the production kernel, downloads. */
+int pgmi_op_layernorm(int device, const float* x, const float* w, const float* b,
+                      int rows, int D, float eps, float* y);               /* modules.py:80-81 */
+int pgmi_op_gemm(int device, int precision, const float* A, const float* W, const float* bias,
+                 const float* residual, int M, int N, int K, int epilogue /*0 none,1 gelu*/,
+                 float* C);          /* C = epi(A W^T + bias) + residual; modules.py:134-140 */
+int pgmi_op_attention(int device, int precision, const float* qkv, const int32_t* kv_len,
+                      int B, int T, int H, int rotary, float* ctx);
+                                     /* multihead_attention.py:354-395; qkv [B*T,3*H*64], q pre-scaled */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PGMI_H */

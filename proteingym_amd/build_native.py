@@ -1,0 +1,74 @@
+"""Builds libpgmi.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+    python -m proteingym_amd.build_native [--force]
+
+hipcc cross-compiles without a GPU; the resulting proteingym_amd/libpgmi.so is git-ignored but
+travels to the GPU box with the repo snapshot.
+"""
+from __future__ import annotations
+
+import concurrent.futures as cf
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OUT = os.path.join(HERE, "libpgmi.so")
+BUILD = os.path.join(HERE, "csrc", "_build")
+SOURCES = ["api.hip", "elementwise.hip", "gemm_f32.hip", "attention_f32.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def _digest() -> str:
+    h = hashlib.sha256()
+    for root in (CSRC, os.path.join(HERE, "..", "include")):
+        for fn in sorted(os.listdir(root)):
+            p = os.path.join(root, fn)
+            if os.path.isfile(p) and fn.split(".")[-1] in ("hip", "h", "cpp"):
+                h.update(fn.encode())
+                h.update(open(p, "rb").read())
+    h.update(" ".join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    os.makedirs(BUILD, exist_ok=True)
+    stamp = os.path.join(BUILD, "stamp")
+    dig = _digest()
+    if not force and os.path.exists(OUT) and os.path.exists(stamp) and open(stamp).read() == dig:
+        return OUT
+    hipcc = _hipcc()
+
+    def compile_one(src):
+        obj = os.path.join(BUILD, src.replace(".", "_") + ".o")
+        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+        if verbose and r.stderr.strip():
+            print(r.stderr, file=sys.stderr)
+        return obj
+
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    open(stamp, "w").write(dig)
+    if verbose:
+        print(f"built {OUT}")
+    return OUT
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,683 @@
+// C ABI of libpgmi.so (include/pgmi.h) and the host-side orchestration of the ESM forward.
+//
+// Forward order follows /root/reference/proteingym/baselines/esm/esm/model/esm1.py:116-177 and
+// esm/model/esm2.py:76-130; the per-layer order follows esm/modules.py:120-142.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace pgmi {
+
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+struct Layer {
+    float *ln1_w, *ln1_b, *wqkv, *bqkv, *wo, *bo, *ln2_w, *ln2_b, *w1, *b1, *w2, *b2;
+};
+
+struct ProfEvent {
+    hipEvent_t start, stop;
+    int cls;
+};
+
+}  // namespace pgmi
+
+using namespace pgmi;
+
+struct pgmi_model {
+    pgmi_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<void*> allocs;          // everything to hipFree
+    // weights
+    float *embed_tokens = nullptr, *embed_positions = nullptr;
+    float *lnb_w = nullptr, *lnb_b = nullptr, *lna_w = nullptr, *lna_b = nullptr;
+    float *hd_w = nullptr, *hd_b = nullptr, *hln_w = nullptr, *hln_b = nullptr, *h_bias = nullptr;
+    std::vector<Layer> layers;
+    float *rot_cos = nullptr, *rot_sin = nullptr;
+    int rot_len = 0;
+    // workspace
+    int max_rows = 0;
+    float *x = nullptr, *h = nullptr, *qkv = nullptr, *g = nullptr, *lp = nullptr, *denom = nullptr;
+    int32_t *tokens = nullptr, *pos_idx = nullptr, *kv_len = nullptr, *row_idx = nullptr, *aux_i = nullptr;
+    // profiling
+    bool prof = false;
+    std::vector<ProfEvent> events;
+    size_t events_used = 0;
+    double prof_ms[PGMI_K_COUNT] = {0};
+    int64_t prof_n[PGMI_K_COUNT] = {0};
+    double prof_flops[PGMI_K_COUNT] = {0};
+    double prof_bytes[PGMI_K_COUNT] = {0};
+};
+
+struct pgmi_assay {
+    pgmi_model* m = nullptr;
+    int n_tok = 0, P = 0, T = 0;
+    int64_t n_mut = 0, n_sub = 0;
+    std::vector<void*> allocs;
+    int32_t *wt = nullptr, *positions = nullptr, *win_start = nullptr, *mask_rel = nullptr;
+    int32_t *sub_pos = nullptr, *sub_wt = nullptr, *sub_mt = nullptr;
+    int64_t* mut_off = nullptr;
+    float* table = nullptr;
+    double* scores = nullptr;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(std::vector<void*>& pool, T** p, size_t n) {
+    void* q = nullptr;
+    if (n == 0) n = 1;
+    hipError_t e = hipMalloc(&q, n * sizeof(T));
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(e));
+        return PGMI_ENOMEM;
+    }
+    pool.push_back(q);
+    *p = static_cast<T*>(q);
+    return PGMI_OK;
+}
+
+template <typename T>
+int dev_upload(std::vector<void*>& pool, T** p, const T* host, size_t n) {
+    int rc = dev_alloc(pool, p, n);
+    if (rc) return rc;
+    if (n) PGMI_HIP(hipMemcpy(*p, host, n * sizeof(T), hipMemcpyHostToDevice));
+    return PGMI_OK;
+}
+
+struct ProfScope {
+    pgmi_model* m;
+    ProfEvent* ev = nullptr;
+    ProfScope(pgmi_model* m_, int cls, double flops, double bytes) : m(m_) {
+        if (!m->prof) return;
+        if (m->events_used == m->events.size()) {
+            ProfEvent e;
+            if (hipEventCreate(&e.start) != hipSuccess || hipEventCreate(&e.stop) != hipSuccess) return;
+            m->events.push_back(e);
+        }
+        ev = &m->events[m->events_used++];
+        ev->cls = cls;
+        m->prof_n[cls] += 1;
+        m->prof_flops[cls] += flops;
+        m->prof_bytes[cls] += bytes;
+        hipEventRecord(ev->start, m->stream);
+    }
+    ~ProfScope() {
+        if (ev) hipEventRecord(ev->stop, m->stream);
+    }
+};
+
+int prof_drain(pgmi_model* m) {
+    if (m->events_used == 0) return PGMI_OK;
+    PGMI_HIP(hipStreamSynchronize(m->stream));
+    for (size_t i = 0; i < m->events_used; ++i) {
+        float ms = 0.f;
+        PGMI_HIP(hipEventElapsedTime(&ms, m->events[i].start, m->events[i].stop));
+        m->prof_ms[m->events[i].cls] += ms;
+    }
+    m->events_used = 0;
+    return PGMI_OK;
+}
+
+int check_cfg(const pgmi_config* c) {
+    if (!c) { set_error("null config"); return PGMI_EINVAL; }
+    if (c->abi_version != PGMI_ABI_VERSION) { set_error("ABI version mismatch: got %d, library is %d", c->abi_version, PGMI_ABI_VERSION); return PGMI_EINVAL; }
+    if (c->arch != PGMI_ARCH_ESM1B && c->arch != PGMI_ARCH_ESM2) { set_error("unknown arch %d", c->arch); return PGMI_EINVAL; }
+    if (c->layers <= 0 || c->embed_dim <= 0 || c->heads <= 0 || c->ffn_dim <= 0) { set_error("non-positive model dimension"); return PGMI_EINVAL; }
+    if (c->embed_dim != c->heads * kHeadDim) { set_error("unsupported head_dim %d (embed_dim %d / heads %d): this build supports head_dim 64", c->heads ? c->embed_dim / c->heads : 0, c->embed_dim, c->heads); return PGMI_EINVAL; }
+    if (c->embed_dim % 32 || c->ffn_dim % 32) { set_error("embed_dim and ffn_dim must be multiples of 32"); return PGMI_EINVAL; }
+    if (c->vocab != PGMI_VOCAB) { set_error("vocab must be %d", PGMI_VOCAB); return PGMI_EINVAL; }
+    if (c->arch == PGMI_ARCH_ESM1B && c->max_positions <= 0) { set_error("ESM-1b arch needs max_positions"); return PGMI_EINVAL; }
+    if (c->precision != PGMI_PREC_FP32) { set_error("precision %d not available in this build (fp32 only)", c->precision); return PGMI_EINVAL; }
+    return PGMI_OK;
+}
+
+// trailing-only padding, at least one real token per sequence
+int check_tokens(const int32_t* tokens, int B, int T) {
+    for (int b = 0; b < B; ++b) {
+        const int32_t* t = tokens + (size_t)b * T;
+        bool seen_pad = false;
+        if (t[0] == PGMI_TOK_PAD) { set_error("sequence %d is empty (all <pad>)", b); return PGMI_EINVAL; }
+        for (int i = 0; i < T; ++i) {
+            if (t[i] < 0 || t[i] >= PGMI_VOCAB) { set_error("token id %d out of range at [%d,%d]", t[i], b, i); return PGMI_EINVAL; }
+            if (t[i] == PGMI_TOK_PAD) seen_pad = true;
+            else if (seen_pad) { set_error("interior <pad> at [%d,%d]: only trailing padding is supported", b, i); return PGMI_EINVAL; }
+        }
+    }
+    return PGMI_OK;
+}
+
+int ensure_rotary(pgmi_model* m, int T) {
+    if (m->cfg.arch != PGMI_ARCH_ESM2 || T <= m->rot_len) return PGMI_OK;
+    // rotary_embedding.py:40,52-58: inv_freq = 1/10000^(2i/d) in f32; freqs = t * inv_freq (f32);
+    // emb = cat(freqs, freqs); cos/sin taken in f32.
+    const int n = std::max(T, 1026);
+    std::vector<float> c((size_t)n * 64), s((size_t)n * 64);
+    float inv[32];
+    for (int i = 0; i < 32; ++i) inv[i] = 1.0f / powf(10000.0f, (float)(2 * i) / 64.0f);
+    for (int t = 0; t < n; ++t)
+        for (int i = 0; i < 32; ++i) {
+            const float f = (float)t * inv[i];
+            c[(size_t)t * 64 + i] = c[(size_t)t * 64 + 32 + i] = cosf(f);
+            s[(size_t)t * 64 + i] = s[(size_t)t * 64 + 32 + i] = sinf(f);
+        }
+    int rc = dev_upload(m->allocs, &m->rot_cos, c.data(), c.size());
+    if (rc) return rc;
+    rc = dev_upload(m->allocs, &m->rot_sin, s.data(), s.size());
+    if (rc) return rc;
+    m->rot_len = n;
+    return PGMI_OK;
+}
+
+// Runs the encoder on tokens already in m->tokens [B,T]; leaves the residual stream in m->x.
+int run_encoder(pgmi_model* m, int B, int T) {
+    const pgmi_config& c = m->cfg;
+    const int M = B * T, D = c.embed_dim, F = c.ffn_dim, H = c.heads;
+    hipStream_t s = m->stream;
+    if (c.arch == PGMI_ARCH_ESM1B && T > c.max_positions) {
+        set_error("Sequence length %d above maximum sequence length of %d", T, c.max_positions);   // modules.py:256-260
+        return PGMI_EINVAL;
+    }
+    int rc = ensure_rotary(m, T);
+    if (rc) return rc;
+    {
+        ProfScope p(m, PGMI_K_EMBED, 0, (double)M * D * 4);
+        launch_seq_stats(m->tokens, B, T, c.token_dropout, m->denom, m->pos_idx, m->kv_len, s);
+        launch_embed(m->tokens, m->denom, m->pos_idx, m->embed_tokens, m->embed_positions, c.token_dropout, M, T, D, m->x, s);
+        if (c.emb_layer_norm_before) {
+            launch_layernorm(m->x, m->lnb_w, m->lnb_b, M, D, 1e-5f, m->x, s);
+            launch_zero_pad_rows(m->tokens, M, D, m->x, s);
+        }
+    }
+    const double ln_bytes = 2.0 * M * D * 4;
+    for (int l = 0; l < c.layers; ++l) {
+        const Layer& L = m->layers[l];
+        { ProfScope p(m, PGMI_K_LAYERNORM, 0, ln_bytes);
+          launch_layernorm(m->x, L.ln1_w, L.ln1_b, M, D, 1e-5f, m->h, s); }
+        { ProfScope p(m, PGMI_K_GEMM_QKV, 2.0 * M * 3 * D * D, 0);
+          rc = launch_gemm_f32(m->h, L.wqkv, L.bqkv, nullptr, m->qkv, M, 3 * D, D, EPI_NONE, s);
+          if (rc) return rc; }
+        { ProfScope p(m, PGMI_K_ATTENTION, 4.0 * M * T * D, 0);
+          if (c.arch == PGMI_ARCH_ESM2) launch_rotary(m->qkv, m->rot_cos, m->rot_sin, M, T, H, s);
+          rc = launch_attention_f32(m->qkv, m->kv_len, B, T, H, m->h, s);
+          if (rc) return rc; }
+        { ProfScope p(m, PGMI_K_GEMM_OUT, 2.0 * M * D * D, 0);
+          rc = launch_gemm_f32(m->h, L.wo, L.bo, m->x, m->x, M, D, D, EPI_NONE, s);
+          if (rc) return rc; }
+        { ProfScope p(m, PGMI_K_LAYERNORM, 0, ln_bytes);
+          launch_layernorm(m->x, L.ln2_w, L.ln2_b, M, D, 1e-5f, m->h, s); }
+        { ProfScope p(m, PGMI_K_GEMM_FC1, 2.0 * M * F * D, 0);
+          rc = launch_gemm_f32(m->h, L.w1, L.b1, nullptr, m->g, M, F, D, EPI_GELU, s);
+          if (rc) return rc; }
+        { ProfScope p(m, PGMI_K_GEMM_FC2, 2.0 * M * F * D, 0);
+          rc = launch_gemm_f32(m->g, L.w2, L.b2, m->x, m->x, M, D, F, EPI_NONE, s);
+          if (rc) return rc; }
+    }
+    PGMI_HIP(hipGetLastError());
+    return PGMI_OK;
+}
+
+// LM head (modules.py:322-328) + log-softmax on R rows.  If row_idx != null the rows are
+// gathered from m->x first (masked positions only), else R must be the full M rows of m->x.
+// Result in m->lp [R,V].
+int run_head(pgmi_model* m, int R, const int32_t* row_idx) {
+    const pgmi_config& c = m->cfg;
+    const int D = c.embed_dim;
+    hipStream_t s = m->stream;
+    ProfScope p(m, PGMI_K_HEAD, 2.0 * R * D * (D + c.vocab), 0);
+    if (row_idx) {
+        launch_gather_rows(m->x, row_idx, R, D, m->h, s);
+        launch_layernorm(m->h, m->lna_w, m->lna_b, R, D, 1e-5f, m->h, s);
+    } else {
+        launch_layernorm(m->x, m->lna_w, m->lna_b, R, D, 1e-5f, m->h, s);
+    }
+    int rc = launch_gemm_f32(m->h, m->hd_w, m->hd_b, nullptr, m->g, R, D, D, EPI_GELU, s);
+    if (rc) return rc;
+    launch_layernorm(m->g, m->hln_w, m->hln_b, R, D, 1e-5f, m->g, s);
+    launch_vocab_logsoftmax(m->g, m->embed_tokens, m->h_bias, R, D, c.vocab, m->lp, s);
+    PGMI_HIP(hipGetLastError());
+    return PGMI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pgmi_abi_version(void) { return PGMI_ABI_VERSION; }
+
+const char* pgmi_last_error(void) { return g_err; }
+
+int pgmi_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int64_t pgmi_weight_count(const pgmi_config* c) {
+    if (!c || c->layers <= 0 || c->embed_dim <= 0 || c->ffn_dim <= 0) return -1;
+    const int64_t D = c->embed_dim, F = c->ffn_dim, V = c->vocab;
+    int64_t n = V * D;
+    if (c->arch == PGMI_ARCH_ESM1B) n += (int64_t)(c->max_positions + 2) * D;
+    if (c->emb_layer_norm_before) n += 2 * D;
+    n += (int64_t)c->layers * (2 * D + 4 * (D * D + D) + 2 * D + (F * D + F) + (D * F + D));
+    n += 2 * D + (D * D + D) + 2 * D + V;
+    return n;
+}
+
+int pgmi_model_create(const pgmi_config* cfg, const float* w, int64_t n_weights, int device, pgmi_model** out) {
+    if (!out) { set_error("null out"); return PGMI_EINVAL; }
+    *out = nullptr;
+    int rc = check_cfg(cfg);
+    if (rc) return rc;
+    if (!w || n_weights != pgmi_weight_count(cfg)) {
+        set_error("weight blob has %lld elements, config needs %lld", (long long)n_weights, (long long)pgmi_weight_count(cfg));
+        return PGMI_EINVAL;
+    }
+    const int ndev = pgmi_device_count();
+    if (ndev <= 0) { set_error("no HIP device visible (libpgmi has no CPU fallback)"); return PGMI_ENODEV; }
+    if (device < 0 || device >= ndev) { set_error("device %d out of range (%d visible)", device, ndev); return PGMI_EINVAL; }
+    PGMI_HIP(hipSetDevice(device));
+    pgmi_model* m = new pgmi_model();
+    m->cfg = *cfg;
+    m->device = device;
+#define TRY(e) do { rc = (e); if (rc) { pgmi_model_destroy(m); return rc; } } while (0)
+    if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete m; return PGMI_EHIP; }
+    const size_t D = cfg->embed_dim, F = cfg->ffn_dim, V = cfg->vocab;
+    const float* p = w;
+    {   // embed_tokens with the <mask> row zeroed (pretrained.py:97)
+        std::vector<float> e(p, p + V * D);
+        for (size_t i = 0; i < D; ++i) e[(size_t)PGMI_TOK_MASK * D + i] = 0.f;
+        TRY(dev_upload(m->allocs, &m->embed_tokens, e.data(), e.size()));
+        p += V * D;
+    }
+    if (cfg->arch == PGMI_ARCH_ESM1B) {
+        const size_t n = (size_t)(cfg->max_positions + 2) * D;
+        TRY(dev_upload(m->allocs, &m->embed_positions, p, n));
+        p += n;
+    }
+    if (cfg->emb_layer_norm_before) {
+        TRY(dev_upload(m->allocs, &m->lnb_w, p, D)); p += D;
+        TRY(dev_upload(m->allocs, &m->lnb_b, p, D)); p += D;
+    }
+    const float qscale = 1.0f / sqrtf((float)kHeadDim);     // multihead_attention.py:261 (exact 1/8)
+    m->layers.resize(cfg->layers);
+    std::vector<float> wq(3 * D * D), bq(3 * D);
+    for (int l = 0; l < cfg->layers; ++l) {
+        Layer& L = m->layers[l];
+        TRY(dev_upload(m->allocs, &L.ln1_w, p, D)); p += D;
+        TRY(dev_upload(m->allocs, &L.ln1_b, p, D)); p += D;
+        for (int k = 0; k < 3; ++k) {            // fused [3D, D] projection, q rows pre-scaled
+            const float sc = (k == 0) ? qscale : 1.0f;
+            for (size_t i = 0; i < D * D; ++i) wq[k * D * D + i] = p[i] * sc;
+            p += D * D;
+            for (size_t i = 0; i < D; ++i) bq[k * D + i] = p[i] * sc;
+            p += D;
+        }
+        TRY(dev_upload(m->allocs, &L.wqkv, wq.data(), wq.size()));
+        TRY(dev_upload(m->allocs, &L.bqkv, bq.data(), bq.size()));
+        TRY(dev_upload(m->allocs, &L.wo, p, D * D)); p += D * D;
+        TRY(dev_upload(m->allocs, &L.bo, p, D)); p += D;
+        TRY(dev_upload(m->allocs, &L.ln2_w, p, D)); p += D;
+        TRY(dev_upload(m->allocs, &L.ln2_b, p, D)); p += D;
+        TRY(dev_upload(m->allocs, &L.w1, p, F * D)); p += F * D;
+        TRY(dev_upload(m->allocs, &L.b1, p, F)); p += F;
+        TRY(dev_upload(m->allocs, &L.w2, p, D * F)); p += D * F;
+        TRY(dev_upload(m->allocs, &L.b2, p, D)); p += D;
+    }
+    TRY(dev_upload(m->allocs, &m->lna_w, p, D)); p += D;
+    TRY(dev_upload(m->allocs, &m->lna_b, p, D)); p += D;
+    TRY(dev_upload(m->allocs, &m->hd_w, p, D * D)); p += D * D;
+    TRY(dev_upload(m->allocs, &m->hd_b, p, D)); p += D;
+    TRY(dev_upload(m->allocs, &m->hln_w, p, D)); p += D;
+    TRY(dev_upload(m->allocs, &m->hln_b, p, D)); p += D;
+    TRY(dev_upload(m->allocs, &m->h_bias, p, V)); p += V;
+    if (p - w != n_weights) { set_error("internal: blob walk mismatch"); pgmi_model_destroy(m); return PGMI_EINVAL; }
+
+    m->max_rows = cfg->max_rows > 0 ? cfg->max_rows : 98304;
+    if (m->max_rows < 2048) m->max_rows = 2048;
+    const size_t R = m->max_rows;
+    TRY(dev_alloc(m->allocs, &m->x, R * D));
+    TRY(dev_alloc(m->allocs, &m->h, R * D));
+    TRY(dev_alloc(m->allocs, &m->qkv, R * 3 * D));
+    TRY(dev_alloc(m->allocs, &m->g, R * std::max(F, D)));
+    TRY(dev_alloc(m->allocs, &m->lp, R * V));
+    TRY(dev_alloc(m->allocs, &m->denom, R));
+    TRY(dev_alloc(m->allocs, &m->tokens, R));
+    TRY(dev_alloc(m->allocs, &m->pos_idx, R));
+    TRY(dev_alloc(m->allocs, &m->kv_len, R));
+    TRY(dev_alloc(m->allocs, &m->row_idx, R));
+    TRY(dev_alloc(m->allocs, &m->aux_i, R));
+#undef TRY
+    *out = m;
+    return PGMI_OK;
+}
+
+void pgmi_model_destroy(pgmi_model* m) {
+    if (!m) return;
+    hipSetDevice(m->device);
+    if (m->stream) hipStreamSynchronize(m->stream);
+    for (auto& e : m->events) { hipEventDestroy(e.start); hipEventDestroy(e.stop); }
+    for (void* p : m->allocs) hipFree(p);
+    if (m->stream) hipStreamDestroy(m->stream);
+    delete m;
+}
+
+int pgmi_model_device(const pgmi_model* m) { return m ? m->device : -1; }
+
+int pgmi_synchronize(pgmi_model* m) {
+    if (!m) { set_error("null model"); return PGMI_EINVAL; }
+    PGMI_HIP(hipStreamSynchronize(m->stream));
+    return PGMI_OK;
+}
+
+int pgmi_token_logprobs(pgmi_model* m, const int32_t* tokens, int B, int T, float* out) {
+    if (!m || !tokens || !out || B <= 0 || T <= 0) { set_error("bad argument"); return PGMI_EINVAL; }
+    if (T > m->max_rows) { set_error("T=%d exceeds workspace rows %d", T, m->max_rows); return PGMI_EINVAL; }
+    int rc = check_tokens(tokens, B, T);
+    if (rc) return rc;
+    PGMI_HIP(hipSetDevice(m->device));
+    const int per = m->max_rows / T;
+    const int V = m->cfg.vocab;
+    for (int b0 = 0; b0 < B; b0 += per) {
+        const int bc = std::min(per, B - b0);
+        PGMI_HIP(hipMemcpyAsync(m->tokens, tokens + (size_t)b0 * T, (size_t)bc * T * 4, hipMemcpyHostToDevice, m->stream));
+        rc = run_encoder(m, bc, T);
+        if (rc) return rc;
+        rc = run_head(m, bc * T, nullptr);
+        if (rc) return rc;
+        PGMI_HIP(hipMemcpyAsync(out + (size_t)b0 * T * V, m->lp, (size_t)bc * T * V * 4, hipMemcpyDeviceToHost, m->stream));
+        PGMI_HIP(hipStreamSynchronize(m->stream));
+    }
+    return PGMI_OK;
+}
+
+int pgmi_masked_logprobs(pgmi_model* m, const int32_t* tokens, const int32_t* mask_pos, int B, int T, float* out) {
+    if (!m || !tokens || !mask_pos || !out || B <= 0 || T <= 0) { set_error("bad argument"); return PGMI_EINVAL; }
+    if (T > m->max_rows) { set_error("T=%d exceeds workspace rows %d", T, m->max_rows); return PGMI_EINVAL; }
+    int rc = check_tokens(tokens, B, T);
+    if (rc) return rc;
+    for (int b = 0; b < B; ++b)
+        if (mask_pos[b] < 0 || mask_pos[b] >= T) { set_error("mask_pos[%d]=%d out of range", b, mask_pos[b]); return PGMI_EINVAL; }
+    PGMI_HIP(hipSetDevice(m->device));
+    const int per = m->max_rows / T;
+    const int V = m->cfg.vocab;
+    std::vector<int32_t> ridx;
+    for (int b0 = 0; b0 < B; b0 += per) {
+        const int bc = std::min(per, B - b0);
+        ridx.resize(bc);
+        for (int b = 0; b < bc; ++b) ridx[b] = b * T + mask_pos[b0 + b];
+        PGMI_HIP(hipMemcpyAsync(m->tokens, tokens + (size_t)b0 * T, (size_t)bc * T * 4, hipMemcpyHostToDevice, m->stream));
+        PGMI_HIP(hipMemcpyAsync(m->aux_i, mask_pos + b0, (size_t)bc * 4, hipMemcpyHostToDevice, m->stream));
+        PGMI_HIP(hipMemcpyAsync(m->row_idx, ridx.data(), (size_t)bc * 4, hipMemcpyHostToDevice, m->stream));
+        launch_apply_mask(m->tokens, m->aux_i, bc, T, m->stream);
+        rc = run_encoder(m, bc, T);
+        if (rc) return rc;
+        rc = run_head(m, bc, m->row_idx);
+        if (rc) return rc;
+        PGMI_HIP(hipMemcpyAsync(out + (size_t)b0 * V, m->lp, (size_t)bc * V * 4, hipMemcpyDeviceToHost, m->stream));
+        PGMI_HIP(hipStreamSynchronize(m->stream));
+    }
+    return PGMI_OK;
+}
+
+void pgmi_optimal_window(int position, int n, int window, int* start, int* end) {
+    // proteingym/utils/scoring_utils.py:43-52
+    const int half = window / 2;
+    int s, e;
+    if (n <= window) { s = 0; e = n; }
+    else if (position < half) { s = 0; e = window; }
+    else if (position >= n - half) { s = n - window; e = n; }
+    else { s = std::max(0, position - half); e = std::min(n, position + half); }
+    if (start) *start = s;
+    if (end) *end = e;
+}
+
+int pgmi_assay_create(pgmi_model* m, const int32_t* wt_tokens, int n_tok, const int32_t* positions, int P,
+                      int window, const int32_t* sub_pos, const int32_t* sub_wt, const int32_t* sub_mt,
+                      const int64_t* mut_off, int64_t n_mut, pgmi_assay** out) {
+    if (!out) { set_error("null out"); return PGMI_EINVAL; }
+    *out = nullptr;
+    if (!m || !wt_tokens || n_tok <= 0 || P < 0 || (P > 0 && !positions) || window <= 0 || n_mut < 0) { set_error("bad argument"); return PGMI_EINVAL; }
+    for (int i = 0; i < n_tok; ++i)
+        if (wt_tokens[i] < 0 || wt_tokens[i] >= PGMI_VOCAB || wt_tokens[i] == PGMI_TOK_PAD) { set_error("wt token %d invalid at %d", wt_tokens[i], i); return PGMI_EINVAL; }
+    const int T = std::min(n_tok, window);
+    if (T > m->max_rows) { set_error("T=%d exceeds workspace rows %d", T, m->max_rows); return PGMI_EINVAL; }
+    std::vector<int32_t> ws(P), mr(P);
+    for (int i = 0; i < P; ++i) {
+        if (positions[i] < 0 || positions[i] >= n_tok) { set_error("position %d out of range", positions[i]); return PGMI_EINVAL; }
+        int s, e;
+        pgmi_optimal_window(positions[i], n_tok, window, &s, &e);
+        if (e - s != T) { set_error("internal: window length %d != %d", e - s, T); return PGMI_EINVAL; }
+        ws[i] = s;
+        mr[i] = positions[i] - s;
+    }
+    const int64_t n_sub = n_mut ? mut_off[n_mut] : 0;
+    for (int64_t k = 0; k < n_sub; ++k)
+        if (sub_pos[k] < 0 || sub_pos[k] >= n_tok || sub_wt[k] < 0 || sub_wt[k] >= PGMI_VOCAB || sub_mt[k] < 0 || sub_mt[k] >= PGMI_VOCAB) {
+            set_error("substitution %lld out of range", (long long)k);
+            return PGMI_EINVAL;
+        }
+    PGMI_HIP(hipSetDevice(m->device));
+    pgmi_assay* a = new pgmi_assay();
+    a->m = m; a->n_tok = n_tok; a->P = P; a->T = T; a->n_mut = n_mut; a->n_sub = n_sub;
+    int rc;
+#define TRY(e) do { rc = (e); if (rc) { pgmi_assay_destroy(a); return rc; } } while (0)
+    TRY(dev_upload(a->allocs, &a->wt, wt_tokens, (size_t)n_tok));
+    TRY(dev_upload(a->allocs, &a->positions, positions, (size_t)P));
+    TRY(dev_upload(a->allocs, &a->win_start, ws.data(), (size_t)P));
+    TRY(dev_upload(a->allocs, &a->mask_rel, mr.data(), (size_t)P));
+    TRY(dev_upload(a->allocs, &a->sub_pos, sub_pos, (size_t)n_sub));
+    TRY(dev_upload(a->allocs, &a->sub_wt, sub_wt, (size_t)n_sub));
+    TRY(dev_upload(a->allocs, &a->sub_mt, sub_mt, (size_t)n_sub));
+    TRY(dev_upload(a->allocs, &a->mut_off, mut_off, (size_t)(n_mut + 1)));
+    TRY(dev_alloc(a->allocs, &a->table, (size_t)n_tok * PGMI_VOCAB));
+    TRY(dev_alloc(a->allocs, &a->scores, (size_t)n_mut));
+#undef TRY
+    *out = a;
+    return PGMI_OK;
+}
+
+void pgmi_assay_destroy(pgmi_assay* a) {
+    if (!a) return;
+    if (a->m) { hipSetDevice(a->m->device); hipStreamSynchronize(a->m->stream); }
+    for (void* p : a->allocs) hipFree(p);
+    delete a;
+}
+
+int pgmi_assay_run(pgmi_model* m, pgmi_assay* a, double* scores_host, float* table_host, double* scores_dev) {
+    if (!m || !a || a->m != m) { set_error("bad model/assay handle"); return PGMI_EINVAL; }
+    PGMI_HIP(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    const int T = a->T, V = m->cfg.vocab;
+    const int per = m->max_rows / T;
+    launch_fill_f32(a->table, (int64_t)a->n_tok * V, NAN, s);
+    for (int p0 = 0; p0 < a->P; p0 += per) {
+        const int bc = std::min(per, a->P - p0);
+        launch_make_masked_windows(a->wt, a->win_start + p0, a->mask_rel + p0, bc, T, m->tokens, s);
+        int rc = run_encoder(m, bc, T);
+        if (rc) return rc;
+        // rows to keep: b*T + mask_rel[b]  (compute_fitness.py:503: token_probs[:, i-start])
+        launch_row_index(a->mask_rel + p0, bc, T, m->row_idx, s);
+        rc = run_head(m, bc, m->row_idx);
+        if (rc) return rc;
+        launch_scatter_rows(m->lp, a->positions + p0, bc, V, a->table, s);
+    }
+    {
+        ProfScope p(m, PGMI_K_SCORE, 0, (double)a->n_sub * 20);
+        launch_score_mutants(a->table, V, a->sub_pos, a->sub_wt, a->sub_mt, a->mut_off, a->n_mut, a->scores, s);
+    }
+    PGMI_HIP(hipGetLastError());
+    if (scores_dev && a->n_mut) PGMI_HIP(hipMemcpyAsync(scores_dev, a->scores, (size_t)a->n_mut * 8, hipMemcpyDeviceToDevice, s));
+    if (scores_host && a->n_mut) PGMI_HIP(hipMemcpyAsync(scores_host, a->scores, (size_t)a->n_mut * 8, hipMemcpyDeviceToHost, s));
+    if (table_host) PGMI_HIP(hipMemcpyAsync(table_host, a->table, (size_t)a->n_tok * V * 4, hipMemcpyDeviceToHost, s));
+    PGMI_HIP(hipStreamSynchronize(s));
+    return PGMI_OK;
+}
+
+int pgmi_parse_mutants(const char* text, const int64_t* str_off, int64_t n_mut, const char* sequence,
+                       int seq_len, int offset_idx, int32_t* sub_pos, int32_t* sub_wt, int32_t* sub_mt,
+                       int64_t* mut_off, int64_t* n_sub_out) {
+    if (!text || !str_off || !sequence || n_mut < 0 || !n_sub_out) { set_error("bad argument"); return PGMI_EINVAL; }
+    // alphabet: esm/constants.py:8 + esm/data.py:151-157 ("ESM-1b"/"roberta_large")
+    static const char* standard = "LAGVSERTIDPKQNFYMHWCXBUZO.-";
+    int32_t idx[256];
+    for (int i = 0; i < 256; ++i) idx[i] = PGMI_TOK_UNK;
+    for (int i = 0; standard[i]; ++i) idx[(unsigned char)standard[i]] = 4 + i;
+    const bool fill = sub_pos && sub_wt && sub_mt && mut_off;
+    int64_t n = 0;
+    for (int64_t i = 0; i < n_mut; ++i) {
+        if (fill) mut_off[i] = n;
+        const char* p = text + str_off[i];
+        const char* end = text + str_off[i + 1];
+        while (p < end) {                       // one "A25G" token up to ':' (row.split(":"))
+            const char* q = p;
+            while (q < end && *q != ':') ++q;
+            const int64_t len = q - p;
+            if (len < 3) { set_error("malformed mutation '%.*s' in mutant %lld", (int)len, p, (long long)i); return PGMI_EPARSE; }
+            const char wt = p[0], mt = q[-1];
+            long pos = 0;
+            bool neg = false;
+            const char* d = p + 1;
+            if (*d == '-') { neg = true; ++d; }
+            if (d >= q - 1) { set_error("malformed mutation '%.*s' in mutant %lld", (int)len, p, (long long)i); return PGMI_EPARSE; }
+            for (; d < q - 1; ++d) {
+                if (*d < '0' || *d > '9') { set_error("malformed mutation '%.*s' in mutant %lld", (int)len, p, (long long)i); return PGMI_EPARSE; }
+                pos = pos * 10 + (*d - '0');
+                if (pos > 100000000) { set_error("position overflow in mutant %lld", (long long)i); return PGMI_EPARSE; }
+            }
+            if (neg) pos = -pos;
+            const long k = pos - offset_idx;    // idx of label_row (compute_fitness.py:243)
+            // the reference would IndexError for idx >= len; a negative idx would silently wrap in
+            // python -- no dataset relies on that, it is rejected here.
+            if (k < 0 || k >= seq_len) { set_error("mutation '%.*s': position %ld out of range for sequence of length %d", (int)len, p, pos, seq_len); return PGMI_EPARSE; }
+            if (sequence[k] != wt) { set_error("The listed wildtype does not match the provided sequence ('%.*s': sequence has %c)", (int)len, p, sequence[k]); return PGMI_EPARSE; }
+            if (fill) {
+                sub_pos[n] = (int32_t)(1 + k);  // "add 1 for BOS" (compute_fitness.py:248-249)
+                sub_wt[n] = idx[(unsigned char)wt];
+                sub_mt[n] = idx[(unsigned char)mt];
+            }
+            ++n;
+            p = (q < end) ? q + 1 : q;
+            if (q < end && p == end) { set_error("trailing ':' in mutant %lld", (long long)i); return PGMI_EPARSE; }
+        }
+        if (str_off[i + 1] == str_off[i]) { set_error("empty mutant string at row %lld", (long long)i); return PGMI_EPARSE; }
+    }
+    if (fill) mut_off[n_mut] = n;
+    *n_sub_out = n;
+    return PGMI_OK;
+}
+
+int pgmi_profile_enable(pgmi_model* m, int on) {
+    if (!m) { set_error("null model"); return PGMI_EINVAL; }
+    int rc = prof_drain(m);
+    m->prof = on != 0;
+    return rc;
+}
+
+int pgmi_profile_reset(pgmi_model* m) {
+    if (!m) { set_error("null model"); return PGMI_EINVAL; }
+    int rc = prof_drain(m);
+    for (int i = 0; i < PGMI_K_COUNT; ++i) { m->prof_ms[i] = 0; m->prof_n[i] = 0; m->prof_flops[i] = 0; m->prof_bytes[i] = 0; }
+    return rc;
+}
+
+int pgmi_profile_get(pgmi_model* m, int k, double* ms, int64_t* launches, double* flops, double* bytes) {
+    if (!m || k < 0 || k >= PGMI_K_COUNT) { set_error("bad argument"); return PGMI_EINVAL; }
+    int rc = prof_drain(m);
+    if (rc) return rc;
+    if (ms) *ms = m->prof_ms[k];
+    if (launches) *launches = m->prof_n[k];
+    if (flops) *flops = m->prof_flops[k];
+    if (bytes) *bytes = m->prof_bytes[k];
+    return PGMI_OK;
+}
+
+// ---- single-op entry points for the numerics tests -------------------------------------------
+int pgmi_op_layernorm(int device, const float* x, const float* w, const float* b, int rows, int D, float eps, float* y) {
+    if (!x || !w || !b || !y || rows <= 0 || D <= 0 || D % 4) { set_error("bad argument"); return PGMI_EINVAL; }
+    if (pgmi_device_count() <= 0) { set_error("no HIP device visible"); return PGMI_ENODEV; }
+    PGMI_HIP(hipSetDevice(device));
+    std::vector<void*> pool;
+    float *dx, *dw, *db, *dy;
+    int rc = 0;
+    if ((rc = dev_upload(pool, &dx, x, (size_t)rows * D)) || (rc = dev_upload(pool, &dw, w, (size_t)D)) ||
+        (rc = dev_upload(pool, &db, b, (size_t)D)) || (rc = dev_alloc(pool, &dy, (size_t)rows * D))) {
+        for (void* p : pool) hipFree(p);
+        return rc;
+    }
+    launch_layernorm(dx, dw, db, rows, D, eps, dy, nullptr);
+    hipError_t e = hipMemcpy(y, dy, (size_t)rows * D * 4, hipMemcpyDeviceToHost);
+    for (void* p : pool) hipFree(p);
+    if (e != hipSuccess) { set_error("layernorm op failed: %s", hipGetErrorString(e)); return PGMI_EHIP; }
+    return PGMI_OK;
+}
+
+int pgmi_op_gemm(int device, int precision, const float* A, const float* W, const float* bias, const float* residual,
+                 int M, int N, int K, int epilogue, float* C) {
+    if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) { set_error("bad argument"); return PGMI_EINVAL; }
+    if (precision != PGMI_PREC_FP32) { set_error("precision %d not available in this build", precision); return PGMI_EINVAL; }
+    if (pgmi_device_count() <= 0) { set_error("no HIP device visible"); return PGMI_ENODEV; }
+    PGMI_HIP(hipSetDevice(device));
+    std::vector<void*> pool;
+    float *dA, *dW, *dB = nullptr, *dR = nullptr, *dC;
+    int rc = 0;
+    if ((rc = dev_upload(pool, &dA, A, (size_t)M * K)) || (rc = dev_upload(pool, &dW, W, (size_t)N * K)) ||
+        (bias && (rc = dev_upload(pool, &dB, bias, (size_t)N))) ||
+        (residual && (rc = dev_upload(pool, &dR, residual, (size_t)M * N))) ||
+        (rc = dev_alloc(pool, &dC, (size_t)M * N))) {
+        for (void* p : pool) hipFree(p);
+        return rc;
+    }
+    rc = launch_gemm_f32(dA, dW, dB, dR, dC, M, N, K, epilogue, nullptr);
+    hipError_t e = hipMemcpy(C, dC, (size_t)M * N * 4, hipMemcpyDeviceToHost);
+    for (void* p : pool) hipFree(p);
+    if (rc) return rc;
+    if (e != hipSuccess) { set_error("gemm op failed: %s", hipGetErrorString(e)); return PGMI_EHIP; }
+    return PGMI_OK;
+}
+
+int pgmi_op_attention(int device, int precision, const float* qkv, const int32_t* kv_len, int B, int T, int H,
+                      int rotary, float* ctx) {
+    if (!qkv || !ctx || B <= 0 || T <= 0 || H <= 0) { set_error("bad argument"); return PGMI_EINVAL; }
+    if (precision != PGMI_PREC_FP32) { set_error("precision %d not available in this build", precision); return PGMI_EINVAL; }
+    if (pgmi_device_count() <= 0) { set_error("no HIP device visible"); return PGMI_ENODEV; }
+    PGMI_HIP(hipSetDevice(device));
+    std::vector<void*> pool;
+    float *dq, *dc;
+    int32_t* dl = nullptr;
+    const size_t D = (size_t)H * kHeadDim;
+    int rc = 0;
+    if ((rc = dev_upload(pool, &dq, qkv, (size_t)B * T * 3 * D)) || (kv_len && (rc = dev_upload(pool, &dl, kv_len, (size_t)B))) ||
+        (rc = dev_alloc(pool, &dc, (size_t)B * T * D))) {
+        for (void* p : pool) hipFree(p);
+        return rc;
+    }
+    if (rotary) {
+        pgmi_model tmp;
+        tmp.cfg.arch = PGMI_ARCH_ESM2;
+        rc = ensure_rotary(&tmp, T);
+        if (!rc) launch_rotary(dq, tmp.rot_cos, tmp.rot_sin, B * T, T, H, nullptr);
+        hipDeviceSynchronize();
+        for (void* p : tmp.allocs) hipFree(p);
+    }
+    if (!rc) rc = launch_attention_f32(dq, dl, B, T, H, dc, nullptr);
+    hipError_t e = hipMemcpy(ctx, dc, (size_t)B * T * D * 4, hipMemcpyDeviceToHost);
+    for (void* p : pool) hipFree(p);
+    if (rc) return rc;
+    if (e != hipSuccess) { set_error("attention op failed: %s", hipGetErrorString(e)); return PGMI_EHIP; }
+    return PGMI_OK;
+}
+
+}  // extern "C"

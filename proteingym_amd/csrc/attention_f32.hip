@@ -1,0 +1,197 @@
+// Fused multi-head self-attention, fp32 operands on the matrix cores (parity-gated mode).
+//
+// Replaces  S = q k^T ; softmax_fp32(S) ; O = P v  of
+// /root/reference/proteingym/baselines/esm/esm/multihead_attention.py:357-387 (ESM-1v reaches
+// the same math through F.multi_head_attention_forward, :196-230).  q arrives pre-scaled by
+// head_dim^-0.5 (folded into the packed q_proj weights; 1/8 is exact).  Non-causal; keys
+// >= kv_len[b] are masked with -inf exactly like key_padding_mask (:370-376).  The [B*H,T,T]
+// score tensor is never materialised.
+//
+// One wave owns 32 query rows of one (sequence, head); up to 4 waves (same head) share the
+// K/V tiles of 32 keys staged in LDS.  Everything is arranged so that no cross-lane data
+// movement is needed except one lane<->lane+32 exchange per tile for the row max:
+//   S^T = K Q^T  (A = K tile from LDS, B = Q held in 32 VGPRs)  -> C layout puts query
+//        r = lane&31 in the lane and 16 of the tile's 32 keys in the lane's registers;
+//   online softmax per lane (row stats live in the lane that owns the query);
+//   O^T = V^T P^T (A = V^T read from LDS, B = P straight from the S^T accumulator
+//        registers: register v of lane (r,kh) is P[r][key (v&3)+8(v>>2)+4kh], which is
+//        exactly the B-operand layout for the k pair (key, key+4)) -> query again in the
+//        lane, so the rescale by exp(m_old-m_new) and the final 1/l are per-lane scalars.
+// MFMA: v_mfma_f32_32x32x2_f32, 64 per (32q x 32k) tile = 4096 cycles for 262144 FLOP = the
+// fp32 matrix peak; the ~100 VALU ops of the softmax hide behind the second wave on the SIMD.
+#include "common.h"
+
+namespace pgmi {
+
+constexpr int KT = 32;          // keys per tile
+constexpr int KS_STRIDE = 68;   // K tile row stride (floats): conflict-free ds_read_b128
+constexpr int VS_STRIDE = 64;
+
+template <int WPB>
+__global__ __launch_bounds__(WPB * 64) void attention_f32_kernel(
+    const float* __restrict__ qkv, const int32_t* __restrict__ kv_len, int T, int H,
+    float* __restrict__ ctx) {
+    constexpr int NT = WPB * 64;
+    constexpr int NL = (512 + NT - 1) / NT;   // float4 loads per thread per tensor per tile
+    __shared__ __attribute__((aligned(16))) float lds[2 * KT * KS_STRIDE + 2 * KT * VS_STRIDE];
+    float* Ks = lds;                          // [2][KT][KS_STRIDE]
+    float* Vs = lds + 2 * KT * KS_STRIDE;     // [2][KT][VS_STRIDE]
+
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, kh = lane >> 5;
+    const int D = H * kHeadDim;
+    const size_t RS = (size_t)3 * D;
+    const float* base = qkv + (size_t)b * T * RS + (size_t)h * kHeadDim;
+    const int Tk = kv_len ? kv_len[b] : T;
+    const int q0 = (blockIdx.x * WPB + wave) * 32;
+    const bool active = q0 < T;
+
+    // Q fragment: lane (r,kh) holds Q[q0+r][8g+4kh+e]
+    f32x4 qf[8];
+    {
+        const int qrow = min(q0 + r, T - 1);
+        const float* qp = base + (size_t)qrow * RS + kh * 4;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) qf[g] = *reinterpret_cast<const f32x4*>(qp + g * 8);
+    }
+
+    // staging of K/V tiles through registers
+    f32x4 k_st[NL], v_st[NL];
+    auto stage_load = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int f = tid + NT * i;
+            if (f < 512) {
+                const int key = kt * KT + (f >> 4), c4 = f & 15;
+                if (key < T) {
+                    const float* p = base + (size_t)key * RS + D + c4 * 4;
+                    k_st[i] = *reinterpret_cast<const f32x4*>(p);
+                    v_st[i] = *reinterpret_cast<const f32x4*>(p + D);
+                } else {
+                    k_st[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    v_st[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+    };
+    auto stage_store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int f = tid + NT * i;
+            if (f < 512) {
+                const int key = f >> 4, c4 = f & 15;
+                *reinterpret_cast<f32x4*>(Ks + buf * KT * KS_STRIDE + key * KS_STRIDE + c4 * 4) = k_st[i];
+                *reinterpret_cast<f32x4*>(Vs + buf * KT * VS_STRIDE + key * VS_STRIDE + c4 * 4) = v_st[i];
+            }
+        }
+    };
+
+    const int nkt = (Tk + KT - 1) / KT;      // tiles holding at least one valid key
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+
+    f32x16 o[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) o[dt][v] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    int cur = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = kt + 1 < nkt;
+        if (more) stage_load(kt + 1);
+        if (active) {
+            const float* Kb = Ks + cur * KT * KS_STRIDE + r * KS_STRIDE + kh * 4;
+            const float* Vb = Vs + cur * KT * VS_STRIDE + r;
+            f32x16 st;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) st[v] = 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const f32x4 kf = *reinterpret_cast<const f32x4*>(Kb + g * 8);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    st = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[e], qf[g][e], st, 0, 0, 0);
+            }
+            if (kt * KT + KT > Tk) {          // wave-uniform: tile straddles the valid-key limit
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int key = kt * KT + (v & 3) + 8 * (v >> 2) + 4 * kh;
+                    if (key >= Tk) st[v] = -INFINITY;
+                }
+            }
+            float mloc = st[0];
+#pragma unroll
+            for (int v = 1; v < 16; ++v) mloc = fmaxf(mloc, st[v]);
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+            const float m_new = fmaxf(m_run, mloc);
+            const float alpha = expf(m_run - m_new);
+            float psum = 0.f;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                st[v] = expf(st[v] - m_new);
+                psum += st[v];
+            }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) o[dt][v] *= alpha;
+            // O^T += V^T P^T : k pair for register v is (key_v, key_v + 4), key_v = (v&3)+8(v>>2)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int key = (v & 3) + 8 * (v >> 2);
+                const float* vp = Vb + (key + 4 * kh) * VS_STRIDE;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[dt * 32], st[v], o[dt], 0, 0, 0);
+            }
+        }
+        if (more) stage_store(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    if (active) {
+        const float l_tot = l_run + __shfl_xor(l_run, 32);
+        if (q0 + r < T) {
+            const float inv = 1.0f / l_tot;
+            float* op = ctx + ((size_t)b * T + q0 + r) * D + (size_t)h * kHeadDim + 4 * kh;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    f32x4 val;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) val[e] = o[dt][4 * g + e] * inv;
+                    *reinterpret_cast<f32x4*>(op + dt * 32 + 8 * g) = val;
+                }
+        }
+    }
+}
+
+int launch_attention_f32(const float* qkv, const int32_t* kv_len, int B, int T, int H, float* ctx,
+                         hipStream_t s) {
+    if (B <= 0 || T <= 0 || H <= 0) {
+        set_error("attention_f32: bad shape B=%d T=%d H=%d", B, T, H);
+        return PGMI_EINVAL;
+    }
+    const int n32 = (T + 31) / 32;
+    const int nblk = (n32 + 3) / 4;
+    const int wpb = (n32 + nblk - 1) / nblk;
+    const dim3 grid(nblk, H, B);
+    switch (wpb) {
+        case 1: hipLaunchKernelGGL(attention_f32_kernel<1>, grid, dim3(64), 0, s, qkv, kv_len, T, H, ctx); break;
+        case 2: hipLaunchKernelGGL(attention_f32_kernel<2>, grid, dim3(128), 0, s, qkv, kv_len, T, H, ctx); break;
+        case 3: hipLaunchKernelGGL(attention_f32_kernel<3>, grid, dim3(192), 0, s, qkv, kv_len, T, H, ctx); break;
+        default: hipLaunchKernelGGL(attention_f32_kernel<4>, grid, dim3(256), 0, s, qkv, kv_len, T, H, ctx); break;
+    }
+    PGMI_HIP(hipGetLastError());
+    return PGMI_OK;
+}
+
+}  // namespace pgmi

@@ -1,0 +1,71 @@
+// Shared declarations for libpgmi (gfx950 / MI355X only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/pgmi.h"
+
+namespace pgmi {
+
+void set_error(const char* fmt, ...);
+
+#define PGMI_HIP(expr)                                                                   \
+    do {                                                                                 \
+        hipError_t _e = (expr);                                                          \
+        if (_e != hipSuccess) {                                                          \
+            pgmi::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),       \
+                            __FILE__, __LINE__);                                         \
+            return PGMI_EHIP;                                                            \
+        }                                                                                \
+    } while (0)
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kWave = 64;
+constexpr int kHeadDim = 64;
+
+enum Epilogue { EPI_NONE = 0, EPI_GELU = 1 };
+
+// ---- elementwise.hip ---------------------------------------------------------------------
+// tokens_out[b,t] = (t == mask_pos[b]) ? <mask> : wt[start[b] + t]
+void launch_make_masked_windows(const int32_t* wt, const int32_t* win_start, const int32_t* mask_rel,
+                                int B, int T, int32_t* tokens_out, hipStream_t s);
+// tokens[b, mask_pos[b]] = <mask> (in place)
+void launch_apply_mask(int32_t* tokens, const int32_t* mask_pos, int B, int T, hipStream_t s);
+// per sequence: scale[b] (token-dropout rescale), pos_idx[b,t] (learned-position index), kv_len[b]
+void launch_seq_stats(const int32_t* tokens, int B, int T, int token_dropout, float* scale,
+                      int32_t* pos_idx, int32_t* kv_len, hipStream_t s);
+void launch_zero_pad_rows(const int32_t* tokens, int rows, int D, float* x, hipStream_t s);
+void launch_embed(const int32_t* tokens, const float* scale, const int32_t* pos_idx,
+                  const float* embed_tokens, const float* embed_positions, int token_dropout,
+                  int rows, int T, int D, float* x, hipStream_t s);
+void launch_layernorm(const float* x, const float* w, const float* b, int rows, int D, float eps,
+                      float* y, hipStream_t s);
+// y[i,:] = x[row_idx[i],:]
+void launch_gather_rows(const float* x, const int32_t* row_idx, int n, int D, float* y, hipStream_t s);
+// out[r,:] = log_softmax(h[r,:] @ E^T + bias); E [V,D]
+void launch_vocab_logsoftmax(const float* h, const float* E, const float* bias, int rows, int D,
+                             int V, float* out, hipStream_t s);
+void launch_scatter_rows(const float* src, const int32_t* dst_row, int n, int V, float* table,
+                         hipStream_t s);
+void launch_row_index(const int32_t* mask_rel, int B, int T, int32_t* out, hipStream_t s);
+void launch_fill_f32(float* p, int64_t n, float v, hipStream_t s);
+void launch_score_mutants(const float* table, int V, const int32_t* sub_pos, const int32_t* sub_wt,
+                          const int32_t* sub_mt, const int64_t* mut_off, int64_t n_mut,
+                          double* scores, hipStream_t s);
+void launch_rotary(float* qkv, const float* cos_t, const float* sin_t, int rows, int T, int H,
+                   hipStream_t s);
+
+// ---- gemm_f32.hip ------------------------------------------------------------------------
+// C[M,N] = epi(A[M,K] W[N,K]^T + bias[N]) (+ residual[M,N]); K % 32 == 0.
+int launch_gemm_f32(const float* A, const float* W, const float* bias, const float* residual,
+                    float* C, int M, int N, int K, int epilogue, hipStream_t s);
+
+// ---- attention_f32.hip -------------------------------------------------------------------
+// qkv [B*T, 3*H*64] (q pre-scaled by 1/8), ctx [B*T, H*64]; kv_len[b] (nullable) = valid keys.
+int launch_attention_f32(const float* qkv, const int32_t* kv_len, int B, int T, int H, float* ctx,
+                         hipStream_t s);
+
+}  // namespace pgmi

@@ -1,0 +1,320 @@
+// HBM-bound kernels of the ESM forward: masked-window construction, embedding (+token-dropout
+// rescale, learned positions), LayerNorm, rotary, row gather/scatter, the vocabulary
+// projection + log-softmax on the kept rows, and the per-mutant table lookup.
+// One wave64 per row wherever a row reduction is needed (shuffle reductions, no LDS).
+#include "common.h"
+
+namespace pgmi {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ---- masked windows: compute_fitness.py:490-495 ------------------------------------------
+__global__ void make_masked_windows_kernel(const int32_t* __restrict__ wt,
+                                           const int32_t* __restrict__ win_start,
+                                           const int32_t* __restrict__ mask_rel, int B, int T,
+                                           int32_t* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)B * T) return;
+    const int b = (int)(i / T), t = (int)(i % T);
+    out[i] = (t == mask_rel[b]) ? PGMI_TOK_MASK : wt[win_start[b] + t];
+}
+void launch_make_masked_windows(const int32_t* wt, const int32_t* win_start, const int32_t* mask_rel,
+                                int B, int T, int32_t* out, hipStream_t s) {
+    const int64_t n = (int64_t)B * T;
+    hipLaunchKernelGGL(make_masked_windows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s,
+                       wt, win_start, mask_rel, B, T, out);
+}
+
+__global__ void apply_mask_kernel(int32_t* tokens, const int32_t* __restrict__ mask_pos, int B, int T) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) tokens[(int64_t)b * T + mask_pos[b]] = PGMI_TOK_MASK;
+}
+void launch_apply_mask(int32_t* tokens, const int32_t* mask_pos, int B, int T, hipStream_t s) {
+    hipLaunchKernelGGL(apply_mask_kernel, dim3((B + 255) / 256), dim3(256), 0, s, tokens, mask_pos, B, T);
+}
+
+// ---- per-sequence statistics ---------------------------------------------------------------
+// scale[b] = 1 or the token-dropout factor (1-0.15*0.8)/(1 - n_mask/n_nonpad)  (esm1.py:125-131);
+// the embed kernel applies it as (x*0.88f)/denom, the reference's op order.
+// pos_idx[b,t] = cumsum(tok != pad)*(tok != pad) + pad_idx          (modules.py:261-262)
+// kv_len[b]    = index of the last non-pad token + 1 (the host only admits trailing padding, so
+//                this is the number of valid keys for the attention mask).
+__global__ void seq_stats_kernel(const int32_t* __restrict__ tokens, int B, int T, int token_dropout,
+                                 float* __restrict__ denom, int32_t* __restrict__ pos_idx,
+                                 int32_t* __restrict__ kv_len) {
+    const int b = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (b >= B) return;
+    const int32_t* tk = tokens + (int64_t)b * T;
+    int running = 0, n_mask = 0, last_valid = -1;
+    for (int t0 = 0; t0 < T; t0 += 64) {
+        const int t = t0 + lane;
+        const int tok = (t < T) ? tk[t] : PGMI_TOK_PAD;
+        const int valid = (t < T) && (tok != PGMI_TOK_PAD);
+        // inclusive prefix sum of `valid` within the wave
+        const unsigned long long bal = __ballot(valid);
+        const unsigned long long below = bal & ((lane == 63) ? ~0ull : ((1ull << (lane + 1)) - 1ull));
+        const int incl = __popcll(below);
+        if (t < T) pos_idx[(int64_t)b * T + t] = valid ? (running + incl + PGMI_TOK_PAD) : PGMI_TOK_PAD;
+        running += __popcll(bal);
+        n_mask += __popcll(__ballot((t < T) && tok == PGMI_TOK_MASK));
+        if (bal) last_valid = t0 + 63 - __clzll(bal);
+    }
+    if (lane == 0) {
+        float d = 1.0f;
+        if (token_dropout) d = 1.0f - (float)n_mask / (float)running;
+        denom[b] = d;
+        kv_len[b] = last_valid + 1;
+    }
+}
+void launch_seq_stats(const int32_t* tokens, int B, int T, int token_dropout, float* denom,
+                      int32_t* pos_idx, int32_t* kv_len, hipStream_t s) {
+    hipLaunchKernelGGL(seq_stats_kernel, dim3((B + 3) / 4), dim3(256), 0, s, tokens, B, T, token_dropout,
+                       denom, pos_idx, kv_len);
+}
+
+// ---- embedding: esm1.py:123-139 / esm2.py:83-94 -------------------------------------------
+// x = E[tok] (zero for <mask> under token dropout) * 0.88 / denom[b] + Wpos[pos_idx]; pad rows -> 0.
+__global__ void embed_kernel(const int32_t* __restrict__ tokens, const float* __restrict__ denom,
+                             const int32_t* __restrict__ pos_idx, const float* __restrict__ E,
+                             const float* __restrict__ P, int token_dropout, int rows, int T, int D,
+                             float* __restrict__ x) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int tok = tokens[row];
+    const int b = row / T;
+    const float dn = denom[b];
+    const f32x4* e = reinterpret_cast<const f32x4*>(E + (size_t)tok * D);
+    const f32x4* p = P ? reinterpret_cast<const f32x4*>(P + (size_t)pos_idx[row] * D) : nullptr;
+    f32x4* xo = reinterpret_cast<f32x4*>(x + (size_t)row * D);
+    const bool is_pad = tok == PGMI_TOK_PAD;
+    const bool zero_emb = token_dropout && tok == PGMI_TOK_MASK;
+    for (int i = lane; i < D / 4; i += 64) {
+        f32x4 v = zero_emb ? f32x4{0.f, 0.f, 0.f, 0.f} : e[i];
+        if (token_dropout) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] = (v[c] * 0.88f) / dn;
+        }
+        if (p) {
+            const f32x4 pv = p[i];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v[c] += pv[c];
+        }
+        if (is_pad) v = f32x4{0.f, 0.f, 0.f, 0.f};
+        xo[i] = v;
+    }
+}
+void launch_embed(const int32_t* tokens, const float* denom, const int32_t* pos_idx, const float* E,
+                  const float* P, int token_dropout, int rows, int T, int D, float* x, hipStream_t s) {
+    hipLaunchKernelGGL(embed_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, tokens, denom, pos_idx, E, P,
+                       token_dropout, rows, T, D, x);
+}
+
+// zero the rows of <pad> tokens (esm1.py:138-139), needed after emb_layer_norm_before
+__global__ void zero_pad_rows_kernel(const int32_t* __restrict__ tokens, int rows, int D, float* __restrict__ x) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows || tokens[row] != PGMI_TOK_PAD) return;
+    for (int i = lane; i < D; i += 64) x[(size_t)row * D + i] = 0.f;
+}
+void launch_zero_pad_rows(const int32_t* tokens, int rows, int D, float* x, hipStream_t s) {
+    hipLaunchKernelGGL(zero_pad_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, tokens, rows, D, x);
+}
+
+// ---- LayerNorm (torch.nn.LayerNorm, modules.py:80-81): biased variance, eps inside sqrt ----
+// One wave per row, the row held in registers (D <= 64*4*NV), two-pass mean / variance.
+// Algorithmic bytes: 2*D*4 per row (read + write); HBM-bound.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* x,   // may alias y (in place)
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ bsh, int rows, int D,
+                                                        float eps, float* y) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const int nv = D >> 2;
+    const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * D);
+    f32x4 v[NV];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        v[i] = (c < nv) ? xr[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+        s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float d = v[i][k] - mean;
+                q += d * d;
+            }
+        }
+    }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
+    const f32x4* wr = reinterpret_cast<const f32x4*>(w);
+    const f32x4* br = reinterpret_cast<const f32x4*>(bsh);
+    f32x4* yr = reinterpret_cast<f32x4*>(y + (size_t)row * D);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nv) {
+            const f32x4 wv = wr[c], bv = br[c];
+            f32x4 o;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) o[k] = (v[i][k] - mean) * rstd * wv[k] + bv[k];
+            yr[c] = o;
+        }
+    }
+}
+void launch_layernorm(const float* x, const float* w, const float* b, int rows, int D, float eps,
+                      float* y, hipStream_t s) {
+    const dim3 grid((rows + 3) / 4), block(256);
+    const int nv = (D / 4 + 63) / 64;
+    if (nv <= 1) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, w, b, rows, D, eps, y);
+    else if (nv <= 2) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, w, b, rows, D, eps, y);
+    else if (nv <= 5) hipLaunchKernelGGL(layernorm_kernel<5>, grid, block, 0, s, x, w, b, rows, D, eps, y);
+    else if (nv <= 10) hipLaunchKernelGGL(layernorm_kernel<10>, grid, block, 0, s, x, w, b, rows, D, eps, y);
+    else hipLaunchKernelGGL(layernorm_kernel<20>, grid, block, 0, s, x, w, b, rows, D, eps, y);
+}
+
+// ---- rotary (rotary_embedding.py:11-20,47-69): half-split rotation of q (already scaled) and k
+// qkv [rows, 3*H*64]; tables cos/sin [T, 64] (emb = cat(freqs,freqs)) built on the host in f32
+// exactly as the reference does.  One thread handles the pair (d, d+32) of one head.
+__global__ void rotary_kernel(float* __restrict__ qkv, const float* __restrict__ cos_t,
+                              const float* __restrict__ sin_t, int64_t n, int T, int H) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;                      // n = rows * 2 * H * 32
+    const int d = (int)(i & 31);
+    const int64_t j = i >> 5;
+    const int h = (int)(j % H);
+    const int64_t k2 = j / H;
+    const int which = (int)(k2 & 1);         // 0 = q, 1 = k
+    const int64_t row = k2 >> 1;
+    const int t = (int)(row % T);
+    float* p = qkv + row * (size_t)(3 * H * 64) + (size_t)which * H * 64 + h * 64 + d;
+    const float x1 = p[0], x2 = p[32];
+    const float c1 = cos_t[t * 64 + d], s1 = sin_t[t * 64 + d];
+    const float c2 = cos_t[t * 64 + d + 32], s2 = sin_t[t * 64 + d + 32];
+    p[0] = x1 * c1 + (-x2) * s1;             // x*cos + rotate_half(x)*sin, first half: -x2
+    p[32] = x2 * c2 + x1 * s2;               // second half: +x1
+}
+void launch_rotary(float* qkv, const float* cos_t, const float* sin_t, int rows, int T, int H, hipStream_t s) {
+    const int64_t n = (int64_t)rows * 2 * H * 32;
+    hipLaunchKernelGGL(rotary_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, qkv, cos_t, sin_t, n, T, H);
+}
+
+// ---- row gather / scatter -------------------------------------------------------------------
+__global__ void gather_rows_kernel(const float* __restrict__ x, const int32_t* __restrict__ idx, int n,
+                                   int D, float* __restrict__ y) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    const f32x4* src = reinterpret_cast<const f32x4*>(x + (size_t)idx[row] * D);
+    f32x4* dst = reinterpret_cast<f32x4*>(y + (size_t)row * D);
+    for (int i = lane; i < D / 4; i += 64) dst[i] = src[i];
+}
+void launch_gather_rows(const float* x, const int32_t* idx, int n, int D, float* y, hipStream_t s) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, s, x, idx, n, D, y);
+}
+
+__global__ void scatter_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ dst_row,
+                                    int n, int V, float* __restrict__ table) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * V) return;
+    const int rI = i / V, c = i % V;
+    table[(size_t)dst_row[rI] * V + c] = src[i];
+}
+void launch_scatter_rows(const float* src, const int32_t* dst_row, int n, int V, float* table, hipStream_t s) {
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3((n * V + 255) / 256), dim3(256), 0, s, src, dst_row, n, V, table);
+}
+
+__global__ void row_index_kernel(const int32_t* __restrict__ mask_rel, int B, int T, int32_t* __restrict__ out) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < B) out[b] = b * T + mask_rel[b];
+}
+void launch_row_index(const int32_t* mask_rel, int B, int T, int32_t* out, hipStream_t s) {
+    hipLaunchKernelGGL(row_index_kernel, dim3((B + 255) / 256), dim3(256), 0, s, mask_rel, B, T, out);
+}
+
+__global__ void fill_f32_kernel(float* p, int64_t n, float v) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+void launch_fill_f32(float* p, int64_t n, float v, hipStream_t s) {
+    hipLaunchKernelGGL(fill_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, p, n, v);
+}
+
+// ---- vocabulary projection + log-softmax (modules.py:327 ; compute_fitness.py:502) ---------
+// One wave per row: logits[v] = <h, E[v]> + bias[v] for the 33 symbols, then x - max - log(sum exp).
+__global__ __launch_bounds__(256) void vocab_logsoftmax_kernel(const float* __restrict__ h,
+                                                               const float* __restrict__ E,
+                                                               const float* __restrict__ bias, int rows,
+                                                               int D, int V, float* __restrict__ out) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* hr = h + (size_t)row * D;
+    float my_logit = -INFINITY;            // lane v (< V) ends up owning logit v
+    for (int v = 0; v < V; ++v) {
+        const float* ev = E + (size_t)v * D;
+        float acc = 0.f;
+        for (int i = lane; i < D; i += 64) acc = fmaf(hr[i], ev[i], acc);
+        acc = wave_sum(acc);
+        if (lane == v) my_logit = acc + bias[v];
+    }
+    const float mx = wave_max(my_logit);
+    const float ex = (lane < V) ? expf(my_logit - mx) : 0.f;
+    const float lse = logf(wave_sum(ex));
+    if (lane < V) out[(size_t)row * V + lane] = (my_logit - mx) - lse;
+}
+void launch_vocab_logsoftmax(const float* h, const float* E, const float* bias, int rows, int D, int V,
+                             float* out, hipStream_t s) {
+    hipLaunchKernelGGL(vocab_logsoftmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, h, E, bias, rows, D, V, out);
+}
+
+// ---- label_row (compute_fitness.py:240-250): score = sum_subs f32(lp[mt] - lp[wt]) in double ---
+__global__ void score_mutants_kernel(const float* __restrict__ table, int V,
+                                     const int32_t* __restrict__ sub_pos,
+                                     const int32_t* __restrict__ sub_wt,
+                                     const int32_t* __restrict__ sub_mt,
+                                     const int64_t* __restrict__ mut_off, int64_t n_mut,
+                                     double* __restrict__ scores) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_mut) return;
+    double sc = 0.0;
+    for (int64_t k = mut_off[i]; k < mut_off[i + 1]; ++k) {
+        const float* rowp = table + (size_t)sub_pos[k] * V;
+        const float d = rowp[sub_mt[k]] - rowp[sub_wt[k]];
+        sc += (double)d;
+    }
+    scores[i] = sc;
+}
+void launch_score_mutants(const float* table, int V, const int32_t* sub_pos, const int32_t* sub_wt,
+                          const int32_t* sub_mt, const int64_t* mut_off, int64_t n_mut, double* scores,
+                          hipStream_t s) {
+    if (n_mut <= 0) return;
+    hipLaunchKernelGGL(score_mutants_kernel, dim3((unsigned)((n_mut + 255) / 256)), dim3(256), 0, s, table, V,
+                       sub_pos, sub_wt, sub_mt, mut_off, n_mut, scores);
+}
+
+}  // namespace pgmi

@@ -1,0 +1,359 @@
+"""Host-side mirror of the reference's ESM operator seam, backed by libpgmi.so (HIP, gfx950).
+
+Reference interface being mirrored (all under /root/reference/proteingym/baselines/esm):
+  * ``pretrained.load_model_and_alphabet(path) -> (model, alphabet)``  esm/pretrained.py:24-28,67-218
+  * ``alphabet.get_idx / get_batch_converter``                         esm/data.py:92-174,262-297
+  * ``model(tokens)["logits"]``                                         esm/model/esm1.py:116-177, esm2.py:76-130
+  * the masked-marginals loop and ``label_row``                         compute_fitness.py:240-250,486-514
+
+Same names, argument meaning and error behaviour; the arithmetic runs in hand-written HIP
+kernels through the C ABI (include/pgmi.h).  No CPU fallback exists: without the built library
+and a GPU every compute call raises ``PgmiError``.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import os
+import re
+from pathlib import Path
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib
+from ._lib import PgmiError, Config
+
+# esm/constants.py:8
+proteinseq_toks = {
+    'toks': ['L', 'A', 'G', 'V', 'S', 'E', 'R', 'T', 'I', 'D', 'P', 'K', 'Q', 'N', 'F', 'Y', 'M',
+             'H', 'W', 'C', 'X', 'B', 'U', 'Z', 'O', '.', '-']
+}
+
+
+class Alphabet:
+    """The 33-symbol ESM-1b / ESM2 alphabet (esm/data.py:92-174, arch "roberta_large"/"ESM-1b")."""
+
+    def __init__(self):
+        self.standard_toks = list(proteinseq_toks["toks"])
+        self.prepend_toks = ["<cls>", "<pad>", "<eos>", "<unk>"]
+        self.append_toks = ["<mask>"]
+        self.prepend_bos = True
+        self.append_eos = True
+        self.all_toks = list(self.prepend_toks) + self.standard_toks
+        for i in range((8 - (len(self.all_toks) % 8)) % 8):
+            self.all_toks.append(f"<null_{i + 1}>")
+        self.all_toks.extend(self.append_toks)
+        self.tok_to_idx = {tok: i for i, tok in enumerate(self.all_toks)}
+        self.unk_idx = self.tok_to_idx["<unk>"]
+        self.padding_idx = self.get_idx("<pad>")
+        self.cls_idx = self.get_idx("<cls>")
+        self.mask_idx = self.get_idx("<mask>")
+        self.eos_idx = self.get_idx("<eos>")
+
+    @classmethod
+    def from_architecture(cls, name: str) -> "Alphabet":
+        if name in ("ESM-1b", "roberta_large"):
+            return cls()
+        raise ValueError("Unknown architecture selected")
+
+    def __len__(self):
+        return len(self.all_toks)
+
+    def get_idx(self, tok):
+        return self.tok_to_idx.get(tok, self.unk_idx)
+
+    def get_tok(self, ind):
+        return self.all_toks[ind]
+
+    def to_dict(self):
+        return self.tok_to_idx.copy()
+
+    def encode(self, text: str) -> List[int]:
+        """One token per residue letter; unknown letters -> <unk>.  (The reference's tokenizer
+        also recognises literal special-token strings such as "<mask>" inside the text,
+        data.py:176-251; protein sequences never contain them.)"""
+        return [self.get_idx(ch) for ch in text]
+
+    def get_batch_converter(self, truncation_seq_length: int = None):
+        return BatchConverter(self, truncation_seq_length)
+
+
+class BatchConverter:
+    """esm/data.py:262-297: (label, seq) pairs -> (labels, strs, int64 tokens [B, maxlen+2])."""
+
+    def __init__(self, alphabet, truncation_seq_length: int = None):
+        self.alphabet = alphabet
+        self.truncation_seq_length = truncation_seq_length
+
+    def __call__(self, raw_batch: Sequence[Tuple[str, str]]):
+        labels, strs = zip(*raw_batch)
+        enc = [self.alphabet.encode(s) for s in strs]
+        if self.truncation_seq_length:
+            enc = [e[: self.truncation_seq_length] for e in enc]
+        max_len = max(len(e) for e in enc)
+        tokens = np.full((len(enc), max_len + 2), self.alphabet.padding_idx, dtype=np.int64)
+        for i, e in enumerate(enc):
+            tokens[i, 0] = self.alphabet.cls_idx
+            tokens[i, 1:len(e) + 1] = e
+            tokens[i, len(e) + 1] = self.alphabet.eos_idx
+        return list(labels), list(strs), tokens
+
+
+# ---- checkpoint -> flat weight blob ------------------------------------------------------------
+def _upgrade_state_dict(path: str):
+    """esm/pretrained.py:67-99 (v1) and :162-181 (v2).  torch is used only to unpickle the .pt."""
+    import torch
+    torch.serialization.add_safe_globals([argparse.Namespace])
+    data = torch.load(str(path), map_location="cpu", weights_only=False)
+    model_name = Path(path).stem
+    if model_name.startswith("esm2"):                                   # pretrained.py:187
+        c = data["cfg"]["model"]
+        pat = re.compile("^" + "|".join(["encoder.sentence_encoder.", "encoder."]))
+        sd = {pat.sub("", k): v for k, v in data["model"].items()}
+        cfg = dict(arch=_lib.ARCH_ESM2, layers=int(c.encoder_layers),
+                   embed_dim=int(c.encoder_embed_dim), heads=int(c.encoder_attention_heads),
+                   ffn_dim=4 * int(c.encoder_embed_dim), max_positions=0,
+                   token_dropout=int(bool(c.token_dropout)), emb_layer_norm_before=0)
+    else:
+        a = data["args"]
+        if a.arch != "roberta_large":
+            raise ValueError("Unknown architecture selected")           # only ESM-1b/1v v1 + ESM2
+        prs1 = lambda s: "".join(s.split("encoder.")[1:] if "encoder" in s else s)
+        prs2 = lambda s: "".join(s.split("sentence_encoder.")[1:] if "sentence_encoder" in s else s)
+        sd = {prs1(prs2(k)): v for k, v in data["model"].items()}
+        cfg = dict(arch=_lib.ARCH_ESM1B, layers=int(a.encoder_layers),
+                   embed_dim=int(a.encoder_embed_dim), heads=int(a.encoder_attention_heads),
+                   ffn_dim=int(a.encoder_ffn_embed_dim), max_positions=int(a.max_positions),
+                   token_dropout=int(bool(getattr(a, "token_dropout", False))),
+                   emb_layer_norm_before=int(any(k.startswith("emb_layer_norm_before") for k in sd)))
+    sd = {k: v for k, v in sd.items() if not k.startswith("contact_head")}
+    return cfg, sd
+
+
+def expected_keys(cfg) -> List[str]:
+    """State-dict keys in ABI blob order (include/pgmi.h, pgmi_weight_count)."""
+    keys = ["embed_tokens.weight"]
+    if cfg["arch"] == _lib.ARCH_ESM1B:
+        keys.append("embed_positions.weight")
+    if cfg["emb_layer_norm_before"]:
+        keys += ["emb_layer_norm_before.weight", "emb_layer_norm_before.bias"]
+    for i in range(cfg["layers"]):
+        p = f"layers.{i}."
+        keys += [p + "self_attn_layer_norm.weight", p + "self_attn_layer_norm.bias"]
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            keys += [p + f"self_attn.{n}.weight", p + f"self_attn.{n}.bias"]
+        keys += [p + "final_layer_norm.weight", p + "final_layer_norm.bias",
+                 p + "fc1.weight", p + "fc1.bias", p + "fc2.weight", p + "fc2.bias"]
+    keys += ["emb_layer_norm_after.weight", "emb_layer_norm_after.bias",
+             "lm_head.dense.weight", "lm_head.dense.bias",
+             "lm_head.layer_norm.weight", "lm_head.layer_norm.bias", "lm_head.bias"]
+    return keys
+
+
+def pack_state_dict(cfg, sd) -> np.ndarray:
+    """Strict key check as esm/pretrained.py:192-210, then flatten to one fp32 blob."""
+    keys = expected_keys(cfg)
+    allowed_extra = {"lm_head.weight"}                     # tied to embed_tokens (esm1.py:101-105)
+    if cfg["arch"] == _lib.ARCH_ESM2:
+        allowed_extra |= {f"layers.{i}.self_attn.rot_emb.inv_freq" for i in range(cfg["layers"])}
+    missing = [k for k in keys if k not in sd]
+    unexpected = [k for k in sd if k not in keys and k not in allowed_extra]
+    msgs = []
+    if missing:
+        msgs.append(f"Missing key(s) in state_dict: {set(missing)}.")
+    if unexpected:
+        msgs.append(f"Unexpected key(s) in state_dict: {set(unexpected)}.")
+    if msgs:
+        raise RuntimeError("Error(s) in loading state_dict:\n\t" + "\n\t".join(msgs))
+    parts = []
+    for k in keys:
+        t = sd[k]
+        a = t.detach().to("cpu").float().numpy() if hasattr(t, "detach") else np.asarray(t, np.float32)
+        parts.append(np.ascontiguousarray(a, dtype=np.float32).ravel())
+    return np.concatenate(parts)
+
+
+class EsmModel:
+    """Device-resident ESM-1b/1v/ESM2 masked LM.  ``model(tokens)["logits"]`` mirrors the
+    reference call (compute_fitness.py:502) but returns log-probabilities, i.e. already
+    ``log_softmax``-ed logits -- log_softmax is idempotent, so reference-style callers that
+    apply ``torch.log_softmax(..., dim=-1)`` on top get the same numbers."""
+
+    def __init__(self, cfg: dict, weights: np.ndarray, device: int = 0, precision: str = "fp32",
+                 max_rows: int = 0):
+        lib = _lib.load()
+        self.cfg = dict(cfg)
+        self.precision = precision
+        c = Config(abi_version=_lib.ABI_VERSION, arch=cfg["arch"], layers=cfg["layers"],
+                   embed_dim=cfg["embed_dim"], heads=cfg["heads"], ffn_dim=cfg["ffn_dim"], vocab=33,
+                   max_positions=cfg["max_positions"], token_dropout=cfg["token_dropout"],
+                   emb_layer_norm_before=cfg["emb_layer_norm_before"],
+                   precision=_lib.PRECISIONS[precision], max_rows=max_rows)
+        self._c = c
+        n = lib.pgmi_weight_count(C.byref(c))
+        w = _lib.as_f32(weights)
+        if w.size != n:
+            raise PgmiError(f"weight blob has {w.size} elements, config needs {n}")
+        h = C.c_void_p()
+        _lib.check(lib.pgmi_model_create(C.byref(c), _lib.ptr(w, _lib._f32p), w.size, device, C.byref(h)))
+        self._h = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().pgmi_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def eval(self):
+        return self
+
+    def cuda(self, *a, **k):
+        return self
+
+    # -- forward --------------------------------------------------------------------------------
+    def token_logprobs(self, tokens) -> np.ndarray:
+        t = _lib.as_i32(np.asarray(tokens))
+        assert t.ndim == 2
+        B, T = t.shape
+        out = np.empty((B, T, 33), dtype=np.float32)
+        _lib.check(_lib.load().pgmi_token_logprobs(self._h, _lib.ptr(t, _lib._i32p), B, T, _lib.ptr(out, _lib._f32p)))
+        return out
+
+    def __call__(self, tokens, **_):
+        return {"logits": self.token_logprobs(tokens)}
+
+    def masked_logprobs(self, tokens, mask_pos) -> np.ndarray:
+        t = _lib.as_i32(np.asarray(tokens))
+        mp = _lib.as_i32(np.asarray(mask_pos))
+        B, T = t.shape
+        out = np.empty((B, 33), dtype=np.float32)
+        _lib.check(_lib.load().pgmi_masked_logprobs(self._h, _lib.ptr(t, _lib._i32p), _lib.ptr(mp, _lib._i32p),
+                                                    B, T, _lib.ptr(out, _lib._f32p)))
+        return out
+
+    # -- profiling ------------------------------------------------------------------------------
+    def profile_enable(self, on=True):
+        _lib.check(_lib.load().pgmi_profile_enable(self._h, int(on)))
+
+    def profile_reset(self):
+        _lib.check(_lib.load().pgmi_profile_reset(self._h))
+
+    def profile(self) -> dict:
+        lib = _lib.load()
+        out = {}
+        for k, name in enumerate(_lib.K_NAMES):
+            ms, n, fl, by = C.c_double(), C.c_int64(), C.c_double(), C.c_double()
+            _lib.check(lib.pgmi_profile_get(self._h, k, C.byref(ms), C.byref(n), C.byref(fl), C.byref(by)))
+            out[name] = dict(ms=ms.value, launches=n.value, flops=fl.value, bytes=by.value)
+        return out
+
+
+class Assay:
+    """One DMS assay resident on the device (pgmi_assay_*): wild-type tokens, the positions to
+    mask, and the flattened substitutions of every mutant."""
+
+    def __init__(self, model: EsmModel, sequence: str, mutants: Sequence[str], offset_idx: int = 1,
+                 alphabet: Optional[Alphabet] = None, window: int = 1024, all_positions: bool = False):
+        lib = _lib.load()
+        self.model = model
+        alphabet = alphabet or Alphabet()
+        _, _, toks = alphabet.get_batch_converter()([("protein1", sequence)])
+        self.wt_tokens = _lib.as_i32(toks[0])
+        self.n_tok = int(self.wt_tokens.size)
+        sub_pos, sub_wt, sub_mt, mut_off = parse_mutants(mutants, sequence, offset_idx)
+        self.n_mut = len(mutants)
+        if all_positions:
+            positions = np.arange(self.n_tok, dtype=np.int32)   # what the reference runs (:489)
+        else:
+            positions = np.unique(sub_pos).astype(np.int32)     # rows some mutant reads
+        self.positions = positions
+        h = C.c_void_p()
+        _lib.check(lib.pgmi_assay_create(
+            model._h, _lib.ptr(self.wt_tokens, _lib._i32p), self.n_tok,
+            _lib.ptr(positions, _lib._i32p), int(positions.size), int(window),
+            _lib.ptr(sub_pos, _lib._i32p), _lib.ptr(sub_wt, _lib._i32p), _lib.ptr(sub_mt, _lib._i32p),
+            _lib.ptr(mut_off, _lib._i64p), self.n_mut, C.byref(h)))
+        self._h = h
+        self.T = min(self.n_tok, window)
+
+    def run(self, want_table: bool = False, scores_dev_ptr: int = 0):
+        lib = _lib.load()
+        scores = np.empty(self.n_mut, dtype=np.float64)
+        table = np.empty((self.n_tok, 33), dtype=np.float32) if want_table else None
+        _lib.check(lib.pgmi_assay_run(self.model._h, self._h, _lib.ptr(scores, _lib._f64p),
+                                      _lib.ptr(table, _lib._f32p) if want_table else None,
+                                      C.c_void_p(scores_dev_ptr) if scores_dev_ptr else None))
+        return (scores, table) if want_table else scores
+
+    def run_device_only(self, scores_dev_ptr: int = 0):
+        """Run with no host copies (bench: results stay in HBM / go to a device buffer)."""
+        _lib.check(_lib.load().pgmi_assay_run(self.model._h, self._h, None, None,
+                                              C.c_void_p(scores_dev_ptr) if scores_dev_ptr else None))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().pgmi_assay_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def parse_mutants(mutants: Sequence[str], sequence: str, offset_idx: int):
+    """label_row's string handling (compute_fitness.py:240-250) for a whole column at once, in
+    C++ (pgmi_parse_mutants).  Raises AssertionError on a wild-type mismatch like the reference."""
+    lib = _lib.load()
+    enc = [str(m).encode() for m in mutants]
+    off = np.zeros(len(enc) + 1, dtype=np.int64)
+    np.cumsum([len(e) for e in enc], out=off[1:])
+    text = b"".join(enc)
+    seq = sequence.encode()
+    n_sub = C.c_int64()
+    rc = lib.pgmi_parse_mutants(text, _lib.ptr(off, _lib._i64p), len(enc), seq, len(seq), int(offset_idx),
+                                None, None, None, None, C.byref(n_sub))
+    _raise_parse(rc)
+    n = n_sub.value
+    sub_pos = np.empty(n, np.int32); sub_wt = np.empty(n, np.int32); sub_mt = np.empty(n, np.int32)
+    mut_off = np.empty(len(enc) + 1, np.int64)
+    rc = lib.pgmi_parse_mutants(text, _lib.ptr(off, _lib._i64p), len(enc), seq, len(seq), int(offset_idx),
+                                _lib.ptr(sub_pos, _lib._i32p), _lib.ptr(sub_wt, _lib._i32p),
+                                _lib.ptr(sub_mt, _lib._i32p), _lib.ptr(mut_off, _lib._i64p), C.byref(n_sub))
+    _raise_parse(rc)
+    return sub_pos, sub_wt, sub_mt, mut_off
+
+
+def _raise_parse(rc):
+    if rc == 0:
+        return
+    msg = _lib.load().pgmi_last_error().decode(errors="replace")
+    if "does not match" in msg:
+        raise AssertionError(msg)                          # compute_fitness.py:244
+    raise ValueError(msg)
+
+
+def get_optimal_window(mutation_position_relative, seq_len_wo_special, model_window):
+    """proteingym/utils/scoring_utils.py:43-52 (C implementation: pgmi_optimal_window)."""
+    s, e = C.c_int32(), C.c_int32()
+    _lib.load().pgmi_optimal_window(int(mutation_position_relative), int(seq_len_wo_special),
+                                    int(model_window), C.byref(s), C.byref(e))
+    return [s.value, e.value]
+
+
+def load_model_and_alphabet(model_location: str, device: int = 0, precision: str = "fp32",
+                            max_rows: int = 0):
+    """Mirror of esm/pretrained.py:24-28 for local ``.pt`` files."""
+    if not str(model_location).endswith(".pt"):
+        raise ValueError("only local .pt checkpoints are supported (no network): " + str(model_location))
+    cfg, sd = _upgrade_state_dict(model_location)
+    blob = pack_state_dict(cfg, sd)
+    return EsmModel(cfg, blob, device=device, precision=precision, max_rows=max_rows), Alphabet()

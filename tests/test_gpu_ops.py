@@ -1,0 +1,92 @@
+"""GPU numerics of each HIP kernel against the torch fp32 op it replaces (through the C ABI)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from proteingym_amd import _lib
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(a, ty=_lib._f32p):
+    return a.ctypes.data_as(ty) if a is not None else None
+
+
+@pytest.mark.parametrize("rows,D", [(7, 128), (1000, 1280), (33, 2560), (5, 64), (3, 320)])
+def test_layernorm(lib, rows, D):
+    rng = np.random.default_rng(0)
+    x = (rng.standard_normal((rows, D)) * 3 + 0.5).astype(np.float32)
+    w = (1 + 0.1 * rng.standard_normal(D)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(D)).astype(np.float32)
+    y = np.empty_like(x)
+    _lib.check(lib.pgmi_op_layernorm(0, _p(x), _p(w), _p(b), rows, D, 1e-5, _p(y)))
+    ref = torch.nn.functional.layer_norm(torch.from_numpy(x), (D,), torch.from_numpy(w), torch.from_numpy(b), 1e-5).numpy()
+    assert np.abs(y - ref).max() < 2e-5
+
+
+@pytest.mark.parametrize("M,N,K,epi,res", [
+    (128, 128, 32, 0, False), (300, 384, 128, 0, False), (257, 1280, 1280, 1, False),
+    (513, 1280, 5120, 0, True), (64, 3840, 1280, 0, False), (1, 128, 256, 1, True), (1000, 96, 64, 0, True)])
+def test_gemm_fp32(lib, M, N, K, epi, res):
+    rng = np.random.default_rng(1)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)   # asymmetric, non-square
+    bias = rng.standard_normal(N).astype(np.float32)
+    R = rng.standard_normal((M, N)).astype(np.float32) if res else None
+    Cc = np.empty((M, N), np.float32)
+    _lib.check(lib.pgmi_op_gemm(0, _lib.PREC_FP32, _p(A), _p(W), _p(bias), _p(R), M, N, K, epi, _p(Cc)))
+    ref = torch.from_numpy(A).double() @ torch.from_numpy(W).double().T + torch.from_numpy(bias).double()
+    if epi:
+        ref = ref * 0.5 * (1.0 + torch.erf(ref / np.sqrt(2.0)))
+    if res:
+        ref = ref + torch.from_numpy(R).double()
+    err = np.abs(Cc - ref.numpy()).max()
+    assert err < 2e-5 * np.sqrt(K / 128), err
+
+
+@pytest.mark.parametrize("B,T,H,kv", [(2, 32, 2, None), (3, 70, 2, None), (2, 288, 4, None), (1, 1024, 2, None),
+                                      (3, 72, 2, [72, 43, 1]), (2, 129, 1, [100, 129])])
+def test_attention_fp32(lib, B, T, H, kv):
+    rng = np.random.default_rng(2)
+    D = H * 64
+    qkv = rng.standard_normal((B, T, 3 * D)).astype(np.float32)
+    qkv[..., :D] *= 0.4
+    kvl = np.asarray(kv, np.int32) if kv is not None else None
+    ctx = np.empty((B, T, D), np.float32)
+    _lib.check(lib.pgmi_op_attention(0, _lib.PREC_FP32, _p(qkv), _p(kvl, _lib._i32p) if kvl is not None else None,
+                                     B, T, H, 0, _p(ctx)))
+    t = torch.from_numpy(qkv).double()
+    q, k, v = [t[..., i * D:(i + 1) * D].reshape(B, T, H, 64).transpose(1, 2) for i in range(3)]
+    s = q @ k.transpose(-1, -2)
+    if kv is not None:
+        mask = torch.arange(T)[None, :] >= torch.tensor(kv)[:, None]
+        s = s.masked_fill(mask[:, None, None, :], float("-inf"))
+    ref = (torch.softmax(s, -1) @ v).transpose(1, 2).reshape(B, T, D).numpy()
+    if kv is not None:   # rows of padded queries are don't-care
+        for b in range(B):
+            ctx[b, kv[b]:] = 0
+            ref[b, kv[b]:] = 0
+    assert np.abs(ctx - ref).max() < 2e-5
+
+
+def test_attention_rotary(lib):
+    rng = np.random.default_rng(3)
+    B, T, H = 2, 50, 2
+    D = H * 64
+    qkv = rng.standard_normal((B, T, 3 * D)).astype(np.float32)
+    ctx = np.empty((B, T, D), np.float32)
+    _lib.check(lib.pgmi_op_attention(0, _lib.PREC_FP32, _p(qkv), None, B, T, H, 1, _p(ctx)))
+    t = torch.from_numpy(qkv)
+    q, k, v = [t[..., i * D:(i + 1) * D].reshape(B, T, H, 64).transpose(1, 2) for i in range(3)]
+    inv_freq = 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))
+    fr = torch.einsum("i,j->ij", torch.arange(T).float(), inv_freq)
+    emb = torch.cat((fr, fr), -1)
+    cos, sin = emb.cos().double(), emb.sin().double()
+    rot = lambda x: torch.cat((-x[..., 32:], x[..., :32]), -1)
+    q, k, v = q.double(), k.double(), v.double()
+    q = q * cos + rot(q) * sin
+    k = k * cos + rot(k) * sin
+    ref = (torch.softmax(q @ k.transpose(-1, -2), -1) @ v).transpose(1, 2).reshape(B, T, D).numpy()
+    assert np.abs(ctx - ref).max() < 3e-5
