@@ -1,0 +1,195 @@
+#!/usr/bin/env python
+"""Benchmark of the hot path: mutants scored per second, ESM-1v 650M masked-marginals.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--precision fp32]
+
+One *step* = one pass of the hot path over one assay-shaped batch resident in HBM:
+BASELINE.json configs[1] -- ESM-1v 650M (33 x 1280 x 20 heads x 5120), one assay shaped like
+BLAT_ECOLX_Stiffler_2015 (L=286 -> T=288 tokens, 4 996 single mutants), ONE checkpoint:
+masked windows -> 33-layer forward over every masked position -> LM head on the masked rows
+-> log-softmax table -> per-mutant score (label_row).  Synthetic sequence, synthetic
+random-init weights (no network), deterministic seeds.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU): assays shard over ranks with no
+data-path collective (each rank scores its own assay of the same shape: weak scaling), followed
+by the RCCL all_gather of the per-mutant score vectors that the north-star names.  value =
+all ranks' mutants / max-over-ranks time.
+
+Extra objects on the JSON line: `roofline` (dominant kernel = the FFN GEMMs, HIP-event timed
+inside the timed region, against the MFMA peak of the dtype) and `cpu_baseline` (the oracle's
+CPU restatement of the reference path timed on this box's host cores, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "f16x3": 2500.0}   # MI355X_MICROARCH.md, dense
+L_BLAT, N_MUT_BLAT = 286, 4996
+
+
+def usable_cores() -> int:
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota
+    (the GPU box shows 256 logical CPUs but grants a 16-CPU quota; oversubscribing it with 256
+    threads is ~1000x slower)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return max(1, n)
+
+
+def cpu_baseline(cfg, blob, seq, n_mut, budget_s):
+    """The reference algorithm on the host cores: batch-1 masked forwards (compute_fitness.py:
+    489-503) through oracle/esm_oracle.py (torch CPU fp32), bounded to ~budget_s seconds: when a
+    full 33-layer forward does not fit the budget, k of the 33 (identical-cost) layers are timed
+    and scaled by 33/k."""
+    import torch
+    from oracle import esm_oracle as eo
+    from proteingym_amd import synthetic
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    ocfg, W = eo.from_arrays(arrays=synthetic.blob_to_arrays(cfg, blob), **cfg)
+    toks = eo.tokenize(seq)
+    n_tok, L = len(toks), ocfg["layers"]
+
+    def fwd(i, k):
+        t = toks.copy()
+        t[i] = eo.MASK
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            torch.log_softmax(eo.forward_logits(ocfg, W, t[None], n_layers=k), dim=-1)[0, i]
+        return time.perf_counter() - t0
+
+    fwd(1, 2)                                   # warm-up (threads, first-touch of two layers)
+    per_layer = fwd(2, 2) / 2
+    reps = 3
+    k = int(max(2, min(L, budget_s / reps / max(per_layer, 1e-6))))
+    if k < L:
+        fwd(3, k)                               # first touch of the k layers' weights: not timed
+    ts = [fwd(4 + r, k) for r in range(reps)]
+    per_fwd = float(np.mean(ts)) * L / k
+    assay_s = per_fwd * n_tok                   # the reference runs all L+2 positions, batch 1
+    return {"value": n_mut / assay_s, "unit": "mutants/s", "cores": cores, "kind": "port",
+            "sample": f"{reps} batch-1 masked forwards at T={n_tok} through {k} of {L} layers "
+                      f"(oracle/esm_oracle.py, torch CPU fp32, {cores} threads), scaled x{L}/{k}: "
+                      f"{per_fwd:.3f} s/forward, x{n_tok} forwards for the assay"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "f16x3"])
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline time budget (0 = skip)")
+    ap.add_argument("--layers", type=int, default=33, help="debug only; the headline config is 33")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
+
+    import torch
+    from proteingym_amd import build_native, esm as pesm, synthetic
+    build_native.build(verbose=False)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    cfg = dict(synthetic.ESM1V_650M, layers=args.layers)
+    blob = synthetic.random_weights(cfg, seed=1)                      # same "checkpoint" on every rank
+    model = pesm.EsmModel(cfg, blob, device=local_rank, precision=args.precision)
+    seq, muts, _ = synthetic.random_assay(seed=23 + rank, L=L_BLAT, n_single=N_MUT_BLAT, n_multi=0)
+    assay = pesm.Assay(model, seq, muts, offset_idx=1)                # uploads: inputs resident in HBM
+    n_mut = len(muts)
+    scores_dev = torch.zeros(n_mut, dtype=torch.float64, device="cuda")
+    gathered = torch.zeros(world * n_mut, dtype=torch.float64, device="cuda") if world > 1 else None
+
+    def step():
+        assay.run_device_only(scores_dev.data_ptr())                  # whole hot path, synchronised at return
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, scores_dev)         # RCCL over xGMI
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    model.profile_reset()
+    model.profile_enable(True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    model.profile_enable(False)
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    prof = model.profile()
+    if rank == 0:
+        ffn_ms = prof["gemm_fc1"]["ms"] + prof["gemm_fc2"]["ms"]
+        ffn_fl = prof["gemm_fc1"]["flops"] + prof["gemm_fc2"]["flops"]
+        ffn_n = prof["gemm_fc1"]["launches"] + prof["gemm_fc2"]["launches"]
+        achieved = ffn_fl / (ffn_ms * 1e-3) / 1e12 if ffn_ms > 0 else 0.0
+        peak = PEAK_TFLOPS[args.precision]
+        total_fl = sum(v["flops"] for v in prof.values())
+        kern = {k: {"ms_per_step": round(v["ms"] / args.steps, 3), "launches_per_step": v["launches"] // args.steps,
+                    "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 and v["flops"] > 0 else None,
+                    "gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 and v["bytes"] > 0 else None}
+                for k, v in prof.items()}
+        out = {
+            "metric": "mutants scored/sec (ESM-1v 650M masked-marginal)",
+            "value": world * n_mut * args.steps / dt,
+            "unit": "mutants/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"fp32": "f32", "bf16": "bf16", "f16x3": "f16x3"}[args.precision],
+            "data": "synthetic",
+            "config": {"workload": "ESM-1v 650M (33x1280, 20 heads, FFN 5120) masked-marginals, one "
+                                   "BLAT_ECOLX_Stiffler_2015-shaped assay per GPU per step (L=286, T=288, "
+                                   f"{len(assay.positions)} masked positions run, {n_mut} single mutants), 1 checkpoint; "
+                                   "assays shard over ranks + RCCL all_gather of score vectors",
+                       "precision": args.precision, "layers": args.layers,
+                       "positions_run": int(len(assay.positions)), "tokens_per_step": int(len(assay.positions) * assay.T)},
+            "roofline": {"bound": "mfma", "kernel": "gemm (fc1+GELU, fc2+residual)", "achieved": achieved,
+                         "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "avg_launch_ms": ffn_ms / max(ffn_n, 1), "traffic": None,
+                         "whole_step_tflops": total_fl / dt / 1e12},
+            "kernels": kern,
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            model.close()
+            out["cpu_baseline"] = cpu_baseline(cfg, blob, seq, n_mut, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -90,8 +90,8 @@ int64_t pgmi_weight_count(const pgmi_config* cfg);
 
 /* Replaces pretrained.load_model_and_alphabet + model.cuda() (compute_fitness.py:349-353):
  * uploads the blob to `device`, packs it for the selected precision, allocates workspace.
- * The <mask> embedding row is zeroed here as pretrained.py:97 does for v1 checkpoints
- * (harmless for ESM2: the forward zeroes masked rows whenever token_dropout is set). */
+ * embed_tokens must be the value load_state_dict leaves in the tied embed_tokens/lm_head.weight
+ * parameter, i.e. after the host applied pretrained.py:97 (<mask> row zeroing for v1 files). */
 int pgmi_model_create(const pgmi_config* cfg, const float* weights, int64_t n_weights,
                       int device, pgmi_model** out);
 void pgmi_model_destroy(pgmi_model* m);

@@ -85,13 +85,18 @@ def load_checkpoint(path: str, dtype=torch.float32):
             raise ValueError("oracle restates only the roberta_large (ESM-1b/1v) v1 arch")
         prs1 = lambda s: "".join(s.split("encoder.")[1:] if "encoder" in s else s)
         prs2 = lambda s: "".join(s.split("sentence_encoder.")[1:] if "sentence_encoder" in s else s)
-        sd = {prs1(prs2(k)): v.clone() for k, v in data["model"].items()}  # pretrained.py:91-96
-        sd["embed_tokens.weight"][MASK].zero_()                      # pretrained.py:97
+        sd = {prs1(prs2(k)): v for k, v in data["model"].items()}       # pretrained.py:91-96
+        sd["embed_tokens.weight"][MASK].zero_()                      # pretrained.py:97 (in place:
+        # reaches lm_head.weight too when the file stores the tied tensors with shared storage)
         cfg = dict(arch="esm1b", layers=int(a.encoder_layers), embed_dim=int(a.encoder_embed_dim),
                    ffn_dim=int(a.encoder_ffn_embed_dim), heads=int(a.encoder_attention_heads),
                    token_dropout=bool(getattr(a, "token_dropout", False)),
                    emb_layer_norm_before=any(k.startswith("emb_layer_norm_before") for k in sd),
                    max_positions=int(a.max_positions))
+    # embed_tokens / lm_head.weight are one tied parameter (esm1.py:101-105): load_state_dict
+    # (pretrained.py:216) leaves the lm_head.weight entry (copied last) in it.
+    if "lm_head.weight" in sd:
+        sd["embed_tokens.weight"] = sd["lm_head.weight"]
     W = {k: v.to(dtype) for k, v in sd.items() if not k.startswith("contact_head")}
     return cfg, W
 
@@ -122,10 +127,12 @@ def _rotate_half(x):
     return torch.cat((-x2, x1), dim=-1)
 
 
-def forward_logits(cfg, W, tokens: np.ndarray) -> torch.Tensor:
+def forward_logits(cfg, W, tokens: np.ndarray, n_layers: int = None) -> torch.Tensor:
     """tokens int64 [B,T] -> logits [B,T,33].  Follows esm1.py:116-177 / esm2.py:76-130.
     Key padding (tokens == <pad>) is honoured exactly as the reference does: embeddings of pad
-    rows zeroed, pad keys masked with -inf before the softmax."""
+    rows zeroed, pad keys masked with -inf before the softmax.
+    ``n_layers`` (default: all) truncates the encoder -- only bench.py's bounded CPU-baseline
+    sample uses it, to time k of the 33 identical-cost layers."""
     tok = torch.as_tensor(np.asarray(tokens), dtype=torch.int64)
     B, T = tok.shape
     D, H = cfg["embed_dim"], cfg["heads"]
@@ -153,7 +160,7 @@ def forward_logits(cfg, W, tokens: np.ndarray) -> torch.Tensor:
     if cfg["arch"] == "esm2":
         cos, sin = _rotary_tables(T, dh, dtype)
     scaling = dh ** -0.5
-    for i in range(cfg["layers"]):
+    for i in range(cfg["layers"] if n_layers is None else min(n_layers, cfg["layers"])):
         p = f"layers.{i}."
         res = x
         h = _layer_norm(x, W[p + "self_attn_layer_norm.weight"], W[p + "self_attn_layer_norm.bias"])
@@ -325,3 +332,15 @@ def score_dms(checkpoints, sequence: str, mutants, offset_idx: int = 1,
             ens += cols[str(path).split("/")[-1].split(".")[0]]
         cols["Ensemble_ESM1v"] = ens / len(checkpoints)
     return cols
+
+
+def from_arrays(arch: int, layers: int, embed_dim: int, heads: int, ffn_dim: int, max_positions: int,
+                token_dropout: int, emb_layer_norm_before: int, arrays, dtype=torch.float32, **_):
+    """Build (cfg, W) from in-memory arrays keyed by upgraded state-dict names (used with
+    synthetic weights at the real 650M shape, where writing a .pt first would be wasteful).
+    ``arch``: 1 = ESM-1b/1v, 2 = ESM2 (the ABI's numbering, include/pgmi.h)."""
+    cfg = dict(arch="esm1b" if arch == 1 else "esm2", layers=layers, embed_dim=embed_dim, heads=heads,
+               ffn_dim=ffn_dim, max_positions=max_positions, token_dropout=bool(token_dropout),
+               emb_layer_norm_before=bool(emb_layer_norm_before))
+    W = {k: torch.as_tensor(np.asarray(v)).to(dtype) for k, v in arrays.items()}
+    return cfg, W

@@ -296,12 +296,10 @@ int pgmi_model_create(const pgmi_config* cfg, const float* w, int64_t n_weights,
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete m; return PGMI_EHIP; }
     const size_t D = cfg->embed_dim, F = cfg->ffn_dim, V = cfg->vocab;
     const float* p = w;
-    {   // embed_tokens with the <mask> row zeroed (pretrained.py:97)
-        std::vector<float> e(p, p + V * D);
-        for (size_t i = 0; i < D; ++i) e[(size_t)PGMI_TOK_MASK * D + i] = 0.f;
-        TRY(dev_upload(m->allocs, &m->embed_tokens, e.data(), e.size()));
-        p += V * D;
-    }
+    // embed_tokens == the tied lm_head.weight (esm1.py:101-105).  The host passes the matrix that
+    // load_state_dict leaves in the tied parameter (pretrained.py:97,216), see proteingym_amd/esm.py.
+    TRY(dev_upload(m->allocs, &m->embed_tokens, p, V * D));
+    p += V * D;
     if (cfg->arch == PGMI_ARCH_ESM1B) {
         const size_t n = (size_t)(cfg->max_positions + 2) * D;
         TRY(dev_upload(m->allocs, &m->embed_positions, p, n));

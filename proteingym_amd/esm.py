@@ -122,12 +122,20 @@ def _upgrade_state_dict(path: str):
         prs1 = lambda s: "".join(s.split("encoder.")[1:] if "encoder" in s else s)
         prs2 = lambda s: "".join(s.split("sentence_encoder.")[1:] if "sentence_encoder" in s else s)
         sd = {prs1(prs2(k)): v for k, v in data["model"].items()}
+        sd["embed_tokens.weight"][32].zero_()      # in place, "For token drop" (pretrained.py:97)
         cfg = dict(arch=_lib.ARCH_ESM1B, layers=int(a.encoder_layers),
                    embed_dim=int(a.encoder_embed_dim), heads=int(a.encoder_attention_heads),
                    ffn_dim=int(a.encoder_ffn_embed_dim), max_positions=int(a.max_positions),
                    token_dropout=int(bool(getattr(a, "token_dropout", False))),
                    emb_layer_norm_before=int(any(k.startswith("emb_layer_norm_before") for k in sd)))
     sd = {k: v for k, v in sd.items() if not k.startswith("contact_head")}
+    # embed_tokens.weight and lm_head.weight are ONE tied parameter (esm1.py:101-105); load_state_dict
+    # (pretrained.py:216) copies the entries in module order, so the value the model ends up with
+    # is the lm_head.weight entry.  In real fair-esm files both entries share storage, so the
+    # in-place zeroing above reaches both; in files where they do not, the reference keeps the
+    # un-zeroed lm_head.weight row -- reproduce either case by using that entry for both roles.
+    if "lm_head.weight" in sd:
+        sd["embed_tokens.weight"] = sd["lm_head.weight"]
     return cfg, sd
 
 

@@ -1,0 +1,159 @@
+"""Synthetic inputs of the reference's shapes (no network: no real checkpoints or DMS files).
+
+* random-weight ESM-1v / ESM2 models of a given architecture, as the flat ABI blob
+  (include/pgmi.h) or as a fair-esm ``.pt`` file (layouts: SURVEY.md Appendix A,
+  /root/reference/proteingym/baselines/esm/esm/pretrained.py:85-99,162-181);
+* DMS assays shaped like rows of reference_files/DMS_substitutions.csv
+  (``data/dms_substitutions_shapes.csv`` holds seq_len and mutant counts of the 217 assays;
+  SURVEY.md section 8d describes the generator: positions uniform over [1,L], target amino acid
+  uniform over the 19 non-wild-type letters, multi-mutants of depth 2-5).
+"""
+from __future__ import annotations
+
+import argparse
+import os
+from typing import Dict, List, Tuple
+
+import numpy as np
+
+from . import _lib
+from .esm import expected_keys
+
+AA = "ACDEFGHIKLMNPQRSTVWY"
+
+ESM1V_650M = dict(arch=_lib.ARCH_ESM1B, layers=33, embed_dim=1280, heads=20, ffn_dim=5120,
+                  max_positions=1024, token_dropout=1, emb_layer_norm_before=0)
+ESM2_650M = dict(arch=_lib.ARCH_ESM2, layers=33, embed_dim=1280, heads=20, ffn_dim=5120,
+                 max_positions=0, token_dropout=1, emb_layer_norm_before=0)
+ESM2_3B = dict(arch=_lib.ARCH_ESM2, layers=36, embed_dim=2560, heads=40, ffn_dim=10240,
+               max_positions=0, token_dropout=1, emb_layer_norm_before=0)
+
+
+def key_shapes(cfg) -> List[Tuple[str, Tuple[int, ...]]]:
+    D, F, V = cfg["embed_dim"], cfg["ffn_dim"], 33
+    out = []
+    for k in expected_keys(cfg):
+        leaf = k.split(".")[-2] + "." + k.split(".")[-1]
+        if k == "embed_tokens.weight":
+            s = (V, D)
+        elif k == "embed_positions.weight":
+            s = (cfg["max_positions"] + 2, D)
+        elif k == "lm_head.bias":
+            s = (V,)
+        elif leaf == "fc1.weight":
+            s = (F, D)
+        elif leaf == "fc1.bias":
+            s = (F,)
+        elif leaf == "fc2.weight":
+            s = (D, F)
+        elif k.endswith("_proj.weight") or k == "lm_head.dense.weight":
+            s = (D, D)
+        else:
+            s = (D,)
+        out.append((k, s))
+    return out
+
+
+def random_weights(cfg, seed: int, embed_std: float = 0.25) -> np.ndarray:
+    """Flat fp32 blob in ABI order.  Linear layers U(-1/sqrt(fan_in), 1/sqrt(fan_in)) (the
+    nn.Linear default scale), LayerNorm gamma 1+0.1N / beta 0.05N, embeddings N(0, embed_std^2)."""
+    rng = np.random.default_rng(seed)
+    n = sum(int(np.prod(s)) for _, s in key_shapes(cfg))
+    blob = np.empty(n, dtype=np.float32)
+    o = 0
+    for k, s in key_shapes(cfg):
+        m = int(np.prod(s))
+        v = blob[o:o + m]
+        if "layer_norm" in k:
+            v[:] = rng.standard_normal(m, dtype=np.float32)
+            if k.endswith("weight"):
+                v *= 0.1
+                v += 1.0
+            else:
+                v *= 0.05
+        elif k.startswith("embed_"):
+            v[:] = rng.standard_normal(m, dtype=np.float32)
+            v *= embed_std
+        else:
+            fan_in = s[-1] if len(s) == 2 else {"fc1.bias": cfg["embed_dim"], "fc2.bias": cfg["ffn_dim"]}.get(
+                k.split(".")[-2] + ".bias", cfg["embed_dim"])
+            b = 1.0 / np.sqrt(fan_in)
+            v[:] = rng.random(m, dtype=np.float32)
+            v *= 2 * b
+            v -= b
+        o += m
+    return blob
+
+
+def blob_to_arrays(cfg, blob: np.ndarray) -> Dict[str, np.ndarray]:
+    out, o = {}, 0
+    for k, s in key_shapes(cfg):
+        m = int(np.prod(s))
+        out[k] = blob[o:o + m].reshape(s)
+        o += m
+    assert o == blob.size
+    out["lm_head.weight"] = out["embed_tokens.weight"]     # tied (esm1.py:101-105)
+    return out
+
+
+def save_fair_esm_checkpoint(path: str, cfg, blob: np.ndarray):
+    """Write the blob as a fair-esm v1 (ESM-1b/1v) or v2 (ESM2; file stem must start with
+    'esm2') checkpoint that both the reference loader and this package read."""
+    import torch
+    arrs = blob_to_arrays(cfg, blob)
+    model = {}
+    for k, v in arrs.items():
+        pref = "encoder." if k.startswith("lm_head") else "encoder.sentence_encoder."
+        model[pref + k] = torch.from_numpy(np.ascontiguousarray(v)).clone()
+    # like real fair-esm files, the tied tensors share storage
+    model["encoder.lm_head.weight"] = model["encoder.sentence_encoder.embed_tokens.weight"]
+    stem = os.path.basename(path).split(".")[0]
+    if cfg["arch"] == _lib.ARCH_ESM2:
+        assert stem.startswith("esm2"), "ESM2 checkpoints are dispatched by file stem (pretrained.py:187)"
+        inv = 1.0 / (10000 ** (np.arange(0, 64, 2, dtype=np.float32) / 64))
+        for i in range(cfg["layers"]):
+            model[f"encoder.sentence_encoder.layers.{i}.self_attn.rot_emb.inv_freq"] = torch.from_numpy(inv.copy())
+        c = argparse.Namespace(encoder_layers=cfg["layers"], encoder_embed_dim=cfg["embed_dim"],
+                               encoder_attention_heads=cfg["heads"], token_dropout=bool(cfg["token_dropout"]))
+        torch.save({"cfg": {"model": c}, "model": model}, path)
+    else:
+        assert not stem.startswith("esm2")
+        a = argparse.Namespace(arch="roberta_large", encoder_layers=cfg["layers"],
+                               encoder_embed_dim=cfg["embed_dim"], encoder_ffn_embed_dim=cfg["ffn_dim"],
+                               encoder_attention_heads=cfg["heads"], max_positions=cfg["max_positions"],
+                               token_dropout=bool(cfg["token_dropout"]))
+        torch.save({"args": a, "model": model}, path)
+    return path
+
+
+def random_sequence(rng, L: int) -> str:
+    return "".join(rng.choice(list(AA), size=L))
+
+
+def random_assay(seed: int, L: int, n_single: int, n_multi: int, offset: int = 1):
+    """(sequence, mutants list, DMS_score) shaped like one DMS_substitutions row."""
+    rng = np.random.default_rng(seed)
+    seq = random_sequence(rng, L)
+    aa = np.array(list(AA))
+    seq_arr = np.array(list(seq))
+
+    def one(p):
+        choices = aa[aa != seq_arr[p]]
+        return f"{seq_arr[p]}{p + offset}{choices[rng.integers(0, 19)]}"
+
+    muts = [one(int(p)) for p in rng.integers(0, L, size=n_single)]
+    for _ in range(n_multi):
+        k = int(rng.integers(2, 6))
+        ps = np.sort(rng.choice(L, size=min(k, L), replace=False))
+        muts.append(":".join(one(int(p)) for p in ps))
+    score = rng.standard_normal(len(muts))
+    return seq, muts, score
+
+
+def dms_shapes():
+    import csv
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "dms_substitutions_shapes.csv")
+    with open(path) as f:
+        return [dict(DMS_index=i, DMS_id=r["DMS_id"], seq_len=int(r["seq_len"]),
+                     n_total=int(r["DMS_total_number_mutants"]), n_single=int(r["DMS_number_single_mutants"]),
+                     n_multi=int(r["DMS_number_multiple_mutants"])) for i, r in enumerate(csv.DictReader(f))]
