@@ -1,0 +1,139 @@
+"""Score many DMS assays with one or more ESM checkpoints on all GPUs of a node.
+
+    python -m torch.distributed.run --nproc-per-node 8 -m proteingym_amd.run_benchmark \\
+        --model-location esm1v_1.pt ... esm1v_5.pt --model_type ESM1v \\
+        --dms_mapping reference_files/DMS_substitutions.csv --dms-input DMS_ProteinGym_substitutions \\
+        --dms-output scores/ESM1v [--dms_indices 0 1 2 ...]
+
+One process per GPU.  The (assay) work list is LPT-balanced over ranks by algorithmic FLOPs; every
+rank scores its assays with every checkpoint (weights replicated: 2.6 GB per checkpoint), then
+one RCCL all_gather moves the per-mutant score vectors to all ranks and rank 0 writes one
+``<DMS_id>.csv`` per assay with exactly the columns the reference CLI writes
+(/root/reference/proteingym/baselines/esm/compute_fitness.py:505,532-543).  Existing CSVs that
+already hold every requested column are skipped (resume), unless --overwrite-prior-scores.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import time
+
+import numpy as np
+import pandas as pd
+
+from . import dist as pdist
+from . import esm as pesm
+
+
+def create_parser():
+    p = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    p.add_argument("--model-location", type=str, nargs="+", required=True)
+    p.add_argument("--model_type", type=str, nargs="+", default=["ESM1v"])
+    p.add_argument("--dms_mapping", type=str, required=True)
+    p.add_argument("--dms-input", type=str, required=True)
+    p.add_argument("--dms-output", type=str, required=True)
+    p.add_argument("--dms_indices", type=int, nargs="*", default=None, help="default: every row of the mapping")
+    p.add_argument("--mutation-col", type=str, default="mutant")
+    p.add_argument("--precision", type=str, default="fp32", choices=sorted(pesm._lib.PRECISIONS))
+    p.add_argument("--all-positions", action="store_true")
+    p.add_argument("--overwrite-prior-scores", action="store_true")
+    p.add_argument("--backend", type=str, default=None, help="torch.distributed backend (default nccl)")
+    return p
+
+
+def column_names(model_locations, model_type):
+    cols = [m.split("/")[-1].split(".")[0] for m in model_locations]
+    return cols, (["Ensemble_ESM1v"] if "ESM1v" in model_type else [])
+
+
+def main(args):
+    rank, local_rank, world = pdist.init_from_env(args.backend)
+    mapping = pd.read_csv(args.dms_mapping)
+    indices = list(range(len(mapping))) if args.dms_indices is None else list(args.dms_indices)
+    cols, ens_cols = column_names(args.model_location, args.model_type)
+    os.makedirs(args.dms_output, exist_ok=True)
+
+    todo = []
+    for i in indices:
+        row = mapping.iloc[i]
+        out = os.path.join(args.dms_output, str(row["DMS_id"]) + ".csv")
+        if os.path.exists(out) and not args.overwrite_prior_scores:
+            have = pd.read_csv(out, nrows=0).columns
+            if all(c in have for c in cols + ens_cols):
+                continue
+        todo.append(i)
+    costs = [pdist.assay_cost(len(str(mapping.iloc[i]["target_seq"]))) for i in todo]
+    assignment = pdist.lpt_partition(costs, world)
+    mine = [todo[k] for k in assignment[rank]]
+
+    t0 = time.time()
+    frames, local = {}, {}
+    for i in mine:
+        row = mapping.iloc[i].replace(np.nan, "")
+        mutant_col = row["DMS_mutant_column"] if "DMS_mutant_column" in mapping.columns else args.mutation_col
+        frames[i] = (pd.read_csv(os.path.join(args.dms_input, row["DMS_filename"])), mutant_col,
+                     str(row["target_seq"]).upper(),
+                     row["start_idx"] if "start_idx" in mapping.columns and row["start_idx"] != "" else 1)
+    for ci, loc in enumerate(args.model_location):
+        model, alphabet = pesm.load_model_and_alphabet(loc, device=local_rank, precision=args.precision)
+        for i in mine:
+            df, mutant_col, seq, offset = frames[i]
+            assay = pesm.Assay(model, seq, [str(m) for m in df[mutant_col]], offset_idx=int(offset),
+                               alphabet=alphabet, all_positions=args.all_positions)
+            local.setdefault(i, []).append(assay.run())
+            assay.close()
+        model.close()
+    # exchange: per item a [n_checkpoints * n_mut] vector
+    sizes = []
+    n_rows = {}
+    for k, i in enumerate(todo):
+        row = mapping.iloc[i]
+        n = int(row["DMS_total_number_mutants"]) if "DMS_total_number_mutants" in mapping.columns and i not in frames \
+            else (len(frames[i][0]) if i in frames else None)
+        n_rows[i] = n
+    if world > 1:
+        import torch
+        import torch.distributed as tdist
+        cnt = torch.zeros(len(todo), dtype=torch.int64, device="cuda" if tdist.get_backend() == "nccl" else "cpu")
+        for k, i in enumerate(todo):
+            if i in frames:
+                cnt[k] = len(frames[i][0])
+        tdist.all_reduce(cnt)                       # exact row counts (files may differ from the mapping)
+        for k, i in enumerate(todo):
+            n_rows[i] = int(cnt[k])
+    sizes = [n_rows[i] * len(cols) for i in todo]
+    payload = {assignment[rank][j]: np.concatenate(local[i]) for j, i in enumerate(mine)}
+    dev = None
+    if world > 1:
+        import torch.distributed as tdist
+        dev = "cuda" if tdist.get_backend() == "nccl" else "cpu"
+    allv = pdist.gather_score_vectors(payload, sizes, assignment, device=dev)
+
+    if rank == 0:
+        n_mut = 0
+        for k, i in enumerate(todo):
+            row = mapping.iloc[i].replace(np.nan, "")
+            df = frames[i][0] if i in frames else pd.read_csv(os.path.join(args.dms_input, row["DMS_filename"]))
+            v = allv[k].reshape(len(cols), -1)
+            for c, name in enumerate(cols):
+                df[name] = v[c]
+            if ens_cols:                                   # compute_fitness.py:532-537
+                df["Ensemble_ESM1v"] = 0.0
+                for name in cols:
+                    df["Ensemble_ESM1v"] += df[name]
+                df["Ensemble_ESM1v"] /= len(cols)
+            out = os.path.join(args.dms_output, str(row["DMS_id"]) + ".csv")
+            df.to_csv(out + ".tmp", index=False)
+            os.replace(out + ".tmp", out)
+            n_mut += len(df)
+        dt = time.time() - t0
+        print(f"scored {len(todo)} assays / {n_mut} mutants x {len(cols)} checkpoint(s) on {world} GPU(s) "
+              f"in {dt:.1f}s = {n_mut / max(dt, 1e-9):.1f} mutants/s (ensemble rate)")
+    if world > 1:
+        import torch.distributed as tdist
+        tdist.barrier()
+        tdist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main(create_parser().parse_args())

@@ -1,0 +1,92 @@
+"""The drop-in CLI (proteingym_amd/compute_fitness.py) and the multi-assay runner on a GPU:
+output CSVs equal the reference CLI's (columns frozen in tests/golden/golden_esm.npz)."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _run_cli(argv):
+    from proteingym_amd import compute_fitness as cf
+    cf.main(cf.create_parser().parse_args(argv))
+
+
+def test_cli_masked_marginals_ensemble(lib, golden, golden_dir, tmp_path):
+    out = tmp_path / "o"
+    _run_cli(["--model-location", os.path.join(golden_dir, "esm1v_toy_1.pt"), os.path.join(golden_dir, "esm1v_toy_2.pt"),
+              "--model_type", "ESM1v", "--dms-input", os.path.join(golden_dir, "TOY_DMS.csv"), "--dms-output", str(out),
+              "--target_seq", str(golden["seq"]), "--scoring-strategy", "masked-marginals", "--scoring-window", "optimal"])
+    df = pd.read_csv(out / "TOY_DMS.csv")
+    assert list(df.columns) == list(golden["cli/columns"])      # same columns, same order
+    for c in ("esm1v_toy_1", "esm1v_toy_2", "Ensemble_ESM1v"):
+        assert np.abs(df[c].to_numpy() - golden[f"cli/{c}"]).max() < TOL
+    src = pd.read_csv(os.path.join(golden_dir, "TOY_DMS.csv"))
+    assert df[list(src.columns)].equals(src)                     # input columns preserved
+
+
+def test_cli_esm2_has_no_ensemble_column(lib, golden, golden_dir, tmp_path):
+    out = tmp_path / "o"
+    _run_cli(["--model-location", os.path.join(golden_dir, "esm2_toy.pt"), "--model_type", "ESM2",
+              "--dms-input", os.path.join(golden_dir, "TOY_DMS.csv"), "--dms-output", str(out),
+              "--target_seq", str(golden["seq"]), "--scoring-strategy", "masked-marginals"])
+    df = pd.read_csv(out / "TOY_DMS.csv")
+    assert "Ensemble_ESM1v" not in df.columns
+    assert np.abs(df["esm2_toy"].to_numpy() - golden["cli/esm2_toy"]).max() < TOL
+
+
+def test_cli_wt_marginals_short_and_overlapping(lib, golden, golden_dir, tmp_path):
+    out = tmp_path / "o"
+    _run_cli(["--model-location", os.path.join(golden_dir, "esm1b_toy_lnb.pt"), "--model_type", "ESM1b",
+              "--dms-input", os.path.join(golden_dir, "TOY_DMS.csv"), "--dms-output", str(out),
+              "--target_seq", str(golden["seq"]), "--scoring-strategy", "wt-marginals"])
+    df = pd.read_csv(out / "TOY_DMS.csv")
+    assert np.abs(df["esm1b_toy_lnb"].to_numpy() - golden["cli_wt/esm1b_toy_lnb"]).max() < TOL
+    out2 = tmp_path / "o2"
+    _run_cli(["--model-location", os.path.join(golden_dir, "esm1v_toy_1.pt"), "--model_type", "ESM1b",
+              "--dms-input", os.path.join(golden_dir, "TOY_LONG_DMS.csv"), "--dms-output", str(out2),
+              "--target_seq", str(golden["seq_long"]), "--scoring-strategy", "wt-marginals",
+              "--scoring-window", "overlapping"])
+    df = pd.read_csv(out2 / "TOY_LONG_DMS.csv")
+    assert np.abs(df["esm1v_toy_1"].to_numpy() - golden["cli_wt_long/esm1v_toy_1"]).max() < TOL
+
+
+def test_cli_pseudo_ppl(lib, golden, golden_dir, tmp_path):
+    src = pd.read_csv(os.path.join(golden_dir, "TOY_DMS.csv")).iloc[:6][["mutant", "DMS_score"]]
+    src.to_csv(tmp_path / "TOY_PPPL.csv", index=False)
+    out = tmp_path / "o"
+    _run_cli(["--model-location", os.path.join(golden_dir, "esm2_toy.pt"), "--model_type", "ESM2",
+              "--dms-input", str(tmp_path / "TOY_PPPL.csv"), "--dms-output", str(out),
+              "--target_seq", str(golden["seq"]), "--scoring-strategy", "pseudo-ppl"])
+    df = pd.read_csv(out / "TOY_PPPL.csv")
+    assert "mutated_sequence" in df.columns
+    assert np.abs(df["esm2_toy"].to_numpy() - golden["cli_pppl/esm2_toy"]).max() < 5e-4   # sum of 68 terms
+
+
+def test_cli_dms_index_mapping_and_runner(lib, golden, golden_dir, tmp_path):
+    """--dms_index/--dms_mapping resolution (compute_fitness.py:288-305) and the multi-assay runner."""
+    mapping = pd.DataFrame({"DMS_id": ["TOY_A", "TOY_B"], "DMS_filename": ["TOY_DMS.csv", "TOY_DMS.csv"],
+                            "target_seq": [str(golden["seq"]).lower(), str(golden["seq"])],
+                            "DMS_total_number_mutants": [100, 100]})
+    mapping.to_csv(tmp_path / "map.csv", index=False)
+    out = tmp_path / "o"
+    _run_cli(["--model-location", os.path.join(golden_dir, "esm1v_toy_1.pt"), "--model_type", "ESM1v",
+              "--dms_index", "0", "--dms_mapping", str(tmp_path / "map.csv"), "--dms-input", golden_dir,
+              "--dms-output", str(out), "--scoring-strategy", "masked-marginals"])
+    df = pd.read_csv(out / "TOY_A.csv")
+    assert np.abs(df["esm1v_toy_1"].to_numpy() - golden["cli/esm1v_toy_1"]).max() < TOL
+    assert np.abs(df["Ensemble_ESM1v"].to_numpy() - golden["cli/esm1v_toy_1"]).max() < TOL
+    from proteingym_amd import run_benchmark as rb
+    out2 = tmp_path / "o2"
+    rb.main(rb.create_parser().parse_args(
+        ["--model-location", os.path.join(golden_dir, "esm1v_toy_1.pt"), os.path.join(golden_dir, "esm1v_toy_2.pt"),
+         "--model_type", "ESM1v", "--dms_mapping", str(tmp_path / "map.csv"), "--dms-input", golden_dir,
+         "--dms-output", str(out2)]))
+    for name in ("TOY_A", "TOY_B"):
+        df = pd.read_csv(out2 / f"{name}.csv")
+        assert list(df.columns) == list(golden["cli/columns"])
+        for c in ("esm1v_toy_1", "esm1v_toy_2", "Ensemble_ESM1v"):
+            assert np.abs(df[c].to_numpy() - golden[f"cli/{c}"]).max() < TOL

@@ -1,0 +1,138 @@
+"""Host-side logic and the C-ABI surface -- no GPU needed (no compute calls)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import esm_oracle as eo, ref_harness as rh
+from proteingym_amd import _lib, esm as pesm, synthetic, dist as pdist
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+
+
+def test_abi_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "pgmi.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b(pgmi_[a-z0-9_]+)\s*\(", hdr))
+    bound = {n for n, _, _ in _lib.SIGNATURES}
+    assert declared == bound, (declared ^ bound)
+    for n in declared:
+        assert hasattr(lib, n)
+    assert lib.pgmi_abi_version() == _lib.ABI_VERSION
+
+
+def test_no_cpu_fallback(lib):
+    """Without a GPU the product path must fail loudly, not fall back."""
+    if lib.pgmi_device_count() > 0:
+        pytest.skip("GPU present")
+    cfg = dict(synthetic.ESM1V_650M, layers=1, embed_dim=128, heads=2, ffn_dim=256)
+    with pytest.raises(pesm.PgmiError, match="no HIP device|no CPU fallback"):
+        pesm.EsmModel(cfg, synthetic.random_weights(cfg, 0))
+
+
+def test_weight_count_and_config_validation(lib):
+    cfg = dict(synthetic.ESM1V_650M)
+    c = _lib.Config(abi_version=1, vocab=33, precision=0, max_rows=0, **cfg)
+    n = lib.pgmi_weight_count(C.byref(c))
+    assert n == sum(int(np.prod(s)) for _, s in synthetic.key_shapes(cfg)) == 652355873 - 33 * 1280 + 33 * 1280
+    c2 = dict(cfg, heads=16)                                   # head_dim 80: unsupported
+    blob = np.zeros(8, np.float32)
+    with pytest.raises(pesm.PgmiError):
+        pesm.EsmModel(c2, blob)
+
+
+def test_alphabet_matches_oracle_and_reference_vocab():
+    a = pesm.Alphabet()
+    assert a.all_toks == eo.ALL_TOKS and len(a) == 33
+    assert (a.cls_idx, a.padding_idx, a.eos_idx, a.unk_idx, a.mask_idx) == (0, 1, 2, 3, 32)
+    seq = "MKTAYIAKQXBZJ"
+    _, _, t = a.get_batch_converter()([("p", seq), ("q", seq[:5])])
+    assert np.array_equal(t[0], eo.tokenize(seq))
+    assert t[1, 6] == a.eos_idx and (t[1, 7:] == a.padding_idx).all()
+    assert a.get_idx("J") == a.unk_idx
+
+
+def test_parse_mutants_matches_label_row_parsing(lib):
+    seq, muts, _ = synthetic.random_assay(seed=3, L=50, n_single=40, n_multi=30, offset=5)
+    sub_pos, sub_wt, sub_mt, off = pesm.parse_mutants(muts, seq, 5)
+    k = 0
+    for i, m in enumerate(muts):
+        assert off[i] == k
+        for s in m.split(":"):
+            idx = int(s[1:-1]) - 5
+            assert sub_pos[k] == 1 + idx and sub_wt[k] == eo.get_idx(s[0]) and sub_mt[k] == eo.get_idx(s[-1])
+            k += 1
+    assert off[-1] == k
+    with pytest.raises(AssertionError, match="does not match"):
+        pesm.parse_mutants([("C" if seq[0] != "C" else "A") + "5G"], seq, 5)
+    for bad in ("A", "AG", "A5", "AxG", "A5G:", "A999G"):
+        with pytest.raises((ValueError, AssertionError)):
+            pesm.parse_mutants([bad], seq, 5)
+
+
+def test_optimal_window_matches_oracle(lib):
+    for n in (10, 1024, 1025, 1102, 2000, 3425):
+        for i in list(range(0, n, 37)) + [n - 1, max(0, n - 513), 511, 512]:
+            if 0 <= i < n:
+                assert pesm.get_optimal_window(i, n, 1024) == eo.get_optimal_window(i, n, 1024)
+
+
+def test_checkpoint_packing_and_key_checks(golden_dir, tmp_path):
+    import torch
+    cfg, sd = pesm._upgrade_state_dict(os.path.join(golden_dir, "esm1b_toy_lnb.pt"))
+    assert cfg["emb_layer_norm_before"] == 1 and cfg["arch"] == _lib.ARCH_ESM1B
+    blob = pesm.pack_state_dict(cfg, sd)
+    assert blob.size == sum(int(np.prod(s)) for _, s in synthetic.key_shapes(cfg))
+    bad = dict(sd)
+    bad.pop("layers.0.fc1.bias")
+    with pytest.raises(RuntimeError, match="Missing key"):
+        pesm.pack_state_dict(cfg, bad)
+    bad = dict(sd, extra=torch.zeros(1))
+    with pytest.raises(RuntimeError, match="Unexpected key"):
+        pesm.pack_state_dict(cfg, bad)
+    cfg2, sd2 = pesm._upgrade_state_dict(os.path.join(golden_dir, "esm2_toy.pt"))
+    assert cfg2["arch"] == _lib.ARCH_ESM2 and cfg2["ffn_dim"] == 4 * cfg2["embed_dim"]
+    # synthetic checkpoints round-trip through the fair-esm file layout and the oracle loader
+    c = dict(synthetic.ESM1V_650M, layers=1, embed_dim=128, heads=2, ffn_dim=256)
+    b = synthetic.random_weights(c, 5)
+    p = synthetic.save_fair_esm_checkpoint(str(tmp_path / "esm1v_syn.pt"), c, b)
+    c3, sd3 = pesm._upgrade_state_dict(p)
+    b3 = pesm.pack_state_dict(c3, sd3)
+    exp = b.copy()
+    exp[32 * 128:33 * 128] = 0                               # <mask> row zeroed at load (shared storage)
+    assert np.array_equal(b3, exp)
+    ocfg, W = eo.load_checkpoint(p)
+    assert float(W["lm_head.weight"][32].abs().max()) == 0.0
+
+
+def test_cli_parser_has_the_reference_flags():
+    from proteingym_amd import compute_fitness as cf
+    ours = {a.option_strings[0]: (a.nargs, a.default) for a in cf.create_parser()._actions if a.option_strings}
+    frozen = ["--model_type", "--model-location", "--sequence", "--dms-input", "--dms_index", "--dms_mapping",
+              "--mutation-col", "--dms-output", "--offset-idx", "--scoring-strategy", "--msa-path",
+              "--msa-sampling-strategy", "--msa-samples", "--msa-weights-folder", "--seeds", "--filter-msa",
+              "--hhfilter-min-cov", "--hhfilter-max-seq-id", "--hhfilter-min-seq-id", "--path-to-hhfilter",
+              "--scoring-window", "--overwrite-prior-scores", "--target_seq", "--weight_file_name",
+              "--MSA_start", "--MSA_end", "--nogpu"]
+    for f in frozen:
+        assert f in ours, f
+    if rh.reference_available():
+        ref = {a.option_strings[0]: (a.nargs, a.default)
+               for a in rh.load_reference().create_parser()._actions if a.option_strings}
+        for k, v in ref.items():
+            assert ours[k] == v, (k, ours[k], v)
+
+
+def test_lpt_partition_and_costs():
+    shapes = synthetic.dms_shapes()
+    assert len(shapes) == 217 and sum(s["seq_len"] + 2 for s in shapes) == 86613
+    assert sum(s["n_total"] for s in shapes) == 2465767
+    costs = [pdist.assay_cost(s["seq_len"]) for s in shapes]
+    assert abs(sum(costs) / 83.0e15 - 1) < 0.02                # 83.0 PFLOP per checkpoint
+    parts = pdist.lpt_partition(costs, 8)
+    assert sorted(i for p in parts for i in p) == list(range(217))
+    loads = [sum(costs[i] for i in p) for p in parts]
+    assert max(loads) / (sum(loads) / 8) < 1.05
+    assert abs(pdist.forward_flops(288) / 0.389e12 - 1) < 0.01  # 0.389 TFLOP per forward

@@ -1,0 +1,91 @@
+"""The oracle (oracle/esm_oracle.py) against the reference's own outputs.
+
+* test_oracle_reproduces_golden*: against tests/golden/golden_esm.npz, frozen from the unmodified
+  reference by tests/golden/make_golden.py -- runs everywhere (also on the GPU box).
+* test_oracle_vs_live_reference: runs the reference itself (only where /root/reference exists).
+"""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from oracle import esm_oracle as eo, ref_harness as rh
+
+NAMES = ["esm1v_toy_1", "esm1v_toy_2", "esm1b_toy_lnb", "esm2_toy"]
+TOL = 2e-5      # fp32 summation-order noise between two CPU implementations of the same formulae
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_oracle_reproduces_golden_tables(golden, golden_dir, name):
+    cfg, W = eo.load_checkpoint(os.path.join(golden_dir, name + ".pt"))
+    seq = str(golden["seq"])
+    with torch.no_grad():
+        wt = torch.log_softmax(eo.forward_logits(cfg, W, eo.tokenize(seq)[None]), -1)[0].numpy()
+    assert np.abs(wt - golden[f"{name}/wt_logprobs"]).max() < TOL
+    mm = eo.masked_marginals_table(cfg, W, seq, batch=16)
+    assert np.abs(mm - golden[f"{name}/mm_table"]).max() < TOL
+    pt = golden[f"{name}/pad_tokens"]
+    with torch.no_grad():
+        lp = torch.log_softmax(eo.forward_logits(cfg, W, pt), -1).numpy()
+    valid = pt != eo.PAD
+    assert np.abs(lp[valid] - golden[f"{name}/pad_logprobs"][valid]).max() < TOL
+
+
+def test_oracle_reproduces_golden_cli_scores(golden, golden_dir):
+    seq = str(golden["seq"])
+    df = pd.read_csv(os.path.join(golden_dir, "TOY_DMS.csv"))
+    ck = [os.path.join(golden_dir, n + ".pt") for n in ("esm1v_toy_1", "esm1v_toy_2")]
+    cols = eo.score_dms(ck, seq, list(df["mutant"]), model_type=["ESM1v"])
+    for c in ("esm1v_toy_1", "esm1v_toy_2", "Ensemble_ESM1v"):
+        assert np.abs(cols[c] - golden[f"cli/{c}"]).max() < TOL
+    for n in ("esm2_toy", "esm1b_toy_lnb"):
+        cols = eo.score_dms([os.path.join(golden_dir, n + ".pt")], seq, list(df["mutant"]), model_type=["X"])
+        assert np.abs(cols[n] - golden[f"cli/{n}"]).max() < TOL
+        assert "Ensemble_ESM1v" not in cols
+
+
+def test_oracle_reproduces_golden_long_and_other_strategies(golden, golden_dir):
+    seq, seq_long = str(golden["seq"]), str(golden["seq_long"])
+    dfl = pd.read_csv(os.path.join(golden_dir, "TOY_LONG_DMS.csv"))
+    df = pd.read_csv(os.path.join(golden_dir, "TOY_DMS.csv"))
+    # optimal 1024-window for a 1102-token protein: only positions some mutant touches are needed
+    cfg, W = eo.load_checkpoint(os.path.join(golden_dir, "esm2_toy.pt"))
+    muts = list(dfl["mutant"])[:12]
+    pos = sorted({1 + int(s[1:-1]) - 1 for m in muts for s in m.split(":")})
+    table = eo.masked_marginals_table(cfg, W, seq_long, positions=pos)
+    got = np.array([eo.label_row(m, seq_long, table, 1) for m in muts])
+    assert np.abs(got - golden["cli_long/esm2_toy"][:12]).max() < TOL
+    # wt-marginals, short and long/overlapping
+    c = eo.score_dms([os.path.join(golden_dir, "esm1b_toy_lnb.pt")], seq, list(df["mutant"]),
+                     strategy="wt-marginals", model_type=["ESM1b"])
+    assert np.abs(c["esm1b_toy_lnb"] - golden["cli_wt/esm1b_toy_lnb"]).max() < TOL
+    c = eo.score_dms([os.path.join(golden_dir, "esm1v_toy_1.pt")], seq_long, list(dfl["mutant"]),
+                     strategy="wt-marginals", model_type=["ESM1b"], scoring_window="overlapping")
+    assert np.abs(c["esm1v_toy_1"] - golden["cli_wt_long/esm1v_toy_1"]).max() < TOL
+    # pseudo-ppl with the reference's off-by-one
+    c = eo.score_dms([os.path.join(golden_dir, "esm2_toy.pt")], seq, list(df["mutant"])[:6],
+                     strategy="pseudo-ppl", model_type=["ESM2"])
+    assert np.abs(c["esm2_toy"] - golden["cli_pppl/esm2_toy"]).max() < 2e-4   # sum of ~68 terms
+
+
+@pytest.mark.skipif(not rh.reference_available(), reason="/root/reference not present (GPU box)")
+def test_oracle_vs_live_reference(tmp_path):
+    p = rh.make_esm1v_checkpoint(str(tmp_path / "esm1v_live.pt"), 2, 64, 128, 1, seed=9, embed_std=0.3)
+    model, alphabet = rh.reference_model(p)
+    cfg, W = eo.load_checkpoint(p)
+    seq = "MKTAYIAKQRQISFVKSHFSRQLEERLGLIEVQAPILSRVGDGTQDNLSGAEKAVQ"
+    _, _, bt = alphabet.get_batch_converter()([("x", seq)])
+    assert np.array_equal(bt[0].numpy(), eo.tokenize(seq))
+    t = eo.tokenize(seq).copy()
+    t[7] = eo.MASK
+    with torch.no_grad():
+        ref = model(torch.tensor(t)[None])["logits"]
+        mine = eo.forward_logits(cfg, W, t[None])
+    assert float((ref - mine).abs().max()) < TOL
+    cf = rh.load_reference()
+    for i in (0, 10, 511, 512, 513, 600, 1500, 1988, 1989, 2500):
+        for n in (100, 1024, 1025, 2000, 2501):
+            if i < n:
+                assert cf.get_optimal_window(i, n, 1024) == eo.get_optimal_window(i, n, 1024)
