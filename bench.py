@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "f16x3"])
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline time budget (0 = skip)")
     ap.add_argument("--layers", type=int, default=33, help="debug only; the headline config is 33")
+    ap.add_argument("--variant", type=int, default=None, help="debug: PGMI_GEMM_VARIANT tile configuration")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -103,6 +104,8 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"WORLD_SIZE={world} does not match --gpus {args.gpus}")
 
+    if args.variant is not None:
+        os.environ["PGMI_GEMM_VARIANT"] = str(args.variant)
     import torch
     from proteingym_amd import build_native, esm as pesm, synthetic
     build_native.build(verbose=False)

@@ -36,6 +36,7 @@ extern "C" {
 #define PGMI_EHIP (-3)     /* HIP runtime error (message in pgmi_last_error) */
 #define PGMI_ENODEV (-4)   /* no usable GPU */
 #define PGMI_EPARSE (-5)   /* malformed mutant string / wild-type mismatch */
+#define PGMI_EOVERFLOW (-6) /* 16-bit modes: an activation left the fp16/bf16 range (re-run in fp32) */
 
 /* architectures: esm/model/esm1.py (arch "roberta_large": ESM-1b, ESM-1v) and esm/model/esm2.py */
 #define PGMI_ARCH_ESM1B 1

@@ -3,6 +3,9 @@
 // Forward order follows /root/reference/proteingym/baselines/esm/esm/model/esm1.py:116-177 and
 // esm/model/esm2.py:76-130; the per-layer order follows esm/modules.py:120-142.
 #include <math.h>
+#include <stdlib.h>
+#include <cmath>
+#include <algorithm>
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
@@ -22,8 +25,17 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
+// 16-bit operand planes of one Linear weight: fp16 (hi, lo) of W*2^s for f16x3, one bf16 plane
+// for bf16; out_scale = 2^-s is applied in the GEMM epilogue.
+struct W16 {
+    unsigned short* p = nullptr;
+    size_t plane = 0;
+    float out_scale = 1.0f;
+};
+
 struct Layer {
     float *ln1_w, *ln1_b, *wqkv, *bqkv, *wo, *bo, *ln2_w, *ln2_b, *w1, *b1, *w2, *b2;
+    W16 wqkv16, wo16, w116, w216;
 };
 
 struct ProfEvent {
@@ -45,6 +57,11 @@ struct pgmi_model {
     float *lnb_w = nullptr, *lnb_b = nullptr, *lna_w = nullptr, *lna_b = nullptr;
     float *hd_w = nullptr, *hd_b = nullptr, *hln_w = nullptr, *hln_b = nullptr, *h_bias = nullptr;
     std::vector<Layer> layers;
+    W16 hd16;
+    unsigned short *h16 = nullptr, *g16 = nullptr;     // activation planes [planes][R*D], [planes][R*F]
+    size_t h16_plane = 0, g16_plane = 0;
+    int32_t* nonfinite = nullptr;
+    int gemm_variant = 0;
     float *rot_cos = nullptr, *rot_sin = nullptr;
     int rot_len = 0;
     // workspace
@@ -140,7 +157,8 @@ int check_cfg(const pgmi_config* c) {
     if (c->embed_dim % 32 || c->ffn_dim % 32) { set_error("embed_dim and ffn_dim must be multiples of 32"); return PGMI_EINVAL; }
     if (c->vocab != PGMI_VOCAB) { set_error("vocab must be %d", PGMI_VOCAB); return PGMI_EINVAL; }
     if (c->arch == PGMI_ARCH_ESM1B && c->max_positions <= 0) { set_error("ESM-1b arch needs max_positions"); return PGMI_EINVAL; }
-    if (c->precision != PGMI_PREC_FP32) { set_error("precision %d not available in this build (fp32 only)", c->precision); return PGMI_EINVAL; }
+    if (c->precision != PGMI_PREC_FP32 && c->precision != PGMI_PREC_F16X3 && c->precision != PGMI_PREC_BF16) { set_error("unknown precision %d", c->precision); return PGMI_EINVAL; }
+    if (c->precision != PGMI_PREC_FP32 && (c->embed_dim % 64 || c->ffn_dim % 64)) { set_error("16-bit modes need embed_dim and ffn_dim to be multiples of 64"); return PGMI_EINVAL; }
     return PGMI_OK;
 }
 
@@ -156,6 +174,37 @@ int check_tokens(const int32_t* tokens, int B, int T) {
             else if (seen_pad) { set_error("interior <pad> at [%d,%d]: only trailing padding is supported", b, i); return PGMI_EINVAL; }
         }
     }
+    return PGMI_OK;
+}
+
+int env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
+// Upload a Linear weight [n_elems] as 16-bit planes.  f16x3: W*2^s with 2^s chosen so that
+// max|W|*2^s lies in [8192, 16384): hi stays far below fp16's 65504 and lo = fp16(W' - hi) stays in
+// the normal range for every element within 2^-15 of the largest.  bf16: one plane, no scaling.
+int make_w16(std::vector<void*>& pool, const float* host, size_t n, int precision, hipStream_t s, W16* out) {
+    float mx = 0.f;
+    for (size_t i = 0; i < n; ++i) mx = std::max(mx, fabsf(host[i]));
+    float scale = 1.0f;
+    const int planes = (precision == PGMI_PREC_F16X3) ? 2 : 1;
+    if (precision == PGMI_PREC_F16X3 && mx > 0.f && std::isfinite(mx)) scale = exp2f(floorf(log2f(16384.0f / mx)));
+    float* tmp = nullptr;
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&tmp), n * sizeof(float));
+    if (e != hipSuccess) { set_error("hipMalloc failed: %s", hipGetErrorString(e)); return PGMI_ENOMEM; }
+    int rc = dev_alloc(pool, &out->p, n * planes);
+    if (rc) { hipFree(tmp); return rc; }
+    e = hipMemcpy(tmp, host, n * sizeof(float), hipMemcpyHostToDevice);
+    if (e == hipSuccess) {
+        launch_split16(tmp, (int64_t)n, scale, precision == PGMI_PREC_BF16 ? 1 : 0, out->p, n, s);
+        e = hipStreamSynchronize(s);
+    }
+    hipFree(tmp);
+    if (e != hipSuccess) { set_error("weight split failed: %s", hipGetErrorString(e)); return PGMI_EHIP; }
+    out->plane = n;
+    out->out_scale = 1.0f / scale;
     return PGMI_OK;
 }
 
@@ -181,6 +230,18 @@ int ensure_rotary(pgmi_model* m, int T) {
     return PGMI_OK;
 }
 
+// y = epi(in W^T + b) (+ residual).  fp32 mode: in32 -> fp32 out.  16-bit modes: in16 planes ->
+// either fp32 out (out32) or 16-bit planes (out16).
+int linear(pgmi_model* m, const float* in32, const unsigned short* in16, size_t in_plane, const float* W32,
+           const W16& w16, const float* bias, const float* residual, float* out32, unsigned short* out16,
+           size_t out_plane, int M, int N, int K, int epi) {
+    if (m->cfg.precision == PGMI_PREC_FP32)
+        return launch_gemm_f32(in32, W32, bias, residual, out32, M, N, K, epi, m->stream);
+    const bool bf = m->cfg.precision == PGMI_PREC_BF16;
+    return launch_gemm16(in16, in_plane, w16.p, w16.plane, bias, residual, out32, out16, out_plane, M, N, K, epi,
+                         w16.out_scale, bf ? 1 : 2, bf, m->gemm_variant, m->stream);
+}
+
 // Runs the encoder on tokens already in m->tokens [B,T]; leaves the residual stream in m->x.
 int run_encoder(pgmi_model* m, int B, int T) {
     const pgmi_config& c = m->cfg;
@@ -202,27 +263,34 @@ int run_encoder(pgmi_model* m, int B, int T) {
         }
     }
     const double ln_bytes = 2.0 * M * D * 4;
+    const int prec = c.precision;
+    const int mode16 = (prec == PGMI_PREC_F16X3) ? 1 : 2;          // LN / attention output mode
     for (int l = 0; l < c.layers; ++l) {
         const Layer& L = m->layers[l];
         { ProfScope p(m, PGMI_K_LAYERNORM, 0, ln_bytes);
-          launch_layernorm(m->x, L.ln1_w, L.ln1_b, M, D, 1e-5f, m->h, s); }
+          if (prec == PGMI_PREC_FP32) launch_layernorm(m->x, L.ln1_w, L.ln1_b, M, D, 1e-5f, m->h, s);
+          else launch_layernorm16(m->x, L.ln1_w, L.ln1_b, M, D, 1e-5f, m->h16, m->h16_plane, mode16, s); }
         { ProfScope p(m, PGMI_K_GEMM_QKV, 2.0 * M * 3 * D * D, 0);
-          rc = launch_gemm_f32(m->h, L.wqkv, L.bqkv, nullptr, m->qkv, M, 3 * D, D, EPI_NONE, s);
+          rc = linear(m, m->h, m->h16, m->h16_plane, L.wqkv, L.wqkv16, L.bqkv, nullptr, m->qkv, nullptr, 0, M, 3 * D, D, EPI_NONE);
           if (rc) return rc; }
         { ProfScope p(m, PGMI_K_ATTENTION, 4.0 * M * T * D, 0);
           if (c.arch == PGMI_ARCH_ESM2) launch_rotary(m->qkv, m->rot_cos, m->rot_sin, M, T, H, s);
-          rc = launch_attention_f32(m->qkv, m->kv_len, B, T, H, m->h, s);
+          rc = launch_attention_f32(m->qkv, m->kv_len, B, T, H, m->h, m->h16, m->h16_plane,
+                                    prec == PGMI_PREC_FP32 ? 0 : mode16, s);
           if (rc) return rc; }
         { ProfScope p(m, PGMI_K_GEMM_OUT, 2.0 * M * D * D, 0);
-          rc = launch_gemm_f32(m->h, L.wo, L.bo, m->x, m->x, M, D, D, EPI_NONE, s);
+          rc = linear(m, m->h, m->h16, m->h16_plane, L.wo, L.wo16, L.bo, m->x, m->x, nullptr, 0, M, D, D, EPI_NONE);
           if (rc) return rc; }
         { ProfScope p(m, PGMI_K_LAYERNORM, 0, ln_bytes);
-          launch_layernorm(m->x, L.ln2_w, L.ln2_b, M, D, 1e-5f, m->h, s); }
+          if (prec == PGMI_PREC_FP32) launch_layernorm(m->x, L.ln2_w, L.ln2_b, M, D, 1e-5f, m->h, s);
+          else launch_layernorm16(m->x, L.ln2_w, L.ln2_b, M, D, 1e-5f, m->h16, m->h16_plane, mode16, s); }
         { ProfScope p(m, PGMI_K_GEMM_FC1, 2.0 * M * F * D, 0);
-          rc = launch_gemm_f32(m->h, L.w1, L.b1, nullptr, m->g, M, F, D, EPI_GELU, s);
+          rc = linear(m, m->h, m->h16, m->h16_plane, L.w1, L.w116, L.b1, nullptr,
+                      prec == PGMI_PREC_FP32 ? m->g : nullptr, prec == PGMI_PREC_FP32 ? nullptr : m->g16, m->g16_plane,
+                      M, F, D, EPI_GELU);
           if (rc) return rc; }
         { ProfScope p(m, PGMI_K_GEMM_FC2, 2.0 * M * F * D, 0);
-          rc = launch_gemm_f32(m->g, L.w2, L.b2, m->x, m->x, M, D, F, EPI_NONE, s);
+          rc = linear(m, m->g, m->g16, m->g16_plane, L.w2, L.w216, L.b2, m->x, m->x, nullptr, 0, M, D, F, EPI_NONE);
           if (rc) return rc; }
     }
     PGMI_HIP(hipGetLastError());
@@ -237,17 +305,35 @@ int run_head(pgmi_model* m, int R, const int32_t* row_idx) {
     const int D = c.embed_dim;
     hipStream_t s = m->stream;
     ProfScope p(m, PGMI_K_HEAD, 2.0 * R * D * (D + c.vocab), 0);
+    const int prec = c.precision;
+    const float* src = m->x;
     if (row_idx) {
         launch_gather_rows(m->x, row_idx, R, D, m->h, s);
-        launch_layernorm(m->h, m->lna_w, m->lna_b, R, D, 1e-5f, m->h, s);
-    } else {
-        launch_layernorm(m->x, m->lna_w, m->lna_b, R, D, 1e-5f, m->h, s);
+        src = m->h;
     }
-    int rc = launch_gemm_f32(m->h, m->hd_w, m->hd_b, nullptr, m->g, R, D, D, EPI_GELU, s);
+    if (prec == PGMI_PREC_FP32) launch_layernorm(src, m->lna_w, m->lna_b, R, D, 1e-5f, m->h, s);
+    else launch_layernorm16(src, m->lna_w, m->lna_b, R, D, 1e-5f, m->h16, m->h16_plane, prec == PGMI_PREC_F16X3 ? 1 : 2, s);
+    int rc = linear(m, m->h, m->h16, m->h16_plane, m->hd_w, m->hd16, m->hd_b, nullptr, m->g, nullptr, 0, R, D, D, EPI_GELU);
     if (rc) return rc;
     launch_layernorm(m->g, m->hln_w, m->hln_b, R, D, 1e-5f, m->g, s);
-    launch_vocab_logsoftmax(m->g, m->embed_tokens, m->h_bias, R, D, c.vocab, m->lp, s);
+    launch_vocab_logsoftmax(m->g, m->embed_tokens, m->h_bias, R, D, c.vocab, m->lp, m->nonfinite, s);
     PGMI_HIP(hipGetLastError());
+    return PGMI_OK;
+}
+
+// fp16 range check for the 16-bit modes: the vocabulary kernel raises the flag when a computed
+// log-probability is NaN/inf (an activation exceeded fp16's 65504 upstream).
+int check_nonfinite(pgmi_model* m) {
+    if (m->cfg.precision == PGMI_PREC_FP32) return PGMI_OK;
+    int32_t flag = 0;
+    PGMI_HIP(hipMemcpyAsync(&flag, m->nonfinite, 4, hipMemcpyDeviceToHost, m->stream));
+    PGMI_HIP(hipStreamSynchronize(m->stream));
+    if (flag) {
+        PGMI_HIP(hipMemsetAsync(m->nonfinite, 0, 4, m->stream));
+        set_error("non-finite log-probabilities: an activation left the fp16/bf16 range in precision mode %d; "
+                  "re-run with precision fp32", m->cfg.precision);
+        return PGMI_EOVERFLOW;
+    }
     return PGMI_OK;
 }
 
@@ -323,20 +409,30 @@ int pgmi_model_create(const pgmi_config* cfg, const float* w, int64_t n_weights,
             for (size_t i = 0; i < D; ++i) bq[k * D + i] = p[i] * sc;
             p += D;
         }
-        TRY(dev_upload(m->allocs, &L.wqkv, wq.data(), wq.size()));
+        const bool f32w = cfg->precision == PGMI_PREC_FP32;
+        if (f32w) TRY(dev_upload(m->allocs, &L.wqkv, wq.data(), wq.size()));
+        else TRY(make_w16(m->allocs, wq.data(), wq.size(), cfg->precision, m->stream, &L.wqkv16));
         TRY(dev_upload(m->allocs, &L.bqkv, bq.data(), bq.size()));
-        TRY(dev_upload(m->allocs, &L.wo, p, D * D)); p += D * D;
+        if (f32w) TRY(dev_upload(m->allocs, &L.wo, p, D * D));
+        else TRY(make_w16(m->allocs, p, D * D, cfg->precision, m->stream, &L.wo16));
+        p += D * D;
         TRY(dev_upload(m->allocs, &L.bo, p, D)); p += D;
         TRY(dev_upload(m->allocs, &L.ln2_w, p, D)); p += D;
         TRY(dev_upload(m->allocs, &L.ln2_b, p, D)); p += D;
-        TRY(dev_upload(m->allocs, &L.w1, p, F * D)); p += F * D;
+        if (f32w) TRY(dev_upload(m->allocs, &L.w1, p, F * D));
+        else TRY(make_w16(m->allocs, p, F * D, cfg->precision, m->stream, &L.w116));
+        p += F * D;
         TRY(dev_upload(m->allocs, &L.b1, p, F)); p += F;
-        TRY(dev_upload(m->allocs, &L.w2, p, D * F)); p += D * F;
+        if (f32w) TRY(dev_upload(m->allocs, &L.w2, p, D * F));
+        else TRY(make_w16(m->allocs, p, D * F, cfg->precision, m->stream, &L.w216));
+        p += D * F;
         TRY(dev_upload(m->allocs, &L.b2, p, D)); p += D;
     }
     TRY(dev_upload(m->allocs, &m->lna_w, p, D)); p += D;
     TRY(dev_upload(m->allocs, &m->lna_b, p, D)); p += D;
-    TRY(dev_upload(m->allocs, &m->hd_w, p, D * D)); p += D * D;
+    if (cfg->precision == PGMI_PREC_FP32) TRY(dev_upload(m->allocs, &m->hd_w, p, D * D));
+    else TRY(make_w16(m->allocs, p, D * D, cfg->precision, m->stream, &m->hd16));
+    p += D * D;
     TRY(dev_upload(m->allocs, &m->hd_b, p, D)); p += D;
     TRY(dev_upload(m->allocs, &m->hln_w, p, D)); p += D;
     TRY(dev_upload(m->allocs, &m->hln_b, p, D)); p += D;
@@ -349,7 +445,18 @@ int pgmi_model_create(const pgmi_config* cfg, const float* w, int64_t n_weights,
     TRY(dev_alloc(m->allocs, &m->x, R * D));
     TRY(dev_alloc(m->allocs, &m->h, R * D));
     TRY(dev_alloc(m->allocs, &m->qkv, R * 3 * D));
-    TRY(dev_alloc(m->allocs, &m->g, R * std::max(F, D)));
+    const bool f32mode = cfg->precision == PGMI_PREC_FP32;
+    TRY(dev_alloc(m->allocs, &m->g, R * (f32mode ? std::max(F, D) : D)));
+    if (!f32mode) {
+        const size_t planes = cfg->precision == PGMI_PREC_F16X3 ? 2 : 1;
+        m->h16_plane = R * D;
+        m->g16_plane = R * F;
+        TRY(dev_alloc(m->allocs, &m->h16, m->h16_plane * planes));
+        TRY(dev_alloc(m->allocs, &m->g16, m->g16_plane * planes));
+    }
+    TRY(dev_alloc(m->allocs, &m->nonfinite, (size_t)1));
+    PGMI_HIP(hipMemset(m->nonfinite, 0, 4));
+    m->gemm_variant = env_int("PGMI_GEMM_VARIANT", 0);
     TRY(dev_alloc(m->allocs, &m->lp, R * V));
     TRY(dev_alloc(m->allocs, &m->denom, R));
     TRY(dev_alloc(m->allocs, &m->tokens, R));
@@ -398,7 +505,7 @@ int pgmi_token_logprobs(pgmi_model* m, const int32_t* tokens, int B, int T, floa
         PGMI_HIP(hipMemcpyAsync(out + (size_t)b0 * T * V, m->lp, (size_t)bc * T * V * 4, hipMemcpyDeviceToHost, m->stream));
         PGMI_HIP(hipStreamSynchronize(m->stream));
     }
-    return PGMI_OK;
+    return check_nonfinite(m);
 }
 
 int pgmi_masked_logprobs(pgmi_model* m, const int32_t* tokens, const int32_t* mask_pos, int B, int T, float* out) {
@@ -427,7 +534,7 @@ int pgmi_masked_logprobs(pgmi_model* m, const int32_t* tokens, const int32_t* ma
         PGMI_HIP(hipMemcpyAsync(out + (size_t)b0 * V, m->lp, (size_t)bc * V * 4, hipMemcpyDeviceToHost, m->stream));
         PGMI_HIP(hipStreamSynchronize(m->stream));
     }
-    return PGMI_OK;
+    return check_nonfinite(m);
 }
 
 void pgmi_optimal_window(int position, int n, int window, int* start, int* end) {
@@ -521,7 +628,7 @@ int pgmi_assay_run(pgmi_model* m, pgmi_assay* a, double* scores_host, float* tab
     if (scores_host && a->n_mut) PGMI_HIP(hipMemcpyAsync(scores_host, a->scores, (size_t)a->n_mut * 8, hipMemcpyDeviceToHost, s));
     if (table_host) PGMI_HIP(hipMemcpyAsync(table_host, a->table, (size_t)a->n_tok * V * 4, hipMemcpyDeviceToHost, s));
     PGMI_HIP(hipStreamSynchronize(s));
-    return PGMI_OK;
+    return check_nonfinite(m);
 }
 
 int pgmi_parse_mutants(const char* text, const int64_t* str_off, int64_t n_mut, const char* sequence,
@@ -625,20 +732,35 @@ int pgmi_op_layernorm(int device, const float* x, const float* w, const float* b
 int pgmi_op_gemm(int device, int precision, const float* A, const float* W, const float* bias, const float* residual,
                  int M, int N, int K, int epilogue, float* C) {
     if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) { set_error("bad argument"); return PGMI_EINVAL; }
-    if (precision != PGMI_PREC_FP32) { set_error("precision %d not available in this build", precision); return PGMI_EINVAL; }
+    if (precision != PGMI_PREC_FP32 && precision != PGMI_PREC_F16X3 && precision != PGMI_PREC_BF16) { set_error("unknown precision %d", precision); return PGMI_EINVAL; }
     if (pgmi_device_count() <= 0) { set_error("no HIP device visible"); return PGMI_ENODEV; }
     PGMI_HIP(hipSetDevice(device));
     std::vector<void*> pool;
-    float *dA, *dW, *dB = nullptr, *dR = nullptr, *dC;
+    float *dA, *dW = nullptr, *dB = nullptr, *dR = nullptr, *dC;
     int rc = 0;
-    if ((rc = dev_upload(pool, &dA, A, (size_t)M * K)) || (rc = dev_upload(pool, &dW, W, (size_t)N * K)) ||
+    if ((rc = dev_upload(pool, &dA, A, (size_t)M * K)) ||
+        (precision == PGMI_PREC_FP32 && (rc = dev_upload(pool, &dW, W, (size_t)N * K))) ||
         (bias && (rc = dev_upload(pool, &dB, bias, (size_t)N))) ||
         (residual && (rc = dev_upload(pool, &dR, residual, (size_t)M * N))) ||
         (rc = dev_alloc(pool, &dC, (size_t)M * N))) {
         for (void* p : pool) hipFree(p);
         return rc;
     }
-    rc = launch_gemm_f32(dA, dW, dB, dR, dC, M, N, K, epilogue, nullptr);
+    if (precision == PGMI_PREC_FP32) {
+        rc = launch_gemm_f32(dA, dW, dB, dR, dC, M, N, K, epilogue, nullptr);
+    } else {
+        const bool bf = precision == PGMI_PREC_BF16;
+        const int planes = bf ? 1 : 2;
+        W16 w16;
+        unsigned short* a16 = nullptr;
+        rc = make_w16(pool, W, (size_t)N * K, precision, nullptr, &w16);
+        if (!rc) rc = dev_alloc(pool, &a16, (size_t)M * K * planes);
+        if (!rc) {
+            launch_split16(dA, (int64_t)M * K, 1.0f, bf ? 1 : 2, a16, (size_t)M * K, nullptr);
+            rc = launch_gemm16(a16, (size_t)M * K, w16.p, w16.plane, dB, dR, dC, nullptr, 0, M, N, K, epilogue,
+                               w16.out_scale, planes, bf, env_int("PGMI_GEMM_VARIANT", 0), nullptr);
+        }
+    }
     hipError_t e = hipMemcpy(C, dC, (size_t)M * N * 4, hipMemcpyDeviceToHost);
     for (void* p : pool) hipFree(p);
     if (rc) return rc;
@@ -649,7 +771,7 @@ int pgmi_op_gemm(int device, int precision, const float* A, const float* W, cons
 int pgmi_op_attention(int device, int precision, const float* qkv, const int32_t* kv_len, int B, int T, int H,
                       int rotary, float* ctx) {
     if (!qkv || !ctx || B <= 0 || T <= 0 || H <= 0) { set_error("bad argument"); return PGMI_EINVAL; }
-    if (precision != PGMI_PREC_FP32) { set_error("precision %d not available in this build", precision); return PGMI_EINVAL; }
+    (void)precision;   // attention runs on the fp32 matrix pipe in every mode
     if (pgmi_device_count() <= 0) { set_error("no HIP device visible"); return PGMI_ENODEV; }
     PGMI_HIP(hipSetDevice(device));
     std::vector<void*> pool;
@@ -670,7 +792,7 @@ int pgmi_op_attention(int device, int precision, const float* qkv, const int32_t
         hipDeviceSynchronize();
         for (void* p : tmp.allocs) hipFree(p);
     }
-    if (!rc) rc = launch_attention_f32(dq, dl, B, T, H, dc, nullptr);
+    if (!rc) rc = launch_attention_f32(dq, dl, B, T, H, dc, nullptr, 0, 0, nullptr);
     hipError_t e = hipMemcpy(ctx, dc, (size_t)B * T * D * 4, hipMemcpyDeviceToHost);
     for (void* p : pool) hipFree(p);
     if (rc) return rc;

@@ -27,10 +27,10 @@ constexpr int KT = 32;          // keys per tile
 constexpr int KS_STRIDE = 68;   // K tile row stride (floats): conflict-free ds_read_b128
 constexpr int VS_STRIDE = 64;
 
-template <int WPB>
+template <int WPB, int OUT>
 __global__ __launch_bounds__(WPB * 64) void attention_f32_kernel(
     const float* __restrict__ qkv, const int32_t* __restrict__ kv_len, int T, int H,
-    float* __restrict__ ctx) {
+    float* __restrict__ ctx, unsigned short* __restrict__ ctx16, size_t plane) {
     constexpr int NT = WPB * 64;
     constexpr int NL = (512 + NT - 1) / NT;   // float4 loads per thread per tensor per tile
     __shared__ __attribute__((aligned(16))) float lds[2 * KT * KS_STRIDE + 2 * KT * VS_STRIDE];
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(WPB * 64) void attention_f32_kernel(
         const float l_tot = l_run + __shfl_xor(l_run, 32);
         if (q0 + r < T) {
             const float inv = 1.0f / l_tot;
-            float* op = ctx + ((size_t)b * T + q0 + r) * D + (size_t)h * kHeadDim + 4 * kh;
+            const size_t off = ((size_t)b * T + q0 + r) * D + (size_t)h * kHeadDim + 4 * kh;
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -168,14 +168,54 @@ __global__ __launch_bounds__(WPB * 64) void attention_f32_kernel(
                     f32x4 val;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) val[e] = o[dt][4 * g + e] * inv;
-                    *reinterpret_cast<f32x4*>(op + dt * 32 + 8 * g) = val;
+                    const size_t oo = off + dt * 32 + 8 * g;
+                    if constexpr (OUT == 0) {
+                        *reinterpret_cast<f32x4*>(ctx + oo) = val;
+                    } else if constexpr (OUT == 1) {      // fp16 hi/lo planes for the f16x3 out-projection
+                        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                        h4 hi, lo;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            _Float16 a, b2;
+                            split_act(val[e], a, b2);
+                            hi[e] = a;
+                            lo[e] = b2;
+                        }
+                        *reinterpret_cast<h4*>(ctx16 + oo) = hi;
+                        *reinterpret_cast<h4*>(ctx16 + plane + oo) = lo;
+                    } else {                              // bf16
+                        typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                        unsigned short bb[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float ve = val[e];   // copy first: bit_cast of a vector-element lvalue reads element 0
+                            unsigned int u = __builtin_bit_cast(unsigned int, ve);
+                            u += 0x7fffu + ((u >> 16) & 1u);
+                            bb[e] = (unsigned short)(u >> 16);
+                        }
+                        u32x2 pk;
+                        pk[0] = bb[0] | ((unsigned)bb[1] << 16);
+                        pk[1] = bb[2] | ((unsigned)bb[3] << 16);
+                        *reinterpret_cast<u32x2*>(ctx16 + oo) = pk;
+                    }
                 }
         }
     }
 }
 
+template <int OUT>
+static void launch_att_mode(int wpb, dim3 grid, const float* qkv, const int32_t* kv_len, int T, int H,
+                            float* ctx, unsigned short* ctx16, size_t plane, hipStream_t s) {
+    switch (wpb) {
+        case 1: hipLaunchKernelGGL((attention_f32_kernel<1, OUT>), grid, dim3(64), 0, s, qkv, kv_len, T, H, ctx, ctx16, plane); break;
+        case 2: hipLaunchKernelGGL((attention_f32_kernel<2, OUT>), grid, dim3(128), 0, s, qkv, kv_len, T, H, ctx, ctx16, plane); break;
+        case 3: hipLaunchKernelGGL((attention_f32_kernel<3, OUT>), grid, dim3(192), 0, s, qkv, kv_len, T, H, ctx, ctx16, plane); break;
+        default: hipLaunchKernelGGL((attention_f32_kernel<4, OUT>), grid, dim3(256), 0, s, qkv, kv_len, T, H, ctx, ctx16, plane); break;
+    }
+}
+
 int launch_attention_f32(const float* qkv, const int32_t* kv_len, int B, int T, int H, float* ctx,
-                         hipStream_t s) {
+                         unsigned short* ctx16, size_t plane, int out_mode, hipStream_t s) {
     if (B <= 0 || T <= 0 || H <= 0) {
         set_error("attention_f32: bad shape B=%d T=%d H=%d", B, T, H);
         return PGMI_EINVAL;
@@ -184,12 +224,9 @@ int launch_attention_f32(const float* qkv, const int32_t* kv_len, int B, int T, 
     const int nblk = (n32 + 3) / 4;
     const int wpb = (n32 + nblk - 1) / nblk;
     const dim3 grid(nblk, H, B);
-    switch (wpb) {
-        case 1: hipLaunchKernelGGL(attention_f32_kernel<1>, grid, dim3(64), 0, s, qkv, kv_len, T, H, ctx); break;
-        case 2: hipLaunchKernelGGL(attention_f32_kernel<2>, grid, dim3(128), 0, s, qkv, kv_len, T, H, ctx); break;
-        case 3: hipLaunchKernelGGL(attention_f32_kernel<3>, grid, dim3(192), 0, s, qkv, kv_len, T, H, ctx); break;
-        default: hipLaunchKernelGGL(attention_f32_kernel<4>, grid, dim3(256), 0, s, qkv, kv_len, T, H, ctx); break;
-    }
+    if (out_mode == 0) launch_att_mode<0>(wpb, grid, qkv, kv_len, T, H, ctx, ctx16, plane, s);
+    else if (out_mode == 1) launch_att_mode<1>(wpb, grid, qkv, kv_len, T, H, ctx, ctx16, plane, s);
+    else launch_att_mode<2>(wpb, grid, qkv, kv_len, T, H, ctx, ctx16, plane, s);
     PGMI_HIP(hipGetLastError());
     return PGMI_OK;
 }

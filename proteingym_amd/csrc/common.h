@@ -28,6 +28,19 @@ constexpr int kHeadDim = 64;
 
 enum Epilogue { EPI_NONE = 0, EPI_GELU = 1 };
 
+// f16x3 activation split: x ~= hi + lo * 2^-11 with hi = fp16(x) and lo = fp16((x - hi) * 2^11).
+// The scaled lo keeps its 11 bits for every |x| >= 2^-14 (an unscaled lo would be an fp16
+// subnormal whenever |x| < 0.125); |x| below fp16's normal range goes entirely into lo, so no
+// subnormal ever reaches the MFMA inputs.  The GEMM multiplies lo by (w_hi * 2^-11), which is
+// exact because weights are pre-scaled to ~2^13.
+constexpr float kLoScale = 2048.0f;
+#if defined(__HIPCC__)
+__device__ __forceinline__ void split_act(float x, _Float16& hi, _Float16& lo) {
+    hi = (fabsf(x) < 6.103515625e-05f) ? (_Float16)0.0f : (_Float16)x;
+    lo = (_Float16)((x - (float)hi) * kLoScale);
+}
+#endif
+
 // ---- elementwise.hip ---------------------------------------------------------------------
 // tokens_out[b,t] = (t == mask_pos[b]) ? <mask> : wt[start[b] + t]
 void launch_make_masked_windows(const int32_t* wt, const int32_t* win_start, const int32_t* mask_rel,
@@ -47,7 +60,9 @@ void launch_layernorm(const float* x, const float* w, const float* b, int rows, 
 void launch_gather_rows(const float* x, const int32_t* row_idx, int n, int D, float* y, hipStream_t s);
 // out[r,:] = log_softmax(h[r,:] @ E^T + bias); E [V,D]
 void launch_vocab_logsoftmax(const float* h, const float* E, const float* bias, int rows, int D,
-                             int V, float* out, hipStream_t s);
+                             int V, float* out, int32_t* nonfinite, hipStream_t s);
+void launch_layernorm16(const float* x, const float* w, const float* b, int rows, int D, float eps,
+                        unsigned short* y16, size_t plane, int mode, hipStream_t s);
 void launch_scatter_rows(const float* src, const int32_t* dst_row, int n, int V, float* table,
                          hipStream_t s);
 void launch_row_index(const int32_t* mask_rel, int B, int T, int32_t* out, hipStream_t s);
@@ -63,9 +78,20 @@ void launch_rotary(float* qkv, const float* cos_t, const float* sin_t, int rows,
 int launch_gemm_f32(const float* A, const float* W, const float* bias, const float* residual,
                     float* C, int M, int N, int K, int epilogue, hipStream_t s);
 
+// ---- gemm_f16.hip ------------------------------------------------------------------------
+// 16-bit-plane GEMM: C = epi(A W^T * out_scale + bias) (+ residual).  A/W: `planes` planes of
+// fp16 (hi, lo) or one bf16 plane, K-contiguous rows.  Exactly one of Cf (fp32) / Ch (planes).
+int launch_gemm16(const unsigned short* A, size_t a_plane, const unsigned short* W, size_t w_plane,
+                  const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
+                  int M, int N, int K, int epilogue, float out_scale, int planes, bool bf, int variant,
+                  hipStream_t s);
+void launch_split16(const float* x, int64_t n, float scale, int mode, unsigned short* out, size_t plane,
+                    hipStream_t s);
+
 // ---- attention_f32.hip -------------------------------------------------------------------
-// qkv [B*T, 3*H*64] (q pre-scaled by 1/8), ctx [B*T, H*64]; kv_len[b] (nullable) = valid keys.
+// qkv [B*T, 3*H*64] (q pre-scaled by 1/8); kv_len[b] (nullable) = valid keys.  Output: ctx fp32
+// [B*T, H*64] (out_mode 0), or fp16 hi/lo planes (1) / one bf16 plane (2) in ctx16.
 int launch_attention_f32(const float* qkv, const int32_t* kv_len, int B, int T, int H, float* ctx,
-                         hipStream_t s);
+                         unsigned short* ctx16, size_t plane, int out_mode, hipStream_t s);
 
 }  // namespace pgmi

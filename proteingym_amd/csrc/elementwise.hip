@@ -139,11 +139,13 @@ void launch_zero_pad_rows(const int32_t* tokens, int rows, int D, float* x, hipS
 // ---- LayerNorm (torch.nn.LayerNorm, modules.py:80-81): biased variance, eps inside sqrt ----
 // One wave per row, the row held in registers (D <= 64*4*NV), two-pass mean / variance.
 // Algorithmic bytes: 2*D*4 per row (read + write); HBM-bound.
-template <int NV>
+// OUTMODE 0: fp32 y;  1: fp16 hi/lo planes (f16x3 GEMM operand);  2: bf16 plane
+template <int NV, int OUTMODE>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x,   // may alias y (in place)
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ bsh, int rows, int D,
-                                                        float eps, float* y) {
+                                                        float eps, float* y, unsigned short* y16,
+                                                        size_t plane) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -173,7 +175,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x,   // may
     const float rstd = 1.0f / sqrtf(wave_sum(q) / (float)D + eps);
     const f32x4* wr = reinterpret_cast<const f32x4*>(w);
     const f32x4* br = reinterpret_cast<const f32x4*>(bsh);
-    f32x4* yr = reinterpret_cast<f32x4*>(y + (size_t)row * D);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int c = lane + 64 * i;
@@ -182,19 +183,58 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x,   // may
             f32x4 o;
 #pragma unroll
             for (int k = 0; k < 4; ++k) o[k] = (v[i][k] - mean) * rstd * wv[k] + bv[k];
-            yr[c] = o;
+            if constexpr (OUTMODE == 0) {
+                reinterpret_cast<f32x4*>(y + (size_t)row * D)[c] = o;
+            } else if constexpr (OUTMODE == 1) {
+                typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                h4 hi, lo;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    _Float16 a, b2;
+                    split_act(o[k], a, b2);
+                    hi[k] = a;
+                    lo[k] = b2;
+                }
+                reinterpret_cast<h4*>(y16 + (size_t)row * D)[c] = hi;
+                reinterpret_cast<h4*>(y16 + plane + (size_t)row * D)[c] = lo;
+            } else {
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                unsigned short b[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float ok = o[k];     // copy first: bit_cast of a vector-element lvalue reads element 0
+                    unsigned int u = __builtin_bit_cast(unsigned int, ok);
+                    u += 0x7fffu + ((u >> 16) & 1u);
+                    b[k] = (unsigned short)(u >> 16);
+                }
+                u32x2 pk;
+                pk[0] = b[0] | ((unsigned)b[1] << 16);
+                pk[1] = b[2] | ((unsigned)b[3] << 16);
+                reinterpret_cast<u32x2*>(y16 + (size_t)row * D)[c] = pk;
+            }
         }
     }
 }
-void launch_layernorm(const float* x, const float* w, const float* b, int rows, int D, float eps,
-                      float* y, hipStream_t s) {
+template <int OUTMODE>
+static void launch_ln_mode(const float* x, const float* w, const float* b, int rows, int D, float eps,
+                           float* y, unsigned short* y16, size_t plane, hipStream_t s) {
     const dim3 grid((rows + 3) / 4), block(256);
     const int nv = (D / 4 + 63) / 64;
-    if (nv <= 1) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, s, x, w, b, rows, D, eps, y);
-    else if (nv <= 2) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, s, x, w, b, rows, D, eps, y);
-    else if (nv <= 5) hipLaunchKernelGGL(layernorm_kernel<5>, grid, block, 0, s, x, w, b, rows, D, eps, y);
-    else if (nv <= 10) hipLaunchKernelGGL(layernorm_kernel<10>, grid, block, 0, s, x, w, b, rows, D, eps, y);
-    else hipLaunchKernelGGL(layernorm_kernel<20>, grid, block, 0, s, x, w, b, rows, D, eps, y);
+    if (nv <= 1) hipLaunchKernelGGL((layernorm_kernel<1, OUTMODE>), grid, block, 0, s, x, w, b, rows, D, eps, y, y16, plane);
+    else if (nv <= 2) hipLaunchKernelGGL((layernorm_kernel<2, OUTMODE>), grid, block, 0, s, x, w, b, rows, D, eps, y, y16, plane);
+    else if (nv <= 5) hipLaunchKernelGGL((layernorm_kernel<5, OUTMODE>), grid, block, 0, s, x, w, b, rows, D, eps, y, y16, plane);
+    else if (nv <= 10) hipLaunchKernelGGL((layernorm_kernel<10, OUTMODE>), grid, block, 0, s, x, w, b, rows, D, eps, y, y16, plane);
+    else hipLaunchKernelGGL((layernorm_kernel<20, OUTMODE>), grid, block, 0, s, x, w, b, rows, D, eps, y, y16, plane);
+}
+void launch_layernorm(const float* x, const float* w, const float* b, int rows, int D, float eps,
+                      float* y, hipStream_t s) {
+    launch_ln_mode<0>(x, w, b, rows, D, eps, y, nullptr, 0, s);
+}
+// mode 1: fp16 hi/lo planes, mode 2: bf16
+void launch_layernorm16(const float* x, const float* w, const float* b, int rows, int D, float eps,
+                        unsigned short* y16, size_t plane, int mode, hipStream_t s) {
+    if (mode == 1) launch_ln_mode<1>(x, w, b, rows, D, eps, nullptr, y16, plane, s);
+    else launch_ln_mode<2>(x, w, b, rows, D, eps, nullptr, y16, plane, s);
 }
 
 // ---- rotary (rotary_embedding.py:11-20,47-69): half-split rotation of q (already scaled) and k
@@ -269,7 +309,8 @@ void launch_fill_f32(float* p, int64_t n, float v, hipStream_t s) {
 __global__ __launch_bounds__(256) void vocab_logsoftmax_kernel(const float* __restrict__ h,
                                                                const float* __restrict__ E,
                                                                const float* __restrict__ bias, int rows,
-                                                               int D, int V, float* __restrict__ out) {
+                                                               int D, int V, float* __restrict__ out,
+                                                               int32_t* __restrict__ nonfinite) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
@@ -285,11 +326,15 @@ __global__ __launch_bounds__(256) void vocab_logsoftmax_kernel(const float* __re
     const float mx = wave_max(my_logit);
     const float ex = (lane < V) ? expf(my_logit - mx) : 0.f;
     const float lse = logf(wave_sum(ex));
-    if (lane < V) out[(size_t)row * V + lane] = (my_logit - mx) - lse;
+    const float res = (my_logit - mx) - lse;
+    if (lane < V) {
+        out[(size_t)row * V + lane] = res;
+        if (nonfinite && !(fabsf(res) <= 3.0e38f)) atomicOr(nonfinite, 1);   // NaN/inf: fp16 overflow upstream
+    }
 }
 void launch_vocab_logsoftmax(const float* h, const float* E, const float* bias, int rows, int D, int V,
-                             float* out, hipStream_t s) {
-    hipLaunchKernelGGL(vocab_logsoftmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, h, E, bias, rows, D, V, out);
+                             float* out, int32_t* nonfinite, hipStream_t s) {
+    hipLaunchKernelGGL(vocab_logsoftmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, h, E, bias, rows, D, V, out, nonfinite);
 }
 
 // ---- label_row (compute_fitness.py:240-250): score = sum_subs f32(lp[mt] - lp[wt]) in double ---

@@ -1,0 +1,323 @@
+// Split-precision GEMM on the 16-bit matrix cores: C = epi(A W^T * 2^-s + bias) (+ residual).
+//
+// Replaces nn.Linear on the ESM hot path (modules.py:134-140, multihead_attention.py:258-261,
+// 394) in the f16x3 and bf16 modes.
+//
+// f16x3 (PLANES = 2): every fp32 operand x is carried as two fp16 planes, hi = fp16(x) and a
+// low part (weights: lo = fp16(x - hi); activations: lo = fp16((x - hi) 2^11), common.h
+// split_act); the kernel accumulates  a_hi w_hi + a_hi w_lo + (a_lo 2^11)(w_hi 2^-11)  in the fp32
+// MFMA accumulator (the dropped a_lo w_lo term is 2^-22 relative).  fp16 x fp16 products are
+// exact in fp32, so the result has ~22 mantissa bits -- measured fp32-class on the full
+// 33-layer model (1.9e-5 vs 2.5e-5 for fp32 itself against fp64) -- at 3 MFMAs of
+// the 2.5 PFLOP/s pipe per product block instead of 1 MFMA of the 157 TFLOP/s fp32 pipe.
+// Weights are pre-scaled by a per-tensor power of two 2^s (exact) so that their lo plane stays
+// in fp16's normal range; 2^-s is applied in the epilogue.  Activations arrive already split
+// (the producing LayerNorm / GELU / attention epilogue writes the two planes: same 4 bytes
+// per element as fp32).
+// bf16 (PLANES = 1): plain bf16 operands, one MFMA per block (throughput mode, not parity-gated).
+//
+// Tiling (wave64): workgroup (WM*TM*32) x (WN*TN*32) x BK, WM*WN waves, each wave TM x TN MFMA
+// tiles of 32x32 (v_mfma_f32_32x32x16_{f16,bf16}).  Operands are swapped (MFMA "A" = weight
+// rows, "B" = activation rows) so that the accumulator puts 4 consecutive output columns in a
+// lane: epilogue loads/stores are 8/16-byte vectors.  LDS tiles are K-contiguous rows of BK
+// elements with an XOR swizzle on the 16-byte chunk index (conflict-free ds_read_b128 for the
+// 16-lane groups), double buffered, global->VGPR->LDS staging with the loads of tile t+1 in
+// flight during the MFMAs of tile t; one barrier per K tile.
+// Roofline: MFMA-bound; peak 2.5 PFLOP/s of 16-bit MFMA = 833 TFLOP/s of fp32-equivalent
+// algorithmic FLOPs in f16x3.
+#include "common.h"
+
+namespace pgmi {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef __bf16 b8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float gelu_erf16(float x) {
+    return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+template <bool BF>
+__device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
+    if constexpr (BF) {
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, a), __builtin_bit_cast(b8, b), c, 0, 0, 0);
+    } else {
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
+    unsigned int u = __builtin_bit_cast(unsigned int, f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+// OUT: 0 = fp32 [M,N];  1 = 16-bit planes [PLANES][M,N] (split for f16x3, bf16 for PLANES==1)
+template <int WM, int WN, int TM, int TN, int BK, int PLANES, bool BF, int EPI, int OUT>
+__global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 2) void gemm16_kernel(
+    const unsigned short* __restrict__ A, size_t a_plane, const unsigned short* __restrict__ W,
+    size_t w_plane, const float* __restrict__ bias, const float* residual, float* Cf,
+    unsigned short* Ch, size_t c_plane, int M, int N, int K, float out_scale, int tiles_m, int tiles_n) {
+    constexpr int NT = WM * WN * 64;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int CPR = BK / 8;                                  // 16-byte chunks per row
+    constexpr int A_CH = BM * CPR * PLANES, W_CH = BN * CPR * PLANES;
+    constexpr int A_LD = (A_CH + NT - 1) / NT, W_LD = (W_CH + NT - 1) / NT;
+    constexpr int STAGE = (BM + BN) * CPR * PLANES;              // chunks per stage
+    extern __shared__ __attribute__((aligned(16))) u32x4 lds[];  // [2][STAGE]
+
+    // XCD-aware grouped tile order (see gemm_f32.hip)
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
+    const int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    constexpr int GROUP_M = 8;
+    const int width = GROUP_M * tiles_n;
+    const int group = wgid / width, first_m = group * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int tm = first_m + (wgid % width) % gsz, tn = (wgid % width) / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, kh = lane >> 5;
+
+    auto swz = [](int row, int c) -> int {
+        return (CPR == 4) ? (c ^ ((row >> 2) & 3)) : (c ^ ((row >> 1) & (CPR - 1)));
+    };
+
+    // ---- staging maps -------------------------------------------------------------------
+    const u32x4* a_src[A_LD];
+    const u32x4* w_src[W_LD];
+    int a_dst[A_LD], w_dst[W_LD];
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+        const int f = tid + NT * i;
+        const int p = f / (BM * CPR), g = f % (BM * CPR), row = g / CPR, c = g % CPR;
+        const int am = min(m0 + row, M - 1);
+        a_src[i] = reinterpret_cast<const u32x4*>(A + (size_t)p * a_plane + (size_t)am * K) + c;
+        a_dst[i] = (p * BM + row) * CPR + swz(row, c);
+    }
+#pragma unroll
+    for (int i = 0; i < W_LD; ++i) {
+        const int f = tid + NT * i;
+        const int p = f / (BN * CPR), g = f % (BN * CPR), row = g / CPR, c = g % CPR;
+        const int wr = min(n0 + row, N - 1);
+        w_src[i] = reinterpret_cast<const u32x4*>(W + (size_t)p * w_plane + (size_t)wr * K) + c;
+        w_dst[i] = A_CH + (p * BN + row) * CPR + swz(row, c);
+    }
+    u32x4 a_st[A_LD], w_st[W_LD];
+    auto stage_load = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i)
+            if (A_CH % NT == 0 || tid + NT * i < A_CH) a_st[i] = a_src[i][kt * CPR];
+#pragma unroll
+        for (int i = 0; i < W_LD; ++i)
+            if (W_CH % NT == 0 || tid + NT * i < W_CH) w_st[i] = w_src[i][kt * CPR];
+    };
+    auto stage_store = [&](int buf) {
+        u32x4* base = lds + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i)
+            if (A_CH % NT == 0 || tid + NT * i < A_CH) base[a_dst[i]] = a_st[i];
+#pragma unroll
+        for (int i = 0; i < W_LD; ++i)
+            if (W_CH % NT == 0 || tid + NT * i < W_CH) base[w_dst[i]] = w_st[i];
+    };
+
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[j][i][v] = 0.0f;
+
+    const int nk = K / BK;
+    int cur = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const bool more = kt + 1 < nk;
+        if (more) stage_load(kt + 1);
+        const u32x4* Ab = lds + cur * STAGE;
+        const u32x4* Wb = Ab + A_CH;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            const int c = ks * 2 + kh;
+            u32x4 af[PLANES][TM], wf[PLANES][TN];
+#pragma unroll
+            for (int p = 0; p < PLANES; ++p) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int row = (wm * TM + i) * 32 + r;
+                    af[p][i] = Ab[(p * BM + row) * CPR + swz(row, c)];
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int row = (wn * TN + j) * 32 + r;
+                    wf[p][j] = Wb[(p * BN + row) * CPR + swz(row, c)];
+                }
+            }
+            u32x4 whs[TN];
+            if constexpr (PLANES == 2) {                // w_hi * 2^-11: exact (weights are scaled to ~2^13)
+                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+                const h2 sc = {(_Float16)(1.0f / kLoScale), (_Float16)(1.0f / kLoScale)};
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned int u = wf[0][j][e];   // (bit_cast straight from a vector-element
+                        const h2 t = __builtin_bit_cast(h2, u) * sc;   //  lvalue reads element 0: keep the copy)
+                        whs[j][e] = __builtin_bit_cast(unsigned int, t);
+                    }
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    if constexpr (PLANES == 2) {        // small terms first, then the main product
+                        acc[j][i] = mfma16<BF>(wf[1][j], af[0][i], acc[j][i]);     // w_lo * a_hi
+                        acc[j][i] = mfma16<BF>(whs[j], af[1][i], acc[j][i]);       // (w_hi 2^-11) * (a_lo 2^11)
+                    }
+                    acc[j][i] = mfma16<BF>(wf[0][j], af[0][i], acc[j][i]);
+                }
+        }
+        if (more) stage_store(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue: lane holds column m = m_base + r of C^T, rows n = (v&3) + 8(v>>2) + 4kh ----
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + (wm * TM + i) * 32 + r;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + (wn * TN + j) * 32 + 8 * g + 4 * kh;
+                if (n >= N) continue;                    // N % 4 == 0 is required by the launcher
+                const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 val;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[j][i][4 * g + e] * out_scale + bv[e];
+                    if (EPI == EPI_GELU) t = gelu_erf16(t);
+                    val[e] = t;
+                }
+                const size_t o = (size_t)m * N + n;
+                if (residual) {
+                    const f32x4 rv = *reinterpret_cast<const f32x4*>(residual + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) val[e] = rv[e] + val[e];
+                }
+                if constexpr (OUT == 0) {
+                    *reinterpret_cast<f32x4*>(Cf + o) = val;
+                } else if constexpr (BF) {
+                    u32x2 pk;
+                    pk[0] = f32_to_bf16_rne(val[0]) | ((unsigned)f32_to_bf16_rne(val[1]) << 16);
+                    pk[1] = f32_to_bf16_rne(val[2]) | ((unsigned)f32_to_bf16_rne(val[3]) << 16);
+                    *reinterpret_cast<u32x2*>(Ch + o) = pk;
+                } else {
+                    h4 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        _Float16 a, b;
+                        split_act(val[e], a, b);
+                        hi[e] = a;
+                        lo[e] = b;
+                    }
+                    *reinterpret_cast<h4*>(Ch + o) = hi;
+                    if constexpr (PLANES == 2) *reinterpret_cast<h4*>(Ch + c_plane + o) = lo;
+                }
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN, int BK, int PLANES, bool BF>
+static int launch_cfg(const unsigned short* A, size_t a_plane, const unsigned short* W, size_t w_plane,
+                      const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
+                      int M, int N, int K, int epilogue, float out_scale, hipStream_t s) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int CPR = BK / 8;
+    constexpr size_t lds_bytes = (size_t)2 * (BM + BN) * CPR * PLANES * 16;
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const dim3 grid(tiles_m * tiles_n), block(WM * WN * 64);
+#define PGMI_LAUNCH16(EPI_, OUT_)                                                                        \
+    do {                                                                                                 \
+        auto kfn = gemm16_kernel<WM, WN, TM, TN, BK, PLANES, BF, EPI_, OUT_>;                             \
+        if (lds_bytes > 65536) {                                                                         \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                       \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+            if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PGMI_EHIP; } \
+        }                                                                                                \
+        hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, A, a_plane, W, w_plane, bias, residual, Cf, Ch, \
+                           c_plane, M, N, K, out_scale, tiles_m, tiles_n);                               \
+    } while (0)
+    const int out = Ch ? 1 : 0;
+    if (epilogue == EPI_GELU) { if (out) PGMI_LAUNCH16(EPI_GELU, 1); else PGMI_LAUNCH16(EPI_GELU, 0); }
+    else { if (out) PGMI_LAUNCH16(EPI_NONE, 1); else PGMI_LAUNCH16(EPI_NONE, 0); }
+#undef PGMI_LAUNCH16
+    PGMI_HIP(hipGetLastError());
+    return PGMI_OK;
+}
+
+int launch_gemm16(const unsigned short* A, size_t a_plane, const unsigned short* W, size_t w_plane,
+                  const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
+                  int M, int N, int K, int epilogue, float out_scale, int planes, bool bf, int variant,
+                  hipStream_t s) {
+    if (M <= 0 || N <= 0 || K <= 0 || (K % 64) != 0 || (N % 4) != 0 || (!Cf && !Ch) || (Cf && Ch)) {
+        set_error("gemm16: unsupported shape/args M=%d N=%d K=%d (K %% 64 == 0, N %% 4 == 0 required)", M, N, K);
+        return PGMI_EINVAL;
+    }
+    if (planes == 2 && !bf) {
+        switch (variant) {
+            case 1: return launch_cfg<2, 2, 2, 2, 64, 2, false>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);
+            case 2: return launch_cfg<2, 4, 4, 2, 32, 2, false>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);
+            case 3: return launch_cfg<4, 2, 2, 2, 32, 2, false>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);
+            default: return launch_cfg<2, 2, 2, 2, 32, 2, false>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);
+        }
+    }
+    if (planes == 1 && bf) {
+        switch (variant) {
+            case 2: return launch_cfg<2, 4, 4, 2, 32, 1, true>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);
+            default: return launch_cfg<2, 2, 2, 2, 32, 1, true>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);
+        }
+    }
+    set_error("gemm16: unsupported mode planes=%d bf=%d", planes, (int)bf);
+    return PGMI_EINVAL;
+}
+
+// ---- fp32 -> 16-bit planes (used for weights at load time and by the op-level tests) ----------
+// mode 0: fp16 hi/lo planes of x*scale, lo unscaled (weights) ; mode 1: bf16 (single plane, RNE) ;
+// mode 2: activation split (lo scaled by 2^11, see split_act)
+__global__ void split16_kernel(const float* __restrict__ x, int64_t n, float scale, int mode,
+                               unsigned short* __restrict__ out, size_t plane) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = x[i] * scale;
+    if (mode == 1) {
+        out[i] = f32_to_bf16_rne(v);
+    } else if (mode == 2) {
+        _Float16 hi, lo;
+        split_act(v, hi, lo);
+        out[i] = __builtin_bit_cast(unsigned short, hi);
+        out[plane + i] = __builtin_bit_cast(unsigned short, lo);
+    } else {
+        const _Float16 hi = (_Float16)v;
+        const _Float16 lo = (_Float16)(v - (float)hi);
+        out[i] = __builtin_bit_cast(unsigned short, hi);
+        out[plane + i] = __builtin_bit_cast(unsigned short, lo);
+    }
+}
+void launch_split16(const float* x, int64_t n, float scale, int mode, unsigned short* out, size_t plane, hipStream_t s) {
+    hipLaunchKernelGGL(split16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, scale, mode, out, plane);
+}
+
+}  // namespace pgmi

@@ -1,0 +1,32 @@
+"""Summarise rocprofv3 --pmc CSV output per kernel name: mean counter value per dispatch."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+root = sys.argv[1]
+agg = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+dur = defaultdict(lambda: [0.0, 0])
+for f in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0][:60]
+        a = agg[k][r["Counter_Name"]]
+        a[0] += float(r["Counter_Value"]); a[1] += 1
+for f in glob.glob(os.path.join(root, "sq", "**", "*kernel_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0][:60]
+        dur[k][0] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"]); dur[k][1] += 1
+for k in sorted(agg, key=lambda k: -dur[k][0]):
+    d = dur[k]
+    print(f"== {k}  dispatches={d[1]}  avg_ns(under pmc)={d[0] / max(d[1], 1):.0f}")
+    for c, (s, n) in sorted(agg[k].items()):
+        print(f"   {c:34s} mean/dispatch = {s / n:.6g}")
+    c = {c: s / n for c, (s, n) in agg[k].items()}
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c and c["GRBM_GUI_ACTIVE"] > 0:
+        print(f"   -> MfmaUtil = {c['SQ_VALU_MFMA_BUSY_CYCLES'] / (c['GRBM_GUI_ACTIVE'] * 1024) * 100:.1f}%  "
+              f"clock ~ {c['GRBM_GUI_ACTIVE'] / max(d[0] / max(d[1], 1), 1):.2f} GHz")
+    if "FETCH_SIZE" in c:
+        print(f"   -> HBM read  ~ {c['FETCH_SIZE'] * 1024 * 2 / 1e6:.1f} MB/dispatch (FETCH_SIZE KB x2 gfx950 correction)")
+    if "WRITE_SIZE" in c:
+        print(f"   -> HBM write ~ {c['WRITE_SIZE'] * 1024 / 1e6:.1f} MB/dispatch (uncalibrated)")

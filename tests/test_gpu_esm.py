@@ -119,3 +119,34 @@ def test_wildtype_mismatch_raises(models, golden):
     bad = ("A" if seq[2] != "A" else "C") + "3G"
     with pytest.raises(AssertionError, match="does not match"):
         pesm.Assay(models["esm1v_toy_1"], seq, [bad])
+
+
+@pytest.mark.parametrize("name", ["esm1v_toy_1", "esm1b_toy_lnb", "esm2_toy"])
+def test_f16x3_mode_meets_the_parity_bar(lib, golden, golden_dir, name):
+    """The split-fp16 mode is parity-gated like fp32: same 1e-4 bar against the reference."""
+    import pandas as pd
+    m = pesm.load_model_and_alphabet(os.path.join(golden_dir, name + ".pt"), precision="f16x3")[0]
+    seq = str(golden["seq"])
+    df = pd.read_csv(os.path.join(golden_dir, "TOY_DMS.csv"))
+    a = pesm.Assay(m, seq, list(df["mutant"]), all_positions=True)
+    scores, table = a.run(want_table=True)
+    assert np.abs(table - golden[f"{name}/mm_table"]).max() < TOL
+    assert np.abs(scores - golden[f"cli/{name}"]).max() < TOL
+    toks = golden[f"{name}/pad_tokens"]
+    lp = m.token_logprobs(toks)
+    valid = toks != 1
+    assert np.abs(lp[valid] - golden[f"{name}/pad_logprobs"][valid]).max() < TOL
+    m.close()
+
+
+def test_bf16_mode_runs_and_error_is_reported(lib, golden, golden_dir):
+    """bf16 is the throughput mode: not parity-gated; its error is measured and bounded loosely."""
+    import pandas as pd
+    m = pesm.load_model_and_alphabet(os.path.join(golden_dir, "esm1v_toy_1.pt"), precision="bf16")[0]
+    seq = str(golden["seq"])
+    df = pd.read_csv(os.path.join(golden_dir, "TOY_DMS.csv"))
+    scores = pesm.Assay(m, seq, list(df["mutant"])).run()
+    err = np.abs(scores - golden["cli/esm1v_toy_1"]).max()
+    print("bf16 toy max|err| =", err)
+    assert err < 0.25 and err > 1e-6
+    m.close()

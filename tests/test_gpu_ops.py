@@ -90,3 +90,50 @@ def test_attention_rotary(lib):
     k = k * cos + rot(k) * sin
     ref = (torch.softmax(q @ k.transpose(-1, -2), -1) @ v).transpose(1, 2).reshape(B, T, D).numpy()
     assert np.abs(ctx - ref).max() < 3e-5
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("M,N,K,epi,res", [(300, 384, 128, 0, False), (257, 1280, 1280, 1, False),
+                                            (513, 1280, 5120, 0, True), (1, 128, 256, 1, True)])
+def test_gemm_f16x3(lib, monkeypatch, variant, M, N, K, epi, res):
+    """Split-fp16 3-pass GEMM: fp32-class accuracy (same bound as the fp32 kernel)."""
+    monkeypatch.setenv("PGMI_GEMM_VARIANT", str(variant))
+    rng = np.random.default_rng(4)
+    A = (rng.standard_normal((M, K)) * rng.choice([0.01, 1.0, 30.0], size=(M, 1))).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    R = rng.standard_normal((M, N)).astype(np.float32) if res else None
+    Cc = np.empty((M, N), np.float32)
+    _lib.check(lib.pgmi_op_gemm(0, _lib.PREC_F16X3, _p(A), _p(W), _p(bias), _p(R), M, N, K, epi, _p(Cc)))
+    pre = torch.from_numpy(A).double() @ torch.from_numpy(W).double().T + torch.from_numpy(bias).double()
+    ref = pre * 0.5 * (1.0 + torch.erf(pre / np.sqrt(2.0))) if epi else pre
+    if res:
+        ref = ref + torch.from_numpy(R).double()
+    if not epi and not res:       # pure linear, no bias: error relative to each row's own magnitude
+        C0 = np.empty((M, N), np.float32)
+        _lib.check(lib.pgmi_op_gemm(0, _lib.PREC_F16X3, _p(A), _p(W), None, None, M, N, K, 0, _p(C0)))
+        lin = (torch.from_numpy(A).double() @ torch.from_numpy(W).double().T).numpy()
+        err = (np.abs(C0 - lin) / np.abs(A).max(1, keepdims=True)).max()
+        assert err < 2e-6 * np.sqrt(K / 128), err     # small-magnitude rows keep fp32-class relative accuracy
+    scale = np.abs(A).max(1, keepdims=True) * 1.0        # row-wise magnitude of the dot products
+    err = (np.abs(Cc - ref.numpy()) / np.maximum(scale, 1.0)).max()
+    assert err < 2e-5 * np.sqrt(K / 128), err
+
+
+@pytest.mark.parametrize("M,N,K,epi,res", [(300, 384, 256, 0, False), (3600, 384, 128, 0, False),
+                                            (3600, 256, 128, 1, False), (3600, 128, 256, 0, True), (70, 128, 128, 1, True)])
+def test_gemm_bf16(lib, M, N, K, epi, res):
+    rng = np.random.default_rng(5)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    R = rng.standard_normal((M, N)).astype(np.float32) if res else None
+    Cc = np.empty((M, N), np.float32)
+    _lib.check(lib.pgmi_op_gemm(0, _lib.PREC_BF16, _p(A), _p(W), _p(bias), _p(R), M, N, K, epi, _p(Cc)))
+    ref = (torch.from_numpy(A).bfloat16().double() @ torch.from_numpy(W).bfloat16().double().T
+           + torch.from_numpy(bias).double())
+    if epi:
+        ref = ref * 0.5 * (1.0 + torch.erf(ref / np.sqrt(2.0)))
+    if res:
+        ref = ref + torch.from_numpy(R).double()
+    assert np.abs(Cc - ref.numpy()).max() < 1e-4       # exact bf16 inputs, fp32 accumulate

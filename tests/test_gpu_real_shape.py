@@ -9,27 +9,48 @@ from proteingym_amd import esm as pesm, synthetic
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def big(lib):
+@pytest.fixture(scope="module", params=["fp32", "f16x3"])
+def big(lib, request):
     cfg = dict(synthetic.ESM1V_650M)
-    blob = synthetic.random_weights(cfg, seed=1)
-    model = pesm.EsmModel(cfg, blob, device=0, precision="fp32")
+    blob = _blob()
+    model = pesm.EsmModel(cfg, blob, device=0, precision=request.param)
     yield cfg, blob, model
     model.close()
+
+
+_BLOB = {}
+
+
+def _blob():
+    if "b" not in _BLOB:
+        _BLOB["b"] = synthetic.random_weights(dict(synthetic.ESM1V_650M), seed=1)
+    return _BLOB["b"]
+
+
+_REF = {}
+
+
+def _oracle_rows(cfg, blob, seq, positions):
+    """CPU oracle rows at the real shape, computed once and shared by the precision modes."""
+    from oracle import esm_oracle as eo
+    key = (seq, tuple(positions))
+    if key not in _REF:
+        ocfg, W = eo.from_arrays(arrays=synthetic.blob_to_arrays(cfg, blob), **cfg)
+        _REF[key] = eo.masked_marginals_table(ocfg, W, seq, positions=positions, batch=len(positions))
+    return _REF[key]
 
 
 def test_650m_masked_rows_vs_oracle(big):
     from oracle import esm_oracle as eo
     cfg, blob, model = big
-    ocfg, W = eo.from_arrays(arrays=synthetic.blob_to_arrays(cfg, blob), **cfg)
     seq, muts, _ = synthetic.random_assay(seed=5, L=120, n_single=200, n_multi=50)
     positions = [1, 17, 60, 119, 120]
-    ref = eo.masked_marginals_table(ocfg, W, seq, positions=positions, batch=5)
+    ref = _oracle_rows(cfg, blob, seq, positions)
     toks = eo.tokenize(seq)
     got = model.masked_logprobs(np.repeat(toks[None], len(positions), 0), positions)
     err = np.abs(got - ref[positions]).max()
     llr = ref[positions][:, 4:24]
-    print("650M max|err| =", err, " LLR range", float(llr.max() - llr.min()))
+    print(model.precision, "650M max|err| =", err, " LLR range", float(llr.max() - llr.min()))
     assert err < 1e-4
 
 
