@@ -78,8 +78,9 @@ def create_parser():
     # additive
     parser.add_argument("--device", type=int, default=int(os.environ.get("LOCAL_RANK", "0")),
                         help="[pgmi] GPU index (default LOCAL_RANK or 0)")
-    parser.add_argument("--precision", type=str, default="fp32", choices=sorted(pesm._lib.PRECISIONS),
-                        help="[pgmi] GEMM operand precision (fp32 = parity-gated mode)")
+    parser.add_argument("--precision", type=str, default="f16x3", choices=sorted(pesm._lib.PRECISIONS),
+                        help="[pgmi] GEMM arithmetic: f16x3 (default; split-fp16 3-pass, fp32-class accuracy, parity-gated), "
+                             "fp32 (fp32 MFMA, parity-gated, slower), bf16 (fast, NOT parity-gated)")
     parser.add_argument("--all-positions", action="store_true",
                         help="[pgmi] forward every token position like the reference does (default: only "
                              "positions some mutant reads; outputs are identical)")

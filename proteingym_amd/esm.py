@@ -188,7 +188,7 @@ class EsmModel:
     ``log_softmax``-ed logits -- log_softmax is idempotent, so reference-style callers that
     apply ``torch.log_softmax(..., dim=-1)`` on top get the same numbers."""
 
-    def __init__(self, cfg: dict, weights: np.ndarray, device: int = 0, precision: str = "fp32",
+    def __init__(self, cfg: dict, weights: np.ndarray, device: int = 0, precision: str = "f16x3",
                  max_rows: int = 0):
         lib = _lib.load()
         self.cfg = dict(cfg)
@@ -357,7 +357,7 @@ def get_optimal_window(mutation_position_relative, seq_len_wo_special, model_win
     return [s.value, e.value]
 
 
-def load_model_and_alphabet(model_location: str, device: int = 0, precision: str = "fp32",
+def load_model_and_alphabet(model_location: str, device: int = 0, precision: str = "f16x3",
                             max_rows: int = 0):
     """Mirror of esm/pretrained.py:24-28 for local ``.pt`` files."""
     if not str(model_location).endswith(".pt"):

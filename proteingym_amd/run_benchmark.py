@@ -34,7 +34,7 @@ def create_parser():
     p.add_argument("--dms-output", type=str, required=True)
     p.add_argument("--dms_indices", type=int, nargs="*", default=None, help="default: every row of the mapping")
     p.add_argument("--mutation-col", type=str, default="mutant")
-    p.add_argument("--precision", type=str, default="fp32", choices=sorted(pesm._lib.PRECISIONS))
+    p.add_argument("--precision", type=str, default="f16x3", choices=sorted(pesm._lib.PRECISIONS))
     p.add_argument("--all-positions", action="store_true")
     p.add_argument("--overwrite-prior-scores", action="store_true")
     p.add_argument("--backend", type=str, default=None, help="torch.distributed backend (default nccl)")

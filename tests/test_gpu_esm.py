@@ -12,11 +12,12 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4   # BASELINE.json north_star: per-mutant scores within 1e-4 abs of the reference CPU path
 
 
-@pytest.fixture(scope="module")
-def models(lib, golden_dir):
+@pytest.fixture(scope="module", params=["f16x3", "fp32"])
+def models(lib, golden_dir, request):
+    """Both parity-gated precision modes go through every test below."""
     out = {}
     for n in ("esm1v_toy_1", "esm1v_toy_2", "esm1b_toy_lnb", "esm2_toy"):
-        out[n] = pesm.load_model_and_alphabet(os.path.join(golden_dir, n + ".pt"))[0]
+        out[n] = pesm.load_model_and_alphabet(os.path.join(golden_dir, n + ".pt"), precision=request.param)[0]
     yield out
     for m in out.values():
         m.close()
