@@ -194,6 +194,7 @@ def main():
             "kernels": kern,
         }
         if world == 1 and args.cpu_seconds > 0:
+            assay.close()
             model.close()
             out["cpu_baseline"] = cpu_baseline(cfg, blob, seq, n_mut, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -181,6 +181,12 @@ int pgmi_op_attention(int device, int precision, const float* qkv, const int32_t
                       int B, int T, int H, int rotary, float* ctx);
                                      /* multihead_attention.py:354-395; qkv [B*T,3*H*64], q pre-scaled */
 
+/* Tuning utility: times `iters` launches of the production GEMM (device-resident random operands,
+ * HIP events) for one shape; variant selects the tile configuration (negative = library default).
+ * Writes the mean milliseconds per launch. */
+int pgmi_bench_gemm(int device, int precision, int M, int N, int K, int epilogue, int split_out,
+                    int variant, int iters, double* ms_per_launch);
+
 #ifdef __cplusplus
 }
 #endif

@@ -60,6 +60,7 @@ SIGNATURES = [
     ("pgmi_synchronize", C.c_int, [C.c_void_p]),
     ("pgmi_op_layernorm", C.c_int, [C.c_int, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_float, _f32p]),
     ("pgmi_op_gemm", C.c_int, [C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
+    ("pgmi_bench_gemm", C.c_int, [C.c_int] * 9 + [_f64p]),
     ("pgmi_op_attention", C.c_int, [C.c_int, C.c_int, _f32p, _i32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
 ]
 

@@ -47,11 +47,14 @@ struct ProfEvent {
 
 using namespace pgmi;
 
+struct pgmi_assay;
+
 struct pgmi_model {
     pgmi_config cfg;
     int device = 0;
     hipStream_t stream = nullptr;
     std::vector<void*> allocs;          // everything to hipFree
+    std::vector<pgmi_assay*> assays;    // live assays created on this model (orphaned on destroy)
     // weights
     float *embed_tokens = nullptr, *embed_positions = nullptr;
     float *lnb_w = nullptr, *lnb_b = nullptr, *lna_w = nullptr, *lna_b = nullptr;
@@ -473,6 +476,12 @@ void pgmi_model_destroy(pgmi_model* m) {
     if (!m) return;
     hipSetDevice(m->device);
     if (m->stream) hipStreamSynchronize(m->stream);
+    for (pgmi_assay* a : m->assays) {           // assays outliving their model become inert handles
+        for (void* p : a->allocs) hipFree(p);
+        a->allocs.clear();
+        a->m = nullptr;
+    }
+    m->assays.clear();
     for (auto& e : m->events) { hipEventDestroy(e.start); hipEventDestroy(e.stop); }
     for (void* p : m->allocs) hipFree(p);
     if (m->stream) hipStreamDestroy(m->stream);
@@ -590,19 +599,25 @@ int pgmi_assay_create(pgmi_model* m, const int32_t* wt_tokens, int n_tok, const 
     TRY(dev_alloc(a->allocs, &a->table, (size_t)n_tok * PGMI_VOCAB));
     TRY(dev_alloc(a->allocs, &a->scores, (size_t)n_mut));
 #undef TRY
+    m->assays.push_back(a);
     *out = a;
     return PGMI_OK;
 }
 
 void pgmi_assay_destroy(pgmi_assay* a) {
     if (!a) return;
-    if (a->m) { hipSetDevice(a->m->device); hipStreamSynchronize(a->m->stream); }
+    if (a->m) {
+        hipSetDevice(a->m->device);
+        hipStreamSynchronize(a->m->stream);
+        auto& v = a->m->assays;
+        v.erase(std::remove(v.begin(), v.end(), a), v.end());
+    }
     for (void* p : a->allocs) hipFree(p);
     delete a;
 }
 
 int pgmi_assay_run(pgmi_model* m, pgmi_assay* a, double* scores_host, float* table_host, double* scores_dev) {
-    if (!m || !a || a->m != m) { set_error("bad model/assay handle"); return PGMI_EINVAL; }
+    if (!m || !a || a->m != m) { set_error("bad model/assay handle (assay belongs to another or a destroyed model)"); return PGMI_EINVAL; }
     PGMI_HIP(hipSetDevice(m->device));
     hipStream_t s = m->stream;
     const int T = a->T, V = m->cfg.vocab;
@@ -766,6 +781,63 @@ int pgmi_op_gemm(int device, int precision, const float* A, const float* W, cons
     if (rc) return rc;
     if (e != hipSuccess) { set_error("gemm op failed: %s", hipGetErrorString(e)); return PGMI_EHIP; }
     return PGMI_OK;
+}
+
+int pgmi_bench_gemm(int device, int precision, int M, int N, int K, int epilogue, int split_out, int variant,
+                    int iters, double* ms_per_launch) {
+    if (M <= 0 || N <= 0 || K <= 0 || iters <= 0 || !ms_per_launch) { set_error("bad argument"); return PGMI_EINVAL; }
+    if (pgmi_device_count() <= 0) { set_error("no HIP device visible"); return PGMI_ENODEV; }
+    PGMI_HIP(hipSetDevice(device));
+    std::vector<void*> pool;
+    auto cleanup = [&]() { for (void* p : pool) hipFree(p); };
+    std::vector<float> hA((size_t)M * K), hW((size_t)N * K), hb(N);
+    unsigned int st = 12345u;
+    auto rnd = [&]() { st = st * 1664525u + 1013904223u; return ((st >> 8) * (1.0f / 8388608.0f)) - 1.0f; };
+    for (auto& v : hA) v = rnd();
+    for (auto& v : hW) v = rnd() * 0.03f;
+    for (auto& v : hb) v = rnd();
+    float *dA, *dW = nullptr, *dB, *dC = nullptr;
+    unsigned short *a16 = nullptr, *c16 = nullptr;
+    int rc = 0;
+    if ((rc = dev_upload(pool, &dA, hA.data(), hA.size())) || (rc = dev_upload(pool, &dB, hb.data(), hb.size()))) { cleanup(); return rc; }
+    hipEvent_t e0, e1;
+    PGMI_HIP(hipEventCreate(&e0));
+    PGMI_HIP(hipEventCreate(&e1));
+    const bool f32 = precision == PGMI_PREC_FP32;
+    const bool bf = precision == PGMI_PREC_BF16;
+    const int planes = bf ? 1 : 2;
+    W16 w16;
+    if (f32) {
+        if ((rc = dev_upload(pool, &dW, hW.data(), hW.size())) || (rc = dev_alloc(pool, &dC, (size_t)M * N))) { cleanup(); return rc; }
+    } else {
+        if ((rc = make_w16(pool, hW.data(), hW.size(), precision, nullptr, &w16)) ||
+            (rc = dev_alloc(pool, &a16, (size_t)M * K * planes))) { cleanup(); return rc; }
+        launch_split16(dA, (int64_t)M * K, 1.0f, bf ? 1 : 2, a16, (size_t)M * K, nullptr);
+        if (split_out) rc = dev_alloc(pool, &c16, (size_t)M * N * planes);
+        else rc = dev_alloc(pool, &dC, (size_t)M * N);
+        if (rc) { cleanup(); return rc; }
+    }
+    const int var = variant >= 0 ? variant : env_int("PGMI_GEMM_VARIANT", 2);
+    auto run = [&]() -> int {
+        if (f32) return launch_gemm_f32(dA, dW, dB, nullptr, dC, M, N, K, epilogue, nullptr);
+        return launch_gemm16(a16, (size_t)M * K, w16.p, w16.plane, dB, nullptr, split_out ? nullptr : dC,
+                             split_out ? c16 : nullptr, (size_t)M * N, M, N, K, epilogue, w16.out_scale, planes, bf, var, nullptr);
+    };
+    for (int i = 0; i < 2 && !rc; ++i) rc = run();
+    if (!rc) {
+        hipEventRecord(e0, nullptr);
+        for (int i = 0; i < iters && !rc; ++i) rc = run();
+        hipEventRecord(e1, nullptr);
+        hipError_t e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e != hipSuccess) { set_error("bench failed: %s", hipGetErrorString(e)); rc = PGMI_EHIP; }
+        *ms_per_launch = ms / iters;
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    cleanup();
+    return rc;
 }
 
 int pgmi_op_attention(int device, int precision, const float* qkv, const int32_t* kv_len, int B, int T, int H,

@@ -240,6 +240,231 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 2) void gemm16_k
     }
 }
 
+
+// ---- pipelined variant: direct-to-LDS tile loads + fragment prefetch ---------------------------
+// Same tiling/epilogue as gemm16_kernel, different data movement:
+//  * K tiles go global -> LDS with global_load_lds_dwordx4 (1 KiB per wave-instruction, no VGPR
+//    staging, no ds_write pass); the XOR swizzle is applied to the per-lane SOURCE chunk because the
+//    LDS destination of a DMA is lane-linear;
+//  * 3-deep LDS ring: at the single barrier of iteration t (placed between the two k16 steps of
+//    tile t) tile t+1 has landed (every wave drained its own DMA before the barrier), tile t-1's
+//    buffer is free and is immediately re-filled with tile t+2;
+//  * MFMA operand fragments are double-buffered in registers: the ds_read_b128s of the next k16
+//    step (same tile, or the first step of tile t+1 right after the barrier) are issued before the
+//    MFMAs of the current step, so LDS latency hides behind the matrix pipe.
+template <int WM, int WN, int TM, int TN, int PLANES, bool BF, int EPI, int OUT>
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm16p_kernel(
+    const unsigned short* __restrict__ A, size_t a_plane, const unsigned short* __restrict__ W,
+    size_t w_plane, const float* __restrict__ bias, const float* residual, float* Cf,
+    unsigned short* Ch, size_t c_plane, int M, int N, int K, float out_scale, int tiles_m, int tiles_n) {
+    constexpr int BK = 32, CPR = 4, NSTAGE = 3;
+    constexpr int NT = WM * WN * 64;
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr int A_CH = BM * CPR * PLANES, W_CH = BN * CPR * PLANES;
+    constexpr int STAGE = A_CH + W_CH;
+    static_assert(A_CH % NT == 0 && W_CH % NT == 0, "tile must split evenly over the waves");
+    constexpr int A_LD = A_CH / NT, W_LD = W_CH / NT;
+    extern __shared__ __attribute__((aligned(16))) u32x4 lds[];  // [NSTAGE][STAGE]
+
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
+    const int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
+    constexpr int GROUP_M = 8;
+    const int width = GROUP_M * tiles_n;
+    const int group = wgid / width, first_m = group * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int tm = first_m + (wgid % width) % gsz, tn = (wgid % width) / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, kh = lane >> 5;
+
+    // ---- DMA maps: LDS slot (tid + NT*i) <- global chunk (row, c' ^ swizzle(row)) -------------
+    const u32x4* a_src[A_LD];
+    const u32x4* w_src[W_LD];
+#pragma unroll
+    for (int i = 0; i < A_LD; ++i) {
+        const int f = tid + NT * i;
+        const int p = f / (BM * CPR), g = f % (BM * CPR), row = g / CPR, cs = g % CPR;
+        const int c = cs ^ ((row >> 2) & 3);
+        const int am = min(m0 + row, M - 1);
+        a_src[i] = reinterpret_cast<const u32x4*>(A + (size_t)p * a_plane + (size_t)am * K) + c;
+    }
+#pragma unroll
+    for (int i = 0; i < W_LD; ++i) {
+        const int f = tid + NT * i;
+        const int p = f / (BN * CPR), g = f % (BN * CPR), row = g / CPR, cs = g % CPR;
+        const int c = cs ^ ((row >> 2) & 3);
+        const int wr = min(n0 + row, N - 1);
+        w_src[i] = reinterpret_cast<const u32x4*>(W + (size_t)p * w_plane + (size_t)wr * K) + c;
+    }
+    auto issue_tile = [&](int kt, int buf) {
+        u32x4* base = lds + buf * STAGE + wave * 64;          // wave-uniform; the DMA adds lane*16 B
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + kt * CPR),
+                                             (__attribute__((address_space(3))) void*)(base + NT * i), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < W_LD; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + kt * CPR),
+                                             (__attribute__((address_space(3))) void*)(base + A_CH + NT * i), 16, 0, 0);
+    };
+
+    // fragment addressing: row-dependent part is loop-invariant
+    int a_off[TM], w_off[TN], a_sw[TM], w_sw[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int row = (wm * TM + i) * 32 + r;
+        a_off[i] = row * CPR;
+        a_sw[i] = (row >> 2) & 3;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int row = (wn * TN + j) * 32 + r;
+        w_off[j] = A_CH + row * CPR;
+        w_sw[j] = (row >> 2) & 3;
+    }
+    auto load_frags = [&](u32x4 (&af)[PLANES][TM], u32x4 (&wf)[PLANES][TN], int buf, int ks) {
+        const u32x4* Sb = lds + buf * STAGE;
+        const int c = ks * 2 + kh;
+#pragma unroll
+        for (int p = 0; p < PLANES; ++p) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[p][i] = Sb[p * BM * CPR + a_off[i] + (c ^ a_sw[i])];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wf[p][j] = Sb[p * BN * CPR + w_off[j] + (c ^ w_sw[j])];
+        }
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[j][i][v] = 0.0f;
+
+    auto mma_step = [&](const u32x4 (&af)[PLANES][TM], const u32x4 (&wf)[PLANES][TN]) {
+        u32x4 whs[TN];
+        if constexpr (PLANES == 2) {
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            const h2 sc = {(_Float16)(1.0f / kLoScale), (_Float16)(1.0f / kLoScale)};
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned int u = wf[0][j][e];
+                    const h2 t = __builtin_bit_cast(h2, u) * sc;
+                    whs[j][e] = __builtin_bit_cast(unsigned int, t);
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if constexpr (PLANES == 2) {
+                    acc[j][i] = mfma16<BF>(wf[1][j], af[0][i], acc[j][i]);
+                    acc[j][i] = mfma16<BF>(whs[j], af[1][i], acc[j][i]);
+                }
+                acc[j][i] = mfma16<BF>(wf[0][j], af[0][i], acc[j][i]);
+            }
+    };
+
+    const int nk = K / BK;
+    issue_tile(0, 0);
+    __syncthreads();                       // drains this wave's DMA (vmcnt(0)) and publishes tile 0
+    if (nk > 1) issue_tile(1, 1);
+    u32x4 af0[PLANES][TM], wf0[PLANES][TN], af1[PLANES][TM], wf1[PLANES][TN];
+    load_frags(af0, wf0, 0, 0);
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int nbuf = (buf == NSTAGE - 1) ? 0 : buf + 1;
+        load_frags(af1, wf1, buf, 1);
+        mma_step(af0, wf0);
+        __syncthreads();                   // tile kt+1 landed + visible; tile kt-1's buffer is free
+        if (kt + 2 < nk) issue_tile(kt + 2, (nbuf == NSTAGE - 1) ? 0 : nbuf + 1);
+        if (kt + 1 < nk) load_frags(af0, wf0, nbuf, 0);
+        mma_step(af1, wf1);
+        buf = nbuf;
+    }
+
+    // ---- epilogue (identical to gemm16_kernel) ---------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = m0 + (wm * TM + i) * 32 + r;
+        if (m >= M) continue;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + (wn * TN + j) * 32 + 8 * g + 4 * kh;
+                if (n >= N) continue;
+                const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                f32x4 val;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = acc[j][i][4 * g + e] * out_scale + bv[e];
+                    if (EPI == EPI_GELU) t = gelu_erf16(t);
+                    val[e] = t;
+                }
+                const size_t o = (size_t)m * N + n;
+                if (residual) {
+                    const f32x4 rv = *reinterpret_cast<const f32x4*>(residual + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) val[e] = rv[e] + val[e];
+                }
+                if constexpr (OUT == 0) {
+                    *reinterpret_cast<f32x4*>(Cf + o) = val;
+                } else if constexpr (BF) {
+                    u32x2 pk;
+                    pk[0] = f32_to_bf16_rne(val[0]) | ((unsigned)f32_to_bf16_rne(val[1]) << 16);
+                    pk[1] = f32_to_bf16_rne(val[2]) | ((unsigned)f32_to_bf16_rne(val[3]) << 16);
+                    *reinterpret_cast<u32x2*>(Ch + o) = pk;
+                } else {
+                    h4 hi, lo;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        _Float16 a, b;
+                        split_act(val[e], a, b);
+                        hi[e] = a;
+                        lo[e] = b;
+                    }
+                    *reinterpret_cast<h4*>(Ch + o) = hi;
+                    if constexpr (PLANES == 2) *reinterpret_cast<h4*>(Ch + c_plane + o) = lo;
+                }
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int TM, int TN, int PLANES, bool BF>
+static int launch_cfg_p(const unsigned short* A, size_t a_plane, const unsigned short* W, size_t w_plane,
+                        const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
+                        int M, int N, int K, int epilogue, float out_scale, hipStream_t s) {
+    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
+    constexpr size_t lds_bytes = (size_t)3 * (BM + BN) * 4 * PLANES * 16;
+    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    const dim3 grid(tiles_m * tiles_n), block(WM * WN * 64);
+#define PGMI_LAUNCH16P(EPI_, OUT_)                                                                       \
+    do {                                                                                                 \
+        auto kfn = gemm16p_kernel<WM, WN, TM, TN, PLANES, BF, EPI_, OUT_>;                                \
+        if (lds_bytes > 65536) {                                                                         \
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                       \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
+            if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PGMI_EHIP; } \
+        }                                                                                                \
+        hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, A, a_plane, W, w_plane, bias, residual, Cf, Ch, \
+                           c_plane, M, N, K, out_scale, tiles_m, tiles_n);                               \
+    } while (0)
+    const int out = Ch ? 1 : 0;
+    if (epilogue == EPI_GELU) { if (out) PGMI_LAUNCH16P(EPI_GELU, 1); else PGMI_LAUNCH16P(EPI_GELU, 0); }
+    else { if (out) PGMI_LAUNCH16P(EPI_NONE, 1); else PGMI_LAUNCH16P(EPI_NONE, 0); }
+#undef PGMI_LAUNCH16P
+    PGMI_HIP(hipGetLastError());
+    return PGMI_OK;
+}
+
 template <int WM, int WN, int TM, int TN, int BK, int PLANES, bool BF>
 static int launch_cfg(const unsigned short* A, size_t a_plane, const unsigned short* W, size_t w_plane,
                       const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
@@ -281,6 +506,9 @@ int launch_gemm16(const unsigned short* A, size_t a_plane, const unsigned short*
             case 1: return launch_cfg<2, 2, 2, 2, 64, 2, false>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);
             case 2: return launch_cfg<2, 4, 4, 2, 32, 2, false>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);
             case 3: return launch_cfg<4, 2, 2, 2, 32, 2, false>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);
+            case 4: return launch_cfg_p<4, 2, 2, 2, 2, false>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);   // 256x128, 8 waves
+            case 5: return launch_cfg_p<2, 4, 2, 2, 2, false>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);   // 128x256, 8 waves
+            case 6: return launch_cfg_p<2, 2, 2, 2, 2, false>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);   // 128x128, 4 waves
             default: return launch_cfg<2, 2, 2, 2, 32, 2, false>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);
         }
     }

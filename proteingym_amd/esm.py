@@ -295,6 +295,8 @@ class Assay:
         lib = _lib.load()
         scores = np.empty(self.n_mut, dtype=np.float64)
         table = np.empty((self.n_tok, 33), dtype=np.float32) if want_table else None
+        if not self.model._h:
+            raise PgmiError("bad model/assay handle (assay belongs to a destroyed model)")
         _lib.check(lib.pgmi_assay_run(self.model._h, self._h, _lib.ptr(scores, _lib._f64p),
                                       _lib.ptr(table, _lib._f32p) if want_table else None,
                                       C.c_void_p(scores_dev_ptr) if scores_dev_ptr else None))

@@ -151,3 +151,13 @@ def test_bf16_mode_runs_and_error_is_reported(lib, golden, golden_dir):
     print("bf16 toy max|err| =", err)
     assert err < 0.25 and err > 1e-6
     m.close()
+
+
+def test_assay_outliving_its_model_is_inert(lib, golden, golden_dir):
+    m = pesm.load_model_and_alphabet(os.path.join(golden_dir, "esm1v_toy_1.pt"))[0]
+    a = pesm.Assay(m, str(golden["seq"]), ["%s1A" % str(golden["seq"])[0]] if str(golden["seq"])[0] != "A" else ["A1C"])
+    a.run()
+    m.close()
+    with pytest.raises(pesm.PgmiError, match="destroyed model"):
+        a.run()
+    a.close()          # must not touch the freed model

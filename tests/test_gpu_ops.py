@@ -92,7 +92,7 @@ def test_attention_rotary(lib):
     assert np.abs(ctx - ref).max() < 3e-5
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize("M,N,K,epi,res", [(300, 384, 128, 0, False), (257, 1280, 1280, 1, False),
                                             (513, 1280, 5120, 0, True), (1, 128, 256, 1, True)])
 def test_gemm_f16x3(lib, monkeypatch, variant, M, N, K, epi, res):
