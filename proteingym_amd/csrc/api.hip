@@ -63,8 +63,12 @@ struct pgmi_model {
     W16 hd16;
     unsigned short *h16 = nullptr, *g16 = nullptr;     // activation planes [planes][R*D], [planes][R*F]
     size_t h16_plane = 0, g16_plane = 0;
+    unsigned short *qk16 = nullptr, *vt16 = nullptr;   // attention operands (f16x3): [2][R*2D], [2][R*D]
+    size_t qk16_plane = 0, vt16_plane = 0;
     int32_t* nonfinite = nullptr;
     int gemm_variant = 0;
+    int att16 = 3;        // f16x3 attention: 0 fp32 pipe, 1 in-kernel split, 2 prep pass + DMA ring, 3 QKV epilogue + DMA ring (default)
+    int last_B = 0, last_T = 0;
     float *rot_cos = nullptr, *rot_sin = nullptr;
     int rot_len = 0;
     // workspace
@@ -256,6 +260,13 @@ int run_encoder(pgmi_model* m, int B, int T) {
     }
     int rc = ensure_rotary(m, T);
     if (rc) return rc;
+    if (m->vt16 && (B != m->last_B || T != m->last_T)) {
+        // pad keys (t >= T inside the last 32-key tile) are never written by the fused QKV epilogue:
+        // they must hold finite data (their softmax weight is exactly 0)
+        PGMI_HIP(hipMemsetAsync(m->vt16, 0, m->vt16_plane * 2 * sizeof(unsigned short), s));
+        m->last_B = B;
+        m->last_T = T;
+    }
     {
         ProfScope p(m, PGMI_K_EMBED, 0, (double)M * D * 4);
         launch_seq_stats(m->tokens, B, T, c.token_dropout, m->denom, m->pos_idx, m->kv_len, s);
@@ -273,13 +284,27 @@ int run_encoder(pgmi_model* m, int B, int T) {
         { ProfScope p(m, PGMI_K_LAYERNORM, 0, ln_bytes);
           if (prec == PGMI_PREC_FP32) launch_layernorm(m->x, L.ln1_w, L.ln1_b, M, D, 1e-5f, m->h, s);
           else launch_layernorm16(m->x, L.ln1_w, L.ln1_b, M, D, 1e-5f, m->h16, m->h16_plane, mode16, s); }
+        const bool fused_qkv = prec == PGMI_PREC_F16X3 && m->att16 == 3;
         { ProfScope p(m, PGMI_K_GEMM_QKV, 2.0 * M * 3 * D * D, 0);
-          rc = linear(m, m->h, m->h16, m->h16_plane, L.wqkv, L.wqkv16, L.bqkv, nullptr, m->qkv, nullptr, 0, M, 3 * D, D, EPI_NONE);
+          if (fused_qkv)
+              rc = launch_gemm16_qkv(m->h16, m->h16_plane, L.wqkv16.p, L.wqkv16.plane, L.bqkv, M, D, D, L.wqkv16.out_scale,
+                                     m->qk16, m->qk16_plane, m->vt16, m->vt16_plane, m->rot_cos, m->rot_sin,
+                                     c.arch == PGMI_ARCH_ESM2, T, H, m->gemm_variant, s);
+          else
+              rc = linear(m, m->h, m->h16, m->h16_plane, L.wqkv, L.wqkv16, L.bqkv, nullptr, m->qkv, nullptr, 0, M, 3 * D, D, EPI_NONE);
           if (rc) return rc; }
         { ProfScope p(m, PGMI_K_ATTENTION, 4.0 * M * T * D, 0);
-          if (c.arch == PGMI_ARCH_ESM2) launch_rotary(m->qkv, m->rot_cos, m->rot_sin, M, T, H, s);
-          rc = launch_attention_f32(m->qkv, m->kv_len, B, T, H, m->h, m->h16, m->h16_plane,
-                                    prec == PGMI_PREC_FP32 ? 0 : mode16, s);
+          const bool v2 = prec == PGMI_PREC_F16X3 && m->att16 >= 2;
+          if (c.arch == PGMI_ARCH_ESM2 && !v2) launch_rotary(m->qkv, m->rot_cos, m->rot_sin, M, T, H, s);
+          if (v2)
+              rc = launch_attention_f16x3_v2(fused_qkv ? nullptr : m->qkv, m->kv_len, m->rot_cos, m->rot_sin, c.arch == PGMI_ARCH_ESM2, B, T, H,
+                                             m->qk16, m->qk16_plane, m->vt16, m->vt16_plane, nullptr, m->h16,
+                                             m->h16_plane, 1, s);
+          else if (prec == PGMI_PREC_F16X3 && m->att16 == 1)
+              rc = launch_attention_f16x3(m->qkv, m->kv_len, B, T, H, m->h, m->h16, m->h16_plane, 1, s);
+          else
+              rc = launch_attention_f32(m->qkv, m->kv_len, B, T, H, m->h, m->h16, m->h16_plane,
+                                        prec == PGMI_PREC_FP32 ? 0 : mode16, s);
           if (rc) return rc; }
         { ProfScope p(m, PGMI_K_GEMM_OUT, 2.0 * M * D * D, 0);
           rc = linear(m, m->h, m->h16, m->h16_plane, L.wo, L.wo16, L.bo, m->x, m->x, nullptr, 0, M, D, D, EPI_NONE);
@@ -459,6 +484,14 @@ int pgmi_model_create(const pgmi_config* cfg, const float* w, int64_t n_weights,
     }
     TRY(dev_alloc(m->allocs, &m->nonfinite, (size_t)1));
     PGMI_HIP(hipMemset(m->nonfinite, 0, 4));
+    m->att16 = env_int("PGMI_ATT16", 3);
+    if (cfg->precision == PGMI_PREC_F16X3) {
+        m->qk16_plane = R * 2 * D;
+        m->vt16_plane = R * D;
+        TRY(dev_alloc(m->allocs, &m->qk16, m->qk16_plane * 2));
+        TRY(dev_alloc(m->allocs, &m->vt16, m->vt16_plane * 2));
+        PGMI_HIP(hipMemset(m->vt16, 0, m->vt16_plane * 2 * sizeof(unsigned short)));
+    }
     m->gemm_variant = env_int("PGMI_GEMM_VARIANT", 2);   // 256x256 tile, 8 waves (fastest measured)
     TRY(dev_alloc(m->allocs, &m->lp, R * V));
     TRY(dev_alloc(m->allocs, &m->denom, R));
@@ -498,11 +531,11 @@ int pgmi_synchronize(pgmi_model* m) {
 
 int pgmi_token_logprobs(pgmi_model* m, const int32_t* tokens, int B, int T, float* out) {
     if (!m || !tokens || !out || B <= 0 || T <= 0) { set_error("bad argument"); return PGMI_EINVAL; }
-    if (T > m->max_rows) { set_error("T=%d exceeds workspace rows %d", T, m->max_rows); return PGMI_EINVAL; }
+    if (T + 31 > m->max_rows) { set_error("T=%d exceeds workspace rows %d", T, m->max_rows); return PGMI_EINVAL; }
     int rc = check_tokens(tokens, B, T);
     if (rc) return rc;
     PGMI_HIP(hipSetDevice(m->device));
-    const int per = m->max_rows / T;
+    const int per = std::max(1, m->max_rows / ((T + 31) / 32 * 32));     // B * roundup(T,32) <= max_rows
     const int V = m->cfg.vocab;
     for (int b0 = 0; b0 < B; b0 += per) {
         const int bc = std::min(per, B - b0);
@@ -525,7 +558,7 @@ int pgmi_masked_logprobs(pgmi_model* m, const int32_t* tokens, const int32_t* ma
     for (int b = 0; b < B; ++b)
         if (mask_pos[b] < 0 || mask_pos[b] >= T) { set_error("mask_pos[%d]=%d out of range", b, mask_pos[b]); return PGMI_EINVAL; }
     PGMI_HIP(hipSetDevice(m->device));
-    const int per = m->max_rows / T;
+    const int per = std::max(1, m->max_rows / ((T + 31) / 32 * 32));
     const int V = m->cfg.vocab;
     std::vector<int32_t> ridx;
     for (int b0 = 0; b0 < B; b0 += per) {
@@ -621,7 +654,7 @@ int pgmi_assay_run(pgmi_model* m, pgmi_assay* a, double* scores_host, float* tab
     PGMI_HIP(hipSetDevice(m->device));
     hipStream_t s = m->stream;
     const int T = a->T, V = m->cfg.vocab;
-    const int per = m->max_rows / T;
+    const int per = std::max(1, m->max_rows / ((T + 31) / 32 * 32));
     launch_fill_f32(a->table, (int64_t)a->n_tok * V, NAN, s);
     for (int p0 = 0; p0 < a->P; p0 += per) {
         const int bc = std::min(per, a->P - p0);
@@ -843,7 +876,6 @@ int pgmi_bench_gemm(int device, int precision, int M, int N, int K, int epilogue
 int pgmi_op_attention(int device, int precision, const float* qkv, const int32_t* kv_len, int B, int T, int H,
                       int rotary, float* ctx) {
     if (!qkv || !ctx || B <= 0 || T <= 0 || H <= 0) { set_error("bad argument"); return PGMI_EINVAL; }
-    (void)precision;   // attention runs on the fp32 matrix pipe in every mode
     if (pgmi_device_count() <= 0) { set_error("no HIP device visible"); return PGMI_ENODEV; }
     PGMI_HIP(hipSetDevice(device));
     std::vector<void*> pool;
@@ -856,15 +888,23 @@ int pgmi_op_attention(int device, int precision, const float* qkv, const int32_t
         for (void* p : pool) hipFree(p);
         return rc;
     }
-    if (rotary) {
-        pgmi_model tmp;
-        tmp.cfg.arch = PGMI_ARCH_ESM2;
-        rc = ensure_rotary(&tmp, T);
-        if (!rc) launch_rotary(dq, tmp.rot_cos, tmp.rot_sin, B * T, T, H, nullptr);
-        hipDeviceSynchronize();
-        for (void* p : tmp.allocs) hipFree(p);
+    pgmi_model tmp;
+    tmp.cfg.arch = PGMI_ARCH_ESM2;
+    if (rotary) rc = ensure_rotary(&tmp, T);
+    if (!rc && precision == PGMI_PREC_F16X3 && env_int("PGMI_ATT16", 2) == 2) {
+        const size_t Tp = (size_t)(T + 31) / 32 * 32;
+        unsigned short *qk = nullptr, *vt = nullptr;
+        rc = dev_alloc(pool, &qk, (size_t)B * T * 2 * D * 2);
+        if (!rc) rc = dev_alloc(pool, &vt, (size_t)B * Tp * D * 2);
+        if (!rc) rc = launch_attention_f16x3_v2(dq, dl, tmp.rot_cos, tmp.rot_sin, rotary, B, T, H, qk, (size_t)B * T * 2 * D,
+                                                vt, (size_t)B * Tp * D, dc, nullptr, 0, 0, nullptr);
+    } else if (!rc) {
+        if (rotary) launch_rotary(dq, tmp.rot_cos, tmp.rot_sin, B * T, T, H, nullptr);
+        rc = (precision == PGMI_PREC_F16X3) ? launch_attention_f16x3(dq, dl, B, T, H, dc, nullptr, 0, 0, nullptr)
+                                            : launch_attention_f32(dq, dl, B, T, H, dc, nullptr, 0, 0, nullptr);
     }
-    if (!rc) rc = launch_attention_f32(dq, dl, B, T, H, dc, nullptr, 0, 0, nullptr);
+    hipDeviceSynchronize();
+    for (void* p : tmp.allocs) hipFree(p);
     hipError_t e = hipMemcpy(ctx, dc, (size_t)B * T * D * 4, hipMemcpyDeviceToHost);
     for (void* p : pool) hipFree(p);
     if (rc) return rc;

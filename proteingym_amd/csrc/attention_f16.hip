@@ -1,0 +1,604 @@
+// Fused multi-head self-attention on the 16-bit matrix pipe with split-fp16 (f16x3) operands.
+//
+// Same math and interface as attention_f32.hip (q k^T, fp32 softmax, P v; reference:
+// /root/reference/proteingym/baselines/esm/esm/multihead_attention.py:357-387), same wave/lane
+// arrangement (one wave = 32 queries of one head, S^T = K Q^T so the query lives in the lane, P is
+// consumed straight from the accumulator registers), but every product is evaluated as
+//     x y  ~=  x_hi y_hi + 2^-11 (x_hi y_lo + x_lo y_hi),   x_hi = fp16(x), x_lo = fp16((x - x_hi) 2^11)
+// with v_mfma_f32_32x32x16_f16: 24 MFMAs of 32 cycles per (32q x 32k) tile instead of 64 MFMAs of
+// 64 cycles on the fp32 pipe.  The 2^-11 terms are kept in their own accumulators and folded in
+// fp32 (S = main + corr/2048 before the softmax, O likewise at the end), so no fp16 subnormal is
+// ever produced.  fp32 q/k/v tiles are split on the fly while they are staged into LDS:
+//   K planes   [32 keys][64 d]   row-major, 16-byte chunks XOR-swizzled           -> MFMA A operand of S^T
+//   V^T planes [64 d][32 keys]   keys stored in the order the S^T accumulator holds them (bits 2
+//                                and 3 of the key index swapped), so the packed P registers and one
+//                                ds_read_b128 of V^T agree on the k order of the 16-deep MFMA.
+// Roofline: after the switch the kernel is VALU-bound (exp, splits, rescale), not MFMA-bound.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace pgmi {
+
+typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int AKT = 32;                       // keys per tile
+constexpr int K_CH = AKT * 8;                 // chunks per K plane
+constexpr int V_CH = 64 * 4;                  // chunks per V^T plane
+constexpr int A_STAGE = 2 * K_CH + 2 * V_CH;  // chunks per buffer (hi+lo planes of K and V^T) = 16 KB
+
+__device__ __forceinline__ unsigned int pack_h2(_Float16 a, _Float16 b) {
+    const h2 t = {a, b};
+    return __builtin_bit_cast(unsigned int, t);
+}
+__device__ __forceinline__ f32x16 mfma_h(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
+}
+// split 8 floats into packed hi / lo (scaled by 2^11) fragments
+__device__ __forceinline__ void split8(const float (&x)[8], u32x4& hi, u32x4& lo) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        _Float16 h0, l0, h1, l1;
+        split_act(x[2 * e], h0, l0);
+        split_act(x[2 * e + 1], h1, l1);
+        hi[e] = pack_h2(h0, h1);
+        lo[e] = pack_h2(l0, l1);
+    }
+}
+
+template <int WPB, int OUT>
+__global__ __launch_bounds__(WPB * 64) void attention_f16x3_kernel(
+    const float* __restrict__ qkv, const int32_t* __restrict__ kv_len, int T, int H,
+    float* __restrict__ ctx, unsigned short* __restrict__ ctx16, size_t plane) {
+    constexpr int NT = WPB * 64;
+    constexpr int NLK = (512 + NT - 1) / NT;          // K units (one float4 each) per thread per tile
+    constexpr int NLV = (256 + NT - 1) / NT;          // V units (two float4: a key pair) per thread per tile
+    __shared__ __attribute__((aligned(16))) u32x4 lds[2 * A_STAGE];
+
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, kh = lane >> 5;
+    const int D = H * kHeadDim;
+    const size_t RS = (size_t)3 * D;
+    const float* base = qkv + (size_t)b * T * RS + (size_t)h * kHeadDim;
+    const int Tk = kv_len ? kv_len[b] : T;
+    const int q0 = (blockIdx.x * WPB + wave) * 32;
+    const bool active = q0 < T;
+
+    // Q fragments (B operand of S^T = K Q^T): lane (r,kh) holds Q[q0+r][16s + 8kh .. +7]
+    u32x4 qh[4], ql[4];
+    {
+        const int qrow = min(q0 + r, T - 1);
+        const float* qp = base + (size_t)qrow * RS + kh * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(qp + s * 16);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(qp + s * 16 + 4);
+            const float x[8] = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
+            split8(x, qh[s], ql[s]);
+        }
+    }
+
+    // ---- staging: fp32 global tiles -> split fp16 planes in LDS ---------------------------------
+    f32x4 k_st[NLK], v_st[NLV][2];
+    auto stage_load = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < NLK; ++i) {
+            const int f = tid + NT * i;
+            if (f < 512) {
+                const int key = kt * AKT + (f >> 4), c4 = f & 15;
+                k_st[i] = (key < T) ? *reinterpret_cast<const f32x4*>(base + (size_t)key * RS + D + c4 * 4)
+                                    : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NLV; ++i) {
+            const int f = tid + NT * i;
+            if (f < 256) {
+                const int key = kt * AKT + 2 * (f >> 4), c4 = f & 15;
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    v_st[i][u] = (key + u < T) ? *reinterpret_cast<const f32x4*>(base + (size_t)(key + u) * RS + 2 * D + c4 * 4)
+                                               : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    };
+    auto stage_store = [&](int buf) {
+        char* kb = reinterpret_cast<char*>(lds + buf * A_STAGE);                 // K hi plane, lo plane follows
+        char* vb = reinterpret_cast<char*>(lds + buf * A_STAGE + 2 * K_CH);      // V^T hi plane, lo plane follows
+#pragma unroll
+        for (int i = 0; i < NLK; ++i) {
+            const int f = tid + NT * i;
+            if (f < 512) {
+                const int key = f >> 4, c4 = f & 15, c8 = c4 >> 1;
+                _Float16 hh[4], ll[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xe = k_st[i][e];
+                    split_act(xe, hh[e], ll[e]);
+                }
+                const int off = (key * 8 + (c8 ^ ((key >> 1) & 7))) * 16 + (c4 & 1) * 8;
+                *reinterpret_cast<u32x2*>(kb + off) = u32x2{pack_h2(hh[0], hh[1]), pack_h2(hh[2], hh[3])};
+                *reinterpret_cast<u32x2*>(kb + K_CH * 16 + off) = u32x2{pack_h2(ll[0], ll[1]), pack_h2(ll[2], ll[3])};
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NLV; ++i) {
+            const int f = tid + NT * i;
+            if (f < 256) {
+                const int key = 2 * (f >> 4), c4 = f & 15;                       // keys (key, key+1), d = 4*c4 .. +3
+                const int pos = (key & 0x13) | ((key & 4) << 1) | ((key & 8) >> 1);   // swap bits 2 and 3
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float x0 = v_st[i][0][e], x1 = v_st[i][1][e];
+                    _Float16 h0, l0, h1, l1;
+                    split_act(x0, h0, l0);
+                    split_act(x1, h1, l1);
+                    const int d = c4 * 4 + e;
+                    const int off = (d * 4 + ((pos >> 3) ^ ((d >> 2) & 3))) * 16 + (pos & 7) * 2;
+                    *reinterpret_cast<unsigned int*>(vb + off) = pack_h2(h0, h1);
+                    *reinterpret_cast<unsigned int*>(vb + V_CH * 16 + off) = pack_h2(l0, l1);
+                }
+            }
+        }
+    };
+
+    const int nkt = (Tk + AKT - 1) / AKT;
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
+
+    f32x16 om[2], oc[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) { om[dt][v] = 0.f; oc[dt][v] = 0.f; }
+    float m_run = -INFINITY, l_run = 0.f;
+    constexpr float kInvLo = 1.0f / kLoScale;
+
+    int cur = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = kt + 1 < nkt;
+        if (more) stage_load(kt + 1);
+        if (active) {
+            const u32x4* Kb = lds + cur * A_STAGE;
+            const u32x4* Vb = Kb + 2 * K_CH;
+            f32x16 sm, sc;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) { sm[v] = 0.f; sc[v] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int ci = r * 8 + ((2 * s + kh) ^ ((r >> 1) & 7));
+                const u32x4 kfh = Kb[ci], kfl = Kb[K_CH + ci];
+                sc = mfma_h(kfh, ql[s], sc);
+                sc = mfma_h(kfl, qh[s], sc);
+                sm = mfma_h(kfh, qh[s], sm);
+            }
+            float st[16];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) st[v] = fmaf(sc[v], kInvLo, sm[v]);
+            if (kt * AKT + AKT > Tk) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int key = kt * AKT + (v & 3) + 8 * (v >> 2) + 4 * kh;
+                    if (key >= Tk) st[v] = -INFINITY;
+                }
+            }
+            float mloc = st[0];
+#pragma unroll
+            for (int v = 1; v < 16; ++v) mloc = fmaxf(mloc, st[v]);
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+            const float m_new = fmaxf(m_run, mloc);
+            const float alpha = expf(m_run - m_new);
+            float psum = 0.f;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                st[v] = expf(st[v] - m_new);
+                psum += st[v];
+            }
+            l_run = l_run * alpha + psum;
+            m_run = m_new;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) { om[dt][v] *= alpha; oc[dt][v] *= alpha; }
+            // P fragments: registers 8m .. 8m+7 are exactly the k order of MFMA step m
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                const float x[8] = {st[8 * m], st[8 * m + 1], st[8 * m + 2], st[8 * m + 3],
+                                    st[8 * m + 4], st[8 * m + 5], st[8 * m + 6], st[8 * m + 7]};
+                u32x4 ph, pl;
+                split8(x, ph, pl);
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int d = dt * 32 + r;
+                    const int ci = d * 4 + ((2 * m + kh) ^ ((d >> 2) & 3));
+                    const u32x4 vfh = Vb[ci], vfl = Vb[V_CH + ci];
+                    oc[dt] = mfma_h(vfh, pl, oc[dt]);
+                    oc[dt] = mfma_h(vfl, ph, oc[dt]);
+                    om[dt] = mfma_h(vfh, ph, om[dt]);
+                }
+            }
+        }
+        if (more) stage_store(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    if (active) {
+        const float l_tot = l_run + __shfl_xor(l_run, 32);
+        if (q0 + r < T) {
+            const float inv = 1.0f / l_tot;
+            const size_t off = ((size_t)b * T + q0 + r) * D + (size_t)h * kHeadDim + 4 * kh;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float val[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) val[e] = fmaf(oc[dt][4 * g + e], kInvLo, om[dt][4 * g + e]) * inv;
+                    const size_t oo = off + dt * 32 + 8 * g;
+                    if constexpr (OUT == 0) {
+                        *reinterpret_cast<f32x4*>(ctx + oo) = f32x4{val[0], val[1], val[2], val[3]};
+                    } else {
+                        _Float16 hh[4], ll[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) split_act(val[e], hh[e], ll[e]);
+                        *reinterpret_cast<u32x2*>(ctx16 + oo) = u32x2{pack_h2(hh[0], hh[1]), pack_h2(hh[2], hh[3])};
+                        *reinterpret_cast<u32x2*>(ctx16 + plane + oo) = u32x2{pack_h2(ll[0], ll[1]), pack_h2(ll[2], ll[3])};
+                    }
+                }
+        }
+    }
+}
+
+
+// =================================================================================================
+// v2: operands arrive already split.  qkv_prep_kernel turns the fp32 q|k|v rows written by the QKV
+// GEMM into attention-ready fp16 planes once per layer (and applies the ESM2 rotary on the way):
+//   qk16 [plane][M][2D]                 q | k, row-major (hi plane, lo*2^11 plane)
+//   vt16 [plane][B*H*64][Tp]            V transposed per (sequence, head), keys of each 32-key tile
+//                                       stored with bits 2 and 3 of the key index swapped, pad keys = 0
+// attention_f16x3_v2_kernel then moves K / V^T tiles global -> LDS with global_load_lds (swizzle on
+// the source chunk) and does no conversion work at all: per (32q x 32k) tile 24 MFMAs + ~150 VALU.
+// =================================================================================================
+__global__ __launch_bounds__(256) void qkv_prep_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ cos_t, const float* __restrict__ sin_t,
+    int rotary, int T, int H, int Tp, unsigned short* __restrict__ qk16, size_t qk_plane,
+    unsigned short* __restrict__ vt16, size_t vt_plane) {
+    const int b = blockIdx.z, h = blockIdx.y, t0 = blockIdx.x * 32;
+    const int tid = threadIdx.x;
+    const int D = H * kHeadDim;
+    const size_t RS = (size_t)3 * D;
+    // ---- q and k: units of (token, which, 4 dims d..d+3 and the rotary partner d+32..d+35) ----------
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int u = tid + 256 * it;
+        const int which = u >> 8, tok = (u >> 3) & 31, c = u & 7;
+        const int t = t0 + tok;
+        if (t < T) {
+            const float* src = qkv + ((size_t)b * T + t) * RS + (size_t)which * D + h * kHeadDim + 4 * c;
+            f32x4 x1 = *reinterpret_cast<const f32x4*>(src);
+            f32x4 x2 = *reinterpret_cast<const f32x4*>(src + 32);
+            if (rotary) {           // rotary_embedding.py:11-20: x*cos + rotate_half(x)*sin
+                const f32x4 c1 = *reinterpret_cast<const f32x4*>(cos_t + t * 64 + 4 * c);
+                const f32x4 s1 = *reinterpret_cast<const f32x4*>(sin_t + t * 64 + 4 * c);
+                const f32x4 c2 = *reinterpret_cast<const f32x4*>(cos_t + t * 64 + 32 + 4 * c);
+                const f32x4 s2 = *reinterpret_cast<const f32x4*>(sin_t + t * 64 + 32 + 4 * c);
+                f32x4 y1, y2;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    y1[e] = x1[e] * c1[e] + (-x2[e]) * s1[e];
+                    y2[e] = x2[e] * c2[e] + x1[e] * s2[e];
+                }
+                x1 = y1;
+                x2 = y2;
+            }
+            unsigned short* dst = qk16 + ((size_t)b * T + t) * (2 * D) + (size_t)which * D + h * kHeadDim + 4 * c;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const f32x4 x = half ? x2 : x1;
+                _Float16 hh[4], ll[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xe = x[e];
+                    split_act(xe, hh[e], ll[e]);
+                }
+                *reinterpret_cast<u32x2*>(dst + 32 * half) = u32x2{pack_h2(hh[0], hh[1]), pack_h2(hh[2], hh[3])};
+                *reinterpret_cast<u32x2*>(dst + qk_plane + 32 * half) = u32x2{pack_h2(ll[0], ll[1]), pack_h2(ll[2], ll[3])};
+            }
+        }
+    }
+    // ---- v: thread (d, kq) transposes keys 8kq .. 8kq+7 of dimension d ------------------------------
+    {
+        const int d = tid & 63, kq = tid >> 6;
+        _Float16 hh[8], ll[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int t = t0 + 8 * kq + e;
+            const float x = (t < T) ? qkv[((size_t)b * T + t) * RS + 2 * D + h * kHeadDim + d] : 0.0f;
+            split_act(x, hh[e], ll[e]);
+        }
+        // key 8kq+e -> position with bits 2,3 swapped: 16(kq>>1) + 8(e>>2) + 4(kq&1) + (e&3)
+        unsigned short* row = vt16 + (((size_t)b * H + h) * kHeadDim + d) * Tp + t0 + 16 * (kq >> 1) + 4 * (kq & 1);
+        *reinterpret_cast<u32x2*>(row) = u32x2{pack_h2(hh[0], hh[1]), pack_h2(hh[2], hh[3])};
+        *reinterpret_cast<u32x2*>(row + 8) = u32x2{pack_h2(hh[4], hh[5]), pack_h2(hh[6], hh[7])};
+        *reinterpret_cast<u32x2*>(row + vt_plane) = u32x2{pack_h2(ll[0], ll[1]), pack_h2(ll[2], ll[3])};
+        *reinterpret_cast<u32x2*>(row + vt_plane + 8) = u32x2{pack_h2(ll[4], ll[5]), pack_h2(ll[6], ll[7])};
+    }
+}
+
+template <int WPB, int OUT, int NSTG>
+__global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
+    const unsigned short* __restrict__ qk16, size_t qk_plane, const unsigned short* __restrict__ vt16,
+    size_t vt_plane, const int32_t* __restrict__ kv_len, int T, int H, int Tp, float* __restrict__ ctx,
+    unsigned short* __restrict__ ctx16, size_t plane) {
+    constexpr int NT = WPB * 64;
+    // A tile is 16 wave-instructions of 64 chunks (K hi, K lo, V^T hi, V^T lo: 1024 x 16 B).  Every
+    // wave issues the same number NDMA of them (counted vmcnt needs a per-wave constant): when
+    // 16 % WPB != 0 the surplus slots re-issue instruction (i - 16), i.e. write identical bytes twice.
+    constexpr int NDMA = (16 + WPB - 1) / WPB;
+    __shared__ __attribute__((aligned(16))) u32x4 lds[NSTG * A_STAGE];
+
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, kh = lane >> 5;
+    const int D = H * kHeadDim;
+    const int Tk = kv_len ? kv_len[b] : T;
+    const int q0 = (blockIdx.x * WPB + wave) * 32;
+    const bool active = q0 < T;
+
+    // Q fragments straight from the planes: lane (r,kh) holds Q[q0+r][16s + 8kh .. +7]
+    u32x4 qh[4], ql[4];
+    {
+        const int qrow = min(q0 + r, T - 1);
+        const unsigned short* qp = qk16 + ((size_t)b * T + qrow) * (2 * D) + h * kHeadDim + kh * 8;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            qh[s] = *reinterpret_cast<const u32x4*>(qp + s * 16);
+            ql[s] = *reinterpret_cast<const u32x4*>(qp + qk_plane + s * 16);
+        }
+    }
+
+    // DMA map: LDS slot f (0..1023 within a stage) <- global chunk
+    //   f in [0,512):    K plane p=f>>8, key=(f>>3)&31, slot chunk c'=f&7, source chunk c = c' ^ ((key>>1)&7)
+    //   f in [512,1024): V^T plane p=(f-512)>>8, d=((f-512)>>2)&63, c'=f&3, source chunk c = c' ^ ((d>>2)&3)
+    const u32x4* src[NDMA];
+    int step[NDMA];                                       // key index within the tile (K rows), -1 for V^T
+    int slot0[NDMA];                                      // first LDS chunk of the wave-instruction
+#pragma unroll
+    for (int i = 0; i < NDMA; ++i) {
+        int wi = wave + WPB * i;                          // wave-instruction index 0..15 (+ duplicates)
+        if (wi >= 16) wi -= 16;
+        const int f = wi * 64 + lane;
+        slot0[i] = wi * 64;
+        if (f < 512) {
+            const int p = f >> 8, key = (f >> 3) & 31, c = (f & 7) ^ ((key >> 1) & 7);
+            src[i] = reinterpret_cast<const u32x4*>(qk16 + (size_t)p * qk_plane + ((size_t)b * T) * (2 * D) + D + h * kHeadDim) + c;
+            step[i] = key;
+        } else {
+            const int g = f - 512, p = g >> 8, d = (g >> 2) & 63, c = (g & 3) ^ ((d >> 2) & 3);
+            src[i] = reinterpret_cast<const u32x4*>(vt16 + (size_t)p * vt_plane + (((size_t)b * H + h) * kHeadDim + d) * Tp) + c;
+            step[i] = -1;
+        }
+    }
+    auto issue_tile = [&](int kt, int buf) {
+        u32x4* base = lds + buf * A_STAGE;
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) {
+            const u32x4* g;
+            if (step[i] >= 0) {
+                const int key = min(kt * AKT + step[i], T - 1);     // rows past the sequence: clamped (finite, masked by Tk)
+                g = src[i] + (size_t)key * (2 * D / 8);
+            } else {
+                g = src[i] + kt * (AKT / 8);
+            }
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(base + slot0[i]), 16, 0, 0);
+        }
+    };
+
+    // NSTG-deep LDS ring, K/V tiles prefetched NSTG-1 ahead with counted vmcnt (the DMAs stay in
+    // flight across the barrier; a __syncthreads() would drain them)
+    const int nkt = (Tk + AKT - 1) / AKT;
+#pragma unroll
+    for (int t = 0; t < NSTG - 1; ++t)
+        if (t < nkt) issue_tile(t, t);
+
+    f32x16 om[2], oc[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) { om[dt][v] = 0.f; oc[dt][v] = 0.f; }
+    // base-2 online softmax with P scaled by 2^10 (keeps every P hi in fp16's normal range; the
+    // factor cancels in O / l because l accumulates the same scaled P)
+    float m_run = -INFINITY, l_run = 0.f;
+    constexpr float kInvLo = 1.0f / kLoScale;
+    constexpr float kLog2e = 1.4426950408889634f;
+
+    int cur = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        // tile kt landed for this wave once at most `pending` younger tiles remain in flight
+        const int pending = min(NSTG - 2, nkt - 1 - kt);
+        if (pending >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+        else if (pending == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();          // tile kt visible to all waves; slot of tile kt-1 is free
+        asm volatile("" ::: "memory");
+        if (kt + NSTG - 1 < nkt) issue_tile(kt + NSTG - 1, (cur == 0) ? NSTG - 1 : cur - 1);
+        if (active) {
+            const u32x4* Kb = lds + cur * A_STAGE;
+            const u32x4* Vb = Kb + 2 * K_CH;
+            f32x16 sm, sc;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) { sm[v] = 0.f; sc[v] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int ci = r * 8 + ((2 * s + kh) ^ ((r >> 1) & 7));
+                const u32x4 kfh = Kb[ci], kfl = Kb[K_CH + ci];
+                sc = mfma_h(kfh, ql[s], sc);
+                sc = mfma_h(kfl, qh[s], sc);
+                sm = mfma_h(kfh, qh[s], sm);
+            }
+            float st[16];
+#pragma unroll
+            for (int v = 0; v < 16; ++v) st[v] = fmaf(sc[v], kInvLo, sm[v]) * kLog2e;
+            if (kt * AKT + AKT > Tk) {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) {
+                    const int key = kt * AKT + (v & 3) + 8 * (v >> 2) + 4 * kh;
+                    if (key >= Tk) st[v] = -INFINITY;
+                }
+            }
+            float mloc = st[0];
+#pragma unroll
+            for (int v = 1; v < 16; ++v) mloc = fmaxf(mloc, st[v]);
+            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+            const float m_new = fmaxf(m_run, mloc);
+            if (!__all(m_new == m_run)) {                 // exact: no rescale when no lane's max moved
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                l_run *= alpha;
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) { om[dt][v] *= alpha; oc[dt][v] *= alpha; }
+                m_run = m_new;
+            }
+            const float mb = m_run - 10.0f;
+            float psum = 0.f;
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                st[v] = __builtin_amdgcn_exp2f(st[v] - mb);      // P * 2^10 in [0, 1024]
+                psum += st[v];
+            }
+            l_run += psum;
+#pragma unroll
+            for (int m = 0; m < 2; ++m) {
+                u32x4 ph, pl;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {                    // hi by truncation (pkrtz), lo = (p - hi) 2^11
+                    const float p0 = st[8 * m + 2 * e], p1 = st[8 * m + 2 * e + 1];
+                    typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+                    const fp16x2 hi2 = __builtin_amdgcn_cvt_pkrtz(p0, p1);
+                    const float f0 = (float)hi2[0], f1 = (float)hi2[1];
+                    const float l0 = (p0 - f0) * kLoScale, l1 = (p1 - f1) * kLoScale;
+                    const fp16x2 lo2 = __builtin_amdgcn_cvt_pkrtz(l0, l1);
+                    ph[e] = __builtin_bit_cast(unsigned int, hi2);
+                    pl[e] = __builtin_bit_cast(unsigned int, lo2);
+                }
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const int d = dt * 32 + r;
+                    const int ci = d * 4 + ((2 * m + kh) ^ ((d >> 2) & 3));
+                    const u32x4 vfh = Vb[ci], vfl = Vb[V_CH + ci];
+                    oc[dt] = mfma_h(vfh, pl, oc[dt]);
+                    oc[dt] = mfma_h(vfl, ph, oc[dt]);
+                    om[dt] = mfma_h(vfh, ph, om[dt]);
+                }
+            }
+        }
+        cur = (cur == NSTG - 1) ? 0 : cur + 1;
+    }
+
+    if (active) {
+        const float l_tot = l_run + __shfl_xor(l_run, 32);
+        if (q0 + r < T) {
+            const float inv = 1.0f / l_tot;
+            const size_t off = ((size_t)b * T + q0 + r) * D + (size_t)h * kHeadDim + 4 * kh;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float val[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) val[e] = fmaf(oc[dt][4 * g + e], kInvLo, om[dt][4 * g + e]) * inv;
+                    const size_t oo = off + dt * 32 + 8 * g;
+                    if constexpr (OUT == 0) {
+                        *reinterpret_cast<f32x4*>(ctx + oo) = f32x4{val[0], val[1], val[2], val[3]};
+                    } else {
+                        _Float16 hh[4], ll[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) split_act(val[e], hh[e], ll[e]);
+                        *reinterpret_cast<u32x2*>(ctx16 + oo) = u32x2{pack_h2(hh[0], hh[1]), pack_h2(hh[2], hh[3])};
+                        *reinterpret_cast<u32x2*>(ctx16 + plane + oo) = u32x2{pack_h2(ll[0], ll[1]), pack_h2(ll[2], ll[3])};
+                    }
+                }
+        }
+    }
+}
+
+template <int OUT, int NSTG>
+static void launch_att16v2_mode(int wpb, dim3 grid, const unsigned short* qk16, size_t qk_plane,
+                                const unsigned short* vt16, size_t vt_plane, const int32_t* kv_len, int T, int H,
+                                int Tp, float* ctx, unsigned short* ctx16, size_t plane, hipStream_t s) {
+    switch (wpb) {
+        case 1: hipLaunchKernelGGL((attention_f16x3_v2_kernel<1, OUT, NSTG>), grid, dim3(64), 0, s, qk16, qk_plane, vt16, vt_plane, kv_len, T, H, Tp, ctx, ctx16, plane); break;
+        case 2: hipLaunchKernelGGL((attention_f16x3_v2_kernel<2, OUT, NSTG>), grid, dim3(128), 0, s, qk16, qk_plane, vt16, vt_plane, kv_len, T, H, Tp, ctx, ctx16, plane); break;
+        case 3: hipLaunchKernelGGL((attention_f16x3_v2_kernel<3, OUT, NSTG>), grid, dim3(192), 0, s, qk16, qk_plane, vt16, vt_plane, kv_len, T, H, Tp, ctx, ctx16, plane); break;
+        default: hipLaunchKernelGGL((attention_f16x3_v2_kernel<4, OUT, NSTG>), grid, dim3(256), 0, s, qk16, qk_plane, vt16, vt_plane, kv_len, T, H, Tp, ctx, ctx16, plane); break;
+    }
+}
+
+// qkv fp32 [B*T, 3D] -> (rotary) -> split planes -> attention.  Scratch: qk16 2 planes of B*T*2D
+// halfs (plane stride qk_plane), vt16 2 planes of B*H*64*Tp halfs (plane stride vt_plane), Tp = T
+// rounded up to 32.
+int launch_attention_f16x3_v2(const float* qkv, const int32_t* kv_len, const float* cos_t, const float* sin_t,
+                              int rotary, int B, int T, int H, unsigned short* qk16, size_t qk_plane,
+                              unsigned short* vt16, size_t vt_plane, float* ctx, unsigned short* ctx16, size_t plane,
+                              int out_mode, hipStream_t s) {
+    if (B <= 0 || T <= 0 || H <= 0 || out_mode < 0 || out_mode > 1) {
+        set_error("attention_f16x3_v2: bad arguments B=%d T=%d H=%d out=%d", B, T, H, out_mode);
+        return PGMI_EINVAL;
+    }
+    const int n32 = (T + 31) / 32, Tp = n32 * 32;
+    if (qkv)      // operands not prepared by the fused QKV epilogue: run the prep pass
+        hipLaunchKernelGGL(qkv_prep_kernel, dim3(n32, H, B), dim3(256), 0, s, qkv, cos_t, sin_t, rotary, T, H, Tp,
+                           qk16, qk_plane, vt16, vt_plane);
+    const int nblk = (n32 + 3) / 4;
+    int wpb = (n32 + nblk - 1) / nblk;
+    if (wpb == 3) wpb = 4;                        // measured: a 4th (idle) wave that only helps loading beats 3-wave blocks
+    const dim3 grid(nblk, H, B);
+    static const int nstg = getenv("PGMI_ATT_STAGES") ? atoi(getenv("PGMI_ATT_STAGES")) : 3;
+    if (nstg == 4) {
+        if (out_mode == 0) launch_att16v2_mode<0, 4>(wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, T, H, Tp, ctx, ctx16, plane, s);
+        else launch_att16v2_mode<1, 4>(wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, T, H, Tp, ctx, ctx16, plane, s);
+    } else {
+        if (out_mode == 0) launch_att16v2_mode<0, 3>(wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, T, H, Tp, ctx, ctx16, plane, s);
+        else launch_att16v2_mode<1, 3>(wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, T, H, Tp, ctx, ctx16, plane, s);
+    }
+    PGMI_HIP(hipGetLastError());
+    return PGMI_OK;
+}
+
+template <int OUT>
+static void launch_att16_mode(int wpb, dim3 grid, const float* qkv, const int32_t* kv_len, int T, int H,
+                              float* ctx, unsigned short* ctx16, size_t plane, hipStream_t s) {
+    switch (wpb) {
+        case 1: hipLaunchKernelGGL((attention_f16x3_kernel<1, OUT>), grid, dim3(64), 0, s, qkv, kv_len, T, H, ctx, ctx16, plane); break;
+        case 2: hipLaunchKernelGGL((attention_f16x3_kernel<2, OUT>), grid, dim3(128), 0, s, qkv, kv_len, T, H, ctx, ctx16, plane); break;
+        case 3: hipLaunchKernelGGL((attention_f16x3_kernel<3, OUT>), grid, dim3(192), 0, s, qkv, kv_len, T, H, ctx, ctx16, plane); break;
+        default: hipLaunchKernelGGL((attention_f16x3_kernel<4, OUT>), grid, dim3(256), 0, s, qkv, kv_len, T, H, ctx, ctx16, plane); break;
+    }
+}
+
+// out_mode 0: fp32 ctx; 1: fp16 hi/lo planes (the f16x3 out-projection operand)
+int launch_attention_f16x3(const float* qkv, const int32_t* kv_len, int B, int T, int H, float* ctx,
+                           unsigned short* ctx16, size_t plane, int out_mode, hipStream_t s) {
+    if (B <= 0 || T <= 0 || H <= 0 || out_mode < 0 || out_mode > 1) {
+        set_error("attention_f16x3: bad arguments B=%d T=%d H=%d out=%d", B, T, H, out_mode);
+        return PGMI_EINVAL;
+    }
+    const int n32 = (T + 31) / 32;
+    const int nblk = (n32 + 3) / 4;
+    const int wpb = (n32 + nblk - 1) / nblk;
+    const dim3 grid(nblk, H, B);
+    if (out_mode == 0) launch_att16_mode<0>(wpb, grid, qkv, kv_len, T, H, ctx, ctx16, plane, s);
+    else launch_att16_mode<1>(wpb, grid, qkv, kv_len, T, H, ctx, ctx16, plane, s);
+    PGMI_HIP(hipGetLastError());
+    return PGMI_OK;
+}
+
+}  // namespace pgmi

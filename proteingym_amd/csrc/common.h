@@ -85,6 +85,10 @@ int launch_gemm16(const unsigned short* A, size_t a_plane, const unsigned short*
                   const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
                   int M, int N, int K, int epilogue, float out_scale, int planes, bool bf, int variant,
                   hipStream_t s);
+int launch_gemm16_qkv(const unsigned short* A, size_t a_plane, const unsigned short* W, size_t w_plane,
+                      const float* bias, int M, int D, int K, float out_scale, unsigned short* qk16, size_t qk_plane,
+                      unsigned short* vt16, size_t vt_plane, const float* cos_t, const float* sin_t, int rotary,
+                      int T, int H, int variant, hipStream_t s);
 void launch_split16(const float* x, int64_t n, float scale, int mode, unsigned short* out, size_t plane,
                     hipStream_t s);
 
@@ -93,5 +97,18 @@ void launch_split16(const float* x, int64_t n, float scale, int mode, unsigned s
 // [B*T, H*64] (out_mode 0), or fp16 hi/lo planes (1) / one bf16 plane (2) in ctx16.
 int launch_attention_f32(const float* qkv, const int32_t* kv_len, int B, int T, int H, float* ctx,
                          unsigned short* ctx16, size_t plane, int out_mode, hipStream_t s);
+
+// ---- attention_f16.hip -------------------------------------------------------------------
+// Same interface as launch_attention_f32, split-fp16 (f16x3) arithmetic on the 16-bit MFMA pipe.
+// out_mode 0: fp32 ctx; 1: fp16 hi/lo planes.
+int launch_attention_f16x3(const float* qkv, const int32_t* kv_len, int B, int T, int H, float* ctx,
+                           unsigned short* ctx16, size_t plane, int out_mode, hipStream_t s);
+// v2: a prep pass writes attention-ready fp16 planes (rotary fused), the attention kernel moves tiles
+// with direct-to-LDS loads.  Scratch: qk16 (2 planes, stride qk_plane >= B*T*2*H*64 halfs) and vt16
+// (2 planes, stride vt_plane >= B*H*64*roundup(T,32) halfs).
+int launch_attention_f16x3_v2(const float* qkv, const int32_t* kv_len, const float* cos_t, const float* sin_t,
+                              int rotary, int B, int T, int H, unsigned short* qk16, size_t qk_plane,
+                              unsigned short* vt16, size_t vt_plane, float* ctx, unsigned short* ctx16, size_t plane,
+                              int out_mode, hipStream_t s);
 
 }  // namespace pgmi

@@ -39,6 +39,14 @@ __device__ __forceinline__ float gelu_erf16(float x) {
     return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
+struct QkvOut {
+    unsigned short* vt16;
+    size_t vt_plane;
+    const float* cos_t;
+    const float* sin_t;
+    int T, H, Tp, rotary;
+};
+
 template <bool BF>
 __device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
     if constexpr (BF) {
@@ -54,12 +62,16 @@ __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
     return (unsigned short)(u >> 16);
 }
 
-// OUT: 0 = fp32 [M,N];  1 = 16-bit planes [PLANES][M,N] (split for f16x3, bf16 for PLANES==1)
+// OUT: 0 = fp32 [M,N];  1 = 16-bit planes [PLANES][M,N] (split for f16x3, bf16 for PLANES==1);
+//      2 = attention operands straight from the fused QKV projection (f16x3 only): q|k as split
+//          planes qk16 [2][M][2D] (ESM2 rotary applied here, rotary_embedding.py:11-20), v as the
+//          transposed, key-permuted planes vt16 [2][B*H*64][Tp] that attention_f16.hip consumes.
 template <int WM, int WN, int TM, int TN, int BK, int PLANES, bool BF, int EPI, int OUT>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 2) void gemm16_kernel(
     const unsigned short* __restrict__ A, size_t a_plane, const unsigned short* __restrict__ W,
     size_t w_plane, const float* __restrict__ bias, const float* residual, float* Cf,
-    unsigned short* Ch, size_t c_plane, int M, int N, int K, float out_scale, int tiles_m, int tiles_n) {
+    unsigned short* Ch, size_t c_plane, int M, int N, int K, float out_scale, int tiles_m, int tiles_n,
+    QkvOut qo) {
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int CPR = BK / 8;                                  // 16-byte chunks per row
@@ -191,6 +203,75 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 2) void gemm16_k
         cur ^= 1;
     }
 
+    if constexpr (OUT == 2) {
+        static_assert(TN == 2 && PLANES == 2 && !BF, "QKV attention-operand epilogue needs one head (64 columns) per wave");
+        const int Dm = N / 3;
+        const int nb = n0 + wn * 64;                       // first column of this wave's head
+        if (nb >= N) return;
+        const int which = nb / Dm, hcol = nb - which * Dm, hh = hcol >> 6;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + (wm * TM + i) * 32 + r;
+            if (m >= M) continue;
+            const int bb = m / qo.T, t = m - bb * qo.T;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d0 = 8 * g + 4 * kh;             // dims d0..d0+3 (x0) and d0+32.. (x1) of the head
+                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + nb + d0);
+                const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + nb + 32 + d0);
+                float x0[4], x1[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    x0[e] = acc[0][i][4 * g + e] * out_scale + b0[e];
+                    x1[e] = acc[1][i][4 * g + e] * out_scale + b1[e];
+                }
+                if (which < 2) {
+                    if (qo.rotary) {
+                        const f32x4 c1 = *reinterpret_cast<const f32x4*>(qo.cos_t + t * 64 + d0);
+                        const f32x4 s1 = *reinterpret_cast<const f32x4*>(qo.sin_t + t * 64 + d0);
+                        const f32x4 c2 = *reinterpret_cast<const f32x4*>(qo.cos_t + t * 64 + 32 + d0);
+                        const f32x4 s2 = *reinterpret_cast<const f32x4*>(qo.sin_t + t * 64 + 32 + d0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float y0 = x0[e] * c1[e] + (-x1[e]) * s1[e];
+                            const float y1 = x1[e] * c2[e] + x0[e] * s2[e];
+                            x0[e] = y0;
+                            x1[e] = y1;
+                        }
+                    }
+                    unsigned short* dst = Ch + (size_t)m * (2 * Dm) + (size_t)which * Dm + hcol + d0;
+                    h4 hi0, lo0, hi1, lo1;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        _Float16 a, b2;
+                        split_act(x0[e], a, b2); hi0[e] = a; lo0[e] = b2;
+                        split_act(x1[e], a, b2); hi1[e] = a; lo1[e] = b2;
+                    }
+                    *reinterpret_cast<h4*>(dst) = hi0;
+                    *reinterpret_cast<h4*>(dst + c_plane) = lo0;
+                    *reinterpret_cast<h4*>(dst + 32) = hi1;
+                    *reinterpret_cast<h4*>(dst + c_plane + 32) = lo1;
+                } else {
+                    const int tk = t & 31;
+                    const int pos = (t & ~31) + ((tk & 0x13) | ((tk & 4) << 1) | ((tk & 8) >> 1));   // swap key bits 2,3
+                    unsigned short* col = qo.vt16 + (((size_t)bb * qo.H + hh) * kHeadDim + d0) * qo.Tp + pos;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        _Float16 a0, l0, a1, l1;
+                        split_act(x0[e], a0, l0);
+                        split_act(x1[e], a1, l1);
+                        unsigned short* c0 = col + (size_t)e * qo.Tp;
+                        unsigned short* c1p = c0 + (size_t)32 * qo.Tp;
+                        c0[0] = __builtin_bit_cast(unsigned short, a0);
+                        c0[qo.vt_plane] = __builtin_bit_cast(unsigned short, l0);
+                        c1p[0] = __builtin_bit_cast(unsigned short, a1);
+                        c1p[qo.vt_plane] = __builtin_bit_cast(unsigned short, l1);
+                    }
+                }
+            }
+        }
+        return;
+    }
     // ---- epilogue: lane holds column m = m_base + r of C^T, rows n = (v&3) + 8(v>>2) + 4kh ----
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -468,7 +549,8 @@ static int launch_cfg_p(const unsigned short* A, size_t a_plane, const unsigned 
 template <int WM, int WN, int TM, int TN, int BK, int PLANES, bool BF>
 static int launch_cfg(const unsigned short* A, size_t a_plane, const unsigned short* W, size_t w_plane,
                       const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
-                      int M, int N, int K, int epilogue, float out_scale, hipStream_t s) {
+                      int M, int N, int K, int epilogue, float out_scale, hipStream_t s, const QkvOut* qkv = nullptr) {
+    QkvOut qo{};
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int CPR = BK / 8;
     constexpr size_t lds_bytes = (size_t)2 * (BM + BN) * CPR * PLANES * 16;
@@ -483,11 +565,16 @@ static int launch_cfg(const unsigned short* A, size_t a_plane, const unsigned sh
             if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PGMI_EHIP; } \
         }                                                                                                \
         hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, A, a_plane, W, w_plane, bias, residual, Cf, Ch, \
-                           c_plane, M, N, K, out_scale, tiles_m, tiles_n);                               \
+                           c_plane, M, N, K, out_scale, tiles_m, tiles_n, qo);                           \
     } while (0)
-    const int out = Ch ? 1 : 0;
-    if (epilogue == EPI_GELU) { if (out) PGMI_LAUNCH16(EPI_GELU, 1); else PGMI_LAUNCH16(EPI_GELU, 0); }
-    else { if (out) PGMI_LAUNCH16(EPI_NONE, 1); else PGMI_LAUNCH16(EPI_NONE, 0); }
+    if (qkv) {
+        if constexpr (PLANES == 2 && !BF && TN == 2) { qo = *qkv; PGMI_LAUNCH16(EPI_NONE, 2); }
+        else { set_error("gemm16: fused QKV epilogue unavailable for this configuration"); return PGMI_EINVAL; }
+    } else {
+        const int out = Ch ? 1 : 0;
+        if (epilogue == EPI_GELU) { if (out) PGMI_LAUNCH16(EPI_GELU, 1); else PGMI_LAUNCH16(EPI_GELU, 0); }
+        else { if (out) PGMI_LAUNCH16(EPI_NONE, 1); else PGMI_LAUNCH16(EPI_NONE, 0); }
+    }
 #undef PGMI_LAUNCH16
     PGMI_HIP(hipGetLastError());
     return PGMI_OK;
@@ -520,6 +607,25 @@ int launch_gemm16(const unsigned short* A, size_t a_plane, const unsigned short*
     }
     set_error("gemm16: unsupported mode planes=%d bf=%d", planes, (int)bf);
     return PGMI_EINVAL;
+}
+
+// Fused QKV projection for the f16x3 attention: writes qk16 (q|k split planes, [M][2D]) and vt16
+// (transposed key-permuted V planes) instead of an fp32 [M,3D] tensor; rotary applied to q,k if set.
+int launch_gemm16_qkv(const unsigned short* A, size_t a_plane, const unsigned short* W, size_t w_plane,
+                      const float* bias, int M, int D, int K, float out_scale, unsigned short* qk16, size_t qk_plane,
+                      unsigned short* vt16, size_t vt_plane, const float* cos_t, const float* sin_t, int rotary,
+                      int T, int H, int variant, hipStream_t s) {
+    if (M <= 0 || D <= 0 || (K % 64) || (D % 64) || M % T) {
+        set_error("gemm16_qkv: unsupported shape M=%d D=%d K=%d T=%d", M, D, K, T);
+        return PGMI_EINVAL;
+    }
+    QkvOut qo{vt16, vt_plane, cos_t, sin_t, T, H, (T + 31) / 32 * 32, rotary};
+    const int N = 3 * D;
+    switch (variant) {
+        case 0: return launch_cfg<2, 2, 2, 2, 32, 2, false>(A, a_plane, W, w_plane, bias, nullptr, nullptr, qk16, qk_plane, M, N, K, EPI_NONE, out_scale, s, &qo);
+        case 3: return launch_cfg<4, 2, 2, 2, 32, 2, false>(A, a_plane, W, w_plane, bias, nullptr, nullptr, qk16, qk_plane, M, N, K, EPI_NONE, out_scale, s, &qo);
+        default: return launch_cfg<2, 4, 4, 2, 32, 2, false>(A, a_plane, W, w_plane, bias, nullptr, nullptr, qk16, qk_plane, M, N, K, EPI_NONE, out_scale, s, &qo);
+    }
 }
 
 // ---- fp32 -> 16-bit planes (used for weights at load time and by the op-level tests) ----------

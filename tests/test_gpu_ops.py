@@ -46,16 +46,19 @@ def test_gemm_fp32(lib, M, N, K, epi, res):
     assert err < 2e-5 * np.sqrt(K / 128), err
 
 
+@pytest.mark.parametrize("prec", [_lib.PREC_FP32, _lib.PREC_F16X3])
 @pytest.mark.parametrize("B,T,H,kv", [(2, 32, 2, None), (3, 70, 2, None), (2, 288, 4, None), (1, 1024, 2, None),
-                                      (3, 72, 2, [72, 43, 1]), (2, 129, 1, [100, 129])])
-def test_attention_fp32(lib, B, T, H, kv):
+                                      (3, 72, 2, [72, 43, 1]), (2, 129, 1, [100, 129]), (2, 5, 1, None)])
+def test_attention(lib, prec, B, T, H, kv):
     rng = np.random.default_rng(2)
     D = H * 64
     qkv = rng.standard_normal((B, T, 3 * D)).astype(np.float32)
     qkv[..., :D] *= 0.4
     kvl = np.asarray(kv, np.int32) if kv is not None else None
     ctx = np.empty((B, T, D), np.float32)
-    _lib.check(lib.pgmi_op_attention(0, _lib.PREC_FP32, _p(qkv), _p(kvl, _lib._i32p) if kvl is not None else None,
+    qkv[0, 0, :D] *= 6.0            # a spiky query row: the running max jumps (online-softmax rescale path)
+    qkv[..., 2 * D:] += rng.choice([0.0, 1e-3, 5.0], size=(B, T, 1)).astype(np.float32)   # tiny and large V rows
+    _lib.check(lib.pgmi_op_attention(0, prec, _p(qkv), _p(kvl, _lib._i32p) if kvl is not None else None,
                                      B, T, H, 0, _p(ctx)))
     t = torch.from_numpy(qkv).double()
     q, k, v = [t[..., i * D:(i + 1) * D].reshape(B, T, H, 64).transpose(1, 2) for i in range(3)]
@@ -68,16 +71,17 @@ def test_attention_fp32(lib, B, T, H, kv):
         for b in range(B):
             ctx[b, kv[b]:] = 0
             ref[b, kv[b]:] = 0
-    assert np.abs(ctx - ref).max() < 2e-5
+    assert np.abs(ctx - ref).max() < 2e-5 * max(1.0, np.abs(ref).max())
 
 
-def test_attention_rotary(lib):
+@pytest.mark.parametrize("prec", [_lib.PREC_FP32, _lib.PREC_F16X3])
+def test_attention_rotary(lib, prec):
     rng = np.random.default_rng(3)
     B, T, H = 2, 50, 2
     D = H * 64
     qkv = rng.standard_normal((B, T, 3 * D)).astype(np.float32)
     ctx = np.empty((B, T, D), np.float32)
-    _lib.check(lib.pgmi_op_attention(0, _lib.PREC_FP32, _p(qkv), None, B, T, H, 1, _p(ctx)))
+    _lib.check(lib.pgmi_op_attention(0, prec, _p(qkv), None, B, T, H, 1, _p(ctx)))
     t = torch.from_numpy(qkv)
     q, k, v = [t[..., i * D:(i + 1) * D].reshape(B, T, H, 64).transpose(1, 2) for i in range(3)]
     inv_freq = 1.0 / (10000 ** (torch.arange(0, 64, 2).float() / 64))
