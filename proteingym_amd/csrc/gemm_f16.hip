@@ -25,6 +25,8 @@
 // flight during the MFMAs of tile t; one barrier per K tile.
 // Roofline: MFMA-bound; peak 2.5 PFLOP/s of 16-bit MFMA = 833 TFLOP/s of fp32-equivalent
 // algorithmic FLOPs in f16x3.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace pgmi {
@@ -45,6 +47,8 @@ struct QkvOut {
     const float* cos_t;
     const float* sin_t;
     int T, H, Tp, rotary;
+    int dbg_row_mod;      // tuning experiments only: wrap activation rows (keeps the A operand cache-resident)
+    int dbg_flags;        // tuning experiments only: 1 = skip global->LDS staging after tile 0, 2 = also skip ds_reads
 };
 
 template <bool BF>
@@ -107,7 +111,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 2) void gemm16_k
     for (int i = 0; i < A_LD; ++i) {
         const int f = tid + NT * i;
         const int p = f / (BM * CPR), g = f % (BM * CPR), row = g / CPR, c = g % CPR;
-        const int am = min(m0 + row, M - 1);
+        int am = min(m0 + row, M - 1);
+        if (qo.dbg_row_mod) am %= qo.dbg_row_mod;
         a_src[i] = reinterpret_cast<const u32x4*>(A + (size_t)p * a_plane + (size_t)am * K) + c;
         a_dst[i] = (p * BM + row) * CPR + swz(row, c);
     }
@@ -152,15 +157,17 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 2) void gemm16_k
 
     const int nk = K / BK;
     int cur = 0;
+    const bool dbg_nostage = qo.dbg_flags & 1, dbg_noread = qo.dbg_flags & 2;
+    u32x4 af[PLANES][TM], wf[PLANES][TN];
     for (int kt = 0; kt < nk; ++kt) {
-        const bool more = kt + 1 < nk;
-        if (more) stage_load(kt + 1);
+        const bool more = (kt + 1 < nk) && !dbg_nostage;
+        if (more && !(qo.dbg_flags & 8)) stage_load(kt + 1);
         const u32x4* Ab = lds + cur * STAGE;
         const u32x4* Wb = Ab + A_CH;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             const int c = ks * 2 + kh;
-            u32x4 af[PLANES][TM], wf[PLANES][TN];
+            if (!(dbg_noread && kt > 0))
 #pragma unroll
             for (int p = 0; p < PLANES; ++p) {
 #pragma unroll
@@ -198,9 +205,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 2) void gemm16_k
                     acc[j][i] = mfma16<BF>(wf[0][j], af[0][i], acc[j][i]);
                 }
         }
-        if (more) stage_store(cur ^ 1);
+        if (more && !(qo.dbg_flags & 4)) stage_store(cur ^ 1);
         __syncthreads();
-        cur ^= 1;
+        if (!dbg_nostage && !(qo.dbg_flags & 12)) cur ^= 1;
     }
 
     if constexpr (OUT == 2) {
@@ -551,6 +558,10 @@ static int launch_cfg(const unsigned short* A, size_t a_plane, const unsigned sh
                       const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
                       int M, int N, int K, int epilogue, float out_scale, hipStream_t s, const QkvOut* qkv = nullptr) {
     QkvOut qo{};
+    static const int dbg_mod = getenv("PGMI_GEMM_DBG_ROWMOD") ? atoi(getenv("PGMI_GEMM_DBG_ROWMOD")) : 0;
+    static const int dbg_flags = getenv("PGMI_GEMM_DBG_FLAGS") ? atoi(getenv("PGMI_GEMM_DBG_FLAGS")) : 0;
+    qo.dbg_row_mod = dbg_mod;
+    qo.dbg_flags = dbg_flags;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
     constexpr int CPR = BK / 8;
     constexpr size_t lds_bytes = (size_t)2 * (BM + BN) * CPR * PLANES * 16;
