@@ -162,3 +162,141 @@ def reference_model(path):
     model, alphabet = cf.pretrained.load_model_and_alphabet(str(path))
     model.eval()
     return model, alphabet
+
+
+# ---- Tranception ----------------------------------------------------------------------------
+# The reference module targets transformers==4.32.1 (environments/proteingym_env.txt:119); this
+# image has 5.x.  Out-of-tree shims, none of which touches the arithmetic:
+#   * transformers.modeling_utils.{Conv1D, SequenceSummary, find_pruneable_heads_and_indices,
+#     prune_conv1d_layer} and transformers.file_utils docstring decorators were moved/removed
+#     (tranception/model_pytorch.py:13-27) -> re-exported / no-op decorators;
+#   * transformers.utils.model_parallel_utils is gone (:33) -> stub (model-parallel code is dead
+#     on the scoring path);
+#   * PreTrainedModel.init_weights() is called before post_init() by the old-style constructors
+#     (:386,:642) -> provide the attribute it expects; get_head_mask() was removed (:524) ->
+#     returns [None]*n_layer exactly like the old implementation does for head_mask=None;
+#   * Bio.Align.Applications (tranception/utils/msa_utils.py:7) -> stub (indel re-alignment only).
+REF_TRANCEPTION = os.path.join(REF_ROOT, "proteingym", "baselines", "tranception")
+_tr = None
+
+
+def load_reference_tranception():
+    """Returns (tranception package, tokenizer) from the unmodified reference."""
+    global _tr
+    if _tr is not None:
+        return _tr
+    import transformers
+    import transformers.modeling_utils as mu
+    import transformers.file_utils as fu
+    from transformers.pytorch_utils import Conv1D
+    if not hasattr(mu, "Conv1D"):
+        mu.Conv1D = Conv1D
+    for name in ("SequenceSummary", "find_pruneable_heads_and_indices", "prune_conv1d_layer"):
+        if not hasattr(mu, name):
+            setattr(mu, name, getattr(transformers.pytorch_utils, name, None) or (lambda *a, **k: None))
+    for name in ("ModelOutput", "add_code_sample_docstrings", "add_start_docstrings",
+                 "add_start_docstrings_to_model_forward", "replace_return_docstrings"):
+        if not hasattr(fu, name):
+            src = getattr(transformers.utils, name, None)
+            setattr(fu, name, src if src is not None else (lambda *a, **k: (lambda f: f)))
+    if "transformers.utils.model_parallel_utils" not in sys.modules:
+        mp = types.ModuleType("transformers.utils.model_parallel_utils")
+        mp.assert_device_map = lambda *a, **k: None
+        mp.get_device_map = lambda *a, **k: None
+        sys.modules["transformers.utils.model_parallel_utils"] = mp
+    for n in ["Bio", "Bio.Align", "Bio.Align.Applications"]:
+        sys.modules.setdefault(n, types.ModuleType(n))
+    sys.modules["Bio.Align.Applications"].ClustalOmegaCommandline = object
+    if not getattr(mu.PreTrainedModel, "_pgmi_patched", False):
+        _orig_iw = mu.PreTrainedModel.init_weights
+
+        def _iw(self):
+            if not hasattr(self, "all_tied_weights_keys"):
+                self.all_tied_weights_keys = {}
+            return _orig_iw(self)
+        mu.PreTrainedModel.init_weights = _iw
+        if not hasattr(mu.PreTrainedModel, "get_head_mask"):
+            mu.PreTrainedModel.get_head_mask = lambda self, head_mask, n, *a, **k: [None] * n
+        mu.PreTrainedModel._pgmi_patched = True
+    if REF_TRANCEPTION not in sys.path:
+        sys.path.insert(0, REF_TRANCEPTION)
+    import tranception
+    from tranception import config as tconfig, model_pytorch  # noqa: F401
+    from transformers import PreTrainedTokenizerFast
+    tok = PreTrainedTokenizerFast(
+        tokenizer_file=os.path.join(REF_TRANCEPTION, "tranception", "utils", "tokenizers", "Basic_tokenizer"),
+        unk_token="[UNK]", sep_token="[SEP]", pad_token="[PAD]", cls_token="[CLS]", mask_token="[MASK]")
+    _tr = (tranception, tok)
+    return _tr
+
+
+def make_tranception_checkpoint(dirpath, n_layer, n_embd, n_head, seed, n_ctx=1024, embed_std=0.3):
+    """Random-weight Tranception checkpoint directory (config.json + pytorch_model.bin, the two
+    files score_tranception_proteingym.py:79,100 read) built with the reference constructor."""
+    import json
+    import torch
+    tranception, tok = load_reference_tranception()
+    cfg = tranception.config.TranceptionConfig(
+        vocab_size=25, n_embd=n_embd, n_head=n_head, n_layer=n_layer, n_positions=n_ctx, n_ctx=n_ctx,
+        attention_mode="tranception", position_embedding="grouped_alibi", activation_function="squared_relu",
+        attn_pdrop=0.0, resid_pdrop=0.0, embd_pdrop=0.0, bos_token_id=1, eos_token_id=2)
+    torch.manual_seed(seed)
+    model = tranception.model_pytorch.TranceptionLMHeadModel(cfg)
+    g = torch.Generator().manual_seed(500 + seed)
+    sd = model.state_dict()
+    with torch.no_grad():
+        for k, v in sd.items():
+            if k.endswith(".attn.bias") or k.endswith("masked_bias") or k.endswith("alibi"):
+                continue
+            if k.endswith("wte.weight"):
+                v.copy_(torch.randn(v.shape, generator=g) * embed_std)
+            elif "ln_" in k:
+                v.copy_((1.0 if k.endswith("weight") else 0.0) + (0.1 if k.endswith("weight") else 0.05) * torch.randn(v.shape, generator=g))
+            elif "depthwiseconv" in k:
+                v.copy_(torch.randn(v.shape, generator=g) * (0.4 if k.endswith("weight") else 0.05))
+            elif k.endswith(".bias"):
+                v.copy_(0.02 * torch.randn(v.shape, generator=g))
+            elif k.endswith("c_attn.weight") or k.endswith("c_fc.weight") or k.endswith("c_proj.weight"):
+                v.copy_(torch.randn(v.shape, generator=g) / (v.shape[0] ** 0.5))      # Conv1D: [in, out]
+        sd["lm_head.weight"] = sd["transformer.wte.weight"]                            # tied (GPT2 default)
+    os.makedirs(dirpath, exist_ok=True)
+    keep = {k: v.clone() for k, v in sd.items()
+            if not (k.endswith(".attn.bias") or k.endswith("masked_bias"))}      # causal-mask buffers
+    torch.save(keep, os.path.join(dirpath, "pytorch_model.bin"))
+    jc = dict(vocab_size=25, n_embd=n_embd, n_head=n_head, n_layer=n_layer, n_positions=n_ctx, n_ctx=n_ctx,
+              n_inner=None, activation_function="squared_relu", layer_norm_epsilon=cfg.layer_norm_epsilon,
+              scale_attn_weights=True, attention_mode="tranception", position_embedding="grouped_alibi",
+              model_type="tranception", architectures=["TranceptionLMHeadModel"])
+    json.dump(jc, open(os.path.join(dirpath, "config.json"), "w"), indent=1)
+    return dirpath
+
+
+def reference_tranception_model(dirpath, scoring_window="optimal", retrieval=None):
+    """Instantiate the reference model from a checkpoint directory the way
+    score_tranception_proteingym.py:79-104 does (config.json -> TranceptionConfig, forced
+    attention_mode / position_embedding, tokenizer, optional retrieval fields) and load the
+    weights with load_state_dict (from_pretrained's file handling differs across transformers
+    versions; the tensors and module code are the reference's)."""
+    import json
+    import torch
+    tranception, tok = load_reference_tranception()
+    c = json.load(open(os.path.join(dirpath, "config.json")))
+    c.pop("model_type", None)
+    c.pop("architectures", None)
+    cfg = tranception.config.TranceptionConfig(**c)
+    cfg.attention_mode = "tranception"
+    cfg.position_embedding = "grouped_alibi"
+    cfg.tokenizer = tok
+    cfg.scoring_window = scoring_window
+    if retrieval:
+        for k, v in retrieval.items():
+            setattr(cfg, k, v)
+    else:
+        cfg.retrieval_aggregation_mode = None
+    model = tranception.model_pytorch.TranceptionLMHeadModel(cfg)
+    sd = torch.load(os.path.join(dirpath, "pytorch_model.bin"), map_location="cpu")
+    missing, unexpected = model.load_state_dict(sd, strict=False)
+    bad = [k for k in missing if not (k.endswith(".attn.bias") or k.endswith("masked_bias") or k.endswith("alibi"))]
+    assert not bad and not unexpected, (bad, unexpected)
+    model.eval()
+    return model, tok

@@ -1,0 +1,323 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement ("port") of ProteinGym's Tranception scoring path.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+file.  The product (``proteingym_amd``) never does.
+
+Restated (file:line relative to /root/reference/proteingym/baselines/tranception):
+  * tokenizer (25 symbols, [CLS] seq [SEP], right-padding)   tranception/utils/tokenizers/Basic_tokenizer
+  * ALiBi slopes / grouped bias                               tranception/model_pytorch.py:50-71,373-380
+  * causal depth-wise convolution on q,k,v                    :73-88,240-251
+  * attention (scale, causal -1e4 fill, +alibi, softmax)      :155-183
+  * block (ln_1, attn, ln_2, squared-ReLU MLP)                :265-360 ; tranception/activations.py:79-84
+  * model + LM head (tied to wte)                             :438-632,731-783
+  * retrieval fusion                                          :783-846
+  * MSA prior                                                 tranception/utils/msa_utils.py:63-138
+  * scoring: slices, NLL, /len, delta to WT, mirror, average  tranception/utils/scoring_utils.py:77-203 ;
+                                                              model_pytorch.py:878-928
+
+PINNING: the reference has no tests for this path.  The oracle is pinned against the reference
+itself, run in this container through the import shims of oracle/ref_harness.py
+(load_reference_tranception): tests/golden/make_golden_tranception.py froze its outputs into
+tests/golden/golden_tranception.npz, tests/test_oracle_pinning.py checks this file against them.
+"""
+from __future__ import annotations
+
+import json
+import math
+import os
+
+import numpy as np
+import pandas as pd
+import torch
+
+VOCAB = {'[UNK]': 0, '[CLS]': 1, '[SEP]': 2, '[PAD]': 3, '[MASK]': 4, 'A': 5, 'C': 6, 'D': 7, 'E': 8, 'F': 9,
+         'G': 10, 'H': 11, 'I': 12, 'K': 13, 'L': 14, 'M': 15, 'N': 16, 'P': 17, 'Q': 18, 'R': 19, 'S': 20,
+         'T': 21, 'V': 22, 'W': 23, 'Y': 24}
+CLS, SEP, PAD, UNK = 1, 2, 3, 0
+AA_vocab = "ACDEFGHIKLMNPQRSTVWY"
+
+
+def encode(seq: str):
+    """[CLS] + one token per letter (unknown -> [UNK]) + [SEP] (the tokenizer's TemplateProcessing)."""
+    return [CLS] + [VOCAB.get(c, UNK) for c in seq] + [SEP]
+
+
+def encode_batch(seqs, n_ctx=1024):
+    """model_pytorch.py:930-939: X/B/J/Z replaced by random eligible letters (np.random.choice, as
+    the reference -- seed numpy for reproducibility), truncation to n_ctx, right-padding with [PAD].
+    Returns (input_ids int64 [B,T], attention_mask int64 [B,T])."""
+    def rep(s, ch, choices):
+        idx = [i for i, c in enumerate(s) if c == ch]
+        if not idx:
+            return s
+        r = np.random.choice(a=list(choices), size=len(idx), replace=True)
+        s = list(s)
+        for i, p in enumerate(idx):
+            s[p] = r[i]
+        return "".join(s)
+    out = []
+    for s in seqs:
+        for ch, choices in (("X", AA_vocab), ("B", "DN"), ("J", "IL"), ("Z", "EQ")):
+            s = rep(s, ch, choices)
+        out.append(encode(s)[:n_ctx])
+    T = max(len(e) for e in out)
+    ids = np.full((len(out), T), PAD, dtype=np.int64)
+    mask = np.zeros((len(out), T), dtype=np.int64)
+    for i, e in enumerate(out):
+        ids[i, :len(e)] = e
+        mask[i, :len(e)] = 1
+    return ids, mask
+
+
+def get_slopes(n, mode="standard_alibi"):
+    """model_pytorch.py:50-71."""
+    def pow2(n):
+        start = (2 ** (-2 ** -(math.log2(n) - 3)))
+        return [start * start ** i for i in range(n)]
+    if mode == "grouped_alibi":
+        n = n // 4
+    if math.log2(n).is_integer():
+        result = pow2(n)
+    else:
+        c = 2 ** math.floor(math.log2(n))
+        result = pow2(c) + get_slopes(2 * c)[0::2][:n - c]
+    if mode == "grouped_alibi":
+        result = result * 4
+    return result
+
+
+def load_checkpoint(dirpath, dtype=torch.float32):
+    """config.json + pytorch_model.bin (score_tranception_proteingym.py:79,100)."""
+    c = json.load(open(os.path.join(dirpath, "config.json")))
+    sd = torch.load(os.path.join(dirpath, "pytorch_model.bin"), map_location="cpu")
+    cfg = dict(n_layer=int(c["n_layer"]), n_embd=int(c["n_embd"]), n_head=int(c["n_head"]),
+               n_ctx=int(c.get("n_ctx", c.get("n_positions", 1024))),
+               n_inner=int(c["n_inner"]) if c.get("n_inner") else 4 * int(c["n_embd"]),
+               eps=float(c.get("layer_norm_epsilon", 1e-5)), vocab=int(c.get("vocab_size", 25)))
+    W = {k: v.to(dtype) for k, v in sd.items()}
+    if "lm_head.weight" not in W:                       # tied to wte (GPT2 tie_word_embeddings)
+        W["lm_head.weight"] = W["transformer.wte.weight"]
+    return cfg, W
+
+
+def _ln(x, w, b, eps):
+    mu = x.mean(-1, keepdim=True)
+    xc = x - mu
+    var = (xc * xc).mean(-1, keepdim=True)
+    return xc / torch.sqrt(var + eps) * w + b
+
+
+def _dwconv(x, w, b):
+    """SpatialDepthWiseConvolution (model_pytorch.py:73-88): x [B,h,T,dh]; per-channel causal conv,
+    y[t] = sum_j w[c,j] x[t-(k-1)+j] + b[c]  (Conv1d padding k-1, last k-1 outputs dropped)."""
+    k = w.shape[-1]
+    B, h, T, dh = x.shape
+    xp = torch.nn.functional.pad(x, (0, 0, k - 1, 0))                 # pad time on the left
+    y = torch.zeros_like(x)
+    for j in range(k):
+        y = y + xp[:, :, j:j + T, :] * w[:, 0, j]
+    return y + b
+
+
+def forward_logits(cfg, W, input_ids, attention_mask=None):
+    """input_ids int64 [B,T] -> logits [B,T,vocab]  (model_pytorch.py:438-632, 731-783)."""
+    ids = torch.as_tensor(np.asarray(input_ids), dtype=torch.int64)
+    B, T = ids.shape
+    D, H = cfg["n_embd"], cfg["n_head"]
+    dh = D // H
+    dtype = W["transformer.wte.weight"].dtype
+    x = W["transformer.wte.weight"][ids]                                 # no positional embedding
+    slopes = torch.tensor(get_slopes(H, mode="grouped_alibi"), dtype=torch.float32)
+    alibi = (slopes[:, None] * torch.arange(T, dtype=torch.float32)[None, :]).to(dtype)   # [H,T] bias on the key index
+    causal = torch.tril(torch.ones(T, T, dtype=torch.bool))
+    if attention_mask is not None:
+        am = (1.0 - torch.as_tensor(np.asarray(attention_mask)).to(dtype)) * -10000.0      # :505-506
+    hk = H // 4
+    for i in range(cfg["n_layer"]):
+        p = f"transformer.h.{i}."
+        h = _ln(x, W[p + "ln_1.weight"], W[p + "ln_1.bias"], cfg["eps"])
+        qkv = h @ W[p + "attn.c_attn.weight"] + W[p + "attn.c_attn.bias"]             # Conv1D: x W + b, W [in,out]
+        q, k, v = [t.view(B, T, H, dh).permute(0, 2, 1, 3) for t in qkv.split(D, dim=2)]
+        ql, kl, vl = [q[:, :hk]], [k[:, :hk]], [v[:, :hk]]
+        for ki in range(3):                                                            # kernels 3,5,7 (:240-251)
+            sl = slice((ki + 1) * hk, (ki + 2) * hk)
+            ql.append(_dwconv(q[:, sl], W[p + f"attn.query_depthwiseconv.{ki}.conv.weight"], W[p + f"attn.query_depthwiseconv.{ki}.conv.bias"]))
+            kl.append(_dwconv(k[:, sl], W[p + f"attn.key_depthwiseconv.{ki}.conv.weight"], W[p + f"attn.key_depthwiseconv.{ki}.conv.bias"]))
+            vl.append(_dwconv(v[:, sl], W[p + f"attn.value_depthwiseconv.{ki}.conv.weight"], W[p + f"attn.value_depthwiseconv.{ki}.conv.bias"]))
+        q, k, v = torch.cat(ql, 1), torch.cat(kl, 1), torch.cat(vl, 1)
+        s = (q @ k.transpose(-1, -2)) / (float(dh) ** 0.5)                             # :158-159
+        s = torch.where(causal, s, torch.tensor(-1e4, dtype=dtype))                    # :161-165
+        s = s + alibi[None, :, None, :]                                                # :167-168
+        if attention_mask is not None:
+            s = s + am[:, None, None, :]
+        a = torch.softmax(s, dim=-1)
+        ctx = (a @ v).permute(0, 2, 1, 3).reshape(B, T, D)
+        x = x + (ctx @ W[p + "attn.c_proj.weight"] + W[p + "attn.c_proj.bias"])
+        h = _ln(x, W[p + "ln_2.weight"], W[p + "ln_2.bias"], cfg["eps"])
+        h = torch.relu(h @ W[p + "mlp.c_fc.weight"] + W[p + "mlp.c_fc.bias"])
+        h = h * h                                                                       # squared ReLU
+        x = x + (h @ W[p + "mlp.c_proj.weight"] + W[p + "mlp.c_proj.bias"])
+    x = _ln(x, W["transformer.ln_f.weight"], W["transformer.ln_f.bias"], cfg["eps"])
+    return x @ W["lm_head.weight"].T
+
+
+# ---- retrieval prior (tranception/utils/msa_utils.py:63-138, uniform weights branch + weights) ----
+def process_msa_data(path):
+    from collections import defaultdict
+    msa = defaultdict(str)
+    name = ""
+    with open(path) as f:
+        for line in f:
+            line = line.rstrip()
+            if line.startswith(">"):
+                name = line
+            else:
+                msa[name] += line.upper()
+    return msa
+
+
+def get_msa_prior(MSA_data_file, MSA_start, MSA_end, len_target_seq, weights=None, filter_MSA=True):
+    """``weights``: optional {sequence name -> weight}; names missing from it are dropped like the
+    reference drops sequences without an EVE weight (msa_utils.py:104-115)."""
+    msa = process_msa_data(MSA_data_file)
+    V = len(VOCAB)
+
+    def one_hot(s):
+        o = np.zeros((len(s), V))
+        for j, c in enumerate(s):
+            if c in VOCAB:
+                o[j, VOCAB[c]] = 1.0
+        return o.flatten()
+    if filter_MSA:
+        names = list(msa.keys())
+        ref = one_hot(msa[names[0]])
+        for n in names:
+            if np.dot(ref, one_hot(msa[n])) / np.dot(ref, ref) < 0.2:
+                del msa[n]
+    if weights is not None:
+        for n in list(msa.keys()):
+            if n not in weights:
+                del msa[n]
+        w = np.array([weights[n] for n in msa.keys()])
+    else:
+        w = np.ones(len(msa))
+    one_hots = np.zeros((len(msa), MSA_end - MSA_start, V))
+    for i, n in enumerate(msa.keys()):
+        for j, c in enumerate(msa[n]):
+            if c in VOCAB:
+                one_hots[i, j, VOCAB[c]] = 1.0
+    weighted = (one_hots + 1e-5) * w[:, None, None]
+    norm = weighted.sum(-1).sum(0)
+    avg = weighted.sum(0) / np.tile(norm.reshape(-1, 1), (1, V))
+    prior = np.zeros((len_target_seq, V))
+    prior[MSA_start:MSA_end, :] = avg
+    return prior
+
+
+# ---- scoring ---------------------------------------------------------------------------------
+def get_mutated_sequence(focus_seq, mutant, start_idx=1):
+    s = list(focus_seq)
+    for m in mutant.split(":"):
+        a, pos, b = m[0], int(m[1:-1]), m[-1]
+        rp = pos - start_idx
+        assert a == focus_seq[rp], "Invalid from_AA or mutant position: " + str(m)
+        assert b in AA_vocab, "Mutant to_AA is invalid: " + str(m)
+        s[rp] = b
+    return "".join(s)
+
+
+def get_optimal_window(p, n, w):
+    h = w // 2
+    if n <= w:
+        return [0, n]
+    elif p < h:
+        return [0, w]
+    elif p >= n - h:
+        return [n - w, n]
+    return [max(0, p - h), min(n, p + h)]
+
+
+def get_sequence_slices(df, target_seq, model_context_len, start_idx=1):
+    """scoring_utils.py:152-183, scoring_window == 'optimal', substitutions."""
+    df = df.reset_index(drop=True).copy()
+    n = len(df)
+    bary = df["mutant"].apply(lambda x: int(np.array([int(m[1:-1]) - start_idx for m in x.split(":")]).mean()))
+    win = bary.apply(lambda x: get_optimal_window(x, len(target_seq), model_context_len))
+    df["sliced_mutated_sequence"] = [df["mutated_sequence"][i][win[i][0]:win[i][1]] for i in range(n)]
+    df["window_start"] = win.map(lambda x: x[0])
+    df["window_end"] = win.map(lambda x: x[1])
+    del df["mutant"]
+    wt = df.copy()
+    wt["mutated_sequence"] = [target_seq] * n
+    wt["sliced_mutated_sequence"] = [target_seq[wt["window_start"][i]:wt["window_end"][i]] for i in range(n)]
+    return pd.concat([df, wt], axis=0).drop_duplicates()
+
+
+def sequence_scores(cfg, W, sliced, window_start, window_end, reverse=False, retrieval=None, batch=20):
+    """Sum over positions of log p(token t+1 | tokens <= t) for each sliced sequence
+    (scoring_utils.py:97-128), with the MSA-prior fusion of model_pytorch.py:806-830 when
+    ``retrieval`` = dict(log_prior [L,25], MSA_start, MSA_end, weight) is given."""
+    out = []
+    with torch.no_grad():
+        for b0 in range(0, len(sliced), batch):
+            seqs = list(sliced[b0:b0 + batch])
+            ids, mask = encode_batch(seqs, cfg["n_ctx"])
+            lg = forward_logits(cfg, W, ids, mask)
+            lp = torch.log_softmax(lg[:, :-1, :], dim=-1)
+            if retrieval is not None:
+                fused = lp.clone()
+                a = retrieval["weight"]
+                for s in range(len(seqs)):
+                    st, en = int(window_start[b0 + s]), int(window_end[b0 + s])
+                    lo, hi = max(st, retrieval["MSA_start"]), min(en, retrieval["MSA_end"])
+                    if hi <= lo:
+                        continue
+                    pr = torch.as_tensor(retrieval["log_prior"][lo:hi], dtype=lp.dtype)
+                    if reverse:
+                        pr = torch.flip(pr, dims=(0,))
+                        a0 = max(0, en - retrieval["MSA_end"])
+                    else:
+                        a0 = max(0, retrieval["MSA_start"] - st)
+                    fused[s, a0:a0 + (hi - lo)] = (1 - a) * lp[s, a0:a0 + (hi - lo)] + a * pr
+                lp = fused
+            tgt = torch.as_tensor(ids[:, 1:])
+            ll = torch.gather(lp, 2, tgt.unsqueeze(-1)).squeeze(-1)
+            m = torch.as_tensor(mask[:, 1:]).to(ll.dtype)
+            out.extend((ll * m).sum(1).tolist())
+    return np.array(out)
+
+
+def score_mutants(cfg, W, df, target_seq, scoring_mirror=True, retrieval=None):
+    """model_pytorch.py:878-928 for substitutions with scoring_window 'optimal'.  Returns a DataFrame
+    with mutated_sequence, avg_score_L_to_R, (avg_score_R_to_L), avg_score -- WT row appended with 0
+    when present in the input."""
+    d = df.copy()
+    if "mutated_sequence" not in d:
+        d["mutated_sequence"] = d["mutant"].apply(lambda x: get_mutated_sequence(target_seq, x))
+    if "mutant" not in d:
+        d["mutant"] = d["mutated_sequence"]
+    d = d[["mutated_sequence", "mutant"]]
+    sl = get_sequence_slices(d, target_seq, cfg["n_ctx"] - 2).reset_index(drop=True)
+
+    def direction(name, rev):
+        s = sl.copy()
+        seqs = s["sliced_mutated_sequence"].apply(lambda x: x[::-1]) if rev else s["sliced_mutated_sequence"]
+        s["score"] = sequence_scores(cfg, W, list(seqs), list(s["window_start"]), list(s["window_end"]), reverse=rev,
+                                     retrieval=retrieval)
+        s["score"] = s["score"] / s["mutated_sequence"].map(len)
+        mut = s[s.mutated_sequence != target_seq]
+        wt = s[s.mutated_sequence == target_seq]
+        dl = pd.merge(mut, wt, how="left", on=["window_start"], suffixes=("", "_wt"))
+        dl[name] = dl["score"] - dl["score_wt"]
+        return dl[["mutated_sequence", name]]
+    out = direction("avg_score_L_to_R", False)
+    if scoring_mirror:
+        r = direction("avg_score_R_to_L", True)
+        out = pd.merge(out, r, on="mutated_sequence", how="left", suffixes=("", "_R_to_L"))
+        out["avg_score"] = (out["avg_score_L_to_R"] + out["avg_score_R_to_L"]) / 2.0
+    else:
+        out["avg_score"] = out["avg_score_L_to_R"]
+    if target_seq in df["mutated_sequence"].values if "mutated_sequence" in df else False:
+        cols = ["mutated_sequence", "avg_score_L_to_R"] + (["avg_score_R_to_L"] if scoring_mirror else []) + ["avg_score"]
+        out = pd.concat([out, pd.DataFrame([[target_seq] + [0] * (len(cols) - 1)], columns=cols)], ignore_index=True)
+    return out
