@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PGMI_ABI_VERSION 1
+#define PGMI_ABI_VERSION 2
 
 /* error codes */
 #define PGMI_OK 0
@@ -41,6 +41,9 @@ extern "C" {
 /* architectures: esm/model/esm1.py (arch "roberta_large": ESM-1b, ESM-1v) and esm/model/esm2.py */
 #define PGMI_ARCH_ESM1B 1
 #define PGMI_ARCH_ESM2 2
+/* Tranception: GPT2-style causal LM with grouped ALiBi, depth-wise conv on q/k/v, squared ReLU
+ * (proteingym/baselines/tranception/tranception/model_pytorch.py) */
+#define PGMI_ARCH_TRANCEPTION 3
 
 /* GEMM operand precision.  Residual stream, LayerNorm statistics, softmax and every
  * accumulator are fp32 in all modes. */
@@ -69,6 +72,7 @@ typedef struct pgmi_config {
     int32_t emb_layer_norm_before;/* pretrained.py:80-82,98 */
     int32_t precision;            /* PGMI_PREC_* */
     int32_t max_rows;             /* workspace rows (B*T per internal chunk); 0 = default */
+    float ln_eps;                 /* LayerNorm epsilon; 0 = 1e-5 (ESM: modules.py:80-81; Tranception: config.layer_norm_epsilon) */
 } pgmi_config;
 
 typedef struct pgmi_model pgmi_model;
@@ -180,6 +184,27 @@ int pgmi_op_gemm(int device, int precision, const float* A, const float* W, cons
 int pgmi_op_attention(int device, int precision, const float* qkv, const int32_t* kv_len,
                       int B, int T, int H, int rotary, float* ctx);
                                      /* multihead_attention.py:354-395; qkv [B*T,3*H*64], q pre-scaled */
+
+/* ---- Tranception (arch PGMI_ARCH_TRANCEPTION; vocab 25, max_positions = n_ctx, precision f16x3) ------
+ * Weight blob order (fp32, names as in the HF state dict, Conv1D weights as stored = [in,out]):
+ *   transformer.wte.weight [V,D];
+ *   per layer h.{i}: ln_1 w,b; attn.c_attn W[D,3D], b[3D];
+ *        attn.{query,key,value}_depthwiseconv.{0,1,2}.conv weight [64,k] (k = 3,5,7), bias [64]  (in that order);
+ *        attn.c_proj W[D,D], b; ln_2 w,b; mlp.c_fc W[D,F], b[F]; mlp.c_proj W[F,D], b[D];
+ *   transformer.ln_f w,b; lm_head.weight [V,D].
+ *
+ * pgmi_tr_token_logprobs: replaces log_softmax(model(input_ids, attention_mask).logits)
+ *   (model_pytorch.py:731-783); tokens int32 [B,T] right-padded with [PAD]=3; out f32 [B,T,V].
+ * pgmi_tr_sequence_loglik: the scoring reduction of tranception/utils/scoring_utils.py:97-128 --
+ *   out[b] = sum_{t < lens[b]-1} log p(tokens[b,t+1] | tokens[b,<=t]) -- with the inference-time
+ *   retrieval fusion of model_pytorch.py:806-830 when log_prior != NULL: for sequence b, logit rows
+ *   [prior_a0[b], prior_a0[b]+prior_n[b]) are replaced by (1-alpha)*logp + alpha*log_prior[row],
+ *   row = prior_row0[b] + i (or prior_row0[b] + n-1-i when prior_flip[b] != 0: right-to-left scoring).
+ *   lens[b] counts [CLS] and [SEP].  log_prior is f32 [P,V] (host). */
+int pgmi_tr_token_logprobs(pgmi_model* m, const int32_t* tokens, int B, int T, float* out);
+int pgmi_tr_sequence_loglik(pgmi_model* m, const int32_t* tokens, const int32_t* lens, int B, int T,
+                            const float* log_prior, int P, const int32_t* prior_a0, const int32_t* prior_row0,
+                            const int32_t* prior_n, const int32_t* prior_flip, float alpha, float* out);
 
 /* Tuning utility: times `iters` launches of the production GEMM (device-resident random operands,
  * HIP events) for one shape; variant selects the tile configuration (negative = library default).

@@ -11,8 +11,8 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libpgmi.so")
 
-ABI_VERSION = 1
-ARCH_ESM1B, ARCH_ESM2 = 1, 2
+ABI_VERSION = 2
+ARCH_ESM1B, ARCH_ESM2, ARCH_TRANCEPTION = 1, 2, 3
 PREC_FP32, PREC_BF16, PREC_F16X3 = 0, 1, 2
 PRECISIONS = {"fp32": PREC_FP32, "bf16": PREC_BF16, "f16x3": PREC_F16X3}
 K_NAMES = ["embed", "layernorm", "gemm_qkv", "attention", "gemm_out", "gemm_fc1", "gemm_fc2",
@@ -26,7 +26,7 @@ class PgmiError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "abi_version", "arch", "layers", "embed_dim", "heads", "ffn_dim", "vocab",
-        "max_positions", "token_dropout", "emb_layer_norm_before", "precision", "max_rows")]
+        "max_positions", "token_dropout", "emb_layer_norm_before", "precision", "max_rows")] + [("ln_eps", C.c_float)]
 
 
 _lib = None
@@ -60,6 +60,9 @@ SIGNATURES = [
     ("pgmi_synchronize", C.c_int, [C.c_void_p]),
     ("pgmi_op_layernorm", C.c_int, [C.c_int, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_float, _f32p]),
     ("pgmi_op_gemm", C.c_int, [C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
+    ("pgmi_tr_token_logprobs", C.c_int, [C.c_void_p, _i32p, C.c_int, C.c_int, _f32p]),
+    ("pgmi_tr_sequence_loglik", C.c_int, [C.c_void_p, _i32p, _i32p, C.c_int, C.c_int, _f32p, C.c_int,
+                                          _i32p, _i32p, _i32p, _i32p, C.c_float, _f32p]),
     ("pgmi_bench_gemm", C.c_int, [C.c_int] * 9 + [_f64p]),
     ("pgmi_op_attention", C.c_int, [C.c_int, C.c_int, _f32p, _i32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
 ]

@@ -36,6 +36,7 @@ struct W16 {
 struct Layer {
     float *ln1_w, *ln1_b, *wqkv, *bqkv, *wo, *bo, *ln2_w, *ln2_b, *w1, *b1, *w2, *b2;
     W16 wqkv16, wo16, w116, w216;
+    float* conv = nullptr;        // Tranception: [3][4][64][8] right-aligned 7-tap filters + bias (attention_f16.hip)
 };
 
 struct ProfEvent {
@@ -61,6 +62,10 @@ struct pgmi_model {
     float *hd_w = nullptr, *hd_b = nullptr, *hln_w = nullptr, *hln_b = nullptr, *h_bias = nullptr;
     std::vector<Layer> layers;
     W16 hd16;
+    float *tr_lm_head = nullptr, *tr_zero_bias = nullptr, *tr_slopes = nullptr;   // Tranception head / ALiBi slopes
+    float* tr_prior = nullptr;                          // device copy of the retrieval log-prior [P,V]
+    int tr_prior_rows = 0;
+    float ln_eps = 1e-5f;
     unsigned short *h16 = nullptr, *g16 = nullptr;     // activation planes [planes][R*D], [planes][R*F]
     size_t h16_plane = 0, g16_plane = 0;
     unsigned short *qk16 = nullptr, *vt16 = nullptr;   // attention operands (f16x3): [2][R*2D], [2][R*D]
@@ -158,11 +163,16 @@ int prof_drain(pgmi_model* m) {
 int check_cfg(const pgmi_config* c) {
     if (!c) { set_error("null config"); return PGMI_EINVAL; }
     if (c->abi_version != PGMI_ABI_VERSION) { set_error("ABI version mismatch: got %d, library is %d", c->abi_version, PGMI_ABI_VERSION); return PGMI_EINVAL; }
-    if (c->arch != PGMI_ARCH_ESM1B && c->arch != PGMI_ARCH_ESM2) { set_error("unknown arch %d", c->arch); return PGMI_EINVAL; }
+    if (c->arch != PGMI_ARCH_ESM1B && c->arch != PGMI_ARCH_ESM2 && c->arch != PGMI_ARCH_TRANCEPTION) { set_error("unknown arch %d", c->arch); return PGMI_EINVAL; }
     if (c->layers <= 0 || c->embed_dim <= 0 || c->heads <= 0 || c->ffn_dim <= 0) { set_error("non-positive model dimension"); return PGMI_EINVAL; }
     if (c->embed_dim != c->heads * kHeadDim) { set_error("unsupported head_dim %d (embed_dim %d / heads %d): this build supports head_dim 64", c->heads ? c->embed_dim / c->heads : 0, c->embed_dim, c->heads); return PGMI_EINVAL; }
     if (c->embed_dim % 32 || c->ffn_dim % 32) { set_error("embed_dim and ffn_dim must be multiples of 32"); return PGMI_EINVAL; }
-    if (c->vocab != PGMI_VOCAB) { set_error("vocab must be %d", PGMI_VOCAB); return PGMI_EINVAL; }
+    if (c->arch == PGMI_ARCH_TRANCEPTION) {
+        if (c->vocab != 25) { set_error("Tranception vocab must be 25"); return PGMI_EINVAL; }
+        if (c->heads % 4) { set_error("Invalid number of heads. Tranception requires the number of heads to be a multiple of 4."); return PGMI_EINVAL; }
+        if (c->precision != PGMI_PREC_F16X3) { set_error("Tranception is available in precision f16x3 only"); return PGMI_EINVAL; }
+        if (c->max_positions <= 0) { set_error("Tranception needs max_positions = n_ctx"); return PGMI_EINVAL; }
+    } else if (c->vocab != PGMI_VOCAB) { set_error("vocab must be %d", PGMI_VOCAB); return PGMI_EINVAL; }
     if (c->arch == PGMI_ARCH_ESM1B && c->max_positions <= 0) { set_error("ESM-1b arch needs max_positions"); return PGMI_EINVAL; }
     if (c->precision != PGMI_PREC_FP32 && c->precision != PGMI_PREC_F16X3 && c->precision != PGMI_PREC_BF16) { set_error("unknown precision %d", c->precision); return PGMI_EINVAL; }
     if (c->precision != PGMI_PREC_FP32 && (c->embed_dim % 64 || c->ffn_dim % 64)) { set_error("16-bit modes need embed_dim and ffn_dim to be multiples of 64"); return PGMI_EINVAL; }
@@ -349,6 +359,139 @@ int run_head(pgmi_model* m, int R, const int32_t* row_idx) {
     return PGMI_OK;
 }
 
+
+// ALiBi slopes, grouped: tranception/model_pytorch.py:50-71 (get_slopes(n, "grouped_alibi"))
+static void alibi_slopes_pow2(int n, std::vector<double>& out) {
+    const double start = pow(2.0, -pow(2.0, -(log2((double)n) - 3.0)));
+    double v = start;
+    for (int i = 0; i < n; ++i) { out.push_back(v); v *= start; }
+}
+static std::vector<double> alibi_slopes(int n) {
+    std::vector<double> r;
+    const double l2 = log2((double)n);
+    if (l2 == floor(l2)) { alibi_slopes_pow2(n, r); return r; }
+    const int c = 1 << (int)floor(l2);
+    alibi_slopes_pow2(c, r);
+    std::vector<double> e = alibi_slopes(2 * c);
+    for (int i = 0; i < (int)e.size() && (int)r.size() < n; i += 2) r.push_back(e[i]);
+    return r;
+}
+
+// transpose an HF Conv1D weight [in,out] into nn.Linear layout [out,in], optionally scaling the
+// first `scaled_cols` output columns (the q block) by `scale`
+static void conv1d_to_linear(const float* w, size_t in, size_t out, size_t scaled_cols, float scale, std::vector<float>& dst) {
+    dst.resize(in * out);
+    for (size_t o = 0; o < out; ++o) {
+        const float sc = o < scaled_cols ? scale : 1.0f;
+        for (size_t i = 0; i < in; ++i) dst[o * in + i] = w[i * out + o] * sc;
+    }
+}
+
+int create_tranception(pgmi_model* m, const pgmi_config* cfg, const float* w, int64_t n_weights) {
+    const size_t D = cfg->embed_dim, F = cfg->ffn_dim, V = cfg->vocab, H = cfg->heads;
+    const float* p = w;
+    int rc = 0;
+#define TRY(e) do { rc = (e); if (rc) return rc; } while (0)
+    TRY(dev_upload(m->allocs, &m->embed_tokens, p, V * D)); p += V * D;
+    const float qscale = 1.0f / sqrtf((float)kHeadDim);
+    m->layers.resize(cfg->layers);
+    std::vector<float> lin, bq(3 * D), conv(3 * 4 * 64 * 8);
+    static const int ksz[3] = {3, 5, 7};
+    for (int l = 0; l < cfg->layers; ++l) {
+        Layer& L = m->layers[l];
+        TRY(dev_upload(m->allocs, &L.ln1_w, p, D)); p += D;
+        TRY(dev_upload(m->allocs, &L.ln1_b, p, D)); p += D;
+        conv1d_to_linear(p, D, 3 * D, D, qscale, lin); p += D * 3 * D;
+        TRY(make_w16(m->allocs, lin.data(), lin.size(), cfg->precision, m->stream, &L.wqkv16));
+        for (size_t i = 0; i < 3 * D; ++i) bq[i] = p[i] * (i < D ? qscale : 1.0f);
+        p += 3 * D;
+        TRY(dev_upload(m->allocs, &L.bqkv, bq.data(), bq.size()));
+        // conv table: group 0 = identity; groups 1..3 = kernels 3,5,7 right-aligned in 7 taps
+        std::fill(conv.begin(), conv.end(), 0.0f);
+        for (int which = 0; which < 3; ++which) {
+            for (int d = 0; d < 64; ++d) conv[((which * 4 + 0) * 64 + d) * 8 + 6] = 1.0f;
+            for (int ki = 0; ki < 3; ++ki) {
+                const int k = ksz[ki];
+                for (int d = 0; d < 64; ++d)
+                    for (int j = 0; j < k; ++j) conv[((which * 4 + ki + 1) * 64 + d) * 8 + (7 - k) + j] = p[d * k + j];
+                p += 64 * k;
+                // the q projection is pre-scaled by 1/sqrt(dh): scale the q-conv bias the same way
+                for (int d = 0; d < 64; ++d) conv[((which * 4 + ki + 1) * 64 + d) * 8 + 7] = p[d] * (which == 0 ? qscale : 1.0f);
+                p += 64;
+            }
+        }
+        TRY(dev_upload(m->allocs, &L.conv, conv.data(), conv.size()));
+        conv1d_to_linear(p, D, D, 0, 1.0f, lin); p += D * D;
+        TRY(make_w16(m->allocs, lin.data(), lin.size(), cfg->precision, m->stream, &L.wo16));
+        TRY(dev_upload(m->allocs, &L.bo, p, D)); p += D;
+        TRY(dev_upload(m->allocs, &L.ln2_w, p, D)); p += D;
+        TRY(dev_upload(m->allocs, &L.ln2_b, p, D)); p += D;
+        conv1d_to_linear(p, D, F, 0, 1.0f, lin); p += D * F;
+        TRY(make_w16(m->allocs, lin.data(), lin.size(), cfg->precision, m->stream, &L.w116));
+        TRY(dev_upload(m->allocs, &L.b1, p, F)); p += F;
+        conv1d_to_linear(p, F, D, 0, 1.0f, lin); p += F * D;
+        TRY(make_w16(m->allocs, lin.data(), lin.size(), cfg->precision, m->stream, &L.w216));
+        TRY(dev_upload(m->allocs, &L.b2, p, D)); p += D;
+    }
+    TRY(dev_upload(m->allocs, &m->lna_w, p, D)); p += D;
+    TRY(dev_upload(m->allocs, &m->lna_b, p, D)); p += D;
+    TRY(dev_upload(m->allocs, &m->tr_lm_head, p, V * D)); p += V * D;
+    if (p - w != n_weights) { set_error("internal: blob walk mismatch"); return PGMI_EINVAL; }
+    std::vector<float> zb(V, 0.0f), sl;
+    TRY(dev_upload(m->allocs, &m->tr_zero_bias, zb.data(), zb.size()));
+    std::vector<double> quarter = alibi_slopes((int)H / 4);          // grouped: slopes of n/4 heads, tiled 4x
+    for (int rep = 0; rep < 4; ++rep)
+        for (double v : quarter) sl.push_back((float)v);
+    TRY(dev_upload(m->allocs, &m->tr_slopes, sl.data(), sl.size()));
+#undef TRY
+    return PGMI_OK;
+}
+
+// Tranception forward on tokens in m->tokens [B,T]; leaves log-probabilities in m->lp [B*T, V].
+int run_tranception(pgmi_model* m, int B, int T) {
+    const pgmi_config& c = m->cfg;
+    const int M = B * T, D = c.embed_dim, F = c.ffn_dim, H = c.heads;
+    hipStream_t s = m->stream;
+    if (T > c.max_positions) { set_error("sequence of %d tokens exceeds the model context n_ctx=%d", T, c.max_positions); return PGMI_EINVAL; }
+    int rc = 0;
+    if (B != m->last_B || T != m->last_T) {
+        PGMI_HIP(hipMemsetAsync(m->vt16, 0, m->vt16_plane * 2 * sizeof(unsigned short), s));
+        m->last_B = B;
+        m->last_T = T;
+    }
+    { ProfScope p(m, PGMI_K_EMBED, 0, (double)M * D * 4);
+      launch_gather_rows(m->embed_tokens, m->tokens, M, D, m->x, s); }       // wte[input_ids]; no positional embedding
+    const double ln_bytes = 2.0 * M * D * 4;
+    for (int l = 0; l < c.layers; ++l) {
+        const Layer& L = m->layers[l];
+        { ProfScope p(m, PGMI_K_LAYERNORM, 0, ln_bytes);
+          launch_layernorm16(m->x, L.ln1_w, L.ln1_b, M, D, m->ln_eps, m->h16, m->h16_plane, 1, s); }
+        { ProfScope p(m, PGMI_K_GEMM_QKV, 2.0 * M * 3 * D * D, 0);
+          rc = linear(m, nullptr, m->h16, m->h16_plane, nullptr, L.wqkv16, L.bqkv, nullptr, m->qkv, nullptr, 0, M, 3 * D, D, EPI_NONE);
+          if (rc) return rc; }
+        { ProfScope p(m, PGMI_K_ATTENTION, 2.0 * M * T * D, 0);
+          rc = launch_attention_f16x3_v2(m->qkv, nullptr, nullptr, nullptr, 0, B, T, H, m->qk16, m->qk16_plane, m->vt16,
+                                         m->vt16_plane, nullptr, m->h16, m->h16_plane, 1, s, L.conv, m->tr_slopes);
+          if (rc) return rc; }
+        { ProfScope p(m, PGMI_K_GEMM_OUT, 2.0 * M * D * D, 0);
+          rc = linear(m, nullptr, m->h16, m->h16_plane, nullptr, L.wo16, L.bo, m->x, m->x, nullptr, 0, M, D, D, EPI_NONE);
+          if (rc) return rc; }
+        { ProfScope p(m, PGMI_K_LAYERNORM, 0, ln_bytes);
+          launch_layernorm16(m->x, L.ln2_w, L.ln2_b, M, D, m->ln_eps, m->h16, m->h16_plane, 1, s); }
+        { ProfScope p(m, PGMI_K_GEMM_FC1, 2.0 * M * F * D, 0);
+          rc = linear(m, nullptr, m->h16, m->h16_plane, nullptr, L.w116, L.b1, nullptr, nullptr, m->g16, m->g16_plane, M, F, D, EPI_SQRELU);
+          if (rc) return rc; }
+        { ProfScope p(m, PGMI_K_GEMM_FC2, 2.0 * M * F * D, 0);
+          rc = linear(m, nullptr, m->g16, m->g16_plane, nullptr, L.w216, L.b2, m->x, m->x, nullptr, 0, M, D, F, EPI_NONE);
+          if (rc) return rc; }
+    }
+    { ProfScope p(m, PGMI_K_HEAD, 2.0 * M * D * c.vocab, 0);
+      launch_layernorm(m->x, m->lna_w, m->lna_b, M, D, m->ln_eps, m->h, s);
+      launch_vocab_logsoftmax(m->h, m->tr_lm_head, m->tr_zero_bias, M, D, c.vocab, m->lp, m->nonfinite, s); }
+    PGMI_HIP(hipGetLastError());
+    return PGMI_OK;
+}
+
 // fp16 range check for the 16-bit modes: the vocabulary kernel raises the flag when a computed
 // log-probability is NaN/inf (an activation exceeded fp16's 65504 upstream).
 int check_nonfinite(pgmi_model* m) {
@@ -382,6 +525,10 @@ int pgmi_device_count(void) {
 int64_t pgmi_weight_count(const pgmi_config* c) {
     if (!c || c->layers <= 0 || c->embed_dim <= 0 || c->ffn_dim <= 0) return -1;
     const int64_t D = c->embed_dim, F = c->ffn_dim, V = c->vocab;
+    if (c->arch == PGMI_ARCH_TRANCEPTION) {
+        const int64_t conv = 3 * ((64 * 3 + 64) + (64 * 5 + 64) + (64 * 7 + 64));
+        return V * D + (int64_t)c->layers * (2 * D + (D * 3 * D + 3 * D) + conv + (D * D + D) + 2 * D + (D * F + F) + (F * D + D)) + 2 * D + V * D;
+    }
     int64_t n = V * D;
     if (c->arch == PGMI_ARCH_ESM1B) n += (int64_t)(c->max_positions + 2) * D;
     if (c->emb_layer_norm_before) n += 2 * D;
@@ -409,7 +556,11 @@ int pgmi_model_create(const pgmi_config* cfg, const float* w, int64_t n_weights,
 #define TRY(e) do { rc = (e); if (rc) { pgmi_model_destroy(m); return rc; } } while (0)
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete m; return PGMI_EHIP; }
     const size_t D = cfg->embed_dim, F = cfg->ffn_dim, V = cfg->vocab;
+    m->ln_eps = cfg->ln_eps > 0.f ? cfg->ln_eps : 1e-5f;
     const float* p = w;
+    if (cfg->arch == PGMI_ARCH_TRANCEPTION) {
+        TRY(create_tranception(m, cfg, w, n_weights));
+    } else {
     // embed_tokens == the tied lm_head.weight (esm1.py:101-105).  The host passes the matrix that
     // load_state_dict leaves in the tied parameter (pretrained.py:97,216), see proteingym_amd/esm.py.
     TRY(dev_upload(m->allocs, &m->embed_tokens, p, V * D));
@@ -466,9 +617,11 @@ int pgmi_model_create(const pgmi_config* cfg, const float* w, int64_t n_weights,
     TRY(dev_upload(m->allocs, &m->hln_b, p, D)); p += D;
     TRY(dev_upload(m->allocs, &m->h_bias, p, V)); p += V;
     if (p - w != n_weights) { set_error("internal: blob walk mismatch"); pgmi_model_destroy(m); return PGMI_EINVAL; }
+    }
 
     m->max_rows = cfg->max_rows > 0 ? cfg->max_rows : 98304;
     if (m->max_rows < 2048) m->max_rows = 2048;
+    {
     const size_t R = m->max_rows;
     TRY(dev_alloc(m->allocs, &m->x, R * D));
     TRY(dev_alloc(m->allocs, &m->h, R * D));
@@ -500,6 +653,7 @@ int pgmi_model_create(const pgmi_config* cfg, const float* w, int64_t n_weights,
     TRY(dev_alloc(m->allocs, &m->kv_len, R));
     TRY(dev_alloc(m->allocs, &m->row_idx, R));
     TRY(dev_alloc(m->allocs, &m->aux_i, R));
+    }
 #undef TRY
     *out = m;
     return PGMI_OK;
@@ -814,6 +968,82 @@ int pgmi_op_gemm(int device, int precision, const float* A, const float* W, cons
     if (rc) return rc;
     if (e != hipSuccess) { set_error("gemm op failed: %s", hipGetErrorString(e)); return PGMI_EHIP; }
     return PGMI_OK;
+}
+
+int pgmi_tr_token_logprobs(pgmi_model* m, const int32_t* tokens, int B, int T, float* out) {
+    if (!m || !tokens || !out || B <= 0 || T <= 0) { set_error("bad argument"); return PGMI_EINVAL; }
+    if (m->cfg.arch != PGMI_ARCH_TRANCEPTION) { set_error("not a Tranception model"); return PGMI_EINVAL; }
+    for (int64_t i = 0; i < (int64_t)B * T; ++i)
+        if (tokens[i] < 0 || tokens[i] >= m->cfg.vocab) { set_error("token id %d out of range", tokens[i]); return PGMI_EINVAL; }
+    if (T + 31 > m->max_rows) { set_error("T=%d exceeds workspace rows %d", T, m->max_rows); return PGMI_EINVAL; }
+    PGMI_HIP(hipSetDevice(m->device));
+    const int per = std::max(1, m->max_rows / ((T + 31) / 32 * 32));
+    const int V = m->cfg.vocab;
+    for (int b0 = 0; b0 < B; b0 += per) {
+        const int bc = std::min(per, B - b0);
+        PGMI_HIP(hipMemcpyAsync(m->tokens, tokens + (size_t)b0 * T, (size_t)bc * T * 4, hipMemcpyHostToDevice, m->stream));
+        int rc = run_tranception(m, bc, T);
+        if (rc) return rc;
+        PGMI_HIP(hipMemcpyAsync(out + (size_t)b0 * T * V, m->lp, (size_t)bc * T * V * 4, hipMemcpyDeviceToHost, m->stream));
+        PGMI_HIP(hipStreamSynchronize(m->stream));
+    }
+    return check_nonfinite(m);
+}
+
+int pgmi_tr_sequence_loglik(pgmi_model* m, const int32_t* tokens, const int32_t* lens, int B, int T,
+                            const float* log_prior, int P, const int32_t* prior_a0, const int32_t* prior_row0,
+                            const int32_t* prior_n, const int32_t* prior_flip, float alpha, float* out) {
+    if (!m || !tokens || !lens || !out || B <= 0 || T <= 0) { set_error("bad argument"); return PGMI_EINVAL; }
+    if (m->cfg.arch != PGMI_ARCH_TRANCEPTION) { set_error("not a Tranception model"); return PGMI_EINVAL; }
+    if (log_prior && (!prior_a0 || !prior_row0 || !prior_n || !prior_flip || P <= 0)) { set_error("incomplete retrieval arguments"); return PGMI_EINVAL; }
+    const int V = m->cfg.vocab;
+    for (int b = 0; b < B; ++b) {
+        if (lens[b] < 1 || lens[b] > T) { set_error("lens[%d]=%d out of range", b, lens[b]); return PGMI_EINVAL; }
+        for (int t = 0; t < T; ++t) {
+            const int tk = tokens[(size_t)b * T + t];
+            if (tk < 0 || tk >= V) { set_error("token id %d out of range at [%d,%d]", tk, b, t); return PGMI_EINVAL; }
+        }
+        if (log_prior && prior_n[b] > 0 &&
+            (prior_a0[b] < 0 || prior_a0[b] + prior_n[b] > T - 1 || prior_row0[b] < 0 || prior_row0[b] + prior_n[b] > P)) {
+            set_error("retrieval slice of sequence %d out of range", b);
+            return PGMI_EINVAL;
+        }
+    }
+    if (T + 31 > m->max_rows) { set_error("T=%d exceeds workspace rows %d", T, m->max_rows); return PGMI_EINVAL; }
+    PGMI_HIP(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    if (log_prior) {
+        if (P > m->tr_prior_rows) {
+            float* np_ = nullptr;
+            int rc = dev_alloc(m->allocs, &np_, (size_t)P * V);
+            if (rc) return rc;
+            m->tr_prior = np_;
+            m->tr_prior_rows = P;
+        }
+        PGMI_HIP(hipMemcpyAsync(m->tr_prior, log_prior, (size_t)P * V * 4, hipMemcpyHostToDevice, s));
+    }
+    const int per = std::max(1, m->max_rows / ((T + 31) / 32 * 32));
+    for (int b0 = 0; b0 < B; b0 += per) {
+        const int bc = std::min(per, B - b0);
+        PGMI_HIP(hipMemcpyAsync(m->tokens, tokens + (size_t)b0 * T, (size_t)bc * T * 4, hipMemcpyHostToDevice, s));
+        PGMI_HIP(hipMemcpyAsync(m->kv_len, lens + b0, (size_t)bc * 4, hipMemcpyHostToDevice, s));
+        int32_t *da0 = nullptr, *dr0 = nullptr, *dn = nullptr, *dfl = nullptr;
+        if (log_prior) {            // four small int arrays share aux_i / row_idx / pos_idx (pos_idx is unused by Tranception)
+            da0 = m->aux_i; dr0 = m->row_idx; dn = m->pos_idx; dfl = m->pos_idx + bc;
+            PGMI_HIP(hipMemcpyAsync(da0, prior_a0 + b0, (size_t)bc * 4, hipMemcpyHostToDevice, s));
+            PGMI_HIP(hipMemcpyAsync(dr0, prior_row0 + b0, (size_t)bc * 4, hipMemcpyHostToDevice, s));
+            PGMI_HIP(hipMemcpyAsync(dn, prior_n + b0, (size_t)bc * 4, hipMemcpyHostToDevice, s));
+            PGMI_HIP(hipMemcpyAsync(dfl, prior_flip + b0, (size_t)bc * 4, hipMemcpyHostToDevice, s));
+        }
+        int rc = run_tranception(m, bc, T);
+        if (rc) return rc;
+        { ProfScope p(m, PGMI_K_SCORE, 0, (double)bc * T * 8);
+          launch_seq_loglik(m->lp, m->tokens, m->kv_len, bc, T, V, log_prior ? m->tr_prior : nullptr, da0, dr0, dn, dfl, alpha,
+                            m->denom, s); }
+        PGMI_HIP(hipMemcpyAsync(out + b0, m->denom, (size_t)bc * 4, hipMemcpyDeviceToHost, s));
+        PGMI_HIP(hipStreamSynchronize(s));
+    }
+    return check_nonfinite(m);
 }
 
 int pgmi_bench_gemm(int device, int precision, int M, int N, int K, int epilogue, int split_out, int variant,

@@ -265,10 +265,14 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_kernel(
 // attention_f16x3_v2_kernel then moves K / V^T tiles global -> LDS with global_load_lds (swizzle on
 // the source chunk) and does no conversion work at all: per (32q x 32k) tile 24 MFMAs + ~150 VALU.
 // =================================================================================================
+// `conv` (Tranception, tranception/model_pytorch.py:73-88,240-251): per (q|k|v, head group h / (H/4),
+// channel) a causal 7-tap depth-wise filter + bias, conv[((which*4 + group)*64 + d)*8 + j]; taps are
+// right-aligned (kernel sizes 3/5/7 have leading zeros, group 0 is the identity), tap j multiplies
+// the token t-6+j of the same sequence (zero before the sequence start); entry 7 is the bias.
 __global__ __launch_bounds__(256) void qkv_prep_kernel(
     const float* __restrict__ qkv, const float* __restrict__ cos_t, const float* __restrict__ sin_t,
-    int rotary, int T, int H, int Tp, unsigned short* __restrict__ qk16, size_t qk_plane,
-    unsigned short* __restrict__ vt16, size_t vt_plane) {
+    int rotary, const float* __restrict__ conv, int T, int H, int Tp, unsigned short* __restrict__ qk16,
+    size_t qk_plane, unsigned short* __restrict__ vt16, size_t vt_plane) {
     const int b = blockIdx.z, h = blockIdx.y, t0 = blockIdx.x * 32;
     const int tid = threadIdx.x;
     const int D = H * kHeadDim;
@@ -281,8 +285,28 @@ __global__ __launch_bounds__(256) void qkv_prep_kernel(
         const int t = t0 + tok;
         if (t < T) {
             const float* src = qkv + ((size_t)b * T + t) * RS + (size_t)which * D + h * kHeadDim + 4 * c;
-            f32x4 x1 = *reinterpret_cast<const f32x4*>(src);
-            f32x4 x2 = *reinterpret_cast<const f32x4*>(src + 32);
+            f32x4 x1, x2;
+            if (conv) {
+                const float* cw = conv + ((size_t)(which * 4 + h / (H / 4)) * kHeadDim + 4 * c) * 8;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { x1[e] = cw[e * 8 + 7]; x2[e] = cw[(32 + e) * 8 + 7]; }
+#pragma unroll
+                for (int j = 0; j < 7; ++j) {
+                    const int tt = t - 6 + j;
+                    if (tt >= 0) {
+                        const f32x4 a1 = *reinterpret_cast<const f32x4*>(src - (size_t)(6 - j) * RS);
+                        const f32x4 a2 = *reinterpret_cast<const f32x4*>(src - (size_t)(6 - j) * RS + 32);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            x1[e] = fmaf(cw[e * 8 + j], a1[e], x1[e]);
+                            x2[e] = fmaf(cw[(32 + e) * 8 + j], a2[e], x2[e]);
+                        }
+                    }
+                }
+            } else {
+                x1 = *reinterpret_cast<const f32x4*>(src);
+                x2 = *reinterpret_cast<const f32x4*>(src + 32);
+            }
             if (rotary) {           // rotary_embedding.py:11-20: x*cos + rotate_half(x)*sin
                 const f32x4 c1 = *reinterpret_cast<const f32x4*>(cos_t + t * 64 + 4 * c);
                 const f32x4 s1 = *reinterpret_cast<const f32x4*>(sin_t + t * 64 + 4 * c);
@@ -316,11 +340,30 @@ __global__ __launch_bounds__(256) void qkv_prep_kernel(
     {
         const int d = tid & 63, kq = tid >> 6;
         _Float16 hh[8], ll[8];
+        const float* vsrc = qkv + ((size_t)b * T) * RS + 2 * D + h * kHeadDim + d;
+        if (conv) {
+            const float* cw = conv + ((size_t)(2 * 4 + h / (H / 4)) * kHeadDim + d) * 8;
+            float win[14];                                    // tokens t0+8kq-6 .. t0+8kq+7
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int t = t0 + 8 * kq + e;
-            const float x = (t < T) ? qkv[((size_t)b * T + t) * RS + 2 * D + h * kHeadDim + d] : 0.0f;
-            split_act(x, hh[e], ll[e]);
+            for (int j = 0; j < 14; ++j) {
+                const int t = t0 + 8 * kq - 6 + j;
+                win[j] = (t >= 0 && t < T) ? vsrc[(size_t)t * RS] : 0.0f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float y = cw[7];
+#pragma unroll
+                for (int j = 0; j < 7; ++j) y = fmaf(cw[j], win[e + j], y);
+                if (t0 + 8 * kq + e >= T) y = 0.0f;
+                split_act(y, hh[e], ll[e]);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int t = t0 + 8 * kq + e;
+                const float x = (t < T) ? vsrc[(size_t)t * RS] : 0.0f;
+                split_act(x, hh[e], ll[e]);
+            }
         }
         // key 8kq+e -> position with bits 2,3 swapped: 16(kq>>1) + 8(e>>2) + 4(kq&1) + (e&3)
         unsigned short* row = vt16 + (((size_t)b * H + h) * kHeadDim + d) * Tp + t0 + 16 * (kq >> 1) + 4 * (kq & 1);
@@ -334,8 +377,10 @@ __global__ __launch_bounds__(256) void qkv_prep_kernel(
 template <int WPB, int OUT, int NSTG>
 __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
     const unsigned short* __restrict__ qk16, size_t qk_plane, const unsigned short* __restrict__ vt16,
-    size_t vt_plane, const int32_t* __restrict__ kv_len, int T, int H, int Tp, float* __restrict__ ctx,
-    unsigned short* __restrict__ ctx16, size_t plane) {
+    size_t vt_plane, const int32_t* __restrict__ kv_len, const float* __restrict__ slopes, int T, int H,
+    int Tp, float* __restrict__ ctx, unsigned short* __restrict__ ctx16, size_t plane) {
+    // slopes != nullptr selects the Tranception flavour (tranception/model_pytorch.py:155-183): causal
+    // mask (key <= query) and the grouped-ALiBi bias slope[h] * key added to the scaled scores.
     constexpr int NT = WPB * 64;
     // A tile is 16 wave-instructions of 64 chunks (K hi, K lo, V^T hi, V^T lo: 1024 x 16 B).  Every
     // wave issues the same number NDMA of them (counted vmcnt needs a per-wave constant): when
@@ -403,7 +448,11 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
 
     // NSTG-deep LDS ring, K/V tiles prefetched NSTG-1 ahead with counted vmcnt (the DMAs stay in
     // flight across the barrier; a __syncthreads() would drain them)
-    const int nkt = (Tk + AKT - 1) / AKT;
+    const bool causal = slopes != nullptr;
+    const float slope = causal ? slopes[h] : 0.0f;
+    // causal: keys beyond the block's last query tile are never needed (uniform bound for the block)
+    const int last_q = min(T, (int)(blockIdx.x * WPB + WPB) * 32);
+    const int nkt = causal ? (min(Tk, last_q) + AKT - 1) / AKT : (Tk + AKT - 1) / AKT;
 #pragma unroll
     for (int t = 0; t < NSTG - 1; ++t)
         if (t < nkt) issue_tile(t, t);
@@ -429,7 +478,7 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
         __builtin_amdgcn_s_barrier();          // tile kt visible to all waves; slot of tile kt-1 is free
         asm volatile("" ::: "memory");
         if (kt + NSTG - 1 < nkt) issue_tile(kt + NSTG - 1, (cur == 0) ? NSTG - 1 : cur - 1);
-        if (active) {
+        if (active && !(causal && kt * AKT > q0 + 31)) {
             const u32x4* Kb = lds + cur * A_STAGE;
             const u32x4* Vb = Kb + 2 * K_CH;
             f32x16 sm, sc;
@@ -444,8 +493,17 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
                 sm = mfma_h(kfh, qh[s], sm);
             }
             float st[16];
+            if (causal) {
 #pragma unroll
-            for (int v = 0; v < 16; ++v) st[v] = fmaf(sc[v], kInvLo, sm[v]) * kLog2e;
+                for (int v = 0; v < 16; ++v) {
+                    const int key = kt * AKT + (v & 3) + 8 * (v >> 2) + 4 * kh;
+                    const float sv = fmaf(sc[v], kInvLo, sm[v]) + slope * (float)key;
+                    st[v] = (key > q0 + r) ? -INFINITY : sv * kLog2e;
+                }
+            } else {
+#pragma unroll
+                for (int v = 0; v < 16; ++v) st[v] = fmaf(sc[v], kInvLo, sm[v]) * kLog2e;
+            }
             if (kt * AKT + AKT > Tk) {
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
@@ -532,13 +590,14 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
 
 template <int OUT, int NSTG>
 static void launch_att16v2_mode(int wpb, dim3 grid, const unsigned short* qk16, size_t qk_plane,
-                                const unsigned short* vt16, size_t vt_plane, const int32_t* kv_len, int T, int H,
-                                int Tp, float* ctx, unsigned short* ctx16, size_t plane, hipStream_t s) {
+                                const unsigned short* vt16, size_t vt_plane, const int32_t* kv_len,
+                                const float* slopes, int T, int H, int Tp, float* ctx, unsigned short* ctx16,
+                                size_t plane, hipStream_t s) {
     switch (wpb) {
-        case 1: hipLaunchKernelGGL((attention_f16x3_v2_kernel<1, OUT, NSTG>), grid, dim3(64), 0, s, qk16, qk_plane, vt16, vt_plane, kv_len, T, H, Tp, ctx, ctx16, plane); break;
-        case 2: hipLaunchKernelGGL((attention_f16x3_v2_kernel<2, OUT, NSTG>), grid, dim3(128), 0, s, qk16, qk_plane, vt16, vt_plane, kv_len, T, H, Tp, ctx, ctx16, plane); break;
-        case 3: hipLaunchKernelGGL((attention_f16x3_v2_kernel<3, OUT, NSTG>), grid, dim3(192), 0, s, qk16, qk_plane, vt16, vt_plane, kv_len, T, H, Tp, ctx, ctx16, plane); break;
-        default: hipLaunchKernelGGL((attention_f16x3_v2_kernel<4, OUT, NSTG>), grid, dim3(256), 0, s, qk16, qk_plane, vt16, vt_plane, kv_len, T, H, Tp, ctx, ctx16, plane); break;
+        case 1: hipLaunchKernelGGL((attention_f16x3_v2_kernel<1, OUT, NSTG>), grid, dim3(64), 0, s, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane); break;
+        case 2: hipLaunchKernelGGL((attention_f16x3_v2_kernel<2, OUT, NSTG>), grid, dim3(128), 0, s, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane); break;
+        case 3: hipLaunchKernelGGL((attention_f16x3_v2_kernel<3, OUT, NSTG>), grid, dim3(192), 0, s, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane); break;
+        default: hipLaunchKernelGGL((attention_f16x3_v2_kernel<4, OUT, NSTG>), grid, dim3(256), 0, s, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane); break;
     }
 }
 
@@ -548,14 +607,14 @@ static void launch_att16v2_mode(int wpb, dim3 grid, const unsigned short* qk16, 
 int launch_attention_f16x3_v2(const float* qkv, const int32_t* kv_len, const float* cos_t, const float* sin_t,
                               int rotary, int B, int T, int H, unsigned short* qk16, size_t qk_plane,
                               unsigned short* vt16, size_t vt_plane, float* ctx, unsigned short* ctx16, size_t plane,
-                              int out_mode, hipStream_t s) {
+                              int out_mode, hipStream_t s, const float* conv, const float* slopes) {
     if (B <= 0 || T <= 0 || H <= 0 || out_mode < 0 || out_mode > 1) {
         set_error("attention_f16x3_v2: bad arguments B=%d T=%d H=%d out=%d", B, T, H, out_mode);
         return PGMI_EINVAL;
     }
     const int n32 = (T + 31) / 32, Tp = n32 * 32;
     if (qkv)      // operands not prepared by the fused QKV epilogue: run the prep pass
-        hipLaunchKernelGGL(qkv_prep_kernel, dim3(n32, H, B), dim3(256), 0, s, qkv, cos_t, sin_t, rotary, T, H, Tp,
+        hipLaunchKernelGGL(qkv_prep_kernel, dim3(n32, H, B), dim3(256), 0, s, qkv, cos_t, sin_t, rotary, conv, T, H, Tp,
                            qk16, qk_plane, vt16, vt_plane);
     const int nblk = (n32 + 3) / 4;
     int wpb = (n32 + nblk - 1) / nblk;
@@ -563,11 +622,11 @@ int launch_attention_f16x3_v2(const float* qkv, const int32_t* kv_len, const flo
     const dim3 grid(nblk, H, B);
     static const int nstg = getenv("PGMI_ATT_STAGES") ? atoi(getenv("PGMI_ATT_STAGES")) : 3;
     if (nstg == 4) {
-        if (out_mode == 0) launch_att16v2_mode<0, 4>(wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, T, H, Tp, ctx, ctx16, plane, s);
-        else launch_att16v2_mode<1, 4>(wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, T, H, Tp, ctx, ctx16, plane, s);
+        if (out_mode == 0) launch_att16v2_mode<0, 4>(wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane, s);
+        else launch_att16v2_mode<1, 4>(wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane, s);
     } else {
-        if (out_mode == 0) launch_att16v2_mode<0, 3>(wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, T, H, Tp, ctx, ctx16, plane, s);
-        else launch_att16v2_mode<1, 3>(wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, T, H, Tp, ctx, ctx16, plane, s);
+        if (out_mode == 0) launch_att16v2_mode<0, 3>(wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane, s);
+        else launch_att16v2_mode<1, 3>(wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane, s);
     }
     PGMI_HIP(hipGetLastError());
     return PGMI_OK;

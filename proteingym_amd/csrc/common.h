@@ -26,7 +26,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int kWave = 64;
 constexpr int kHeadDim = 64;
 
-enum Epilogue { EPI_NONE = 0, EPI_GELU = 1 };
+enum Epilogue { EPI_NONE = 0, EPI_GELU = 1, EPI_SQRELU = 2 };   // erf-GELU (ESM), squared ReLU (Tranception)
 
 // f16x3 activation split: x ~= hi + lo * 2^-11 with hi = fp16(x) and lo = fp16((x - hi) * 2^11).
 // The scaled lo keeps its 11 bits for every |x| >= 2^-14 (an unscaled lo would be an fp16
@@ -67,6 +67,12 @@ void launch_scatter_rows(const float* src, const int32_t* dst_row, int n, int V,
                          hipStream_t s);
 void launch_row_index(const int32_t* mask_rel, int B, int T, int32_t* out, hipStream_t s);
 void launch_fill_f32(float* p, int64_t n, float v, hipStream_t s);
+// Tranception: per-sequence sum over t < len-1 of log p(tok[t+1] | tok[<=t]) from lp [B*T,V]
+// (scoring_utils.py:118-128), with the retrieval fusion (model_pytorch.py:806-830) on rows
+// [a0, a0+n) when prior != nullptr: value = (1-alpha)*lp + alpha*prior[row0 +/- i].
+void launch_seq_loglik(const float* lp, const int32_t* tokens, const int32_t* lens, int B, int T, int V,
+                       const float* prior, const int32_t* a0, const int32_t* row0, const int32_t* n,
+                       const int32_t* flip, float alpha, float* out, hipStream_t s);
 void launch_score_mutants(const float* table, int V, const int32_t* sub_pos, const int32_t* sub_wt,
                           const int32_t* sub_mt, const int64_t* mut_off, int64_t n_mut,
                           double* scores, hipStream_t s);
@@ -109,6 +115,6 @@ int launch_attention_f16x3(const float* qkv, const int32_t* kv_len, int B, int T
 int launch_attention_f16x3_v2(const float* qkv, const int32_t* kv_len, const float* cos_t, const float* sin_t,
                               int rotary, int B, int T, int H, unsigned short* qk16, size_t qk_plane,
                               unsigned short* vt16, size_t vt_plane, float* ctx, unsigned short* ctx16, size_t plane,
-                              int out_mode, hipStream_t s);
+                              int out_mode, hipStream_t s, const float* conv = nullptr, const float* slopes = nullptr);
 
 }  // namespace pgmi

@@ -337,6 +337,38 @@ void launch_vocab_logsoftmax(const float* h, const float* E, const float* bias, 
     hipLaunchKernelGGL(vocab_logsoftmax_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, h, E, bias, rows, D, V, out, nonfinite);
 }
 
+// ---- Tranception sequence log-likelihood (one wave per sequence) ------------------------------
+__global__ __launch_bounds__(256) void seq_loglik_kernel(const float* __restrict__ lp, const int32_t* __restrict__ tokens,
+                                                         const int32_t* __restrict__ lens, int B, int T, int V,
+                                                         const float* __restrict__ prior, const int32_t* __restrict__ a0,
+                                                         const int32_t* __restrict__ row0, const int32_t* __restrict__ n,
+                                                         const int32_t* __restrict__ flip, float alpha,
+                                                         float* __restrict__ out) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (b >= B) return;
+    const int len = lens[b];
+    float acc = 0.f;
+    for (int t = lane; t < len - 1; t += 64) {
+        const int tgt = tokens[(size_t)b * T + t + 1];
+        float v = lp[((size_t)b * T + t) * V + tgt];
+        if (prior && n[b] > 0 && t >= a0[b] && t < a0[b] + n[b]) {
+            const int i = t - a0[b];
+            const int row = flip[b] ? row0[b] + (n[b] - 1 - i) : row0[b] + i;
+            v = (1.0f - alpha) * v + alpha * prior[(size_t)row * V + tgt];
+        }
+        acc += v;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[b] = acc;
+}
+void launch_seq_loglik(const float* lp, const int32_t* tokens, const int32_t* lens, int B, int T, int V,
+                       const float* prior, const int32_t* a0, const int32_t* row0, const int32_t* n,
+                       const int32_t* flip, float alpha, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(seq_loglik_kernel, dim3((B + 3) / 4), dim3(256), 0, s, lp, tokens, lens, B, T, V, prior, a0, row0, n,
+                       flip, alpha, out);
+}
+
 // ---- label_row (compute_fitness.py:240-250): score = sum_subs f32(lp[mt] - lp[wt]) in double ---
 __global__ void score_mutants_kernel(const float* __restrict__ table, int V,
                                      const int32_t* __restrict__ sub_pos,

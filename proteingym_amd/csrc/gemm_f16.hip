@@ -296,6 +296,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 2) void gemm16_k
                 for (int e = 0; e < 4; ++e) {
                     float t = acc[j][i][4 * g + e] * out_scale + bv[e];
                     if (EPI == EPI_GELU) t = gelu_erf16(t);
+                    if (EPI == EPI_SQRELU) { t = fmaxf(t, 0.0f); t = t * t; }     // tranception/activations.py:79-84
                     val[e] = t;
                 }
                 const size_t o = (size_t)m * N + n;
@@ -494,6 +495,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm16p_kernel(
                 for (int e = 0; e < 4; ++e) {
                     float t = acc[j][i][4 * g + e] * out_scale + bv[e];
                     if (EPI == EPI_GELU) t = gelu_erf16(t);
+                    if (EPI == EPI_SQRELU) { t = fmaxf(t, 0.0f); t = t * t; }     // tranception/activations.py:79-84
                     val[e] = t;
                 }
                 const size_t o = (size_t)m * N + n;
@@ -584,6 +586,7 @@ static int launch_cfg(const unsigned short* A, size_t a_plane, const unsigned sh
     } else {
         const int out = Ch ? 1 : 0;
         if (epilogue == EPI_GELU) { if (out) PGMI_LAUNCH16(EPI_GELU, 1); else PGMI_LAUNCH16(EPI_GELU, 0); }
+        else if (epilogue == EPI_SQRELU) { if (out) PGMI_LAUNCH16(EPI_SQRELU, 1); else PGMI_LAUNCH16(EPI_SQRELU, 0); }
         else { if (out) PGMI_LAUNCH16(EPI_NONE, 1); else PGMI_LAUNCH16(EPI_NONE, 0); }
     }
 #undef PGMI_LAUNCH16

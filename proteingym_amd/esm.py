@@ -197,7 +197,7 @@ class EsmModel:
                    embed_dim=cfg["embed_dim"], heads=cfg["heads"], ffn_dim=cfg["ffn_dim"], vocab=33,
                    max_positions=cfg["max_positions"], token_dropout=cfg["token_dropout"],
                    emb_layer_norm_before=cfg["emb_layer_norm_before"],
-                   precision=_lib.PRECISIONS[precision], max_rows=max_rows)
+                   precision=_lib.PRECISIONS[precision], max_rows=max_rows, ln_eps=0.0)
         self._c = c
         n = lib.pgmi_weight_count(C.byref(c))
         w = _lib.as_f32(weights)

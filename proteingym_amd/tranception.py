@@ -1,0 +1,415 @@
+"""Host-side mirror of the reference's Tranception scorer, backed by libpgmi.so (HIP, gfx950).
+
+Reference (all under /root/reference/proteingym/baselines/tranception):
+  * ``TranceptionLMHeadModel.score_mutants``                        tranception/model_pytorch.py:878-928
+  * ``get_sequence_slices`` / ``get_tranception_scores_mutated_sequences``
+                                                                    tranception/utils/scoring_utils.py:77-203
+  * ``encode_batch`` + Basic_tokenizer (25 symbols)                 model_pytorch.py:930-939
+  * retrieval prior ``get_msa_prior``                               tranception/utils/msa_utils.py:63-138
+  * inference-time retrieval fusion                                 model_pytorch.py:806-830 (on the device)
+Same method names, arguments and output columns; the network itself (36 x [LN, c_attn, depth-wise
+conv on q/k/v, causal grouped-ALiBi attention, c_proj, LN, squared-ReLU MLP], LM head, per-token
+log-likelihood, prior fusion, per-sequence sum) runs in HIP kernels through the C ABI.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+import os
+import re
+from collections import defaultdict
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import pandas as pd
+
+from . import _lib
+from ._lib import PgmiError, Config
+
+VOCAB = {'[UNK]': 0, '[CLS]': 1, '[SEP]': 2, '[PAD]': 3, '[MASK]': 4, 'A': 5, 'C': 6, 'D': 7, 'E': 8, 'F': 9,
+         'G': 10, 'H': 11, 'I': 12, 'K': 13, 'L': 14, 'M': 15, 'N': 16, 'P': 17, 'Q': 18, 'R': 19, 'S': 20,
+         'T': 21, 'V': 22, 'W': 23, 'Y': 24}
+CLS, SEP, PAD, UNK = 1, 2, 3, 0
+AA_vocab = "ACDEFGHIKLMNPQRSTVWY"
+
+
+# ---- scoring_utils mirrors ----------------------------------------------------------------------
+def get_mutated_sequence(focus_seq, mutant, start_idx=1, AA_vocab=AA_vocab):
+    """scoring_utils.py:16-31."""
+    mutated_seq = list(focus_seq)
+    for mutation in mutant.split(":"):
+        from_AA, position, to_AA = mutation[0], int(mutation[1:-1]), mutation[-1]
+        relative_position = position - start_idx
+        assert (from_AA == focus_seq[relative_position]), "Invalid from_AA or mutant position: " + str(mutation) + \
+            " from_AA: " + str(from_AA) + " relative pos: " + str(relative_position) + " focus_seq: " + str(focus_seq)
+        assert (to_AA in AA_vocab), "Mutant to_AA is invalid: " + str(mutation)
+        mutated_seq[relative_position] = to_AA
+    return "".join(mutated_seq)
+
+
+def get_optimal_window(mutation_position_relative, seq_len_wo_special, model_window):
+    """scoring_utils.py:47-60 (same function as proteingym/utils/scoring_utils.py:43-52)."""
+    half = model_window // 2
+    if seq_len_wo_special <= model_window:
+        return [0, seq_len_wo_special]
+    elif mutation_position_relative < half:
+        return [0, model_window]
+    elif mutation_position_relative >= seq_len_wo_special - half:
+        return [seq_len_wo_special - model_window, seq_len_wo_special]
+    return [max(0, mutation_position_relative - half), min(seq_len_wo_special, mutation_position_relative + half)]
+
+
+def sequence_replace_single(sequence, char_to_replace, char_replacements):
+    """scoring_utils.py:62-69 (random replacement via np.random.choice, as the reference)."""
+    positions = [m.start() for m in re.finditer(char_to_replace, sequence)]
+    if not positions:
+        return sequence
+    replacements = np.random.choice(a=list(char_replacements), size=len(positions), replace=True)
+    sequence = list(sequence)
+    for idx, position in enumerate(positions):
+        sequence[position] = replacements[idx]
+    return ''.join(sequence)
+
+
+def get_sequence_slices(df, target_seq, model_context_len, start_idx=1, scoring_window="optimal", indel_mode=False):
+    """scoring_utils.py:152-203."""
+    len_target_seq = len(target_seq)
+    num_mutants = len(df['mutated_sequence'])
+    df = df.reset_index(drop=True)
+    if scoring_window == "optimal":
+        df['mutation_barycenter'] = df['mutant'].apply(lambda x: int(np.array([int(mutation[1:-1]) - start_idx for mutation in x.split(':')]).mean())) \
+            if not indel_mode else df['mutated_sequence'].apply(lambda x: len(x) // 2)
+        df['scoring_optimal_window'] = df['mutation_barycenter'].apply(lambda x: get_optimal_window(x, len_target_seq, model_context_len)) \
+            if not indel_mode else df['mutated_sequence'].apply(lambda x: (0, len(x)))
+        df['sliced_mutated_sequence'] = [df['mutated_sequence'][index][df['scoring_optimal_window'][index][0]:df['scoring_optimal_window'][index][1]] for index in range(num_mutants)]
+        df['window_start'] = df['scoring_optimal_window'].map(lambda x: x[0])
+        df['window_end'] = df['scoring_optimal_window'].map(lambda x: x[1])
+        del df['scoring_optimal_window'], df['mutation_barycenter']
+        if 'mutant' in df:
+            del df['mutant']
+        df_wt = df.copy()
+        df_wt['mutated_sequence'] = [target_seq] * num_mutants
+        if indel_mode:
+            df_wt['window_end'] = df_wt['mutated_sequence'].map(lambda x: len(x))
+        df_wt['sliced_mutated_sequence'] = [target_seq[df_wt['window_start'][index]:df_wt['window_end'][index]] for index in range(num_mutants)]
+        df = pd.concat([df, df_wt], axis=0)
+        df = df.drop_duplicates()
+    elif scoring_window == "sliding":
+        num_windows = 1 + int(len_target_seq / model_context_len)
+        df_list = []
+        start = 0
+        for window_index in range(1, num_windows + 1):
+            df_sliced = df.copy()
+            df_sliced['sliced_mutated_sequence'] = df_sliced['mutated_sequence'].map(lambda x: x[start:start + model_context_len])
+            df_sliced['window_start'] = [start] * num_mutants
+            df_sliced['window_end'] = df_sliced['mutated_sequence'].map(lambda x: min(len(x), start + model_context_len))
+            df_sliced_wt = df_sliced.copy()
+            df_sliced_wt['mutated_sequence'] = [target_seq] * num_mutants
+            df_sliced_wt['sliced_mutated_sequence'] = df_sliced_wt['mutated_sequence'].map(lambda x: x[start:start + model_context_len])
+            df_sliced_wt['window_end'] = df_sliced_wt['mutated_sequence'].map(lambda x: min(len(x), start + model_context_len))
+            df_list.append(df_sliced)
+            df_list.append(df_sliced_wt)
+            start += model_context_len
+        df_final = pd.concat(df_list, axis=0)
+        if 'mutant' in df_final:
+            del df_final['mutant']
+        df = df_final.drop_duplicates()
+    return df.reset_index(drop=True)
+
+
+# ---- retrieval prior (tranception/utils/msa_utils.py:28-138) -------------------------------------
+def process_msa_data(MSA_data_file):
+    msa_data = defaultdict(str)
+    sequence_name = ""
+    with open(MSA_data_file, "r") as msa_file:
+        for line in msa_file:
+            line = line.rstrip()
+            if line.startswith(">"):
+                sequence_name = line
+            else:
+                msa_data[sequence_name] += line.upper()
+    return msa_data
+
+
+def get_msa_prior(MSA_data_file, MSA_weight_file_name, MSA_start, MSA_end, len_target_seq, vocab=VOCAB,
+                  retrieval_aggregation_mode="aggregate_substitution", filter_MSA=True, seq_name_to_weight=None):
+    """Weighted pseudo-count profile of the retrieved MSA.  Sequence weights: pass
+    ``seq_name_to_weight`` ({'>name': w}) for the EVE-style weights the reference derives through
+    ``MSA_processing`` (msa_utils.py:104-115); ``MSA_weight_file_name`` alone is not enough because
+    the .npy holds weights only for the sequences EVE's pre-processing keeps."""
+    msa_data = process_msa_data(MSA_data_file)
+    vocab_size = len(vocab.keys())
+
+    def one_hot(s):
+        o = np.zeros((len(s), vocab_size))
+        for j, letter in enumerate(s):
+            if letter in vocab:
+                o[j, vocab[letter]] = 1.0
+        return o.flatten()
+    if filter_MSA:
+        names = list(msa_data.keys())
+        ref = one_hot(msa_data[names[0]])
+        for name in names:
+            if np.dot(ref, one_hot(msa_data[name])) / np.dot(ref, ref) < 0.2:
+                del msa_data[name]
+    if MSA_weight_file_name is not None and seq_name_to_weight is None:
+        raise NotImplementedError("EVE sequence-weight files need MSA_processing; pass seq_name_to_weight "
+                                  "or MSA_weight_file_name=None (uniform weights)")
+    if seq_name_to_weight is not None:
+        for name in list(msa_data.keys()):
+            if name not in seq_name_to_weight:
+                del msa_data[name]
+        MSA_weight = [seq_name_to_weight[name] for name in msa_data.keys()]
+    else:
+        MSA_weight = [1] * len(list(msa_data.keys()))
+    if retrieval_aggregation_mode in ("aggregate_substitution", "aggregate_indel"):
+        one_hots = np.zeros((len(msa_data), MSA_end - MSA_start, vocab_size))
+        for i, name in enumerate(msa_data.keys()):
+            for j, letter in enumerate(msa_data[name]):
+                if letter in vocab:
+                    one_hots[i, j, vocab[letter]] = 1.0
+        MSA_weight = np.expand_dims(np.array(MSA_weight), axis=(1, 2))
+        weighted_one_hots = (one_hots + np.ones_like(one_hots) * 1e-5) * MSA_weight
+        norm = weighted_one_hots.sum(axis=-1).sum(axis=0)
+        norm = np.tile(norm.reshape(-1, 1), (1, vocab_size))
+        msa_prior = np.zeros((len_target_seq, vocab_size))
+        msa_prior[MSA_start:MSA_end, :] = weighted_one_hots.sum(axis=0) / norm
+    else:
+        msa_prior = np.ones((len_target_seq, vocab_size)) / vocab_size
+    return msa_prior
+
+
+# ---- checkpoint ------------------------------------------------------------------------------------
+def expected_keys(n_layer):
+    keys = ["transformer.wte.weight"]
+    for i in range(n_layer):
+        p = f"transformer.h.{i}."
+        keys += [p + "ln_1.weight", p + "ln_1.bias", p + "attn.c_attn.weight", p + "attn.c_attn.bias"]
+        for which in ("query", "key", "value"):
+            for ki in range(3):
+                keys += [p + f"attn.{which}_depthwiseconv.{ki}.conv.weight", p + f"attn.{which}_depthwiseconv.{ki}.conv.bias"]
+        keys += [p + "attn.c_proj.weight", p + "attn.c_proj.bias", p + "ln_2.weight", p + "ln_2.bias",
+                 p + "mlp.c_fc.weight", p + "mlp.c_fc.bias", p + "mlp.c_proj.weight", p + "mlp.c_proj.bias"]
+    keys += ["transformer.ln_f.weight", "transformer.ln_f.bias", "lm_head.weight"]
+    return keys
+
+
+def load_checkpoint(checkpoint_dir: str):
+    """config.json + pytorch_model.bin / model.safetensors (score_tranception_proteingym.py:79,100).
+    Returns (cfg dict, flat fp32 blob in the ABI order of include/pgmi.h)."""
+    c = json.load(open(os.path.join(checkpoint_dir, "config.json")))
+    bin_path = os.path.join(checkpoint_dir, "pytorch_model.bin")
+    if os.path.exists(bin_path):
+        import torch
+        sd = {k: v.float().numpy() for k, v in torch.load(bin_path, map_location="cpu").items()}
+    else:
+        from safetensors.numpy import load_file
+        sd = load_file(os.path.join(checkpoint_dir, "model.safetensors"))
+    if "lm_head.weight" not in sd:                        # tied to wte (_keys_to_ignore_on_load_missing, :635)
+        sd["lm_head.weight"] = sd["transformer.wte.weight"]
+    n_embd, n_head, n_layer = int(c["n_embd"]), int(c["n_head"]), int(c["n_layer"])
+    cfg = dict(arch=_lib.ARCH_TRANCEPTION, layers=n_layer, embed_dim=n_embd, heads=n_head,
+               ffn_dim=int(c["n_inner"]) if c.get("n_inner") else 4 * n_embd, vocab=int(c.get("vocab_size", 25)),
+               max_positions=int(c.get("n_ctx", c.get("n_positions", 1024))), ln_eps=float(c.get("layer_norm_epsilon", 1e-5)))
+    if c.get("activation_function", "squared_relu") != "squared_relu":
+        raise ValueError("only the squared_relu activation of the released Tranception checkpoints is supported")
+    keys = expected_keys(n_layer)
+    missing = [k for k in keys if k not in sd]
+    if missing:
+        raise RuntimeError(f"Missing key(s) in Tranception state_dict: {missing[:8]}...")
+    parts = []
+    for k in keys:
+        a = np.asarray(sd[k], dtype=np.float32)
+        if k.endswith("conv.weight"):
+            a = a.reshape(a.shape[0], a.shape[-1])        # [dh, 1, k] -> [dh, k]
+        parts.append(np.ascontiguousarray(a).ravel())
+    return cfg, np.concatenate(parts)
+
+
+class TranceptionModel:
+    """Device-resident Tranception.  ``score_mutants`` mirrors the reference method of the same name."""
+
+    def __init__(self, cfg: dict, weights: np.ndarray, device: int = 0, scoring_window: str = "optimal",
+                 retrieval: Optional[dict] = None, max_rows: int = 0):
+        lib = _lib.load()
+        self.cfg = dict(cfg)
+        c = Config(abi_version=_lib.ABI_VERSION, arch=_lib.ARCH_TRANCEPTION, layers=cfg["layers"], embed_dim=cfg["embed_dim"],
+                   heads=cfg["heads"], ffn_dim=cfg["ffn_dim"], vocab=cfg["vocab"], max_positions=cfg["max_positions"],
+                   token_dropout=0, emb_layer_norm_before=0, precision=_lib.PREC_F16X3, max_rows=max_rows,
+                   ln_eps=cfg.get("ln_eps", 1e-5))
+        w = _lib.as_f32(weights)
+        n = lib.pgmi_weight_count(C.byref(c))
+        if w.size != n:
+            raise PgmiError(f"weight blob has {w.size} elements, config needs {n}")
+        h = C.c_void_p()
+        _lib.check(lib.pgmi_model_create(C.byref(c), _lib.ptr(w, _lib._f32p), w.size, device, C.byref(h)))
+        self._h = h
+        self.n_ctx = cfg["max_positions"]
+        self.scoring_window = scoring_window
+        # retrieval: dict(log_prior [L,25] float32, MSA_start (0-based), MSA_end, weight)
+        self.retrieval = retrieval
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().pgmi_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def eval(self):
+        return self
+
+    def cuda(self, *a, **k):
+        return self
+
+    # -- tokenisation (model_pytorch.py:930-939) -------------------------------------------------------
+    def encode_batch(self, sequences: Sequence[str]):
+        out = []
+        for s in sequences:
+            for ch, choices in (("X", AA_vocab), ("B", "DN"), ("J", "IL"), ("Z", "EQ")):
+                s = sequence_replace_single(s, ch, choices)
+            out.append(([CLS] + [VOCAB.get(ch, UNK) for ch in s] + [SEP])[: self.n_ctx])
+        T = max(len(e) for e in out)
+        ids = np.full((len(out), T), PAD, dtype=np.int32)
+        lens = np.zeros(len(out), dtype=np.int32)
+        for i, e in enumerate(out):
+            ids[i, :len(e)] = e
+            lens[i] = len(e)
+        return ids, lens
+
+    def token_logprobs(self, input_ids) -> np.ndarray:
+        t = _lib.as_i32(np.asarray(input_ids))
+        B, T = t.shape
+        out = np.empty((B, T, self.cfg["vocab"]), dtype=np.float32)
+        _lib.check(_lib.load().pgmi_tr_token_logprobs(self._h, _lib.ptr(t, _lib._i32p), B, T, _lib.ptr(out, _lib._f32p)))
+        return out
+
+    def sequence_loglik(self, sliced_sequences, window_start=None, window_end=None, reverse=False) -> np.ndarray:
+        """sum_t log p(token_{t+1} | tokens_{<=t}) per sliced sequence (scoring_utils.py:97-128), fused
+        with the retrieval prior (model_pytorch.py:806-830) when the model was built with one."""
+        lib = _lib.load()
+        seqs = list(sliced_sequences)
+        n = len(seqs)
+        out = np.empty(n, dtype=np.float32)
+        order = np.argsort([len(s) for s in seqs], kind="stable")
+        r = self.retrieval
+        # groups of equal length -> no padding waste; every group goes through one ABI call
+        start = 0
+        while start < n:
+            L = len(seqs[order[start]])
+            end = start
+            while end < n and len(seqs[order[end]]) == L:
+                end += 1
+            idx = order[start:end]
+            ids, lens = self.encode_batch([seqs[i] for i in idx])
+            B, T = ids.shape
+            res = np.empty(B, dtype=np.float32)
+            if r is not None:
+                a0 = np.zeros(B, np.int32); row0 = np.zeros(B, np.int32); nn = np.zeros(B, np.int32)
+                flip = np.full(B, 1 if reverse else 0, np.int32)
+                for j, i in enumerate(idx):
+                    st, en = int(window_start[i]), int(window_end[i])
+                    lo, hi = max(st, r["MSA_start"]), min(en, r["MSA_end"])
+                    if hi <= lo:
+                        print("Non overlapping region detected: min_prior_slice {} and max_prior_slice {}".format(lo, hi))
+                        continue
+                    a0[j] = max(0, en - r["MSA_end"]) if reverse else max(0, r["MSA_start"] - st)
+                    row0[j] = lo
+                    nn[j] = hi - lo
+                lp = _lib.as_f32(r["log_prior"])
+                _lib.check(lib.pgmi_tr_sequence_loglik(self._h, _lib.ptr(ids, _lib._i32p), _lib.ptr(lens, _lib._i32p), B, T,
+                                                       _lib.ptr(lp, _lib._f32p), lp.shape[0], _lib.ptr(a0, _lib._i32p),
+                                                       _lib.ptr(row0, _lib._i32p), _lib.ptr(nn, _lib._i32p),
+                                                       _lib.ptr(flip, _lib._i32p), float(r["weight"]), _lib.ptr(res, _lib._f32p)))
+            else:
+                _lib.check(lib.pgmi_tr_sequence_loglik(self._h, _lib.ptr(ids, _lib._i32p), _lib.ptr(lens, _lib._i32p), B, T,
+                                                       None, 0, None, None, None, None, 0.0, _lib.ptr(res, _lib._f32p)))
+            out[idx] = res
+            start = end
+        return out
+
+    # -- scoring (scoring_utils.py:77-150) ----------------------------------------------------------------
+    def _scores(self, mutated_sequence_df, score_var_name, target_seq, reverse=False):
+        df = mutated_sequence_df
+        ll = self.sequence_loglik(df['sliced_mutated_sequence'], df['window_start'].to_numpy(), df['window_end'].to_numpy(),
+                                  reverse=reverse)
+        scores = pd.DataFrame({'mutated_sequence': list(df['mutated_sequence']),
+                               'sliced_mutated_sequence': list(df['sliced_mutated_sequence']),
+                               'window_start': list(df['window_start']), 'window_end': list(df['window_end']),
+                               'score': ll.astype(np.float32)})
+        if self.scoring_window == "sliding":
+            scores = scores[['mutated_sequence', 'score']].groupby('mutated_sequence').sum().reset_index()
+        scores['score'] = scores['score'] / scores['mutated_sequence'].map(lambda x: len(x))
+        if target_seq is not None:
+            scores_mutated_seq = scores[scores.mutated_sequence != target_seq]
+            scores_wt = scores[scores.mutated_sequence == target_seq]
+            if self.scoring_window == "optimal":
+                delta_scores = pd.merge(scores_mutated_seq, scores_wt, how='left', on=['window_start'], suffixes=('', '_wt'))
+                delta_scores[score_var_name] = delta_scores['score'] - delta_scores['score_wt']
+            else:
+                delta_scores = scores_mutated_seq.copy()
+                delta_scores[score_var_name] = delta_scores['score'] - list(scores_wt['score'])[0]
+            return delta_scores[['mutated_sequence', score_var_name]]
+        scores[score_var_name] = scores['score']
+        return scores[['mutated_sequence', score_var_name]]
+
+    def score_mutants(self, DMS_data, target_seq=None, scoring_mirror=True, batch_size_inference=10, num_workers=10,
+                      indel_mode=False):
+        """model_pytorch.py:878-928 (batch_size_inference / num_workers are accepted and ignored: batching
+        is done on the device side)."""
+        df = DMS_data.copy()
+        if ('mutated_sequence' not in df) and (not indel_mode):
+            df['mutated_sequence'] = df['mutant'].apply(lambda x: get_mutated_sequence(target_seq, x))
+        assert ('mutated_sequence' in df), "DMS file to score does not have mutated_sequence column"
+        if 'mutant' not in df:
+            df['mutant'] = df['mutated_sequence']
+        df = df[['mutated_sequence', 'mutant']]
+        if target_seq is not None:
+            slices = get_sequence_slices(df, target_seq=target_seq, model_context_len=self.n_ctx - 2, indel_mode=indel_mode,
+                                         scoring_window=self.scoring_window)
+        else:
+            slices = get_sequence_slices(df, target_seq=list(df['mutated_sequence'])[0], model_context_len=self.n_ctx - 2,
+                                         indel_mode=indel_mode, scoring_window='sliding')
+        print("Scoring sequences from left to right")
+        scores_L_to_R = self._scores(slices, 'avg_score_L_to_R', target_seq)
+        if scoring_mirror:
+            print("Scoring sequences from right to left")
+            rl = slices.copy()
+            rl['sliced_mutated_sequence'] = rl['sliced_mutated_sequence'].apply(lambda x: x[::-1])
+            scores_R_to_L = self._scores(rl, 'avg_score_R_to_L', target_seq, reverse=True)
+            all_scores = pd.merge(scores_L_to_R, scores_R_to_L, on='mutated_sequence', how='left', suffixes=('', '_R_to_L'))
+            all_scores['avg_score'] = (all_scores['avg_score_L_to_R'] + all_scores['avg_score_R_to_L']) / 2.0
+        else:
+            all_scores = scores_L_to_R
+            all_scores['avg_score'] = all_scores['avg_score_L_to_R']
+        mutant_column = "mutant" if indel_mode else "mutated_sequence"
+        if target_seq in DMS_data[mutant_column].values:
+            if scoring_mirror:
+                wt_row = pd.DataFrame([[target_seq, 0, 0, 0]], columns=[mutant_column, 'avg_score_L_to_R', 'avg_score_R_to_L', 'avg_score'])
+            else:
+                wt_row = pd.DataFrame([[target_seq, 0, 0]], columns=[mutant_column, 'avg_score_L_to_R', 'avg_score'])
+            all_scores = pd.concat([all_scores, wt_row], ignore_index=True)
+        return all_scores
+
+
+def from_pretrained(checkpoint_dir: str, device: int = 0, scoring_window: str = "optimal", retrieval: Optional[dict] = None,
+                    max_rows: int = 0) -> TranceptionModel:
+    """Mirror of ``TranceptionLMHeadModel.from_pretrained(checkpoint, config=config)``
+    (score_tranception_proteingym.py:100).  ``retrieval`` = dict(MSA_filename, MSA_start (0-based),
+    MSA_end, full_protein_length, retrieval_inference_weight, MSA_weight_file_name=None,
+    seq_name_to_weight=None) builds the log-prior exactly as model_pytorch.py:662-672 does."""
+    cfg, blob = load_checkpoint(checkpoint_dir)
+    r = None
+    if retrieval:
+        prior = get_msa_prior(retrieval["MSA_filename"], retrieval.get("MSA_weight_file_name"), retrieval["MSA_start"],
+                              retrieval["MSA_end"], retrieval["full_protein_length"],
+                              seq_name_to_weight=retrieval.get("seq_name_to_weight"))
+        import torch
+        log_prior = torch.log(torch.tensor(prior).float()).numpy()          # same rounding as the reference (:662-672)
+        r = dict(log_prior=log_prior, MSA_start=int(retrieval["MSA_start"]), MSA_end=int(retrieval["MSA_end"]),
+                 weight=float(retrieval.get("retrieval_inference_weight", 0.6)))
+    return TranceptionModel(cfg, blob, device=device, scoring_window=scoring_window, retrieval=r, max_rows=max_rows)

@@ -1,0 +1,79 @@
+"""GPU parity of the Tranception HIP path (through the C ABI) against the reference's own outputs frozen
+in tests/golden/golden_tranception.npz (tests/golden/make_golden_tranception.py)."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+import torch
+
+from proteingym_amd import tranception as ptr
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return np.load(os.path.join(golden_dir, "golden_tranception.npz"))
+
+
+@pytest.fixture(scope="module")
+def model(lib, golden_dir):
+    m = ptr.from_pretrained(os.path.join(golden_dir, "Tranception_toy"))
+    yield m
+    m.close()
+
+
+def test_token_logprobs_vs_reference_logits(model, gold):
+    ids, mask = gold["logits_ids"], gold["logits_mask"].astype(bool)
+    ref = torch.log_softmax(torch.from_numpy(gold["logits"]), -1).numpy()
+    lp = model.token_logprobs(ids)
+    assert np.abs(lp - ref)[mask].max() < TOL          # rows of [PAD] queries are don't-care
+
+
+def _merge(df, r):
+    return pd.merge(df[["mutated_sequence"]], r, on="mutated_sequence", how="left")
+
+
+def test_score_mutants_vs_reference(model, gold, golden_dir):
+    df = pd.read_csv(os.path.join(golden_dir, "TOY_TRANCEPTION_DMS.csv"))
+    r = model.score_mutants(DMS_data=df, target_seq=str(gold["seq"]), scoring_mirror=True)
+    assert list(r.columns) == ["mutated_sequence", "avg_score_L_to_R", "avg_score_R_to_L", "avg_score"]
+    r = _merge(df, r)
+    for c in ("avg_score_L_to_R", "avg_score_R_to_L", "avg_score"):
+        assert np.abs(r[c].to_numpy() - gold[f"scores/{c}"]).max() < TOL
+
+
+def test_long_protein_optimal_window(model, gold, golden_dir):
+    df = pd.read_csv(os.path.join(golden_dir, "TOY_TRANCEPTION_LONG_DMS.csv"))
+    r = _merge(df, model.score_mutants(DMS_data=df, target_seq=str(gold["seq_long"]), scoring_mirror=True))
+    for c in ("avg_score_L_to_R", "avg_score_R_to_L", "avg_score"):
+        assert np.abs(r[c].to_numpy() - gold[f"scores_long/{c}"]).max() < TOL
+
+
+def test_retrieval_vs_reference(lib, gold, golden_dir):
+    seq = str(gold["seq"])
+    ms, me = [int(v) for v in gold["msa_start_end"]]
+    prior = ptr.get_msa_prior(os.path.join(golden_dir, "TOY_MSA.a2m"), None, ms, me, len(seq))
+    assert np.abs(prior - gold["msa_prior"]).max() == 0.0
+    m = ptr.from_pretrained(os.path.join(golden_dir, "Tranception_toy"),
+                            retrieval=dict(MSA_filename=os.path.join(golden_dir, "TOY_MSA.a2m"), MSA_start=ms, MSA_end=me,
+                                           full_protein_length=len(seq), retrieval_inference_weight=0.6))
+    df = pd.read_csv(os.path.join(golden_dir, "TOY_TRANCEPTION_DMS.csv"))
+    r = _merge(df, m.score_mutants(DMS_data=df, target_seq=seq, scoring_mirror=True))
+    for c in ("avg_score_L_to_R", "avg_score_R_to_L", "avg_score"):
+        assert np.abs(r[c].to_numpy() - gold[f"scores_retrieval/{c}"]).max() < TOL
+    m.close()
+
+
+def test_wt_row_and_determinism(model, gold, golden_dir):
+    seq = str(gold["seq"])
+    df = pd.read_csv(os.path.join(golden_dir, "TOY_TRANCEPTION_DMS.csv")).iloc[:5]
+    df = pd.concat([df, pd.DataFrame({"mutant": ["WT"], "mutated_sequence": [seq]})], ignore_index=True)
+    df.loc[df.index[-1], "mutant"] = df["mutant"].iloc[0]      # a syntactically valid triplet for the WT row's slice
+    a = model.score_mutants(DMS_data=df, target_seq=seq)
+    b = model.score_mutants(DMS_data=df, target_seq=seq)
+    assert a.equals(b)
+    wt = a[a.mutated_sequence == seq]
+    assert len(wt) == 1 and float(wt["avg_score"].iloc[0]) == 0.0

@@ -34,7 +34,7 @@ def test_no_cpu_fallback(lib):
 
 def test_weight_count_and_config_validation(lib):
     cfg = dict(synthetic.ESM1V_650M)
-    c = _lib.Config(abi_version=1, vocab=33, precision=0, max_rows=0, **cfg)
+    c = _lib.Config(abi_version=_lib.ABI_VERSION, vocab=33, precision=0, max_rows=0, **cfg)
     n = lib.pgmi_weight_count(C.byref(c))
     assert n == sum(int(np.prod(s)) for _, s in synthetic.key_shapes(cfg)) == 652355873 - 33 * 1280 + 33 * 1280
     c2 = dict(cfg, heads=16)                                   # head_dim 80: unsupported
