@@ -321,3 +321,10 @@ def score_mutants(cfg, W, df, target_seq, scoring_mirror=True, retrieval=None):
         cols = ["mutated_sequence", "avg_score_L_to_R"] + (["avg_score_R_to_L"] if scoring_mirror else []) + ["avg_score"]
         out = pd.concat([out, pd.DataFrame([[target_seq] + [0] * (len(cols) - 1)], columns=cols)], ignore_index=True)
     return out
+
+
+def from_arrays(layers, embed_dim, heads, ffn_dim, vocab, max_positions, arrays, ln_eps=1e-5, dtype=torch.float32, **_):
+    """(cfg, W) from in-memory arrays keyed by HF state-dict names (synthetic real-shape weights)."""
+    cfg = dict(n_layer=layers, n_embd=embed_dim, n_head=heads, n_ctx=max_positions, n_inner=ffn_dim, eps=ln_eps, vocab=vocab)
+    W = {k: torch.as_tensor(np.asarray(v)).to(dtype) for k, v in arrays.items()}
+    return cfg, W

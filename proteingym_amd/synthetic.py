@@ -157,3 +157,75 @@ def dms_shapes():
         return [dict(DMS_index=i, DMS_id=r["DMS_id"], seq_len=int(r["seq_len"]),
                      n_total=int(r["DMS_total_number_mutants"]), n_single=int(r["DMS_number_single_mutants"]),
                      n_multi=int(r["DMS_number_multiple_mutants"])) for i, r in enumerate(csv.DictReader(f))]
+
+
+# ---- Tranception ------------------------------------------------------------------------------------
+TRANCEPTION_L = dict(arch=_lib.ARCH_TRANCEPTION, layers=36, embed_dim=1280, heads=20, ffn_dim=5120, vocab=25,
+                     max_positions=1024, ln_eps=1e-5)     # paper "Large"; real dims come from the checkpoint's config.json
+
+
+def tranception_key_shapes(cfg):
+    from .tranception import expected_keys
+    D, F, V = cfg["embed_dim"], cfg["ffn_dim"], cfg["vocab"]
+    out = []
+    for k in expected_keys(cfg["layers"]):
+        if k in ("transformer.wte.weight", "lm_head.weight"):
+            s = (V, D)
+        elif k.endswith("c_attn.weight"):
+            s = (D, 3 * D)
+        elif k.endswith("c_attn.bias"):
+            s = (3 * D,)
+        elif "depthwiseconv" in k:
+            ksz = (3, 5, 7)[int(k.split("depthwiseconv.")[1][0])]
+            s = (64, ksz) if k.endswith("weight") else (64,)
+        elif k.endswith("attn.c_proj.weight"):
+            s = (D, D)
+        elif k.endswith("mlp.c_fc.weight"):
+            s = (D, F)
+        elif k.endswith("mlp.c_fc.bias"):
+            s = (F,)
+        elif k.endswith("mlp.c_proj.weight"):
+            s = (F, D)
+        else:
+            s = (D,)
+        out.append((k, s))
+    return out
+
+
+def random_tranception_weights(cfg, seed: int, embed_std: float = 0.3) -> np.ndarray:
+    """Flat fp32 blob in the Tranception ABI order; Conv1D weights N(0, 1/fan_in), tied lm_head."""
+    rng = np.random.default_rng(seed)
+    parts = []
+    wte = None
+    for k, s in tranception_key_shapes(cfg):
+        m = int(np.prod(s))
+        if k == "lm_head.weight":
+            v = wte.copy()
+        elif k.endswith("wte.weight"):
+            v = rng.standard_normal(m, dtype=np.float32) * embed_std
+            wte = v
+        elif "ln_" in k:
+            v = rng.standard_normal(m, dtype=np.float32) * (0.1 if k.endswith("weight") else 0.05)
+            if k.endswith("weight"):
+                v += 1.0
+        elif "depthwiseconv" in k:
+            v = rng.standard_normal(m, dtype=np.float32) * (0.4 if k.endswith("weight") else 0.05)
+        elif k.endswith(".bias"):
+            v = rng.standard_normal(m, dtype=np.float32) * 0.02
+        else:
+            v = rng.standard_normal(m, dtype=np.float32) / np.float32(np.sqrt(s[0]))
+        parts.append(v.astype(np.float32))
+    return np.concatenate(parts)
+
+
+def tranception_blob_to_arrays(cfg, blob):
+    out, o = {}, 0
+    for k, s in tranception_key_shapes(cfg):
+        m = int(np.prod(s))
+        a = blob[o:o + m].reshape(s)
+        if k.endswith("conv.weight"):
+            a = a.reshape(s[0], 1, s[1])
+        out[k] = a
+        o += m
+    assert o == blob.size
+    return out

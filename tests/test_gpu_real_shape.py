@@ -75,3 +75,36 @@ def test_650m_full_assay_properties(big):
     if m:
         b = pesm.Assay(model, seq, m).run()
         assert abs(b[2] - (b[0] + b[1])) < 1e-12
+
+
+def test_tranception_large_shape_vs_oracle(lib):
+    """Tranception-L shape (36 x 1280, 20 heads -> grouped ALiBi over 5 slopes, FFN 5120), synthetic
+    weights: per-sequence log-likelihoods and token log-probs of the HIP path vs the CPU oracle."""
+    from oracle import tranception_oracle as to
+    from proteingym_amd import tranception as ptr
+    cfg = dict(synthetic.TRANCEPTION_L)
+    blob = synthetic.random_tranception_weights(cfg, seed=3)
+    model = ptr.TranceptionModel(cfg, blob, device=0)
+    ocfg, W = to.from_arrays(arrays=synthetic.tranception_blob_to_arrays(cfg, blob), **cfg)
+    rng = np.random.default_rng(0)
+    seqs = ["".join(rng.choice(list(synthetic.AA), size=n)) for n in (90, 90, 61, 33)]
+    ids, mask = to.encode_batch(seqs[:2])
+    import torch
+    with torch.no_grad():
+        lg32 = to.forward_logits(ocfg, W, ids, mask)
+        ref = torch.log_softmax(lg32, -1).numpy()
+        W64 = {k: v.double() for k, v in W.items()}
+        ref64 = torch.log_softmax(to.forward_logits(ocfg, W64, ids, mask), -1).numpy()
+    got = model.token_logprobs(ids)
+    noise = np.abs(ref - ref64).max()                  # the fp32 CPU path's own distance to fp64
+    err64 = np.abs(got - ref64).max()
+    print("logit range", float(lg32.max() - lg32.min()), " fp32-oracle vs fp64:", noise, " HIP vs fp64:", err64)
+    assert err64 < max(1e-4, 3.0 * noise)             # same class as the reference's own fp32 arithmetic (token level)
+    err = np.abs(got - ref).max()
+    ref_ll = to.sequence_scores(ocfg, W, seqs, [0] * 4, [len(s) for s in seqs])
+    got_ll = model.sequence_loglik(seqs)
+    print("Tranception-L token log-prob max|err| =", err, " per-residue LL err =",
+          np.abs((got_ll - ref_ll) / np.array([len(s) for s in seqs])).max())
+    assert err < 1e-4 + 3.0 * noise
+    assert np.abs((got_ll - ref_ll) / np.array([len(s) for s in seqs])).max() < 1e-4     # the scored quantity
+    model.close()

@@ -77,3 +77,19 @@ def test_wt_row_and_determinism(model, gold, golden_dir):
     assert a.equals(b)
     wt = a[a.mutated_sequence == seq]
     assert len(wt) == 1 and float(wt["avg_score"].iloc[0]) == 0.0
+
+
+def test_cli_writes_reference_csv(lib, gold, golden_dir, tmp_path):
+    from proteingym_amd import score_tranception_proteingym as cli
+    args = cli.create_parser().parse_args([
+        "--checkpoint", os.path.join(golden_dir, "Tranception_toy"), "--target_seq", str(gold["seq"]),
+        "--DMS_file_name", "TOY_TRANCEPTION_DMS.csv", "--DMS_data_folder", golden_dir,
+        "--output_scores_folder", str(tmp_path / "out"), "--inference_time_retrieval", "--MSA_folder", golden_dir,
+        "--MSA_filename", "TOY_MSA.a2m", "--MSA_start", str(int(gold["msa_start_end"][0]) + 1),
+        "--MSA_end", str(int(gold["msa_start_end"][1]))])
+    cli.main(args)
+    out = pd.read_csv(tmp_path / "out" / "TOY_TRANCEPTION_DMS.csv")
+    assert list(out.columns) == ["mutated_sequence", "avg_score_L_to_R", "avg_score_R_to_L", "avg_score"]
+    df = pd.read_csv(os.path.join(golden_dir, "TOY_TRANCEPTION_DMS.csv"))
+    r = _merge(df, out)
+    assert np.abs(r["avg_score"].to_numpy() - gold["scores_retrieval/avg_score"]).max() < TOL

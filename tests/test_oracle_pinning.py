@@ -89,3 +89,52 @@ def test_oracle_vs_live_reference(tmp_path):
         for n in (100, 1024, 1025, 2000, 2501):
             if i < n:
                 assert cf.get_optimal_window(i, n, 1024) == eo.get_optimal_window(i, n, 1024)
+
+
+# ---- Tranception -----------------------------------------------------------------------------------
+def test_tranception_oracle_reproduces_golden(golden_dir):
+    from oracle import tranception_oracle as to
+    g = np.load(os.path.join(golden_dir, "golden_tranception.npz"))
+    cfg, W = to.load_checkpoint(os.path.join(golden_dir, "Tranception_toy"))
+    with torch.no_grad():
+        lg = to.forward_logits(cfg, W, g["logits_ids"], g["logits_mask"]).numpy()
+    m = g["logits_mask"].astype(bool)
+    assert np.abs(lg - g["logits"])[m].max() < 5e-5
+    seq = str(g["seq"])
+    df = pd.read_csv(os.path.join(golden_dir, "TOY_TRANCEPTION_DMS.csv"))
+    r = pd.merge(df[["mutated_sequence"]], to.score_mutants(cfg, W, df, seq), on="mutated_sequence", how="left")
+    for c in ("avg_score_L_to_R", "avg_score_R_to_L", "avg_score"):
+        assert np.abs(r[c].to_numpy() - g[f"scores/{c}"]).max() < TOL
+    ms, me = [int(v) for v in g["msa_start_end"]]
+    prior = to.get_msa_prior(os.path.join(golden_dir, "TOY_MSA.a2m"), ms, me, len(seq))
+    assert np.abs(prior - g["msa_prior"]).max() == 0.0
+    retr = dict(log_prior=torch.log(torch.tensor(prior).float()).numpy(), MSA_start=ms, MSA_end=me, weight=0.6)
+    r = pd.merge(df[["mutated_sequence"]], to.score_mutants(cfg, W, df, seq, retrieval=retr), on="mutated_sequence", how="left")
+    assert np.abs(r["avg_score"].to_numpy() - g["scores_retrieval/avg_score"]).max() < TOL
+    # slopes (model_pytorch.py:50-71): Tranception-L has 20 heads -> grouped over 5, not a power of two
+    s20 = to.get_slopes(20, mode="grouped_alibi")
+    assert len(s20) == 20 and s20[:5] == s20[5:10] and abs(s20[0] - 2 ** -2) < 1e-12
+
+
+def test_tranception_host_slices_match_oracle(golden_dir):
+    """Product host logic (proteingym_amd/tranception.py) against the oracle: windows, slices, prior."""
+    from oracle import tranception_oracle as to
+    from proteingym_amd import tranception as ptr
+    g = np.load(os.path.join(golden_dir, "golden_tranception.npz"))
+    seql = str(g["seq_long"])
+    df = pd.read_csv(os.path.join(golden_dir, "TOY_TRANCEPTION_LONG_DMS.csv"))[["mutated_sequence", "mutant"]]
+    a = ptr.get_sequence_slices(df.copy(), seql, 1022)
+    b = to.get_sequence_slices(df.copy(), seql, 1022).reset_index(drop=True)
+    assert a[["mutated_sequence", "sliced_mutated_sequence", "window_start", "window_end"]].equals(
+        b[["mutated_sequence", "sliced_mutated_sequence", "window_start", "window_end"]])
+    ms, me = [int(v) for v in g["msa_start_end"]]
+    p = ptr.get_msa_prior(os.path.join(golden_dir, "TOY_MSA.a2m"), None, ms, me, 70)
+    assert np.array_equal(p, g["msa_prior"])
+    cfg, blob = ptr.load_checkpoint(os.path.join(golden_dir, "Tranception_toy"))
+    assert cfg["layers"] == 2 and cfg["embed_dim"] == 256 and cfg["heads"] == 4 and cfg["vocab"] == 25
+    from proteingym_amd import _lib
+    import ctypes as C
+    c = _lib.Config(abi_version=_lib.ABI_VERSION, arch=3, layers=2, embed_dim=256, heads=4, ffn_dim=1024, vocab=25,
+                    max_positions=1024, token_dropout=0, emb_layer_norm_before=0, precision=2, max_rows=0, ln_eps=1e-5)
+    _lib.load()
+    assert _lib.load().pgmi_weight_count(C.byref(c)) == blob.size
