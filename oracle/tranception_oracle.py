@@ -215,6 +215,52 @@ def get_msa_prior(MSA_data_file, MSA_start, MSA_end, len_target_seq, weights=Non
 
 
 # ---- scoring ---------------------------------------------------------------------------------
+def eve_sequence_weights(MSA_location, theta=0.2, seq_gap_thr=0.5, col_gap_thr=1.0):
+    """{sequence name -> weight} as ``MSA_processing`` derives them (msa_utils.py:230-368), written
+    as plain loops: drop WT-gap columns; drop sequences with > 50 % gaps; lower-case columns with
+    > 100 % gaps (none); keep focus columns (upper-case, non-gap in the WT); drop sequences holding a
+    non-AA, non-gap letter there; weight_i = 1 / #{j: matches(i,j) / nongap(i) > 1 - theta}."""
+    AA = "ACDEFGHIKLMNPQRSTVWY"
+    raw, order, name = {}, [], ""
+    with open(MSA_location) as f:
+        for line in f:
+            line = line.rstrip()
+            if line.startswith(">"):
+                name = line
+                if name not in raw:
+                    raw[name] = ""
+                    order.append(name)
+            else:
+                raw[name] += line
+    focus_name = order[0]
+    seqs = {n: raw[n].replace(".", "-").upper() for n in order}
+    keep = [i for i, c in enumerate(seqs[focus_name]) if c != "-"]
+    seqs = {n: "".join(s[i] for i in keep) for n, s in seqs.items()}
+    seqs = {n: s for n, s in seqs.items() if sum(c == "-" for c in s) / len(s) <= seq_gap_thr}
+    ncol = len(keep)
+    col_ok = [sum(s[j] == "-" for s in seqs.values()) / len(seqs) <= col_gap_thr for j in range(ncol)]
+    seqs = {n: "".join(c.upper() if ok else c.lower() for c, ok in zip(s, col_ok)) for n, s in seqs.items()}
+    focus = seqs[focus_name]
+    focus_cols = [j for j, c in enumerate(focus) if c == c.upper() and c != "-"]
+    trimmed = {n: [s[j].upper() for j in focus_cols] for n, s in seqs.items()}
+    trimmed = {n: s for n, s in trimmed.items() if all((c in AA or c == "-") for c in s)}
+    names = list(trimmed.keys())
+    weights = {}
+    for a in names:
+        sa = trimmed[a]
+        nongap = sum(c != "-" for c in sa)
+        if nongap == 0:
+            weights[a] = 0.0
+            continue
+        cnt = 0
+        for b in names:
+            m = sum(1 for x, y in zip(sa, trimmed[b]) if x == y and x != "-")
+            if m / nongap > 1 - theta:
+                cnt += 1
+        weights[a] = 1.0 / cnt
+    return weights
+
+
 def get_mutated_sequence(focus_seq, mutant, start_idx=1):
     s = list(focus_seq)
     for m in mutant.split(":"):

@@ -7,8 +7,7 @@ Same flags, same input resolution (reference file row or manual fields), same ou
 
 Reference: /root/reference/proteingym/baselines/tranception/score_tranception_proteingym.py:14-124.
 Additive flag: --device.  Not supported (raise): --model_framework JAX, indel scoring *with*
-retrieval (needs Clustal Omega re-alignment, msa_utils.update_retrieved_MSA_log_prior_indel), EVE
-sequence-weight files (pass none: uniform MSA weights).
+retrieval (needs Clustal Omega re-alignment, msa_utils.update_retrieved_MSA_log_prior_indel).
 """
 from __future__ import annotations
 
@@ -78,11 +77,8 @@ def main(args=None):
     if args.inference_time_retrieval:
         if args.indel_mode:
             raise NotImplementedError("indel scoring with retrieval needs Clustal Omega re-alignment (not built)")
-        if MSA_weight_file_name is not None:
-            raise NotImplementedError("EVE sequence-weight files are not supported yet: omit --MSA_weights_folder "
-                                      "(uniform MSA weights)")
         retrieval = dict(MSA_filename=MSA_data_file, MSA_start=MSA_start, MSA_end=MSA_end, full_protein_length=len(target_seq),
-                         retrieval_inference_weight=args.retrieval_inference_weight, MSA_weight_file_name=None)
+                         retrieval_inference_weight=args.retrieval_inference_weight, MSA_weight_file_name=MSA_weight_file_name)
         print("Model leverages both autoregressive and retrieval inference")
     else:
         print("Model only uses autoregressive inference")

@@ -131,12 +131,119 @@ def process_msa_data(MSA_data_file):
     return msa_data
 
 
+class MSA_processing:
+    """EVE-style alignment pre-processing and sequence weights (tranception/utils/msa_utils.py:194-368,
+    same constructor arguments and attributes the scorer reads: focus_seq_name, seq_name_to_sequence,
+    seq_name_to_weight, weights, Neff).  Weights are loaded from ``weights_location`` when the file
+    exists, otherwise computed (1 / number of sequences within Hamming distance theta over the focus
+    columns, vectorised over blocks of sequences instead of the reference's per-sequence python map)
+    and saved there, as the reference does."""
+
+    def __init__(self, MSA_location="", theta=0.2, use_weights=True, weights_location="./data/weights",
+                 preprocess_MSA=True, threshold_sequence_frac_gaps=0.5, threshold_focus_cols_frac_gaps=1.0,
+                 remove_sequences_with_indeterminate_AA_in_focus_cols=True):
+        np.random.seed(2021)
+        self.MSA_location = MSA_location
+        self.weights_location = weights_location
+        self.theta = theta
+        self.alphabet = "ACDEFGHIKLMNPQRSTVWY"
+        self.use_weights = use_weights
+        self.preprocess_MSA = preprocess_MSA
+        self.threshold_sequence_frac_gaps = threshold_sequence_frac_gaps
+        self.threshold_focus_cols_frac_gaps = threshold_focus_cols_frac_gaps
+        self.remove_sequences_with_indeterminate_AA_in_focus_cols = remove_sequences_with_indeterminate_AA_in_focus_cols
+        self.gen_alignment()
+
+    def gen_alignment(self):
+        self.aa_dict = {aa: i for i, aa in enumerate(self.alphabet)}
+        self.seq_name_to_sequence = defaultdict(str)
+        name = ""
+        with open(self.MSA_location, "r") as msa_data:
+            for i, line in enumerate(msa_data):
+                line = line.rstrip()
+                if line.startswith(">"):
+                    name = line
+                    if i == 0:
+                        self.focus_seq_name = name
+                else:
+                    self.seq_name_to_sequence[name] += line
+        if self.preprocess_MSA:
+            names = list(self.seq_name_to_sequence.keys())
+            seqs = [self.seq_name_to_sequence[n].replace(".", "-").upper() for n in names]
+            wt = seqs[names.index(self.focus_seq_name)]
+            keep_cols = np.array([aa != '-' for aa in wt])
+            arr = np.array([list(s) for s in seqs])[:, keep_cols]
+            gaps = arr == '-'
+            seq_ok = gaps.mean(axis=1) <= self.threshold_sequence_frac_gaps
+            col_ok = gaps[seq_ok].mean(axis=0) <= self.threshold_focus_cols_frac_gaps
+            self.seq_name_to_sequence = defaultdict(str)
+            for n, row, ok in zip(names, arr, seq_ok):
+                if ok:
+                    self.seq_name_to_sequence[n] = ''.join(a.upper() if c else a.lower() for a, c in zip(row, col_ok))
+        self.focus_seq = self.seq_name_to_sequence[self.focus_seq_name]
+        self.focus_cols = [ix for ix, s in enumerate(self.focus_seq) if s == s.upper() and s != '-']
+        self.focus_seq_trimmed = [self.focus_seq[ix] for ix in self.focus_cols]
+        self.seq_len = len(self.focus_cols)
+        self.alphabet_size = len(self.alphabet)
+        try:
+            start, stop = self.focus_seq_name.split("/")[-1].split("-")
+            self.focus_start_loc, self.focus_stop_loc = int(start), int(stop)
+        except Exception:
+            start, stop = 1, len(self.focus_seq)
+            self.focus_start_loc, self.focus_stop_loc = 1, len(self.focus_seq)
+        self.uniprot_focus_col_to_wt_aa_dict = {c + int(start): self.focus_seq[c] for c in self.focus_cols}
+        self.uniprot_focus_col_to_focus_idx = {c + int(start): c for c in self.focus_cols}
+        self.raw_seq_name_to_sequence = self.seq_name_to_sequence.copy()
+        for seq_name, sequence in self.seq_name_to_sequence.items():
+            sequence = sequence.replace(".", "-")
+            self.seq_name_to_sequence[seq_name] = [sequence[ix].upper() for ix in self.focus_cols]
+        if self.remove_sequences_with_indeterminate_AA_in_focus_cols:
+            alphabet_set = set(self.alphabet)
+            for seq_name in [n for n, sq in self.seq_name_to_sequence.items()
+                             if any((l not in alphabet_set and l != "-") for l in sq)]:
+                del self.seq_name_to_sequence[seq_name]
+        names = list(self.seq_name_to_sequence.keys())
+        # integer encoding: AA index 0..19, -1 for gaps (zero one-hot rows in the reference)
+        enc = np.full((len(names), len(self.focus_cols)), -1, dtype=np.int8)
+        for i, n in enumerate(names):
+            enc[i] = [self.aa_dict.get(l, -1) for l in self.seq_name_to_sequence[n]]
+        self.encoded = enc
+        if self.use_weights:
+            try:
+                self.weights = np.load(file=self.weights_location)
+            except Exception:
+                self.weights = compute_sequence_weights(enc, self.theta)
+                np.save(file=self.weights_location, arr=self.weights)
+        else:
+            self.weights = np.ones(len(names))
+        self.Neff = np.sum(self.weights)
+        self.num_sequences = len(names)
+        self.seq_name_to_weight = {n: self.weights[i] for i, n in enumerate(names)}
+
+
+def compute_sequence_weights(enc: np.ndarray, theta: float, block: int = 256) -> np.ndarray:
+    """msa_utils.py:341-352: weight_i = 1 / #{j : <x_j, x_i> / <x_i, x_i> > 1 - theta} on one-hot
+    encodings, i.e. matches over the non-gap positions of i (0 for an all-gap sequence)."""
+    n = enc.shape[0]
+    w = np.zeros(n)
+    valid = enc >= 0
+    nonempty = valid.sum(1)
+    for i0 in range(0, n, block):
+        a = enc[i0:i0 + block]
+        match = ((a[:, None, :] == enc[None, :, :]) & valid[i0:i0 + block, None, :]).sum(-1)     # [b, n]
+        ne = nonempty[i0:i0 + block]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            frac = match / ne[:, None]
+        cnt = (frac > 1 - theta).sum(1)
+        w[i0:i0 + block] = np.where(ne > 0, 1.0 / np.maximum(cnt, 1), 0.0)
+    return w
+
+
 def get_msa_prior(MSA_data_file, MSA_weight_file_name, MSA_start, MSA_end, len_target_seq, vocab=VOCAB,
                   retrieval_aggregation_mode="aggregate_substitution", filter_MSA=True, seq_name_to_weight=None):
-    """Weighted pseudo-count profile of the retrieved MSA.  Sequence weights: pass
-    ``seq_name_to_weight`` ({'>name': w}) for the EVE-style weights the reference derives through
-    ``MSA_processing`` (msa_utils.py:104-115); ``MSA_weight_file_name`` alone is not enough because
-    the .npy holds weights only for the sequences EVE's pre-processing keeps."""
+    """Weighted pseudo-count profile of the retrieved MSA (msa_utils.py:63-138).  With
+    ``MSA_weight_file_name`` the EVE weights come from ``MSA_processing`` exactly as in the reference
+    (:100-115: sequences without a weight are dropped); ``seq_name_to_weight`` can inject them directly."""
     msa_data = process_msa_data(MSA_data_file)
     vocab_size = len(vocab.keys())
 
@@ -153,8 +260,9 @@ def get_msa_prior(MSA_data_file, MSA_weight_file_name, MSA_start, MSA_end, len_t
             if np.dot(ref, one_hot(msa_data[name])) / np.dot(ref, ref) < 0.2:
                 del msa_data[name]
     if MSA_weight_file_name is not None and seq_name_to_weight is None:
-        raise NotImplementedError("EVE sequence-weight files need MSA_processing; pass seq_name_to_weight "
-                                  "or MSA_weight_file_name=None (uniform weights)")
+        assert os.path.exists(MSA_weight_file_name), "Weights file not located on disk."
+        MSA_EVE = MSA_processing(MSA_location=MSA_data_file, use_weights=True, weights_location=MSA_weight_file_name)
+        seq_name_to_weight = MSA_EVE.seq_name_to_weight
     if seq_name_to_weight is not None:
         for name in list(msa_data.keys()):
             if name not in seq_name_to_weight:

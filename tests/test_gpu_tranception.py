@@ -67,6 +67,22 @@ def test_retrieval_vs_reference(lib, gold, golden_dir):
     m.close()
 
 
+def test_retrieval_with_eve_weights_vs_reference(lib, gold, golden_dir):
+    """--MSA_weights_folder branch: weights file -> MSA_processing -> weighted prior -> fusion on the device."""
+    g = np.load(os.path.join(golden_dir, "golden_msa_weights.npz"))
+    seq = str(gold["seq"])
+    ms, me = [int(v) for v in g["msa_start_end"]]
+    m = ptr.from_pretrained(os.path.join(golden_dir, "Tranception_toy"),
+                            retrieval=dict(MSA_filename=os.path.join(golden_dir, "TOY_MSA_GAPPY.a2m"), MSA_start=ms, MSA_end=me,
+                                           MSA_weight_file_name=os.path.join(golden_dir, "TOY_MSA_GAPPY_weights.npy"),
+                                           full_protein_length=len(seq), retrieval_inference_weight=0.6))
+    df = pd.read_csv(os.path.join(golden_dir, "TOY_TRANCEPTION_DMS.csv"))
+    r = _merge(df, m.score_mutants(DMS_data=df, target_seq=seq, scoring_mirror=True))
+    for c in ("avg_score_L_to_R", "avg_score_R_to_L", "avg_score"):
+        assert np.abs(r[c].to_numpy() - g[f"scores_retrieval_weighted/{c}"]).max() < TOL
+    m.close()
+
+
 def test_wt_row_and_determinism(model, gold, golden_dir):
     seq = str(gold["seq"])
     df = pd.read_csv(os.path.join(golden_dir, "TOY_TRANCEPTION_DMS.csv")).iloc[:5]

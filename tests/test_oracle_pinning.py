@@ -138,3 +138,38 @@ def test_tranception_host_slices_match_oracle(golden_dir):
                     max_positions=1024, token_dropout=0, emb_layer_norm_before=0, precision=2, max_rows=0, ln_eps=1e-5)
     _lib.load()
     assert _lib.load().pgmi_weight_count(C.byref(c)) == blob.size
+
+
+def test_eve_sequence_weights_oracle_and_host_match_reference(golden_dir, tmp_path):
+    """MSA_processing (msa_utils.py:194-368): the oracle's plain-loop restatement and the product's
+    vectorised mirror both reproduce the weights the reference computed (TOY_MSA_GAPPY_weights.npy),
+    the set/order of kept sequences, and the weighted prior."""
+    import shutil
+    from oracle import tranception_oracle as to
+    from proteingym_amd import tranception as ptr
+    g = np.load(os.path.join(golden_dir, "golden_msa_weights.npz"))
+    a2m = os.path.join(golden_dir, "TOY_MSA_GAPPY.a2m")
+    wfile = os.path.join(golden_dir, "TOY_MSA_GAPPY_weights.npy")
+    assert np.array_equal(np.load(wfile), g["weights"])
+    w = to.eve_sequence_weights(a2m)
+    assert list(w.keys()) == list(g["names"])
+    assert np.abs(np.array(list(w.values())) - g["weights"]).max() == 0.0
+    # host: recompute (no weights file at the given location) and load (file present)
+    fresh = str(tmp_path / "w.npy")
+    mp = ptr.MSA_processing(MSA_location=a2m, use_weights=True, weights_location=fresh)
+    assert list(mp.seq_name_to_weight.keys()) == list(g["names"])
+    assert np.array_equal(mp.weights, g["weights"]) and abs(mp.Neff - float(g["Neff"])) < 1e-12
+    assert np.array_equal(np.load(fresh), g["weights"])
+    mp2 = ptr.MSA_processing(MSA_location=a2m, use_weights=True, weights_location=wfile)
+    assert np.array_equal(mp2.weights, g["weights"])
+    ms, me = [int(v) for v in g["msa_start_end"]]
+    assert np.array_equal(ptr.get_msa_prior(a2m, wfile, ms, me, 70), g["msa_prior"])
+    assert np.abs(to.get_msa_prior(a2m, ms, me, 70, weights=w) - g["msa_prior"]).max() == 0.0
+    # oracle retrieval scores with the weighted prior
+    gt = np.load(os.path.join(golden_dir, "golden_tranception.npz"))
+    seq = str(gt["seq"])
+    cfg, W = to.load_checkpoint(os.path.join(golden_dir, "Tranception_toy"))
+    df = pd.read_csv(os.path.join(golden_dir, "TOY_TRANCEPTION_DMS.csv"))
+    retr = dict(log_prior=torch.log(torch.tensor(g["msa_prior"]).float()).numpy(), MSA_start=ms, MSA_end=me, weight=0.6)
+    r = pd.merge(df[["mutated_sequence"]], to.score_mutants(cfg, W, df, seq, retrieval=retr), on="mutated_sequence", how="left")
+    assert np.abs(r["avg_score"].to_numpy() - g["scores_retrieval_weighted/avg_score"]).max() < TOL
