@@ -212,6 +212,20 @@ int pgmi_tr_sequence_loglik(pgmi_model* m, const int32_t* tokens, const int32_t*
 int pgmi_bench_gemm(int device, int precision, int M, int N, int K, int epilogue, int split_out,
                     int variant, int iters, double* ms_per_launch);
 
+/* ---- alignment pre-processing ---------------------------------------------
+ * Cluster sizes (inverse sequence weights) of an alignment: replaces the numba kernel
+ * calc_num_cluster_members_nogaps_parallel (proteingym/utils/weights.py:164-216, called by
+ * calc_weights_fast :13-53) and MSA_processing.compute_weight
+ * (baselines/tranception/tranception/utils/msa_utils.py:341-352).
+ *   matrix  int8 [N][L]  symbols mapped to 0..29; invalid_value marks gaps / lower-case columns
+ *   counts_out int32 [N] #{j : matches(i,j) / nongap(i) > identity_threshold}, self included;
+ *                        0 for a sequence with no valid symbol (the reference gives it weight 0)
+ *   kernel_ms  optional: duration of the pair-count kernel (HIP events on its stream)
+ * The double-precision predicate of the reference is evaluated exactly (per non-gap length on the
+ * host, integer compares on the device): results are bit-identical to the reference's counts. */
+int pgmi_msa_cluster_counts(int device, const int8_t* matrix, int64_t N, int64_t L, int invalid_value,
+                            double identity_threshold, int32_t* counts_out, double* kernel_ms);
+
 #ifdef __cplusplus
 }
 #endif

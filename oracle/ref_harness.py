@@ -56,7 +56,7 @@ def load_reference():
         nb = types.ModuleType("numba")
         _dec = lambda *a, **k: a[0] if (len(a) == 1 and callable(a[0]) and not k) else (lambda f: f)
         nb.jit = nb.njit = _dec
-        nb.prange = range
+        nb.prange = lambda n: range(int(n))
         sys.modules["numba"] = nb
     torch.serialization.add_safe_globals([argparse.Namespace])
     torch.Tensor.cuda = lambda self, *a, **k: self
@@ -300,3 +300,27 @@ def reference_tranception_model(dirpath, scoring_window="optimal", retrieval=Non
     assert not bad and not unexpected, (bad, unexpected)
     model.eval()
     return model, tok
+
+
+# ---- proteingym/utils/weights.py (numba) --------------------------------------------------------
+def load_reference_weights():
+    """Import the reference's proteingym/utils/weights.py unmodified.  numba is not installed in this
+    image; a stub module whose ``jit`` is the identity decorator and whose ``prange`` is ``range`` runs
+    the same function bodies as plain python (slow: small alignments only)."""
+    import importlib.util
+    import types
+    if "numba" not in sys.modules:
+        nb = types.ModuleType("numba")
+        nb.jit = lambda *a, **k: (a[0] if a and callable(a[0]) else (lambda f: f))
+        nb.prange = lambda n: range(int(n))
+        nb.set_num_threads = lambda n: None
+        nb.get_num_threads = lambda: 1
+        nb.config = types.SimpleNamespace(NUMBA_NUM_THREADS=1)
+        sys.modules["numba"] = nb
+    spec = importlib.util.spec_from_file_location("pg_ref_weights", os.path.join(REF_ROOT, "proteingym", "utils", "weights.py"))
+    mod = importlib.util.module_from_spec(spec)
+    # the jitted bodies do ``L = 1.0 * L; for k in range(L)`` (numba accepts the float bound): give the
+    # module a ``range`` that truncates like numba does, instead of touching the source
+    mod.range = lambda *a: range(*[int(v) for v in a])
+    spec.loader.exec_module(mod)
+    return mod

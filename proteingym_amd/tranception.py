@@ -141,8 +141,9 @@ class MSA_processing:
 
     def __init__(self, MSA_location="", theta=0.2, use_weights=True, weights_location="./data/weights",
                  preprocess_MSA=True, threshold_sequence_frac_gaps=0.5, threshold_focus_cols_frac_gaps=1.0,
-                 remove_sequences_with_indeterminate_AA_in_focus_cols=True):
+                 remove_sequences_with_indeterminate_AA_in_focus_cols=True, device=None):
         np.random.seed(2021)
+        self.device = device                 # additive: HIP device for the O(N^2 L) weight computation
         self.MSA_location = MSA_location
         self.weights_location = weights_location
         self.theta = theta
@@ -212,7 +213,7 @@ class MSA_processing:
             try:
                 self.weights = np.load(file=self.weights_location)
             except Exception:
-                self.weights = compute_sequence_weights(enc, self.theta)
+                self.weights = compute_sequence_weights(enc, self.theta, device=self.device)
                 np.save(file=self.weights_location, arr=self.weights)
         else:
             self.weights = np.ones(len(names))
@@ -221,9 +222,15 @@ class MSA_processing:
         self.seq_name_to_weight = {n: self.weights[i] for i, n in enumerate(names)}
 
 
-def compute_sequence_weights(enc: np.ndarray, theta: float, block: int = 256) -> np.ndarray:
+def compute_sequence_weights(enc: np.ndarray, theta: float, block: int = 256, device=None) -> np.ndarray:
     """msa_utils.py:341-352: weight_i = 1 / #{j : <x_j, x_i> / <x_i, x_i> > 1 - theta} on one-hot
-    encodings, i.e. matches over the non-gap positions of i (0 for an all-gap sequence)."""
+    encodings, i.e. matches over the non-gap positions of i (0 for an all-gap sequence).  With
+    ``device`` the pair count runs in the HIP kernel (``pgmi_msa_cluster_counts``); without, on the
+    host in numpy like the reference's own CPU loop."""
+    if device is not None:
+        from . import weights as _w
+        counts = _w.num_cluster_members(enc, 1 - theta, -1, device=device)
+        return np.where(counts > 0, 1.0 / np.maximum(counts, 1), 0.0)
     n = enc.shape[0]
     w = np.zeros(n)
     valid = enc >= 0

@@ -173,3 +173,29 @@ def test_eve_sequence_weights_oracle_and_host_match_reference(golden_dir, tmp_pa
     retr = dict(log_prior=torch.log(torch.tensor(g["msa_prior"]).float()).numpy(), MSA_start=ms, MSA_end=me, weight=0.6)
     r = pd.merge(df[["mutated_sequence"]], to.score_mutants(cfg, W, df, seq, retrieval=retr), on="mutated_sequence", how="left")
     assert np.abs(r["avg_score"].to_numpy() - g["scores_retrieval_weighted/avg_score"]).max() < TOL
+
+
+# ---- alignment pair count / sequence weights (proteingym/utils/weights.py) --------------------------
+MSA_CASES = ["small", "ragged", "wide", "thr_edge", "thr_07", "thr_1m02"]
+
+
+@pytest.mark.parametrize("name", MSA_CASES)
+def test_msa_cluster_oracle_reproduces_reference(golden_dir, name):
+    from oracle import msa_weights_oracle as mo
+    g = np.load(os.path.join(golden_dir, "golden_msa_cluster.npz"))
+    m, thr = g[f"{name}/matrix"], float(g[f"{name}/threshold"])
+    assert np.array_equal(mo.cluster_counts(m, thr, 20), g[f"{name}/counts"])
+    assert np.array_equal(mo.cluster_counts_numpy(m, thr, 20), g[f"{name}/counts"])
+    assert np.abs(mo.calc_weights(m, thr, 20) - g[f"{name}/weights"]).max() == 0.0
+
+
+def test_msa_cluster_oracle_vs_live_reference():
+    from oracle import msa_weights_oracle as mo, ref_harness as rh
+    if not rh.reference_available():
+        pytest.skip("reference checkout not present")
+    w = rh.load_reference_weights()
+    rng = np.random.default_rng(3)
+    m = rng.integers(0, 21, size=(50, 23)).astype(np.int64)
+    m[rng.integers(0, 50, size=20)] = m[0]                      # a cluster of duplicates
+    ref = w.calc_num_cluster_members_nogaps_parallel(m, 0.8, 20)
+    assert np.array_equal(mo.cluster_counts(m, 0.8, 20), ref.astype(np.int32))
