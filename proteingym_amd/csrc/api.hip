@@ -74,6 +74,8 @@ struct pgmi_model {
     int gemm_variant = 0;
     int att16 = 3;        // f16x3 attention: 0 fp32 pipe, 1 in-kernel split, 2 prep pass + DMA ring, 3 QKV epilogue + DMA ring (default)
     int last_B = 0, last_T = 0;
+    int dh = kHeadDim;    // true head dim; heads are laid out in 64 slots: j < dh/2 -> j, else 32 + (j - dh/2)
+    int Da = 0;           // attention width = heads * 64 (== embed_dim when dh == 64)
     float *rot_cos = nullptr, *rot_sin = nullptr;
     int rot_len = 0;
     // workspace
@@ -165,7 +167,13 @@ int check_cfg(const pgmi_config* c) {
     if (c->abi_version != PGMI_ABI_VERSION) { set_error("ABI version mismatch: got %d, library is %d", c->abi_version, PGMI_ABI_VERSION); return PGMI_EINVAL; }
     if (c->arch != PGMI_ARCH_ESM1B && c->arch != PGMI_ARCH_ESM2 && c->arch != PGMI_ARCH_TRANCEPTION) { set_error("unknown arch %d", c->arch); return PGMI_EINVAL; }
     if (c->layers <= 0 || c->embed_dim <= 0 || c->heads <= 0 || c->ffn_dim <= 0) { set_error("non-positive model dimension"); return PGMI_EINVAL; }
-    if (c->embed_dim != c->heads * kHeadDim) { set_error("unsupported head_dim %d (embed_dim %d / heads %d): this build supports head_dim 64", c->heads ? c->embed_dim / c->heads : 0, c->embed_dim, c->heads); return PGMI_EINVAL; }
+    {
+        // head_dim 64 natively; smaller head dims (ESM2 8M/35M/150M: 16/24/32) run zero-padded to 64
+        // lanes per head (see pgmi_model_create).  head_dim 128 (ESM2 15B) is not built.
+        const int dh = c->embed_dim / c->heads;
+        const bool ok = c->embed_dim % c->heads == 0 && (dh == kHeadDim || (dh < kHeadDim && dh % 2 == 0 && c->arch != PGMI_ARCH_TRANCEPTION));
+        if (!ok) { set_error("unsupported head_dim %d (embed_dim %d / heads %d): this build supports head_dim 64 and even head dims below 64 (ESM)", dh, c->embed_dim, c->heads); return PGMI_EINVAL; }
+    }
     if (c->embed_dim % 32 || c->ffn_dim % 32) { set_error("embed_dim and ffn_dim must be multiples of 32"); return PGMI_EINVAL; }
     if (c->arch == PGMI_ARCH_TRANCEPTION) {
         if (c->vocab != 25) { set_error("Tranception vocab must be 25"); return PGMI_EINVAL; }
@@ -232,10 +240,11 @@ int ensure_rotary(pgmi_model* m, int T) {
     const int n = std::max(T, 1026);
     std::vector<float> c((size_t)n * 64), s((size_t)n * 64);
     float inv[32];
-    for (int i = 0; i < 32; ++i) inv[i] = 1.0f / powf(10000.0f, (float)(2 * i) / 64.0f);
+    const int half = m->dh / 2;                            // slots i and 32+i hold dims i and i + dh/2
+    for (int i = 0; i < half; ++i) inv[i] = 1.0f / powf(10000.0f, (float)(2 * i) / (float)m->dh);
     for (int t = 0; t < n; ++t)
         for (int i = 0; i < 32; ++i) {
-            const float f = (float)t * inv[i];
+            const float f = i < half ? (float)t * inv[i] : 0.0f;       // padded slots: cos 1, sin 0
             c[(size_t)t * 64 + i] = c[(size_t)t * 64 + 32 + i] = cosf(f);
             s[(size_t)t * 64 + i] = s[(size_t)t * 64 + 32 + i] = sinf(f);
         }
@@ -262,7 +271,7 @@ int linear(pgmi_model* m, const float* in32, const unsigned short* in16, size_t 
 // Runs the encoder on tokens already in m->tokens [B,T]; leaves the residual stream in m->x.
 int run_encoder(pgmi_model* m, int B, int T) {
     const pgmi_config& c = m->cfg;
-    const int M = B * T, D = c.embed_dim, F = c.ffn_dim, H = c.heads;
+    const int M = B * T, D = c.embed_dim, F = c.ffn_dim, H = c.heads, Da = m->Da;
     hipStream_t s = m->stream;
     if (c.arch == PGMI_ARCH_ESM1B && T > c.max_positions) {
         set_error("Sequence length %d above maximum sequence length of %d", T, c.max_positions);   // modules.py:256-260
@@ -297,11 +306,11 @@ int run_encoder(pgmi_model* m, int B, int T) {
         const bool fused_qkv = prec == PGMI_PREC_F16X3 && m->att16 == 3;
         { ProfScope p(m, PGMI_K_GEMM_QKV, 2.0 * M * 3 * D * D, 0);
           if (fused_qkv)
-              rc = launch_gemm16_qkv(m->h16, m->h16_plane, L.wqkv16.p, L.wqkv16.plane, L.bqkv, M, D, D, L.wqkv16.out_scale,
+              rc = launch_gemm16_qkv(m->h16, m->h16_plane, L.wqkv16.p, L.wqkv16.plane, L.bqkv, M, Da, D, L.wqkv16.out_scale,
                                      m->qk16, m->qk16_plane, m->vt16, m->vt16_plane, m->rot_cos, m->rot_sin,
                                      c.arch == PGMI_ARCH_ESM2, T, H, m->gemm_variant, s);
           else
-              rc = linear(m, m->h, m->h16, m->h16_plane, L.wqkv, L.wqkv16, L.bqkv, nullptr, m->qkv, nullptr, 0, M, 3 * D, D, EPI_NONE);
+              rc = linear(m, m->h, m->h16, m->h16_plane, L.wqkv, L.wqkv16, L.bqkv, nullptr, m->qkv, nullptr, 0, M, 3 * Da, D, EPI_NONE);
           if (rc) return rc; }
         { ProfScope p(m, PGMI_K_ATTENTION, 4.0 * M * T * D, 0);
           const bool v2 = prec == PGMI_PREC_F16X3 && m->att16 >= 2;
@@ -317,7 +326,7 @@ int run_encoder(pgmi_model* m, int B, int T) {
                                         prec == PGMI_PREC_FP32 ? 0 : mode16, s);
           if (rc) return rc; }
         { ProfScope p(m, PGMI_K_GEMM_OUT, 2.0 * M * D * D, 0);
-          rc = linear(m, m->h, m->h16, m->h16_plane, L.wo, L.wo16, L.bo, m->x, m->x, nullptr, 0, M, D, D, EPI_NONE);
+          rc = linear(m, m->h, m->h16, m->h16_plane, L.wo, L.wo16, L.bo, m->x, m->x, nullptr, 0, M, D, Da, EPI_NONE);
           if (rc) return rc; }
         { ProfScope p(m, PGMI_K_LAYERNORM, 0, ln_bytes);
           if (prec == PGMI_PREC_FP32) launch_layernorm(m->x, L.ln2_w, L.ln2_b, M, D, 1e-5f, m->h, s);
@@ -556,6 +565,8 @@ int pgmi_model_create(const pgmi_config* cfg, const float* w, int64_t n_weights,
 #define TRY(e) do { rc = (e); if (rc) { pgmi_model_destroy(m); return rc; } } while (0)
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete m; return PGMI_EHIP; }
     const size_t D = cfg->embed_dim, F = cfg->ffn_dim, V = cfg->vocab;
+    m->dh = cfg->embed_dim / cfg->heads;
+    m->Da = cfg->heads * kHeadDim;
     m->ln_eps = cfg->ln_eps > 0.f ? cfg->ln_eps : 1e-5f;
     const float* p = w;
     if (cfg->arch == PGMI_ARCH_TRANCEPTION) {
@@ -574,26 +585,38 @@ int pgmi_model_create(const pgmi_config* cfg, const float* w, int64_t n_weights,
         TRY(dev_upload(m->allocs, &m->lnb_w, p, D)); p += D;
         TRY(dev_upload(m->allocs, &m->lnb_b, p, D)); p += D;
     }
-    const float qscale = 1.0f / sqrtf((float)kHeadDim);     // multihead_attention.py:261 (exact 1/8)
+    // head layout: every head owns 64 lanes of the attention kernels; dim j of a head sits in slot
+    // j (first half) or 32 + (j - dh/2) (second half) so that rotary pairs (j, j + dh/2) are the
+    // kernels' pairs (i, i + 32).  dh == 64 is the identity layout; smaller heads leave zero slots
+    // (zero weight rows -> q,k,v slots exactly 0 -> scores and context unchanged).
+    const size_t H = cfg->heads, dh = m->dh, Da = m->Da;
+    auto slot = [&](size_t col) { const size_t h = col / dh, j = col % dh; return h * 64 + (j < dh / 2 ? j : 32 + (j - dh / 2)); };
+    const float qscale = 1.0f / sqrtf((float)dh);           // multihead_attention.py:261 (exact 1/8 for dh 64)
     m->layers.resize(cfg->layers);
-    std::vector<float> wq(3 * D * D), bq(3 * D);
+    std::vector<float> wq(3 * Da * D, 0.0f), bq(3 * Da, 0.0f), wo_r(D * Da, 0.0f);
+    (void)H;
     for (int l = 0; l < cfg->layers; ++l) {
         Layer& L = m->layers[l];
         TRY(dev_upload(m->allocs, &L.ln1_w, p, D)); p += D;
         TRY(dev_upload(m->allocs, &L.ln1_b, p, D)); p += D;
-        for (int k = 0; k < 3; ++k) {            // fused [3D, D] projection, q rows pre-scaled
+        for (int k = 0; k < 3; ++k) {            // fused [3Da, D] projection, q rows pre-scaled
             const float sc = (k == 0) ? qscale : 1.0f;
-            for (size_t i = 0; i < D * D; ++i) wq[k * D * D + i] = p[i] * sc;
+            for (size_t o = 0; o < D; ++o) {
+                float* dst = &wq[(k * Da + slot(o)) * D];
+                for (size_t i = 0; i < D; ++i) dst[i] = p[o * D + i] * sc;
+            }
             p += D * D;
-            for (size_t i = 0; i < D; ++i) bq[k * D + i] = p[i] * sc;
+            for (size_t o = 0; o < D; ++o) bq[k * Da + slot(o)] = p[o] * sc;
             p += D;
         }
         const bool f32w = cfg->precision == PGMI_PREC_FP32;
         if (f32w) TRY(dev_upload(m->allocs, &L.wqkv, wq.data(), wq.size()));
         else TRY(make_w16(m->allocs, wq.data(), wq.size(), cfg->precision, m->stream, &L.wqkv16));
         TRY(dev_upload(m->allocs, &L.bqkv, bq.data(), bq.size()));
-        if (f32w) TRY(dev_upload(m->allocs, &L.wo, p, D * D));
-        else TRY(make_w16(m->allocs, p, D * D, cfg->precision, m->stream, &L.wo16));
+        for (size_t o = 0; o < D; ++o)           // out-proj [D, Da]: input columns follow the slot layout
+            for (size_t i = 0; i < D; ++i) wo_r[o * Da + slot(i)] = p[o * D + i];
+        if (f32w) TRY(dev_upload(m->allocs, &L.wo, wo_r.data(), wo_r.size()));
+        else TRY(make_w16(m->allocs, wo_r.data(), wo_r.size(), cfg->precision, m->stream, &L.wo16));
         p += D * D;
         TRY(dev_upload(m->allocs, &L.bo, p, D)); p += D;
         TRY(dev_upload(m->allocs, &L.ln2_w, p, D)); p += D;
@@ -622,15 +645,15 @@ int pgmi_model_create(const pgmi_config* cfg, const float* w, int64_t n_weights,
     m->max_rows = cfg->max_rows > 0 ? cfg->max_rows : 98304;
     if (m->max_rows < 2048) m->max_rows = 2048;
     {
-    const size_t R = m->max_rows;
+    const size_t R = m->max_rows, Da = m->Da, Dw = std::max(D, Da);   // h / h16 hold LN output [.,D] and attention context [.,Da]
     TRY(dev_alloc(m->allocs, &m->x, R * D));
-    TRY(dev_alloc(m->allocs, &m->h, R * D));
-    TRY(dev_alloc(m->allocs, &m->qkv, R * 3 * D));
+    TRY(dev_alloc(m->allocs, &m->h, R * Dw));
+    TRY(dev_alloc(m->allocs, &m->qkv, R * 3 * Da));
     const bool f32mode = cfg->precision == PGMI_PREC_FP32;
     TRY(dev_alloc(m->allocs, &m->g, R * (f32mode ? std::max(F, D) : D)));
     if (!f32mode) {
         const size_t planes = cfg->precision == PGMI_PREC_F16X3 ? 2 : 1;
-        m->h16_plane = R * D;
+        m->h16_plane = R * Dw;
         m->g16_plane = R * F;
         TRY(dev_alloc(m->allocs, &m->h16, m->h16_plane * planes));
         TRY(dev_alloc(m->allocs, &m->g16, m->g16_plane * planes));
@@ -639,8 +662,8 @@ int pgmi_model_create(const pgmi_config* cfg, const float* w, int64_t n_weights,
     PGMI_HIP(hipMemset(m->nonfinite, 0, 4));
     m->att16 = env_int("PGMI_ATT16", 3);
     if (cfg->precision == PGMI_PREC_F16X3) {
-        m->qk16_plane = R * 2 * D;
-        m->vt16_plane = R * D;
+        m->qk16_plane = R * 2 * Da;
+        m->vt16_plane = R * Da;
         TRY(dev_alloc(m->allocs, &m->qk16, m->qk16_plane * 2));
         TRY(dev_alloc(m->allocs, &m->vt16, m->vt16_plane * 2));
         PGMI_HIP(hipMemset(m->vt16, 0, m->vt16_plane * 2 * sizeof(unsigned short)));

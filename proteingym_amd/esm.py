@@ -192,6 +192,13 @@ class EsmModel:
                  max_rows: int = 0):
         lib = _lib.load()
         self.cfg = dict(cfg)
+        if precision != "fp32" and (cfg["embed_dim"] % 64 or cfg["ffn_dim"] % 64):
+            # the 16-bit GEMM tiles need K % 64 == 0 (e.g. ESM2-35M has embed_dim 480): such models run in
+            # the (also parity-gated) fp32 mode -- said out loud, never a silent switch
+            import sys
+            print(f"[proteingym_amd] embed_dim={cfg['embed_dim']} / ffn_dim={cfg['ffn_dim']} is not a multiple of 64: "
+                  f"using precision fp32 instead of {precision}", file=sys.stderr)
+            precision = "fp32"
         self.precision = precision
         c = Config(abi_version=_lib.ABI_VERSION, arch=cfg["arch"], layers=cfg["layers"],
                    embed_dim=cfg["embed_dim"], heads=cfg["heads"], ffn_dim=cfg["ffn_dim"], vocab=33,

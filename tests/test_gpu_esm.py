@@ -161,3 +161,46 @@ def test_assay_outliving_its_model_is_inert(lib, golden, golden_dir):
     with pytest.raises(pesm.PgmiError, match="destroyed model"):
         a.run()
     a.close()          # must not touch the freed model
+
+
+# ---- ESM2 members with head_dim < 64 (8M / 35M / 150M: 16 / 24 / 32), run zero-padded to 64 lanes ----
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
+@pytest.mark.parametrize("name", ["esm2_toy_h16", "esm2_toy_h24", "esm2_toy_h32"])
+def test_small_head_dims_vs_reference(lib, golden_dir, name, precision):
+    import pandas as pd
+    g = np.load(os.path.join(golden_dir, "golden_esm_small_heads.npz"))
+    seq = str(np.load(os.path.join(golden_dir, "golden_esm.npz"))["seq"])
+    m, _ = pesm.load_model_and_alphabet(os.path.join(golden_dir, name + ".pt"), precision=precision)
+    if name == "esm2_toy_h24":
+        assert m.precision == "fp32"                       # embed_dim 96 is not a multiple of 64
+    _, _, toks = pesm.Alphabet().get_batch_converter()([("p", seq)])
+    assert np.abs(m(toks)["logits"][0] - g[f"{name}/wt_logprobs"]).max() < TOL
+    n = toks.shape[1]
+    lp = m.masked_logprobs(np.repeat(toks, n, axis=0), np.arange(n))
+    assert np.abs(lp - g[f"{name}/mm_table"]).max() < TOL
+    pt = g[f"{name}/pad_tokens"]
+    valid = pt != 1
+    assert np.abs(m.token_logprobs(pt)[valid] - g[f"{name}/pad_logprobs"][valid]).max() < TOL
+    df = pd.read_csv(os.path.join(golden_dir, "TOY_DMS.csv"))
+    a = pesm.Assay(m, seq, list(df["mutant"]), offset_idx=1)
+    assert np.abs(a.run() - g[f"cli/{name}"]).max() < TOL
+    a.close()
+    m.close()
+
+
+def test_real_small_esm2_shapes_load_and_match_oracle(lib):
+    """ESM2 8M (6 x 320, 20 heads of 16) and 35M (12 x 480, 20 heads of 24) at their real shapes with
+    synthetic weights against the oracle (no golden at this size; the oracle is pinned on the toys)."""
+    from oracle import esm_oracle as eo
+    from proteingym_amd import synthetic
+    for layers, D in ((6, 320), (3, 480)):
+        cfg = dict(synthetic.ESM2_650M, layers=layers, embed_dim=D, heads=20, ffn_dim=4 * D)
+        blob = synthetic.random_weights(cfg, seed=D)
+        seq, muts, _ = synthetic.random_assay(seed=3, L=50, n_single=40, n_multi=10)
+        m = pesm.EsmModel(cfg, blob, device=0)
+        scores = pesm.Assay(m, seq, muts).run()
+        ocfg, W = eo.from_arrays(arrays=synthetic.blob_to_arrays(cfg, blob), **cfg)
+        table = eo.masked_marginals_table(ocfg, W, seq, batch=8)
+        ref = np.array([eo.label_row(mu, seq, table, 1) for mu in muts])
+        assert np.abs(scores - ref).max() < TOL
+        m.close()

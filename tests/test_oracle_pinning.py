@@ -199,3 +199,16 @@ def test_msa_cluster_oracle_vs_live_reference():
     m[rng.integers(0, 50, size=20)] = m[0]                      # a cluster of duplicates
     ref = w.calc_num_cluster_members_nogaps_parallel(m, 0.8, 20)
     assert np.array_equal(mo.cluster_counts(m, 0.8, 20), ref.astype(np.int32))
+
+
+@pytest.mark.parametrize("name", ["esm2_toy_h16", "esm2_toy_h24", "esm2_toy_h32"])
+def test_oracle_reproduces_small_head_goldens(golden_dir, name):
+    """ESM2 with head_dim 16 / 24 / 32 (rotary over the true head dim)."""
+    g = np.load(os.path.join(golden_dir, "golden_esm_small_heads.npz"))
+    seq = str(np.load(os.path.join(golden_dir, "golden_esm.npz"))["seq"])
+    cfg, W = eo.load_checkpoint(os.path.join(golden_dir, name + ".pt"))
+    table = eo.masked_marginals_table(cfg, W, seq, batch=16)
+    assert np.abs(table - g[f"{name}/mm_table"]).max() < 2e-5
+    df = pd.read_csv(os.path.join(golden_dir, "TOY_DMS.csv"))
+    scores = np.array([eo.label_row(m, seq, table, 1) for m in df["mutant"]])
+    assert np.abs(scores - g[f"cli/{name}"]).max() < 2e-5
