@@ -324,3 +324,39 @@ def load_reference_weights():
     mod.range = lambda *a: range(*[int(v) for v in a])
     spec.loader.exec_module(mod)
     return mod
+
+
+# ---- MSA Transformer (esm/model/msa_transformer.py) -----------------------------------------------
+def make_msa_transformer_checkpoint(path, layers, embed_dim, ffn_dim, heads, seed, max_positions=1024,
+                                    embed_std=0.25, msa_pos_std=0.1):
+    """Random-weight checkpoint in the fair-esm *v1* file layout of esm_msa1b_t12_100M_UR50S
+    (pretrained.py:107-121: ``args.arch == "msa_transformer"``, keys with ``encoder.`` /
+    ``sentence_encoder.`` prefixes and the released file's swapped row/column naming, which the loader
+    swaps back).  The model is built by the reference constructor (msa_transformer.py:84-145)."""
+    import torch
+    load_reference()
+    esm = sys.modules["esm"]
+    torch.manual_seed(seed)
+    alphabet = esm.data.Alphabet.from_architecture("msa_transformer")
+    margs = argparse.Namespace(arch="msa_transformer", layers=layers, embed_dim=embed_dim, ffn_embed_dim=ffn_dim,
+                               attention_heads=heads, dropout=0.1, attention_dropout=0.1, activation_dropout=0.1,
+                               max_positions=max_positions, embed_positions_msa=True, max_tokens_per_msa=2 ** 14,
+                               max_tokens=2 ** 14)
+    model = esm.model.msa_transformer.MSATransformer(margs, alphabet)
+    sd = model.state_dict()
+    _randomize(sd, embed_std, True, seed)
+    g = torch.Generator().manual_seed(seed + 99)
+    sd["msa_position_embedding"] = torch.randn(sd["msa_position_embedding"].shape, generator=g) * msa_pos_std
+    swap = lambda s: s.replace("row", "column") if "row" in s else s.replace("column", "row")
+    out = {}
+    for k, v in sd.items():
+        if k.startswith("contact_head"):
+            continue
+        pref = "encoder." if k.startswith("lm_head") else "encoder.sentence_encoder."
+        out[pref + swap(k)] = v.clone()
+    fargs = argparse.Namespace(arch="msa_transformer", encoder_layers=layers, encoder_embed_dim=embed_dim,
+                               encoder_ffn_embed_dim=ffn_dim, encoder_attention_heads=heads, dropout=0.1,
+                               attention_dropout=0.1, activation_dropout=0.1, max_positions=max_positions,
+                               embed_positions_msa=True, max_tokens_per_msa=2 ** 14, max_tokens=2 ** 14)
+    torch.save({"args": fargs, "model": out}, path)
+    return path
