@@ -44,6 +44,7 @@ extern "C" {
 /* Tranception: GPT2-style causal LM with grouped ALiBi, depth-wise conv on q/k/v, squared ReLU
  * (proteingym/baselines/tranception/tranception/model_pytorch.py) */
 #define PGMI_ARCH_TRANCEPTION 3
+#define PGMI_ARCH_MSA 4          /* MSA Transformer (esm_msa1b): axial attention, esm/model/msa_transformer.py */
 
 /* GEMM operand precision.  Residual stream, LayerNorm statistics, softmax and every
  * accumulator are fp32 in all modes. */
@@ -211,6 +212,33 @@ int pgmi_tr_sequence_loglik(pgmi_model* m, const int32_t* tokens, const int32_t*
  * Writes the mean milliseconds per launch. */
 int pgmi_bench_gemm(int device, int precision, int M, int N, int K, int epilogue, int split_out,
                     int variant, int iters, double* ms_per_launch);
+
+/* ---- MSA Transformer (arch PGMI_ARCH_MSA; vocab 33, head_dim 64, precision f16x3) --------------------
+ * Replaces MSATransformer.forward (proteingym/baselines/esm/esm/model/msa_transformer.py:146-205; tied
+ * row attention esm/axial_attention.py:33-168, column attention :171-297) and the masked-marginals loop
+ * of compute_fitness.py:380-394.
+ * Config: max_positions = args.max_positions (1024), emb_layer_norm_before = 1, token_dropout = 0,
+ * max_rows >= roundup(R,32) * roundup(T,32) for the largest token grid.
+ * Weight blob (fp32, nn.Linear [out,in]), state-dict names after the loader's row/column swap
+ * (pretrained.py:110-116):
+ *   embed_tokens.weight [33,D] (the tied lm_head.weight), embed_positions.weight [max_positions+2, D],
+ *   msa_position_embedding [1024, D] (a [1024,1] parameter is broadcast by the host),
+ *   emb_layer_norm_before.{weight,bias};
+ *   per layer: row_self_attention.{layer_norm.{weight,bias}, layer.q_proj.{weight,bias}, k_proj, v_proj,
+ *              out_proj}, column_self_attention.{same}, feed_forward_layer.{layer_norm.{weight,bias},
+ *              layer.fc1.{weight,bias}, layer.fc2.{weight,bias}};
+ *   emb_layer_norm_after.{weight,bias}; lm_head.dense.{weight,bias}; lm_head.layer_norm.{weight,bias};
+ *   lm_head.bias [33].
+ *
+ * pgmi_msa_token_logprobs: log_softmax(model(tokens[None])["logits"])[0] for one alignment.
+ *   tokens int32 [R][T] (<cls> first in every row, no <pad>), out float32 [R][T][33].
+ * pgmi_msa_masked_logprobs: for i < n, mask column positions[i] of the FIRST row, run the columns
+ *   [starts[i], min(T, starts[i] + window)) of all rows, keep log-probabilities of that cell:
+ *   out float32 [n][33].  (window = T when T <= 1024; else 1024 with starts from pgmi_optimal_window,
+ *   exactly as compute_fitness.py:383-388 crops.)  The alignment stays resident in HBM across the n forwards. */
+int pgmi_msa_token_logprobs(pgmi_model* m, const int32_t* tokens, int R, int T, float* out);
+int pgmi_msa_masked_logprobs(pgmi_model* m, const int32_t* tokens, int R, int T, int window,
+                             const int32_t* positions, const int32_t* starts, int n, float* out);
 
 /* ---- alignment pre-processing ---------------------------------------------
  * Cluster sizes (inverse sequence weights) of an alignment: replaces the numba kernel

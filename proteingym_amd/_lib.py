@@ -65,6 +65,8 @@ SIGNATURES = [
                                           _i32p, _i32p, _i32p, _i32p, C.c_float, _f32p]),
     ("pgmi_bench_gemm", C.c_int, [C.c_int] * 9 + [_f64p]),
     ("pgmi_op_attention", C.c_int, [C.c_int, C.c_int, _f32p, _i32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
+    ("pgmi_msa_token_logprobs", C.c_int, [C.c_void_p, _i32p, C.c_int, C.c_int, _f32p]),
+    ("pgmi_msa_masked_logprobs", C.c_int, [C.c_void_p, _i32p, C.c_int, C.c_int, C.c_int, _i32p, _i32p, C.c_int, _f32p]),
     ("pgmi_msa_cluster_counts", C.c_int, [C.c_int, C.POINTER(C.c_int8), C.c_int64, C.c_int64, C.c_int, C.c_double, _i32p, _f64p]),
 ]
 

@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libpgmi.so")
 BUILD = os.path.join(HERE, "csrc", "_build")
-SOURCES = ["api.hip", "elementwise.hip", "gemm_f32.hip", "gemm_f16.hip", "attention_f32.hip", "attention_f16.hip", "msa_weights.hip"]
+SOURCES = ["api.hip", "elementwise.hip", "gemm_f32.hip", "gemm_f16.hip", "attention_f32.hip", "attention_f16.hip", "msa_weights.hip", "msa_transformer.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 

@@ -190,16 +190,35 @@ def main(args):
         mutant_col = row["DMS_mutant_column"] if "DMS_mutant_column" in mapping_protein_seq_DMS.columns else mutant_col
         args.dms_output = str(args.dms_output) + os.sep + DMS_id + '.csv'
         target_seq_start_index = row["start_idx"] if "start_idx" in mapping_protein_seq_DMS.columns and row["start_idx"] != "" else 1
-        if "MSA_transformer" in args.model_type:
-            raise NotImplementedError("MSA Transformer scoring is out of scope for the MI355X ESM path")
+        target_seq_end_index = target_seq_start_index + len(args.sequence)
+        if "MSA_transformer" in args.model_type:                       # compute_fitness.py:310-325
+            msa_filename = row["MSA_filename"]
+            if msa_filename == "":
+                raise ValueError("No MSA found for DMS: " + str(DMS_id))
+            args.msa_path = str(args.msa_path) + os.sep + msa_filename
+            msa_start_index = int(row["MSA_start"]) if "MSA_start" in mapping_protein_seq_DMS.columns else 1
+            msa_end_index = int(row["MSA_end"]) if "MSA_end" in mapping_protein_seq_DMS.columns else len(args.sequence)
+            MSA_weight_file_name = args.msa_weights_folder + os.sep + row["weight_file_name"] \
+                if ("weight_file_name" in mapping_protein_seq_DMS.columns and args.msa_weights_folder is not None) else None
+            if (target_seq_start_index != msa_start_index) or (target_seq_end_index != msa_end_index):
+                args.sequence = args.sequence[msa_start_index - 1:msa_end_index]
+                target_seq_start_index = msa_start_index
+                target_seq_end_index = msa_end_index
         df = pd.read_csv(args.dms_input)
     else:
         DMS_id = str(args.dms_input).split(os.sep)[-1].split('.csv')[0]
         args.dms_output = str(args.dms_output) + os.sep + DMS_id + '.csv'
         target_seq_start_index = args.offset_idx
         args.sequence = args.target_seq.upper()
-        if "MSA_transformer" in args.model_type:
-            raise NotImplementedError("MSA Transformer scoring is out of scope for the MI355X ESM path")
+        if (args.MSA_start is None) or (args.MSA_end is None):             # compute_fitness.py:333-339
+            if args.msa_path:
+                print("MSA start and end not provided -- Assuming the MSA is covering the full WT sequence")
+            args.MSA_start = 1
+            args.MSA_end = len(args.target_seq)
+        msa_start_index = args.MSA_start
+        msa_end_index = args.MSA_end
+        MSA_weight_file_name = args.msa_weights_folder + os.sep + args.weight_file_name \
+            if (args.msa_weights_folder is not None and args.weight_file_name is not None) else None
         df = pd.read_csv(args.dms_input)
 
     if len(df) == 0:
@@ -210,6 +229,8 @@ def main(args):
                            "use the reference compute_fitness.py for CPU runs")
 
     print("Starting model scoring")
+    if "MSA_transformer" in args.model_type:
+        return score_msa_transformer(args, df, mutant_col, msa_start_index, MSA_weight_file_name)
     for model_location in args.model_location:
         model, alphabet = pesm.load_model_and_alphabet(model_location, device=args.device,
                                                        precision=args.precision)
@@ -246,6 +267,65 @@ def main(args):
     tmp = str(args.dms_output) + ".tmp"
     df.to_csv(tmp, index=False)
     os.replace(tmp, args.dms_output)            # atomic: a crashed shard never leaves a partial CSV
+
+
+def score_msa_transformer(args, df, mutant_col, msa_start_index, MSA_weight_file_name):
+    """compute_fitness.py:360-424 + 538-543: per seed sample the alignment, masked-marginals over the first
+    row, one ``<checkpoint>_seed<k>`` column per seed, then their mean in ``<checkpoint>_ensemble``."""
+    from . import msa_transformer as pmsa
+    seeds = args.seeds if isinstance(args.seeds, (list, tuple)) else [args.seeds]
+    assert args.scoring_strategy in ["masked-marginals", "pseudo-ppl"], "Zero-shot scoring strategy not supported with MSA Transformer"
+    if args.scoring_strategy == "pseudo-ppl":
+        raise NotImplementedError("pseudo-ppl with the MSA Transformer is not built (the reference launcher uses masked-marginals)")
+    for model_location in args.model_location:
+        max_rows = (min(args.msa_samples, 1024) + 31) // 32 * 32 * ((min(len(args.sequence) + 1, 1024) + 31) // 32 * 32)
+        model, alphabet = pmsa.load_model_and_alphabet(model_location, device=args.device, max_rows=max_rows)
+        model_location = model_location.split("/")[-1].split(".")[0]
+        print("Transferred model to GPU")
+        batch_converter = alphabet.get_batch_converter()
+        args.offset_idx = msa_start_index
+        processed_msa = pmsa.process_msa(filename=str(args.msa_path), weight_filename=MSA_weight_file_name,
+                                         filter_msa=args.filter_msa, device=args.device)
+        mutants = [str(m) for m in df[mutant_col]]
+        for seed in seeds:
+            if os.path.exists(args.dms_output):
+                prior_score_df = pd.read_csv(args.dms_output)
+                if f"{model_location}_seed{seed}" in prior_score_df.columns and not args.overwrite_prior_scores:
+                    print(f"Skipping seed {seed} as it is already in the dataframe")
+                    df = prior_score_df
+                    continue
+            data = [pmsa.sample_msa(sampling_strategy=args.msa_sampling_strategy, filename=str(args.msa_path), nseq=args.msa_samples,
+                                    weight_filename=MSA_weight_file_name, processed_msa=processed_msa, random_seed=seed,
+                                    device=args.device)]
+            _, _, batch_tokens = batch_converter(data)
+            print(f"Batch sizes: {batch_tokens.shape}")
+            T = batch_tokens.shape[2]
+            # the reference forwards every column; only the cells some mutant reads are needed (--all-positions restores it)
+            if args.all_positions:
+                positions = list(range(T))
+            else:
+                positions = sorted({1 + int(mu[1:-1]) - args.offset_idx for m in mutants for mu in m.split(":")})
+            rows = model.masked_logprobs(batch_tokens[0], positions, seq_len=len(args.sequence))
+            token_probs = np.full((T, 33), np.nan, dtype=np.float32)
+            token_probs[positions] = rows
+            df[f"{model_location}_seed{seed}"] = [label_row(m, args.sequence, token_probs, alphabet, args.offset_idx) for m in mutants]
+            if os.path.exists(args.dms_output) and not args.overwrite_prior_scores:
+                prior_score_df = pd.read_csv(args.dms_output)
+                assert f"{model_location}_seed{seed}" not in prior_score_df.columns, \
+                    f"Column {model_location}_seed{seed} already exists in {args.dms_output}"
+                prior_score_df = prior_score_df.merge(df[[f"{model_location}_seed{seed}", "mutant"]], on="mutant")
+                prior_score_df.to_csv(args.dms_output, index=False)
+                df = prior_score_df
+            else:
+                df.to_csv(args.dms_output, index=False)
+        model.close()
+    df[f"{model_location}_ensemble"] = 0.0
+    for seed in seeds:
+        df[f"{model_location}_ensemble"] += df[f"{model_location}_seed{seed}"]
+    df[f"{model_location}_ensemble"] /= len(seeds)
+    tmp = str(args.dms_output) + ".tmp"
+    df.to_csv(tmp, index=False)
+    os.replace(tmp, args.dms_output)
 
 
 if __name__ == "__main__":

@@ -37,6 +37,9 @@ struct Layer {
     float *ln1_w, *ln1_b, *wqkv, *bqkv, *wo, *bo, *ln2_w, *ln2_b, *w1, *b1, *w2, *b2;
     W16 wqkv16, wo16, w116, w216;
     float* conv = nullptr;        // Tranception: [3][4][64][8] right-aligned 7-tap filters + bias (attention_f16.hip)
+    // MSA Transformer: ln1/wqkv/wo = tied row attention, c_* = column attention, ln2/w1/w2 = feed forward
+    float *c_ln_w = nullptr, *c_ln_b = nullptr, *c_bqkv = nullptr, *c_bo = nullptr;
+    W16 c_wqkv16, c_wo16;
 };
 
 struct ProfEvent {
@@ -65,6 +68,14 @@ struct pgmi_model {
     float *tr_lm_head = nullptr, *tr_zero_bias = nullptr, *tr_slopes = nullptr;   // Tranception head / ALiBi slopes
     float* tr_prior = nullptr;                          // device copy of the retrieval log-prior [P,V]
     int tr_prior_rows = 0;
+    // MSA Transformer
+    float* msa_pe = nullptr;                            // msa_position_embedding [1024, D]
+    float* xt = nullptr;                                // residual stream in column-major token order
+    int32_t *msa_full = nullptr, *msa_kv_len = nullptr; // device copy of the MSA token grid; [C] = R
+    size_t msa_full_cap = 0;
+    float *tied_part = nullptr, *tied_p = nullptr, *tied_vt = nullptr;   // split-K scores, probabilities, V^T
+    size_t tied_part_cap = 0, tied_p_cap = 0, tied_vt_cap = 0;
+    int msa_kv_R = 0, msa_kv_C = 0;
     float ln_eps = 1e-5f;
     unsigned short *h16 = nullptr, *g16 = nullptr;     // activation planes [planes][R*D], [planes][R*F]
     size_t h16_plane = 0, g16_plane = 0;
@@ -165,7 +176,7 @@ int prof_drain(pgmi_model* m) {
 int check_cfg(const pgmi_config* c) {
     if (!c) { set_error("null config"); return PGMI_EINVAL; }
     if (c->abi_version != PGMI_ABI_VERSION) { set_error("ABI version mismatch: got %d, library is %d", c->abi_version, PGMI_ABI_VERSION); return PGMI_EINVAL; }
-    if (c->arch != PGMI_ARCH_ESM1B && c->arch != PGMI_ARCH_ESM2 && c->arch != PGMI_ARCH_TRANCEPTION) { set_error("unknown arch %d", c->arch); return PGMI_EINVAL; }
+    if (c->arch != PGMI_ARCH_ESM1B && c->arch != PGMI_ARCH_ESM2 && c->arch != PGMI_ARCH_TRANCEPTION && c->arch != PGMI_ARCH_MSA) { set_error("unknown arch %d", c->arch); return PGMI_EINVAL; }
     if (c->layers <= 0 || c->embed_dim <= 0 || c->heads <= 0 || c->ffn_dim <= 0) { set_error("non-positive model dimension"); return PGMI_EINVAL; }
     {
         // head_dim 64 natively; smaller head dims (ESM2 8M/35M/150M: 16/24/32) run zero-padded to 64
@@ -182,6 +193,11 @@ int check_cfg(const pgmi_config* c) {
         if (c->max_positions <= 0) { set_error("Tranception needs max_positions = n_ctx"); return PGMI_EINVAL; }
     } else if (c->vocab != PGMI_VOCAB) { set_error("vocab must be %d", PGMI_VOCAB); return PGMI_EINVAL; }
     if (c->arch == PGMI_ARCH_ESM1B && c->max_positions <= 0) { set_error("ESM-1b arch needs max_positions"); return PGMI_EINVAL; }
+    if (c->arch == PGMI_ARCH_MSA) {
+        if (c->max_positions <= 0) { set_error("MSA Transformer needs max_positions"); return PGMI_EINVAL; }
+        if (c->embed_dim != c->heads * kHeadDim) { set_error("MSA Transformer: head_dim must be 64"); return PGMI_EINVAL; }
+        if (c->precision != PGMI_PREC_F16X3) { set_error("MSA Transformer is available in precision f16x3 only"); return PGMI_EINVAL; }
+    }
     if (c->precision != PGMI_PREC_FP32 && c->precision != PGMI_PREC_F16X3 && c->precision != PGMI_PREC_BF16) { set_error("unknown precision %d", c->precision); return PGMI_EINVAL; }
     if (c->precision != PGMI_PREC_FP32 && (c->embed_dim % 64 || c->ffn_dim % 64)) { set_error("16-bit modes need embed_dim and ffn_dim to be multiples of 64"); return PGMI_EINVAL; }
     return PGMI_OK;
@@ -501,6 +517,172 @@ int run_tranception(pgmi_model* m, int B, int T) {
     return PGMI_OK;
 }
 
+
+// ---- MSA Transformer -------------------------------------------------------------------------------
+// Blob order (include/pgmi.h): embed_tokens, embed_positions [(max_positions+2), D], msa_position_embedding
+// [1024, D], emb_layer_norm_before; per layer {row attention: ln, q, k, v, out; column attention: same;
+// feed forward: ln, fc1, fc2}; emb_layer_norm_after; lm_head dense, layer_norm, bias.
+int create_msa(pgmi_model* m, const pgmi_config* cfg, const float* w, int64_t n_weights) {
+    const size_t D = cfg->embed_dim, F = cfg->ffn_dim, V = cfg->vocab;
+    const float* p = w;
+    int rc = 0;
+#define TRY(e) do { rc = (e); if (rc) return rc; } while (0)
+    TRY(dev_upload(m->allocs, &m->embed_tokens, p, V * D)); p += V * D;
+    { const size_t n = (size_t)(cfg->max_positions + 2) * D; TRY(dev_upload(m->allocs, &m->embed_positions, p, n)); p += n; }
+    TRY(dev_upload(m->allocs, &m->msa_pe, p, (size_t)1024 * D)); p += (size_t)1024 * D;
+    TRY(dev_upload(m->allocs, &m->lnb_w, p, D)); p += D;
+    TRY(dev_upload(m->allocs, &m->lnb_b, p, D)); p += D;
+    const float qscale = 1.0f / sqrtf((float)kHeadDim);      // axial_attention.py:48,212 (exact 1/8); the tied
+    m->layers.resize(cfg->layers);                           // rows' extra 1/sqrt(R) is applied to the scores
+    std::vector<float> wq(3 * D * D), bq(3 * D);
+    auto attn = [&](float** ln_w, float** ln_b, W16* wqkv, float** bqkv, W16* wo, float** bo) -> int {
+        TRY(dev_upload(m->allocs, ln_w, p, D)); p += D;
+        TRY(dev_upload(m->allocs, ln_b, p, D)); p += D;
+        for (int k = 0; k < 3; ++k) {
+            const float sc = (k == 0) ? qscale : 1.0f;
+            for (size_t i = 0; i < D * D; ++i) wq[k * D * D + i] = p[i] * sc;
+            p += D * D;
+            for (size_t i = 0; i < D; ++i) bq[k * D + i] = p[i] * sc;
+            p += D;
+        }
+        TRY(make_w16(m->allocs, wq.data(), wq.size(), cfg->precision, m->stream, wqkv));
+        TRY(dev_upload(m->allocs, bqkv, bq.data(), bq.size()));
+        TRY(make_w16(m->allocs, p, D * D, cfg->precision, m->stream, wo)); p += D * D;
+        TRY(dev_upload(m->allocs, bo, p, D)); p += D;
+        return PGMI_OK;
+    };
+    for (int l = 0; l < cfg->layers; ++l) {
+        Layer& L = m->layers[l];
+        TRY(attn(&L.ln1_w, &L.ln1_b, &L.wqkv16, &L.bqkv, &L.wo16, &L.bo));
+        TRY(attn(&L.c_ln_w, &L.c_ln_b, &L.c_wqkv16, &L.c_bqkv, &L.c_wo16, &L.c_bo));
+        TRY(dev_upload(m->allocs, &L.ln2_w, p, D)); p += D;
+        TRY(dev_upload(m->allocs, &L.ln2_b, p, D)); p += D;
+        TRY(make_w16(m->allocs, p, F * D, cfg->precision, m->stream, &L.w116)); p += F * D;
+        TRY(dev_upload(m->allocs, &L.b1, p, F)); p += F;
+        TRY(make_w16(m->allocs, p, D * F, cfg->precision, m->stream, &L.w216)); p += D * F;
+        TRY(dev_upload(m->allocs, &L.b2, p, D)); p += D;
+    }
+    TRY(dev_upload(m->allocs, &m->lna_w, p, D)); p += D;
+    TRY(dev_upload(m->allocs, &m->lna_b, p, D)); p += D;
+    TRY(make_w16(m->allocs, p, D * D, cfg->precision, m->stream, &m->hd16)); p += D * D;
+    TRY(dev_upload(m->allocs, &m->hd_b, p, D)); p += D;
+    TRY(dev_upload(m->allocs, &m->hln_w, p, D)); p += D;
+    TRY(dev_upload(m->allocs, &m->hln_b, p, D)); p += D;
+    TRY(dev_upload(m->allocs, &m->h_bias, p, V)); p += V;
+#undef TRY
+    if (p - w != n_weights) { set_error("internal: blob walk mismatch"); return PGMI_EINVAL; }
+    return PGMI_OK;
+}
+
+template <typename T>
+static int ensure_cap(pgmi_model* m, T** p, size_t* cap, size_t need) {
+    if (need <= *cap) return PGMI_OK;
+    // grown buffers are owned by the model's pool; the old one stays in the pool until destroy (shapes
+    // change rarely: once per alignment)
+    T* q = nullptr;
+    int rc = dev_alloc(m->allocs, &q, need);
+    if (rc) return rc;
+    *p = q;
+    *cap = need;
+    return PGMI_OK;
+}
+
+// MSA Transformer forward on the token grid in m->tokens [R, C] (one alignment); leaves the residual
+// stream (row-major token order) in m->x.  msa_transformer.py:146-205.
+int run_msa(pgmi_model* m, int R, int C) {
+    const pgmi_config& c = m->cfg;
+    const int M = R * C, D = c.embed_dim, F = c.ffn_dim, H = c.heads;
+    hipStream_t s = m->stream;
+    if (R > 1024) { set_error("Using model with MSA position embedding trained on maximum MSA depth of 1024, but received %d alignments.", R); return PGMI_EINVAL; }
+    if (C > c.max_positions) { set_error("Sequence length %d above maximum sequence length of %d", C, c.max_positions); return PGMI_EINVAL; }
+    const int Rp = (R + 31) / 32 * 32, Cp = (C + 31) / 32 * 32;
+    if ((int64_t)Rp * Cp > m->max_rows) { set_error("alignment of %d x %d tokens exceeds the workspace (%d rows): create the model with max_rows >= %lld", R, C, m->max_rows, (long long)Rp * Cp); return PGMI_EINVAL; }
+    int rc = 0;
+    // split the (r, d) contraction of the tied scores so that the launch fills the chip: S divides R
+    int S = 1;
+    { const int tiles = ((C + 127) / 128) * ((C + 127) / 128) * H;
+      for (int cand = 1; cand <= 16; ++cand) if (R % cand == 0 && tiles * cand <= 2048) S = cand; }
+    rc = ensure_cap(m, &m->tied_part, &m->tied_part_cap, (size_t)H * S * C * Cp); if (rc) return rc;
+    rc = ensure_cap(m, &m->tied_p, &m->tied_p_cap, (size_t)H * C * Cp); if (rc) return rc;
+    rc = ensure_cap(m, &m->tied_vt, &m->tied_vt_cap, (size_t)H * R * 64 * Cp); if (rc) return rc;
+    if (R != m->msa_kv_R || C != m->msa_kv_C) {
+        std::vector<int32_t> kv((size_t)C, R);
+        PGMI_HIP(hipMemcpyAsync(m->msa_kv_len, kv.data(), (size_t)C * 4, hipMemcpyHostToDevice, s));
+        PGMI_HIP(hipStreamSynchronize(s));
+        // pad keys of the column attention (rows >= R inside the last 32-key tile) must hold finite data
+        PGMI_HIP(hipMemsetAsync(m->vt16, 0, m->vt16_plane * 2 * sizeof(unsigned short), s));
+        m->msa_kv_R = R; m->msa_kv_C = C;
+        m->last_B = C; m->last_T = R;
+    }
+    { ProfScope p(m, PGMI_K_EMBED, 0, (double)M * D * 4);
+      launch_seq_stats(m->tokens, R, C, 0, m->denom, m->pos_idx, m->kv_len, s);
+      launch_embed(m->tokens, m->denom, m->pos_idx, m->embed_tokens, m->embed_positions, 0, M, C, D, m->x, s);
+      launch_add_row_embedding(m->x, m->msa_pe, R, C, D, s);
+      launch_layernorm(m->x, m->lnb_w, m->lnb_b, M, D, 1e-5f, m->x, s); }
+    const double ln_bytes = 2.0 * M * D * 4;
+    const size_t ld3 = (size_t)3 * D;
+    for (int l = 0; l < c.layers; ++l) {
+        const Layer& L = m->layers[l];
+        // ---- tied row attention (axial_attention.py:108-168) ----
+        { ProfScope p(m, PGMI_K_LAYERNORM, 0, ln_bytes);
+          launch_layernorm16(m->x, L.ln1_w, L.ln1_b, M, D, 1e-5f, m->h16, m->h16_plane, 1, s); }
+        { ProfScope p(m, PGMI_K_GEMM_QKV, 2.0 * M * 3 * D * D, 0);
+          rc = linear(m, nullptr, m->h16, m->h16_plane, nullptr, L.wqkv16, L.bqkv, nullptr, m->qkv, nullptr, 0, M, 3 * D, D, EPI_NONE);
+          if (rc) return rc; }
+        { ProfScope p(m, PGMI_K_ATTENTION, 4.0 * (double)C * C * R * D, 0);
+          GemmF32Ex g1;                                    // scores: batch = (head, K split)
+          g1.lda = g1.ldw = (int64_t)ld3; g1.ldc = Cp;
+          g1.kblock = 64; g1.a_kbstride = g1.w_kbstride = (int64_t)C * ld3;
+          g1.nbatch = H * S; g1.inner = S;
+          g1.a_s0 = g1.w_s0 = (int64_t)(R / S) * C * ld3; g1.a_s1 = g1.w_s1 = 64;
+          g1.c_s0 = (int64_t)C * Cp; g1.c_s1 = (int64_t)S * C * Cp;
+          rc = launch_gemm_f32_ex(m->qkv, m->qkv + D, m->tied_part, C, C, (R / S) * 64, g1, s);
+          if (rc) return rc;
+          rc = launch_tied_softmax(m->tied_part, H, S, C, Cp, 1.0f / sqrtf((float)R), m->tied_p, s);
+          if (rc) return rc;
+          launch_pack_vt(m->qkv, R, C, Cp, H, m->tied_vt, s);
+          GemmF32Ex g2;                                    // update: batch = head, output scattered to [r, i, h, d]
+          g2.lda = Cp; g2.ldw = Cp; g2.ldc = D;
+          g2.kblock = Cp; g2.a_kbstride = g2.w_kbstride = Cp;
+          g2.nblock = 64; g2.c_nbstride = (int64_t)C * D;
+          g2.nbatch = H; g2.inner = H;
+          g2.a_s0 = (int64_t)C * Cp; g2.w_s0 = (int64_t)R * 64 * Cp; g2.c_s0 = 64;
+          rc = launch_gemm_f32_ex(m->tied_p, m->tied_vt, m->h, C, R * 64, Cp, g2, s);
+          if (rc) return rc;
+          launch_split16(m->h, (int64_t)M * D, 1.0f, 2, m->h16, m->h16_plane, s); }
+        { ProfScope p(m, PGMI_K_GEMM_OUT, 2.0 * M * D * D, 0);
+          rc = linear(m, nullptr, m->h16, m->h16_plane, nullptr, L.wo16, L.bo, m->x, m->x, nullptr, 0, M, D, D, EPI_NONE);
+          if (rc) return rc; }
+        // ---- column attention (axial_attention.py:232-275): ordinary attention over the R rows of a column ----
+        { ProfScope p(m, PGMI_K_LAYERNORM, 0, 2 * ln_bytes);
+          launch_permute_rows(m->x, m->xt, R, C, D, s);                       // -> token order (c, r)
+          launch_layernorm16(m->xt, L.c_ln_w, L.c_ln_b, M, D, 1e-5f, m->h16, m->h16_plane, 1, s); }
+        { ProfScope p(m, PGMI_K_GEMM_QKV, 2.0 * M * 3 * D * D, 0);
+          rc = launch_gemm16_qkv(m->h16, m->h16_plane, L.c_wqkv16.p, L.c_wqkv16.plane, L.c_bqkv, M, D, D, L.c_wqkv16.out_scale,
+                                 m->qk16, m->qk16_plane, m->vt16, m->vt16_plane, nullptr, nullptr, 0, R, H, m->gemm_variant, s);
+          if (rc) return rc; }
+        { ProfScope p(m, PGMI_K_ATTENTION, 4.0 * (double)M * R * D, 0);
+          rc = launch_attention_f16x3_v2(nullptr, m->msa_kv_len, nullptr, nullptr, 0, C, R, H, m->qk16, m->qk16_plane, m->vt16,
+                                         m->vt16_plane, nullptr, m->h16, m->h16_plane, 1, s);
+          if (rc) return rc; }
+        { ProfScope p(m, PGMI_K_GEMM_OUT, 2.0 * M * D * D, 0);
+          rc = linear(m, nullptr, m->h16, m->h16_plane, nullptr, L.c_wo16, L.c_bo, m->xt, m->xt, nullptr, 0, M, D, D, EPI_NONE);
+          if (rc) return rc; }
+        { ProfScope p(m, PGMI_K_LAYERNORM, 0, 2 * ln_bytes);
+          launch_permute_rows(m->xt, m->x, C, R, D, s);                       // back to (r, c)
+          launch_layernorm16(m->x, L.ln2_w, L.ln2_b, M, D, 1e-5f, m->h16, m->h16_plane, 1, s); }
+        // ---- feed forward (modules.py:409-432) ----
+        { ProfScope p(m, PGMI_K_GEMM_FC1, 2.0 * M * F * D, 0);
+          rc = linear(m, nullptr, m->h16, m->h16_plane, nullptr, L.w116, L.b1, nullptr, nullptr, m->g16, m->g16_plane, M, F, D, EPI_GELU);
+          if (rc) return rc; }
+        { ProfScope p(m, PGMI_K_GEMM_FC2, 2.0 * M * F * D, 0);
+          rc = linear(m, nullptr, m->g16, m->g16_plane, nullptr, L.w216, L.b2, m->x, m->x, nullptr, 0, M, D, F, EPI_NONE);
+          if (rc) return rc; }
+    }
+    PGMI_HIP(hipGetLastError());
+    return PGMI_OK;
+}
+
 // fp16 range check for the 16-bit modes: the vocabulary kernel raises the flag when a computed
 // log-probability is NaN/inf (an activation exceeded fp16's 65504 upstream).
 int check_nonfinite(pgmi_model* m) {
@@ -538,6 +720,11 @@ int64_t pgmi_weight_count(const pgmi_config* c) {
         const int64_t conv = 3 * ((64 * 3 + 64) + (64 * 5 + 64) + (64 * 7 + 64));
         return V * D + (int64_t)c->layers * (2 * D + (D * 3 * D + 3 * D) + conv + (D * D + D) + 2 * D + (D * F + F) + (F * D + D)) + 2 * D + V * D;
     }
+    if (c->arch == PGMI_ARCH_MSA) {
+        const int64_t attn = 2 * D + 4 * (D * D + D);
+        return V * D + (int64_t)(c->max_positions + 2) * D + 1024 * D + 2 * D +
+               (int64_t)c->layers * (2 * attn + 2 * D + (F * D + F) + (D * F + D)) + 2 * D + (D * D + D) + 2 * D + V;
+    }
     int64_t n = V * D;
     if (c->arch == PGMI_ARCH_ESM1B) n += (int64_t)(c->max_positions + 2) * D;
     if (c->emb_layer_norm_before) n += 2 * D;
@@ -571,6 +758,8 @@ int pgmi_model_create(const pgmi_config* cfg, const float* w, int64_t n_weights,
     const float* p = w;
     if (cfg->arch == PGMI_ARCH_TRANCEPTION) {
         TRY(create_tranception(m, cfg, w, n_weights));
+    } else if (cfg->arch == PGMI_ARCH_MSA) {
+        TRY(create_msa(m, cfg, w, n_weights));
     } else {
     // embed_tokens == the tied lm_head.weight (esm1.py:101-105).  The host passes the matrix that
     // load_state_dict leaves in the tied parameter (pretrained.py:97,216), see proteingym_amd/esm.py.
@@ -669,6 +858,10 @@ int pgmi_model_create(const pgmi_config* cfg, const float* w, int64_t n_weights,
         PGMI_HIP(hipMemset(m->vt16, 0, m->vt16_plane * 2 * sizeof(unsigned short)));
     }
     m->gemm_variant = env_int("PGMI_GEMM_VARIANT", 2);   // 256x256 tile, 8 waves (fastest measured)
+    if (cfg->arch == PGMI_ARCH_MSA) {
+        TRY(dev_alloc(m->allocs, &m->xt, R * D));
+        TRY(dev_alloc(m->allocs, &m->msa_kv_len, (size_t)2048));
+    }
     TRY(dev_alloc(m->allocs, &m->lp, R * V));
     TRY(dev_alloc(m->allocs, &m->denom, R));
     TRY(dev_alloc(m->allocs, &m->tokens, R));
@@ -751,6 +944,58 @@ int pgmi_masked_logprobs(pgmi_model* m, const int32_t* tokens, const int32_t* ma
         rc = run_head(m, bc, m->row_idx);
         if (rc) return rc;
         PGMI_HIP(hipMemcpyAsync(out + (size_t)b0 * V, m->lp, (size_t)bc * V * 4, hipMemcpyDeviceToHost, m->stream));
+        PGMI_HIP(hipStreamSynchronize(m->stream));
+    }
+    return check_nonfinite(m);
+}
+
+
+static int msa_upload(pgmi_model* m, const int32_t* tokens, int R, int T) {
+    if (!m || m->cfg.arch != PGMI_ARCH_MSA) { set_error("model is not an MSA Transformer"); return PGMI_EINVAL; }
+    if (!tokens || R <= 0 || T <= 0) { set_error("bad argument"); return PGMI_EINVAL; }
+    for (int64_t i = 0; i < (int64_t)R * T; ++i) {
+        if (tokens[i] < 0 || tokens[i] >= PGMI_VOCAB) { set_error("token id %d out of range at [%lld,%lld]", tokens[i], (long long)(i / T), (long long)(i % T)); return PGMI_EINVAL; }
+        if (tokens[i] == PGMI_TOK_PAD) { set_error("<pad> at [%lld,%lld]: the rows of an alignment must have equal length", (long long)(i / T), (long long)(i % T)); return PGMI_EINVAL; }
+    }
+    PGMI_HIP(hipSetDevice(m->device));
+    int rc = ensure_cap(m, &m->msa_full, &m->msa_full_cap, (size_t)R * T);
+    if (rc) return rc;
+    PGMI_HIP(hipMemcpyAsync(m->msa_full, tokens, (size_t)R * T * 4, hipMemcpyHostToDevice, m->stream));
+    return PGMI_OK;
+}
+
+int pgmi_msa_token_logprobs(pgmi_model* m, const int32_t* tokens, int R, int T, float* out) {
+    if (!out) { set_error("bad argument"); return PGMI_EINVAL; }
+    int rc = msa_upload(m, tokens, R, T);
+    if (rc) return rc;
+    launch_msa_window_tokens(m->msa_full, R, T, 0, T, -1, m->tokens, m->stream);
+    rc = run_msa(m, R, T);
+    if (rc) return rc;
+    rc = run_head(m, R * T, nullptr);
+    if (rc) return rc;
+    PGMI_HIP(hipMemcpyAsync(out, m->lp, (size_t)R * T * m->cfg.vocab * 4, hipMemcpyDeviceToHost, m->stream));
+    PGMI_HIP(hipStreamSynchronize(m->stream));
+    return check_nonfinite(m);
+}
+
+int pgmi_msa_masked_logprobs(pgmi_model* m, const int32_t* tokens, int R, int T, int window, const int32_t* positions,
+                             const int32_t* starts, int n, float* out) {
+    if (!positions || !starts || !out || n < 0 || window <= 0) { set_error("bad argument"); return PGMI_EINVAL; }
+    int rc = msa_upload(m, tokens, R, T);
+    if (rc) return rc;
+    const int V = m->cfg.vocab;
+    for (int i = 0; i < n; ++i) {
+        const int st = starts[i], pos = positions[i];
+        const int Tw = std::min(window, T - st);             // python slicing [:, :, start:end] truncates at the end
+        if (st < 0 || st >= T || pos < st || pos >= st + Tw) { set_error("position %d outside its window [%d,%d)", pos, st, st + Tw); return PGMI_EINVAL; }
+        launch_msa_window_tokens(m->msa_full, R, T, st, Tw, pos, m->tokens, m->stream);
+        rc = run_msa(m, R, Tw);
+        if (rc) return rc;
+        const int32_t row = pos - st;                        // row 0 of the grid, column pos - start
+        PGMI_HIP(hipMemcpyAsync(m->row_idx, &row, 4, hipMemcpyHostToDevice, m->stream));
+        rc = run_head(m, 1, m->row_idx);
+        if (rc) return rc;
+        PGMI_HIP(hipMemcpyAsync(out + (size_t)i * V, m->lp, (size_t)V * 4, hipMemcpyDeviceToHost, m->stream));
         PGMI_HIP(hipStreamSynchronize(m->stream));
     }
     return check_nonfinite(m);

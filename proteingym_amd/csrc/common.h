@@ -81,6 +81,24 @@ void launch_rotary(float* qkv, const float* cos_t, const float* sin_t, int rows,
 
 // ---- gemm_f32.hip ------------------------------------------------------------------------
 // C[M,N] = epi(A[M,K] W[N,K]^T + bias[N]) (+ residual[M,N]); K % 32 == 0.
+// ---- msa_transformer.hip ------------------------------------------------------------------
+void launch_msa_window_tokens(const int32_t* full, int R, int Tfull, int start, int Tw, int mask_col, int32_t* out, hipStream_t s);
+void launch_add_row_embedding(float* x, const float* pe, int R, int C, int D, hipStream_t s);
+void launch_permute_rows(const float* src, float* dst, int A, int B, int D, hipStream_t s);
+int launch_tied_softmax(const float* part, int H, int S, int C, int Cp, float scale, float* P, hipStream_t s);
+void launch_pack_vt(const float* qkv, int R, int C, int Cp, int H, float* Vt, hipStream_t s);
+
+// Strided / batched fp32 GEMM: C_b = A_b W_b^T for b in [0, nbatch); b = bo * inner + bi.
+struct GemmF32Ex {
+    int64_t lda = 0, ldw = 0, ldc = 0;                 // row strides (elements)
+    int kblock = 32;                                   // K axis = runs of kblock contiguous elements ...
+    int64_t a_kbstride = 0, w_kbstride = 0;            // ... this far apart (== kblock for a dense row)
+    int nblock = 1 << 30;                              // output N axis = runs of nblock columns ...
+    int64_t c_nbstride = 0;                            // ... this far apart
+    int nbatch = 1, inner = 1;
+    int64_t a_s0 = 0, a_s1 = 0, w_s0 = 0, w_s1 = 0, c_s0 = 0, c_s1 = 0;   // per-batch base offsets (inner, outer)
+};
+int launch_gemm_f32_ex(const float* A, const float* W, float* C, int M, int N, int K, const GemmF32Ex& ex, hipStream_t s);
 int launch_gemm_f32(const float* A, const float* W, const float* bias, const float* residual,
                     float* C, int M, int N, int K, int epilogue, hipStream_t s);
 

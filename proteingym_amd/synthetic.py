@@ -229,3 +229,39 @@ def tranception_blob_to_arrays(cfg, blob):
         o += m
     assert o == blob.size
     return out
+
+
+# ---- MSA Transformer (esm_msa1b_t12_100M_UR50S shape: 12 x 768, 12 heads, F = 3072) ------------------
+MSA_1B = dict(arch=4, layers=12, embed_dim=768, heads=12, ffn_dim=3072, max_positions=1024, embed_positions_msa=True)
+
+
+def random_msa_transformer_arrays(cfg, seed: int, embed_std: float = 0.25) -> Dict[str, np.ndarray]:
+    """State-dict-keyed random arrays (names after the loader's row/column swap) for
+    ``msa_transformer.pack_state_dict`` and the oracle's ``from_arrays``."""
+    from . import msa_transformer as pmsa
+    rng = np.random.default_rng(seed)
+    D, F = cfg["embed_dim"], cfg["ffn_dim"]
+    out = {}
+    for k in pmsa.expected_keys(cfg):
+        if k == "embed_tokens.weight":
+            out[k] = (rng.standard_normal((33, D)) * embed_std).astype(np.float32)
+        elif k == "embed_positions.weight":
+            out[k] = (rng.standard_normal((cfg["max_positions"] + 2, D)) * embed_std).astype(np.float32)
+        elif k == "msa_position_embedding":
+            out[k] = (rng.standard_normal((1, 1024, 1, D)) * 0.1).astype(np.float32)
+        elif "layer_norm" in k:
+            out[k] = (1.0 + 0.1 * rng.standard_normal(D)).astype(np.float32) if k.endswith("weight") \
+                else (0.05 * rng.standard_normal(D)).astype(np.float32)
+        elif k == "lm_head.bias":
+            out[k] = (0.1 * rng.standard_normal(33)).astype(np.float32)
+        else:
+            if "fc1" in k:
+                shape, fan = ((F, D) if k.endswith("weight") else (F,)), D
+            elif "fc2" in k:
+                shape, fan = ((D, F) if k.endswith("weight") else (D,)), F
+            else:
+                shape, fan = ((D, D) if k.endswith("weight") else (D,)), D
+            b = 1.0 / np.sqrt(fan)
+            out[k] = ((rng.random(shape) * 2 - 1) * b).astype(np.float32)
+    out["lm_head.weight"] = out["embed_tokens.weight"]
+    return out
