@@ -857,7 +857,7 @@ int pgmi_model_create(const pgmi_config* cfg, const float* w, int64_t n_weights,
         TRY(dev_alloc(m->allocs, &m->vt16, m->vt16_plane * 2));
         PGMI_HIP(hipMemset(m->vt16, 0, m->vt16_plane * 2 * sizeof(unsigned short)));
     }
-    m->gemm_variant = env_int("PGMI_GEMM_VARIANT", 2);   // 256x256 tile, 8 waves (fastest measured)
+    m->gemm_variant = env_int("PGMI_GEMM_VARIANT", 7);   // 256x256 tile, 8 waves, ping-pong schedule (fastest measured)
     if (cfg->arch == PGMI_ARCH_MSA) {
         TRY(dev_alloc(m->allocs, &m->xt, R * D));
         TRY(dev_alloc(m->allocs, &m->msa_kv_len, (size_t)2048));
@@ -1228,7 +1228,7 @@ int pgmi_op_gemm(int device, int precision, const float* A, const float* W, cons
         if (!rc) {
             launch_split16(dA, (int64_t)M * K, 1.0f, bf ? 1 : 2, a16, (size_t)M * K, nullptr);
             rc = launch_gemm16(a16, (size_t)M * K, w16.p, w16.plane, dB, dR, dC, nullptr, 0, M, N, K, epilogue,
-                               w16.out_scale, planes, bf, env_int("PGMI_GEMM_VARIANT", 2), nullptr);
+                               w16.out_scale, planes, bf, env_int("PGMI_GEMM_VARIANT", 7), nullptr);
         }
     }
     hipError_t e = hipMemcpy(C, dC, (size_t)M * N * 4, hipMemcpyDeviceToHost);
@@ -1348,7 +1348,7 @@ int pgmi_bench_gemm(int device, int precision, int M, int N, int K, int epilogue
         else rc = dev_alloc(pool, &dC, (size_t)M * N);
         if (rc) { cleanup(); return rc; }
     }
-    const int var = variant >= 0 ? variant : env_int("PGMI_GEMM_VARIANT", 2);
+    const int var = variant >= 0 ? variant : env_int("PGMI_GEMM_VARIANT", 7);
     auto run = [&]() -> int {
         if (f32) return launch_gemm_f32(dA, dW, dB, nullptr, dC, M, N, K, epilogue, nullptr);
         return launch_gemm16(a16, (size_t)M * K, w16.p, w16.plane, dB, nullptr, split_out ? nullptr : dC,

@@ -70,7 +70,11 @@ __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
 //      2 = attention operands straight from the fused QKV projection (f16x3 only): q|k as split
 //          planes qk16 [2][M][2D] (ESM2 rotary applied here, rotary_embedding.py:11-20), v as the
 //          transposed, key-permuted planes vt16 [2][B*H*64][Tp] that attention_f16.hip consumes.
-template <int WM, int WN, int TM, int TN, int BK, int PLANES, bool BF, int EPI, int OUT>
+// PP = "ping-pong" schedule (8-wave tiles only): the two waves that share a SIMD run half a K-substep
+// out of phase, separated by workgroup barriers, so that one is always in its MFMA phase while the other
+// does its LDS fragment reads / global->LDS staging.  Without it both waves leave the tile barrier
+// together, read fragments together (matrix pipe idle) and then compete for the pipe.
+template <int WM, int WN, int TM, int TN, int BK, int PLANES, bool BF, int EPI, int OUT, bool PP = false>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 2) void gemm16_kernel(
     const unsigned short* __restrict__ A, size_t a_plane, const unsigned short* __restrict__ W,
     size_t w_plane, const float* __restrict__ bias, const float* residual, float* Cf,
@@ -159,6 +163,90 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 2) void gemm16_k
     int cur = 0;
     const bool dbg_nostage = qo.dbg_flags & 1, dbg_noread = qo.dbg_flags & 2;
     u32x4 af[PLANES][TM], wf[PLANES][TN];
+    if constexpr (PP) {
+        static_assert(PLANES == 2 && BK == 32 && WM * WN == 8, "ping-pong schedule: f16x3, BK 32, 8 waves");
+        u32x4 whs[TN];
+        auto read_frags = [&](const u32x4* Ab, const u32x4* Wb, int ks) {
+            const int c = ks * 2 + kh;
+#pragma unroll
+            for (int p = 0; p < PLANES; ++p) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int row = (wm * TM + i) * 32 + r;
+                    af[p][i] = Ab[(p * BM + row) * CPR + swz(row, c)];
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int row = (wn * TN + j) * 32 + r;
+                    wf[p][j] = Wb[(p * BN + row) * CPR + swz(row, c)];
+                }
+            }
+        };
+        auto scale_whi = [&]() {
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            const h2 sc = {(_Float16)(1.0f / kLoScale), (_Float16)(1.0f / kLoScale)};
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const unsigned int u = wf[0][j][e];
+                    const h2 t = __builtin_bit_cast(h2, u) * sc;
+                    whs[j][e] = __builtin_bit_cast(unsigned int, t);
+                }
+        };
+        auto mfmas = [&]() {
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    acc[j][i] = mfma16<BF>(wf[1][j], af[0][i], acc[j][i]);
+                    acc[j][i] = mfma16<BF>(whs[j], af[1][i], acc[j][i]);
+                    acc[j][i] = mfma16<BF>(wf[0][j], af[0][i], acc[j][i]);
+                }
+        };
+        // phase boundary: everything issued before stays before, LDS traffic of this wave has landed
+        auto phase = [&]() {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0); vmcnt / expcnt untouched
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        const bool late = wave >= (WM * WN) / 2;            // waves 4..7: the second wave of every SIMD
+        const bool pp_noprio = qo.dbg_flags & 16, pp_early_g = qo.dbg_flags & 32;
+        if (nk > 1) stage_load(1);
+        if (late) phase();
+        for (int kt = 0; kt < nk; ++kt) {
+            const u32x4* Ab = lds + cur * STAGE;
+            const u32x4* Wb = Ab + A_CH;
+            // -- memory phase 1 --
+            __builtin_amdgcn_s_setprio(0);
+            if (pp_early_g && kt > 0 && kt + 1 < nk) stage_load(kt + 1);
+            read_frags(Ab, Wb, 0);
+            scale_whi();
+            phase();
+            // -- compute phase 1 --
+            if (!pp_noprio) __builtin_amdgcn_s_setprio(1);
+            mfmas();
+            phase();
+            // -- memory phase 2: fragments of the second substep, tile kt+1 into the other buffer, loads of kt+2 --
+            __builtin_amdgcn_s_setprio(0);
+            read_frags(Ab, Wb, 1);
+            scale_whi();
+            if (kt + 1 < nk) {
+                __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0); lgkmcnt / expcnt untouched
+                stage_store(cur ^ 1);
+                if (!pp_early_g && kt + 2 < nk) stage_load(kt + 2);
+            }
+            phase();
+            // -- compute phase 2 --
+            if (!pp_noprio) __builtin_amdgcn_s_setprio(1);
+            mfmas();
+            phase();
+            cur ^= 1;
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (!late) phase();
+    } else
     for (int kt = 0; kt < nk; ++kt) {
         const bool more = (kt + 1 < nk) && !dbg_nostage;
         if (more && !(qo.dbg_flags & 8)) stage_load(kt + 1);
@@ -555,7 +643,7 @@ static int launch_cfg_p(const unsigned short* A, size_t a_plane, const unsigned 
     return PGMI_OK;
 }
 
-template <int WM, int WN, int TM, int TN, int BK, int PLANES, bool BF>
+template <int WM, int WN, int TM, int TN, int BK, int PLANES, bool BF, bool PP = false>
 static int launch_cfg(const unsigned short* A, size_t a_plane, const unsigned short* W, size_t w_plane,
                       const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
                       int M, int N, int K, int epilogue, float out_scale, hipStream_t s, const QkvOut* qkv = nullptr) {
@@ -571,7 +659,7 @@ static int launch_cfg(const unsigned short* A, size_t a_plane, const unsigned sh
     const dim3 grid(tiles_m * tiles_n), block(WM * WN * 64);
 #define PGMI_LAUNCH16(EPI_, OUT_)                                                                        \
     do {                                                                                                 \
-        auto kfn = gemm16_kernel<WM, WN, TM, TN, BK, PLANES, BF, EPI_, OUT_>;                             \
+        auto kfn = gemm16_kernel<WM, WN, TM, TN, BK, PLANES, BF, EPI_, OUT_, PP>;                         \
         if (lds_bytes > 65536) {                                                                         \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                       \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
@@ -610,6 +698,7 @@ int launch_gemm16(const unsigned short* A, size_t a_plane, const unsigned short*
             case 4: return launch_cfg_p<4, 2, 2, 2, 2, false>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);   // 256x128, 8 waves
             case 5: return launch_cfg_p<2, 4, 2, 2, 2, false>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);   // 128x256, 8 waves
             case 6: return launch_cfg_p<2, 2, 2, 2, 2, false>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);   // 128x128, 4 waves
+            case 7: return launch_cfg<2, 4, 4, 2, 32, 2, false, true>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);   // 256x256, ping-pong
             default: return launch_cfg<2, 2, 2, 2, 32, 2, false>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);
         }
     }
@@ -638,6 +727,7 @@ int launch_gemm16_qkv(const unsigned short* A, size_t a_plane, const unsigned sh
     switch (variant) {
         case 0: return launch_cfg<2, 2, 2, 2, 32, 2, false>(A, a_plane, W, w_plane, bias, nullptr, nullptr, qk16, qk_plane, M, N, K, EPI_NONE, out_scale, s, &qo);
         case 3: return launch_cfg<4, 2, 2, 2, 32, 2, false>(A, a_plane, W, w_plane, bias, nullptr, nullptr, qk16, qk_plane, M, N, K, EPI_NONE, out_scale, s, &qo);
+        case 7: return launch_cfg<2, 4, 4, 2, 32, 2, false, true>(A, a_plane, W, w_plane, bias, nullptr, nullptr, qk16, qk_plane, M, N, K, EPI_NONE, out_scale, s, &qo);
         default: return launch_cfg<2, 4, 4, 2, 32, 2, false>(A, a_plane, W, w_plane, bias, nullptr, nullptr, qk16, qk_plane, M, N, K, EPI_NONE, out_scale, s, &qo);
     }
 }
