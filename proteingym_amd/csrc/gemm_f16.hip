@@ -74,7 +74,7 @@ __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
 // out of phase, separated by workgroup barriers, so that one is always in its MFMA phase while the other
 // does its LDS fragment reads / global->LDS staging.  Without it both waves leave the tile barrier
 // together, read fragments together (matrix pipe idle) and then compete for the pipe.
-template <int WM, int WN, int TM, int TN, int BK, int PLANES, bool BF, int EPI, int OUT, bool PP = false>
+template <int WM, int WN, int TM, int TN, int BK, int PLANES, bool BF, int EPI, int OUT, int PP = 0>
 __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 2) void gemm16_kernel(
     const unsigned short* __restrict__ A, size_t a_plane, const unsigned short* __restrict__ W,
     size_t w_plane, const float* __restrict__ bias, const float* residual, float* Cf,
@@ -117,7 +117,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 2) void gemm16_k
         const int p = f / (BM * CPR), g = f % (BM * CPR), row = g / CPR, c = g % CPR;
         int am = min(m0 + row, M - 1);
         if (qo.dbg_row_mod) am %= qo.dbg_row_mod;
-        a_src[i] = reinterpret_cast<const u32x4*>(A + (size_t)p * a_plane + (size_t)am * K) + c;
+        // PP == 2 (direct-to-LDS): the DMA destination is lane-linear (slot f), so the swizzle picks the SOURCE chunk
+        a_src[i] = reinterpret_cast<const u32x4*>(A + (size_t)p * a_plane + (size_t)am * K) + (PP == 2 ? swz(row, c) : c);
         a_dst[i] = (p * BM + row) * CPR + swz(row, c);
     }
 #pragma unroll
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 2) void gemm16_k
         const int f = tid + NT * i;
         const int p = f / (BN * CPR), g = f % (BN * CPR), row = g / CPR, c = g % CPR;
         const int wr = min(n0 + row, N - 1);
-        w_src[i] = reinterpret_cast<const u32x4*>(W + (size_t)p * w_plane + (size_t)wr * K) + c;
+        w_src[i] = reinterpret_cast<const u32x4*>(W + (size_t)p * w_plane + (size_t)wr * K) + (PP == 2 ? swz(row, c) : c);
         w_dst[i] = A_CH + (p * BN + row) * CPR + swz(row, c);
     }
     u32x4 a_st[A_LD], w_st[W_LD];
@@ -147,8 +148,24 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 2) void gemm16_k
             if (W_CH % NT == 0 || tid + NT * i < W_CH) base[w_dst[i]] = w_st[i];
     };
 
-    stage_load(0);
-    stage_store(0);
+    auto issue_tile = [&](int kt, int buf) {                     // PP == 2: global -> LDS DMA, 1 KiB per wave-instruction
+        u32x4* base = lds + buf * STAGE + wave * 64;             // wave-uniform; the DMA adds lane * 16 B
+#pragma unroll
+        for (int i = 0; i < A_LD; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + kt * CPR),
+                                             (__attribute__((address_space(3))) void*)(base + NT * i), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < W_LD; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + kt * CPR),
+                                             (__attribute__((address_space(3))) void*)(base + A_CH + NT * i), 16, 0, 0);
+    };
+    if constexpr (PP == 2) {
+        static_assert(A_CH % NT == 0 && W_CH % NT == 0, "tile must split evenly over the waves");
+        issue_tile(0, 0);
+    } else {
+        stage_load(0);
+        stage_store(0);
+    }
     __syncthreads();
 
     f32x16 acc[TN][TM];
@@ -163,7 +180,7 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 2) void gemm16_k
     int cur = 0;
     const bool dbg_nostage = qo.dbg_flags & 1, dbg_noread = qo.dbg_flags & 2;
     u32x4 af[PLANES][TM], wf[PLANES][TN];
-    if constexpr (PP) {
+    if constexpr (PP != 0) {
         static_assert(PLANES == 2 && BK == 32 && WM * WN == 8, "ping-pong schedule: f16x3, BK 32, 8 waves");
         u32x4 whs[TN];
         auto read_frags = [&](const u32x4* Ab, const u32x4* Wb, int ks) {
@@ -213,16 +230,16 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 2) void gemm16_k
         };
         const bool late = wave >= (WM * WN) / 2;            // waves 4..7: the second wave of every SIMD
         const bool pp_noprio = qo.dbg_flags & 16, pp_early_g = qo.dbg_flags & 32;
-        if (nk > 1) stage_load(1);
+        if (PP == 1 && nk > 1) stage_load(1);
         if (late) phase();
         for (int kt = 0; kt < nk; ++kt) {
             const u32x4* Ab = lds + cur * STAGE;
             const u32x4* Wb = Ab + A_CH;
             // -- memory phase 1 --
             __builtin_amdgcn_s_setprio(0);
-            if (pp_early_g && kt > 0 && kt + 1 < nk) stage_load(kt + 1);
-            read_frags(Ab, Wb, 0);
-            scale_whi();
+            if (PP == 1 && pp_early_g && kt > 0 && kt + 1 < nk) stage_load(kt + 1);
+            if (!(dbg_noread && kt > 0)) { read_frags(Ab, Wb, 0); scale_whi(); }
+            if (PP == 2 && kt + 1 < nk && !dbg_nostage) issue_tile(kt + 1, cur ^ 1);   // the other buffer was last read two phases ago
             phase();
             // -- compute phase 1 --
             if (!pp_noprio) __builtin_amdgcn_s_setprio(1);
@@ -230,12 +247,13 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 2) void gemm16_k
             phase();
             // -- memory phase 2: fragments of the second substep, tile kt+1 into the other buffer, loads of kt+2 --
             __builtin_amdgcn_s_setprio(0);
-            read_frags(Ab, Wb, 1);
-            scale_whi();
-            if (kt + 1 < nk) {
+            if (!(dbg_noread && kt > 0)) { read_frags(Ab, Wb, 1); scale_whi(); }
+            if (PP == 2) {
+                __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): this wave's share of tile kt+1 has landed
+            } else if (kt + 1 < nk && !dbg_nostage) {
                 __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0); lgkmcnt / expcnt untouched
-                stage_store(cur ^ 1);
-                if (!pp_early_g && kt + 2 < nk) stage_load(kt + 2);
+                if (!(qo.dbg_flags & 4)) stage_store(cur ^ 1);
+                if (!pp_early_g && kt + 2 < nk && !(qo.dbg_flags & 8)) stage_load(kt + 2);
             }
             phase();
             // -- compute phase 2 --
@@ -643,7 +661,7 @@ static int launch_cfg_p(const unsigned short* A, size_t a_plane, const unsigned 
     return PGMI_OK;
 }
 
-template <int WM, int WN, int TM, int TN, int BK, int PLANES, bool BF, bool PP = false>
+template <int WM, int WN, int TM, int TN, int BK, int PLANES, bool BF, int PP = 0>
 static int launch_cfg(const unsigned short* A, size_t a_plane, const unsigned short* W, size_t w_plane,
                       const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
                       int M, int N, int K, int epilogue, float out_scale, hipStream_t s, const QkvOut* qkv = nullptr) {
@@ -698,7 +716,8 @@ int launch_gemm16(const unsigned short* A, size_t a_plane, const unsigned short*
             case 4: return launch_cfg_p<4, 2, 2, 2, 2, false>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);   // 256x128, 8 waves
             case 5: return launch_cfg_p<2, 4, 2, 2, 2, false>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);   // 128x256, 8 waves
             case 6: return launch_cfg_p<2, 2, 2, 2, 2, false>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);   // 128x128, 4 waves
-            case 7: return launch_cfg<2, 4, 4, 2, 32, 2, false, true>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);   // 256x256, ping-pong
+            case 7: return launch_cfg<2, 4, 4, 2, 32, 2, false, 1>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);   // 256x256, ping-pong
+            case 8: return launch_cfg<2, 4, 4, 2, 32, 2, false, 2>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);   // 256x256, ping-pong + direct-to-LDS tile loads
             default: return launch_cfg<2, 2, 2, 2, 32, 2, false>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);
         }
     }
@@ -727,7 +746,8 @@ int launch_gemm16_qkv(const unsigned short* A, size_t a_plane, const unsigned sh
     switch (variant) {
         case 0: return launch_cfg<2, 2, 2, 2, 32, 2, false>(A, a_plane, W, w_plane, bias, nullptr, nullptr, qk16, qk_plane, M, N, K, EPI_NONE, out_scale, s, &qo);
         case 3: return launch_cfg<4, 2, 2, 2, 32, 2, false>(A, a_plane, W, w_plane, bias, nullptr, nullptr, qk16, qk_plane, M, N, K, EPI_NONE, out_scale, s, &qo);
-        case 7: return launch_cfg<2, 4, 4, 2, 32, 2, false, true>(A, a_plane, W, w_plane, bias, nullptr, nullptr, qk16, qk_plane, M, N, K, EPI_NONE, out_scale, s, &qo);
+        case 7: return launch_cfg<2, 4, 4, 2, 32, 2, false, 1>(A, a_plane, W, w_plane, bias, nullptr, nullptr, qk16, qk_plane, M, N, K, EPI_NONE, out_scale, s, &qo);
+        case 8: return launch_cfg<2, 4, 4, 2, 32, 2, false, 2>(A, a_plane, W, w_plane, bias, nullptr, nullptr, qk16, qk_plane, M, N, K, EPI_NONE, out_scale, s, &qo);
         default: return launch_cfg<2, 4, 4, 2, 32, 2, false>(A, a_plane, W, w_plane, bias, nullptr, nullptr, qk16, qk_plane, M, N, K, EPI_NONE, out_scale, s, &qo);
     }
 }
