@@ -4,6 +4,7 @@ import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -59,3 +60,40 @@ def test_single_process_gather_is_identity():
     local = {0: np.arange(4.0), 1: np.zeros(0)}
     out = pdist.gather_score_vectors(local, [4, 0], [[0, 1]])
     assert np.array_equal(out[0], np.arange(4.0)) and out[1].size == 0
+
+
+def _sharded_worker(rank, world, port, mapping_csv, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    from proteingym_amd import run_sharded
+    mine = run_sharded.main(["tranception", "--dry-run", "--backend", "gloo", "--", "--checkpoint", "x",
+                             "--DMS_reference_file_path", mapping_csv, "--DMS_data_folder", "."])
+    q.put((rank, mine))
+
+
+def test_run_sharded_world2_covers_every_assay_once(tmp_path):
+    """Tranception / MSA Transformer multi-GPU runner: assays are LPT-sharded over the ranks, no collective on
+    the data path; two gloo ranks must take disjoint sets that cover the reference file and balance the cost."""
+    import pandas as pd
+    from proteingym_amd import run_sharded
+    rng = np.random.default_rng(0)
+    rows = [{"DMS_id": f"A{i}", "DMS_filename": f"A{i}.csv", "target_seq": "M" * int(rng.integers(40, 1500)),
+             "DMS_total_number_mutants": int(rng.integers(100, 20000))} for i in range(11)]
+    csv = str(tmp_path / "map.csv")
+    pd.DataFrame(rows).to_csv(csv, index=False)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sharded_worker, args=(r, 2, port, csv, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res[0] + res[1]) == list(range(11)) and not set(res[0]) & set(res[1])
+    mapping = pd.read_csv(csv)
+    cost = [sum(run_sharded.assay_cost("tranception", mapping.iloc[i]) for i in res[r]) for r in range(2)]
+    assert max(cost) / sum(cost) < 0.6
+    with pytest.raises(SystemExit):
+        run_sharded.main(["tranception", "--", "--DMS_index", "3", "--DMS_reference_file_path", csv])

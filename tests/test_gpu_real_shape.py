@@ -108,3 +108,24 @@ def test_tranception_large_shape_vs_oracle(lib):
     assert err < 1e-4 + 3.0 * noise
     assert np.abs((got_ll - ref_ll) / np.array([len(s) for s in seqs])).max() < 1e-4     # the scored quantity
     model.close()
+
+
+@pytest.mark.parametrize("name,layers", [("ESM2_3B", 3), ("ESM2_650M", 6)])
+def test_esm2_widths_vs_oracle(lib, name, layers):
+    """ESM2 (rotary, no learned positions) at the 3B width (2560, 40 heads, FFN 10240: BASELINE config 3) and the
+    650M width, truncated in depth so the CPU oracle stays in seconds; default precision (f16x3)."""
+    from oracle import esm_oracle as eo
+    cfg = dict(getattr(synthetic, name), layers=layers)
+    blob = synthetic.random_weights(cfg, seed=9)
+    seq, muts, _ = synthetic.random_assay(seed=2, L=75, n_single=60, n_multi=20)
+    model = pesm.EsmModel(cfg, blob, device=0)
+    a = pesm.Assay(model, seq, muts)
+    scores, table = a.run(want_table=True)
+    ocfg, W = eo.from_arrays(arrays=synthetic.blob_to_arrays(cfg, blob), **cfg)
+    positions = sorted(int(p) for p in a.positions)
+    ref = eo.masked_marginals_table(ocfg, W, seq, positions=positions, batch=16)
+    assert np.abs(table[positions] - ref[positions]).max() < 1e-4
+    ref_scores = np.array([eo.label_row(m, seq, ref, 1) for m in muts])
+    assert np.abs(scores - ref_scores).max() < 1e-4
+    a.close()
+    model.close()
