@@ -48,7 +48,7 @@ def usable_cores() -> int:
     return max(1, n)
 
 
-def cpu_baseline(cfg, blob, seq, n_mut, budget_s):
+def cpu_baseline(cfg, blob, seq, n_mut, budget_s, gpu_table=None):
     """The reference algorithm on the host cores: batch-1 masked forwards (compute_fitness.py:
     489-503) through oracle/esm_oracle.py (torch CPU fp32), bounded to ~budget_s seconds: when a
     full 33-layer forward does not fit the budget, k of the 33 (identical-cost) layers are timed
@@ -62,13 +62,18 @@ def cpu_baseline(cfg, blob, seq, n_mut, budget_s):
     toks = eo.tokenize(seq)
     n_tok, L = len(toks), ocfg["layers"]
 
+    rows = {}
+
     def fwd(i, k):
         t = toks.copy()
         t[i] = eo.MASK
         t0 = time.perf_counter()
         with torch.no_grad():
-            torch.log_softmax(eo.forward_logits(ocfg, W, t[None], n_layers=k), dim=-1)[0, i]
-        return time.perf_counter() - t0
+            row = torch.log_softmax(eo.forward_logits(ocfg, W, t[None], n_layers=k), dim=-1)[0, i]
+        dt = time.perf_counter() - t0
+        if k == L:
+            rows[i] = row.numpy()
+        return dt
 
     fwd(1, 2)                                   # warm-up (threads, first-touch of two layers)
     per_layer = fwd(2, 2) / 2
@@ -79,10 +84,19 @@ def cpu_baseline(cfg, blob, seq, n_mut, budget_s):
     ts = [fwd(4 + r, k) for r in range(reps)]
     per_fwd = float(np.mean(ts)) * L / k
     assay_s = per_fwd * n_tok                   # the reference runs all L+2 positions, batch 1
-    return {"value": n_mut / assay_s, "unit": "mutants/s", "cores": cores, "kind": "port",
-            "sample": f"{reps} batch-1 masked forwards at T={n_tok} through {k} of {L} layers "
-                      f"(oracle/esm_oracle.py, torch CPU fp32, {cores} threads), scaled x{L}/{k}: "
-                      f"{per_fwd:.3f} s/forward, x{n_tok} forwards for the assay"}
+    out = {"value": n_mut / assay_s, "unit": "mutants/s", "cores": cores, "kind": "port",
+           "sample": f"{reps} batch-1 masked forwards at T={n_tok} through {k} of {L} layers "
+                     f"(oracle/esm_oracle.py, torch CPU fp32, {cores} threads), scaled x{L}/{k}: "
+                     f"{per_fwd:.3f} s/forward, x{n_tok} forwards for the assay"}
+    # the full-depth oracle rows just computed double as a live parity check of the GPU table (checker only)
+    parity = None
+    if gpu_table is not None:
+        common = [i for i in rows if not np.isnan(gpu_table[i, 0])]
+        if common:
+            parity = {"max_abs_err_vs_oracle": float(max(np.abs(gpu_table[i] - rows[i]).max() for i in common)),
+                      "rows_compared": len(common), "tolerance": 1e-4,
+                      "what": "log-prob table rows (33 values each) of the timed assay, HIP path vs CPU fp32 oracle"}
+    return out, parity
 
 
 def main():
@@ -94,6 +108,8 @@ def main():
                     help="f16x3 (default) and fp32 are parity-gated (1e-4 abs vs the reference); bf16 is not")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline time budget (0 = skip)")
     ap.add_argument("--layers", type=int, default=33, help="debug only; the headline config is 33")
+    ap.add_argument("--checkpoints", type=int, default=1,
+                    help="score with N checkpoints per step and average (ESM-1v ensemble rate; the headline is 1)")
     ap.add_argument("--variant", type=int, default=None, help="debug: PGMI_GEMM_VARIANT tile configuration")
     args = ap.parse_args()
 
@@ -126,9 +142,17 @@ def main():
     n_mut = len(muts)
     scores_dev = torch.zeros(n_mut, dtype=torch.float64, device="cuda")
     gathered = torch.zeros(world * n_mut, dtype=torch.float64, device="cuda") if world > 1 else None
+    extra = []                                                        # checkpoints 2..N of an ensemble step
+    for c in range(1, args.checkpoints):
+        m2 = pesm.EsmModel(cfg, synthetic.random_weights(cfg, seed=1 + c), device=local_rank, precision=args.precision)
+        extra.append((m2, pesm.Assay(m2, seq, muts, offset_idx=1), torch.zeros(n_mut, dtype=torch.float64, device="cuda")))
 
     def step():
         assay.run_device_only(scores_dev.data_ptr())                  # whole hot path, synchronised at return
+        if extra:                                                     # compute_fitness.py:532-537: plain mean
+            for _, a2, buf in extra:
+                a2.run_device_only(buf.data_ptr())
+            scores_dev.add_(sum(buf for _, _, buf in extra)).div_(args.checkpoints)
         if world > 1:
             dist.all_gather_into_tensor(gathered, scores_dev)         # RCCL over xGMI
 
@@ -178,7 +202,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": "ESM-1v 650M (33x1280, 20 heads, FFN 5120) masked-marginals, one "
                                    "BLAT_ECOLX_Stiffler_2015-shaped assay per GPU per step (L=286, T=288, "
-                                   f"{len(assay.positions)} masked positions run, {n_mut} single mutants), 1 checkpoint; "
+                                   f"{len(assay.positions)} masked positions run, {n_mut} single mutants), "
+                                   f"{args.checkpoints} checkpoint{'s averaged (ensemble rate)' if args.checkpoints > 1 else ''}; "
                                    "assays shard over ranks + RCCL all_gather of score vectors",
                        "precision": args.precision, "layers": args.layers,
                        "positions_run": int(len(assay.positions)), "tokens_per_step": int(len(assay.positions) * assay.T)},
@@ -194,9 +219,13 @@ def main():
             "kernels": kern,
         }
         if world == 1 and args.cpu_seconds > 0:
+            _, gpu_table = assay.run(want_table=True)                 # outside the timed region
+            for m2, a2, _ in extra:
+                a2.close()
+                m2.close()
             assay.close()
             model.close()
-            out["cpu_baseline"] = cpu_baseline(cfg, blob, seq, n_mut, args.cpu_seconds)
+            out["cpu_baseline"], out["parity"] = cpu_baseline(cfg, blob, seq, n_mut, args.cpu_seconds, gpu_table)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

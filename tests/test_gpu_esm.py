@@ -204,3 +204,18 @@ def test_real_small_esm2_shapes_load_and_match_oracle(lib):
         ref = np.array([eo.label_row(mu, seq, table, 1) for mu in muts])
         assert np.abs(scores - ref).max() < TOL
         m.close()
+
+
+def test_spearman_vs_dms_score_identical_to_reference(models, golden, golden_dir):
+    """the downstream metric (per-assay Spearman against DMS_score, 4 decimals --
+    performance_DMS_benchmarks.py) computed from the HIP scores equals the one from the reference CLI's scores."""
+    import pandas as pd
+    from scipy.stats import spearmanr
+    seq = str(golden["seq"])
+    df = pd.read_csv(os.path.join(golden_dir, "TOY_DMS.csv"))
+    for name in ("esm1v_toy_1", "esm2_toy", "esm1b_toy_lnb"):
+        a = pesm.Assay(models[name], seq, list(df["mutant"]), offset_idx=1)
+        mine = spearmanr(a.run(), df["DMS_score"]).correlation
+        ref = spearmanr(golden[f"cli/{name}"], df["DMS_score"]).correlation
+        a.close()
+        assert round(mine, 4) == round(ref, 4)
