@@ -113,7 +113,11 @@ def test_tranception_large_shape_vs_oracle(lib):
 @pytest.mark.parametrize("name,layers", [("ESM2_3B", 3), ("ESM2_650M", 6)])
 def test_esm2_widths_vs_oracle(lib, name, layers):
     """ESM2 (rotary, no learned positions) at the 3B width (2560, 40 heads, FFN 10240: BASELINE config 3) and the
-    650M width, truncated in depth so the CPU oracle stays in seconds; default precision (f16x3)."""
+    650M width, truncated in depth so the CPU oracle stays in seconds; default precision (f16x3).  The synthetic
+    stress weights give a log-prob range of ~55 at the 3B width (real checkpoints: < 20), where the reference's own
+    fp32 arithmetic is 5e-5 away from fp64; the bar is 1e-4 abs against the fp64 oracle or 3x that fp32 noise,
+    whichever is larger (same rule as the Tranception-L test)."""
+    import torch
     from oracle import esm_oracle as eo
     cfg = dict(getattr(synthetic, name), layers=layers)
     blob = synthetic.random_weights(cfg, seed=9)
@@ -121,11 +125,20 @@ def test_esm2_widths_vs_oracle(lib, name, layers):
     model = pesm.EsmModel(cfg, blob, device=0)
     a = pesm.Assay(model, seq, muts)
     scores, table = a.run(want_table=True)
-    ocfg, W = eo.from_arrays(arrays=synthetic.blob_to_arrays(cfg, blob), **cfg)
+    arrays = synthetic.blob_to_arrays(cfg, blob)
     positions = sorted(int(p) for p in a.positions)
-    ref = eo.masked_marginals_table(ocfg, W, seq, positions=positions, batch=16)
-    assert np.abs(table[positions] - ref[positions]).max() < 1e-4
-    ref_scores = np.array([eo.label_row(m, seq, ref, 1) for m in muts])
-    assert np.abs(scores - ref_scores).max() < 1e-4
+    tabs = {}
+    for dt in (torch.float32, torch.float64):
+        ocfg, W = eo.from_arrays(arrays=arrays, dtype=dt, **cfg)
+        tabs[dt] = eo.masked_marginals_table(ocfg, W, seq, positions=positions, batch=16)
+    t32, t64 = tabs[torch.float32], tabs[torch.float64]
+    noise = float(np.abs(t32[positions] - t64[positions]).max())
+    err = float(np.abs(table[positions] - t64[positions]).max())
+    s32 = np.array([eo.label_row(m, seq, t32, 1) for m in muts])
+    s64 = np.array([eo.label_row(m, seq, t64, 1) for m in muts])
+    s_noise, s_err = float(np.abs(s32 - s64).max()), float(np.abs(scores - s64).max())
+    print(f"{name}: table err {err:.2e} (fp32 reference noise {noise:.2e}), score err {s_err:.2e} (noise {s_noise:.2e})")
+    assert err < max(1e-4, 3 * noise)
+    assert s_err < max(1e-4, 3 * s_noise)
     a.close()
     model.close()
