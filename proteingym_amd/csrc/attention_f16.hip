@@ -374,6 +374,93 @@ __global__ __launch_bounds__(256) void qkv_prep_kernel(
     }
 }
 
+// Tranception flavour of the prep pass (conv != nullptr, no rotary): the 38 token rows a 32-token tile
+// needs (6 rows of causal history) are staged ONCE in LDS with coalesced float4 loads and the 7-tap
+// filters are read from an LDS copy, instead of 7 strided global loads per output and per-tap scalar weight
+// loads (the generic kernel above ran at 2.3 TB/s; this pass is HBM-bound: 4 B in + 4 B out per element).
+__global__ __launch_bounds__(256) void qkv_prep_conv_kernel(
+    const float* __restrict__ qkv, const float* __restrict__ conv, int T, int H, int Tp,
+    unsigned short* __restrict__ qk16, size_t qk_plane, unsigned short* __restrict__ vt16, size_t vt_plane) {
+    constexpr int RSTR = 196;                                 // 192 floats (q|k|v of one head) + pad
+    __shared__ __attribute__((aligned(16))) float raw[38 * RSTR];
+    __shared__ __attribute__((aligned(16))) float cwl[3 * 8 * 64];   // [which][tap (7 = bias)][d]
+    const int b = blockIdx.z, h = blockIdx.y, t0 = blockIdx.x * 32;
+    const int tid = threadIdx.x;
+    const int D = H * kHeadDim;
+    const size_t RS = (size_t)3 * D;
+    const int group = h / (H / 4);
+    for (int i = tid; i < 38 * 48; i += 256) {
+        const int row = i / 48, seg = (i % 48) >> 4, c4 = i & 15;
+        const int t = t0 - 6 + row;
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (t >= 0 && t < T)
+            v = *reinterpret_cast<const f32x4*>(qkv + ((size_t)b * T + t) * RS + (size_t)seg * D + h * kHeadDim + c4 * 4);
+        *reinterpret_cast<f32x4*>(&raw[row * RSTR + seg * 64 + c4 * 4]) = v;
+    }
+    for (int i = tid; i < 3 * 64 * 8; i += 256) {
+        const int which = i >> 9, d = (i >> 3) & 63, j = i & 7;
+        cwl[(which * 8 + j) * 64 + d] = conv[((size_t)(which * 4 + group) * kHeadDim + d) * 8 + j];
+    }
+    __syncthreads();
+    // ---- q and k: unit (token, which, dims 4c..4c+3 and 32+4c..32+4c+3) ----------------------------
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int u = tid + 256 * it;
+        const int which = u >> 8, tok = (u >> 3) & 31, c = u & 7;
+        const int t = t0 + tok;
+        if (t < T) {
+            f32x4 x1 = *reinterpret_cast<const f32x4*>(&cwl[(which * 8 + 7) * 64 + 4 * c]);
+            f32x4 x2 = *reinterpret_cast<const f32x4*>(&cwl[(which * 8 + 7) * 64 + 32 + 4 * c]);
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(&cwl[(which * 8 + j) * 64 + 4 * c]);
+                const f32x4 w2 = *reinterpret_cast<const f32x4*>(&cwl[(which * 8 + j) * 64 + 32 + 4 * c]);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(&raw[(tok + j) * RSTR + which * 64 + 4 * c]);
+                const f32x4 a2 = *reinterpret_cast<const f32x4*>(&raw[(tok + j) * RSTR + which * 64 + 32 + 4 * c]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    x1[e] = fmaf(w1[e], a1[e], x1[e]);
+                    x2[e] = fmaf(w2[e], a2[e], x2[e]);
+                }
+            }
+            unsigned short* dst = qk16 + ((size_t)b * T + t) * (2 * D) + (size_t)which * D + h * kHeadDim + 4 * c;
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const f32x4 x = half ? x2 : x1;
+                _Float16 hh[4], ll[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xe = x[e];
+                    split_act(xe, hh[e], ll[e]);
+                }
+                *reinterpret_cast<u32x2*>(dst + 32 * half) = u32x2{pack_h2(hh[0], hh[1]), pack_h2(hh[2], hh[3])};
+                *reinterpret_cast<u32x2*>(dst + qk_plane + 32 * half) = u32x2{pack_h2(ll[0], ll[1]), pack_h2(ll[2], ll[3])};
+            }
+        }
+    }
+    // ---- v: thread (d, kq) transposes keys 8kq .. 8kq+7 of dimension d ------------------------------
+    {
+        const int d = tid & 63, kq = tid >> 6;
+        _Float16 hh[8], ll[8];
+        float w[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) w[j] = cwl[(2 * 8 + j) * 64 + d];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float y = w[7];
+#pragma unroll
+            for (int j = 0; j < 7; ++j) y = fmaf(w[j], raw[(8 * kq + e + j) * RSTR + 128 + d], y);
+            if (t0 + 8 * kq + e >= T) y = 0.0f;
+            split_act(y, hh[e], ll[e]);
+        }
+        unsigned short* row = vt16 + (((size_t)b * H + h) * kHeadDim + d) * Tp + t0 + 16 * (kq >> 1) + 4 * (kq & 1);
+        *reinterpret_cast<u32x2*>(row) = u32x2{pack_h2(hh[0], hh[1]), pack_h2(hh[2], hh[3])};
+        *reinterpret_cast<u32x2*>(row + 8) = u32x2{pack_h2(hh[4], hh[5]), pack_h2(hh[6], hh[7])};
+        *reinterpret_cast<u32x2*>(row + vt_plane) = u32x2{pack_h2(ll[0], ll[1]), pack_h2(ll[2], ll[3])};
+        *reinterpret_cast<u32x2*>(row + vt_plane + 8) = u32x2{pack_h2(ll[4], ll[5]), pack_h2(ll[6], ll[7])};
+    }
+}
+
 template <int WPB, int OUT, int NSTG>
 __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
     const unsigned short* __restrict__ qk16, size_t qk_plane, const unsigned short* __restrict__ vt16,
@@ -613,7 +700,10 @@ int launch_attention_f16x3_v2(const float* qkv, const int32_t* kv_len, const flo
         return PGMI_EINVAL;
     }
     const int n32 = (T + 31) / 32, Tp = n32 * 32;
-    if (qkv)      // operands not prepared by the fused QKV epilogue: run the prep pass
+    static const bool old_prep = getenv("PGMI_PREP_OLD") != nullptr;
+    if (qkv && conv && !rotary && !old_prep)      // Tranception: LDS-staged depth-wise conv + split
+        hipLaunchKernelGGL(qkv_prep_conv_kernel, dim3(n32, H, B), dim3(256), 0, s, qkv, conv, T, H, Tp, qk16, qk_plane, vt16, vt_plane);
+    else if (qkv)      // operands not prepared by the fused QKV epilogue: run the prep pass
         hipLaunchKernelGGL(qkv_prep_kernel, dim3(n32, H, B), dim3(256), 0, s, qkv, cos_t, sin_t, rotary, conv, T, H, Tp,
                            qk16, qk_plane, vt16, vt_plane);
     const int nblk = (n32 + 3) / 4;
