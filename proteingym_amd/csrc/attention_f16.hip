@@ -709,7 +709,9 @@ int launch_attention_f16x3_v2(const float* qkv, const int32_t* kv_len, const flo
     const int nblk = (n32 + 3) / 4;
     int wpb = (n32 + nblk - 1) / nblk;
     if (wpb == 3) wpb = 4;                        // measured: a 4th (idle) wave that only helps loading beats 3-wave blocks
-    const dim3 grid(nblk, H, B);
+    static const int wpb_env = getenv("PGMI_ATT_WPB") ? atoi(getenv("PGMI_ATT_WPB")) : 0;   // tuning only
+    dim3 grid(nblk, H, B);
+    if (wpb_env >= 1 && wpb_env <= 4) { wpb = wpb_env; grid.x = (n32 + wpb - 1) / wpb; }
     static const int nstg = getenv("PGMI_ATT_STAGES") ? atoi(getenv("PGMI_ATT_STAGES")) : 3;
     if (nstg == 4) {
         if (out_mode == 0) launch_att16v2_mode<0, 4>(wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane, s);
