@@ -24,8 +24,10 @@ for k in sorted(agg, key=lambda k: -dur[k][0]):
         print(f"   {c:34s} mean/dispatch = {s / n:.6g}")
     c = {c: s / n for c, (s, n) in agg[k].items()}
     if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c and c["GRBM_GUI_ACTIVE"] > 0:
-        print(f"   -> MfmaUtil = {c['SQ_VALU_MFMA_BUSY_CYCLES'] / (c['GRBM_GUI_ACTIVE'] * 1024) * 100:.1f}%  "
-              f"clock ~ {c['GRBM_GUI_ACTIVE'] / max(d[0] / max(d[1], 1), 1):.2f} GHz")
+        # GRBM_GUI_ACTIVE comes back summed over the 8 XCDs; MFMA busy cycles summed over 256 CUs x 4 SIMDs
+        gui = c['GRBM_GUI_ACTIVE'] / 8.0
+        print(f"   -> MfmaUtil = {c['SQ_VALU_MFMA_BUSY_CYCLES'] / (gui * 1024) * 100:.1f}% of active cycles  "
+              f"clock ~ {gui / max(d[0] / max(d[1], 1), 1):.2f} GHz")
     if "FETCH_SIZE" in c:
         print(f"   -> HBM read  ~ {c['FETCH_SIZE'] * 1024 * 2 / 1e6:.1f} MB/dispatch (FETCH_SIZE KB x2 gfx950 correction)")
     if "WRITE_SIZE" in c:
