@@ -19,82 +19,91 @@ import pandas as pd
 from . import tranception as ptr
 
 
+# (flag, argparse keywords) -- the flag names, types and defaults are the reference's CLI contract
+# (score_tranception_proteingym.py:19-45); help texts are ours.
+_FLAGS = [
+    ("--checkpoint", dict(type=str, help="Tranception checkpoint directory (HuggingFace layout: config.json + weights)")),
+    ("--model_framework", dict(type=str, default="pytorch", help="kept for compatibility; only 'pytorch' maps to the HIP backend")),
+    ("--batch_size_inference", dict(type=int, default=20, help="sequences per device call")),
+    ("--DMS_reference_file_path", dict(type=str, default=None, help="reference CSV listing the assays (DMS_id, target_seq, DMS_filename, MSA_*)")),
+    ("--DMS_index", dict(type=int, default=0, help="row of the reference CSV to score")),
+    ("--target_seq", dict(type=str, default=None, help="wild-type sequence (manual mode, no reference CSV)")),
+    ("--DMS_file_name", dict(type=str, default=None, help="assay CSV inside --DMS_data_folder (manual mode)")),
+    ("--MSA_filename", dict(type=str, default=None, help="alignment (a2m) built on the wild type, inside --MSA_folder (manual mode)")),
+    ("--MSA_weight_file_name", dict(type=str, default=None, help="sequence-weight .npy inside --MSA_weights_folder (manual mode, optional)")),
+    ("--MSA_start", dict(type=int, default=None, help="first target position covered by the alignment, 1-indexed (manual mode)")),
+    ("--MSA_end", dict(type=int, default=None, help="last target position covered by the alignment, 1-indexed (manual mode)")),
+    ("--DMS_data_folder", dict(type=str, help="folder holding the assay CSVs")),
+    ("--output_scores_folder", dict(type=str, default="./", help="where <DMS_id>.csv is written")),
+    ("--deactivate_scoring_mirror", dict(action="store_true", help="score left-to-right only (default: average with the reversed sequence)")),
+    ("--indel_mode", dict(action="store_true", help="the assay holds insertions/deletions (mutated_sequence column) instead of substitutions")),
+    ("--scoring_window", dict(type=str, default="optimal", help="how sequences longer than the context are cropped: optimal | sliding")),
+    ("--num_workers", dict(type=int, default=10, help="accepted for compatibility (no data-loader workers here)")),
+    ("--inference_time_retrieval", dict(action="store_true", help="fuse the autoregressive log-probabilities with the alignment prior")),
+    ("--retrieval_inference_weight", dict(type=float, default=0.6, help="alpha: weight of the alignment prior in the fusion")),
+    ("--MSA_folder", dict(type=str, default=".", help="folder holding the alignments")),
+    ("--MSA_weights_folder", dict(type=str, default=None, help="folder holding the sequence-weight files")),
+    ("--clustal_omega_location", dict(type=str, default=None, help="only used by indel scoring with retrieval (not built here)")),
+    ("--device", dict(type=int, default=int(os.environ.get("LOCAL_RANK", "0")), help="[additive] GPU index")),
+]
+
+
 def create_parser():
-    parser = argparse.ArgumentParser(description='Tranception scoring')
-    parser.add_argument('--checkpoint', type=str, help='Path of Tranception model checkpoint')
-    parser.add_argument('--model_framework', default='pytorch', type=str, help='Underlying framework [pytorch|JAX]')
-    parser.add_argument('--batch_size_inference', default=20, type=int, help='Batch size for inference')
-    parser.add_argument('--DMS_reference_file_path', default=None, type=str, help='Path to reference file with list of DMS to score')
-    parser.add_argument('--DMS_index', default=0, type=int, help='Index of DMS assay in reference file')
-    parser.add_argument('--target_seq', default=None, type=str, help='Full wild type sequence that is mutated in the DMS asssay')
-    parser.add_argument('--DMS_file_name', default=None, type=str, help='Name of DMS assay file')
-    parser.add_argument('--MSA_filename', default=None, type=str, help='Name of MSA (eg., a2m) file constructed on the wild type sequence')
-    parser.add_argument('--MSA_weight_file_name', default=None, type=str, help='Weight of sequences in the MSA (optional)')
-    parser.add_argument('--MSA_start', default=None, type=int, help='Sequence position that the MSA starts at (1-indexing)')
-    parser.add_argument('--MSA_end', default=None, type=int, help='Sequence position that the MSA ends at (1-indexing)')
-    parser.add_argument('--DMS_data_folder', type=str, help='Path to folder that contains all DMS assay datasets')
-    parser.add_argument('--output_scores_folder', default='./', type=str, help='Name of folder to write model scores to')
-    parser.add_argument('--deactivate_scoring_mirror', action='store_true', help='Whether to deactivate sequence scoring from both directions (Left->Right and Right->Left)')
-    parser.add_argument('--indel_mode', action='store_true', help='Flag to be used when scoring insertions and deletions. Otherwise assumes substitutions')
-    parser.add_argument('--scoring_window', default="optimal", type=str, help='Sequence window selection mode (when sequence length longer than model context size)')
-    parser.add_argument('--num_workers', default=10, type=int, help='Number of workers for model scoring data loader')
-    parser.add_argument('--inference_time_retrieval', action='store_true', help='Whether to perform inference-time retrieval')
-    parser.add_argument('--retrieval_inference_weight', default=0.6, type=float, help='Coefficient (alpha) used when aggregating autoregressive transformer and retrieval')
-    parser.add_argument('--MSA_folder', default='.', type=str, help='Path to MSA for neighborhood scoring')
-    parser.add_argument('--MSA_weights_folder', default=None, type=str, help='Path to MSA weights for neighborhood scoring')
-    parser.add_argument('--clustal_omega_location', default=None, type=str, help='Path to Clustal Omega (only needed with scoring indels with retrieval)')
-    parser.add_argument('--device', type=int, default=int(os.environ.get("LOCAL_RANK", "0")), help='[pgmi] GPU index')
+    parser = argparse.ArgumentParser(description="Tranception scoring on MI355X")
+    for flag, kw in _FLAGS:
+        parser.add_argument(flag, **kw)
     return parser
+
+
+def _join(folder, name):
+    return None if folder is None else folder + os.sep + name
+
+
+def resolve_inputs(args):
+    """Assay id, wild type, assay file and (with retrieval) the alignment inputs, from the reference CSV row or from
+    the manual flags -- the resolution order of score_tranception_proteingym.py:49-85 (MSA_start becomes 0-indexed)."""
+    msa = None
+    if args.DMS_reference_file_path:
+        table = pd.read_csv(args.DMS_reference_file_path)
+        dms_id = table["DMS_id"][args.DMS_index]
+        print("Compute scores for DMS: " + str(dms_id))
+        row = table[table["DMS_id"] == dms_id]
+        wild_type = row["target_seq"].values[0].upper()
+        assay_file = row["DMS_filename"].values[0]
+        if args.inference_time_retrieval:
+            weights = _join(args.MSA_weights_folder, row["weight_file_name"].values[0]) if args.MSA_weights_folder else None
+            msa = (_join(args.MSA_folder, table["MSA_filename"][args.DMS_index]), weights,
+                   int(row["MSA_start"].values[0]) - 1, int(row["MSA_end"].values[0]))
+    else:
+        wild_type, assay_file = args.target_seq, args.DMS_file_name
+        dms_id = assay_file.split(".")[0]
+        if args.inference_time_retrieval:
+            weights = _join(args.MSA_weights_folder, args.MSA_weight_file_name) if args.MSA_weights_folder is not None else None
+            msa = (_join(args.MSA_folder, args.MSA_filename), weights, args.MSA_start - 1, args.MSA_end)
+    return dms_id, wild_type, assay_file, msa
 
 
 def main(args=None):
     args = create_parser().parse_args() if args is None else args
     if args.model_framework != "pytorch":
         raise NotImplementedError("only --model_framework pytorch has an MI355X backend")
-    if args.DMS_reference_file_path:
-        mapping = pd.read_csv(args.DMS_reference_file_path)
-        DMS_id = mapping["DMS_id"][args.DMS_index]
-        print("Compute scores for DMS: " + str(DMS_id))
-        row = mapping[mapping["DMS_id"] == DMS_id]
-        target_seq = row["target_seq"].values[0].upper()
-        DMS_file_name = row["DMS_filename"].values[0]
-        if args.inference_time_retrieval:
-            MSA_data_file = args.MSA_folder + os.sep + mapping["MSA_filename"][args.DMS_index] if args.MSA_folder is not None else None
-            MSA_weight_file_name = args.MSA_weights_folder + os.sep + row["weight_file_name"].values[0] if args.MSA_weights_folder else None
-            MSA_start = int(row["MSA_start"].values[0]) - 1
-            MSA_end = int(row["MSA_end"].values[0])
-    else:
-        target_seq = args.target_seq
-        DMS_file_name = args.DMS_file_name
-        DMS_id = DMS_file_name.split(".")[0]
-        if args.inference_time_retrieval:
-            MSA_data_file = args.MSA_folder + os.sep + args.MSA_filename if args.MSA_folder is not None else None
-            MSA_weight_file_name = args.MSA_weights_folder + os.sep + args.MSA_weight_file_name if args.MSA_weights_folder is not None else None
-            MSA_start = args.MSA_start - 1
-            MSA_end = args.MSA_end
-
+    dms_id, wild_type, assay_file, msa = resolve_inputs(args)
     retrieval = None
-    if args.inference_time_retrieval:
+    if msa is not None:
         if args.indel_mode:
             raise NotImplementedError("indel scoring with retrieval needs Clustal Omega re-alignment (not built)")
-        retrieval = dict(MSA_filename=MSA_data_file, MSA_start=MSA_start, MSA_end=MSA_end, full_protein_length=len(target_seq),
-                         retrieval_inference_weight=args.retrieval_inference_weight, MSA_weight_file_name=MSA_weight_file_name)
-        print("Model leverages both autoregressive and retrieval inference")
-    else:
-        print("Model only uses autoregressive inference")
+        retrieval = dict(MSA_filename=msa[0], MSA_weight_file_name=msa[1], MSA_start=msa[2], MSA_end=msa[3],
+                         full_protein_length=len(wild_type), retrieval_inference_weight=args.retrieval_inference_weight)
+    print("Model leverages both autoregressive and retrieval inference" if retrieval else "Model only uses autoregressive inference")
     model = ptr.from_pretrained(args.checkpoint, device=args.device, scoring_window=args.scoring_window, retrieval=retrieval)
-
-    if not os.path.isdir(args.output_scores_folder):
-        os.mkdir(args.output_scores_folder)
-    scoring_filename = args.output_scores_folder + os.sep + DMS_id + ".csv"
-    DMS_data = pd.read_csv(args.DMS_data_folder + os.sep + DMS_file_name, low_memory=False)
-    all_scores = model.score_mutants(DMS_data=DMS_data, target_seq=target_seq,
-                                     scoring_mirror=not args.deactivate_scoring_mirror,
-                                     batch_size_inference=args.batch_size_inference, num_workers=args.num_workers,
-                                     indel_mode=args.indel_mode)
-    tmp = scoring_filename + ".tmp"
-    all_scores.to_csv(tmp, index=False)
-    os.replace(tmp, scoring_filename)
+    os.makedirs(args.output_scores_folder, exist_ok=True)
+    out_csv = args.output_scores_folder + os.sep + dms_id + ".csv"
+    assay = pd.read_csv(args.DMS_data_folder + os.sep + assay_file, low_memory=False)
+    scores = model.score_mutants(DMS_data=assay, target_seq=wild_type, scoring_mirror=not args.deactivate_scoring_mirror,
+                                 batch_size_inference=args.batch_size_inference, num_workers=args.num_workers,
+                                 indel_mode=args.indel_mode)
+    scores.to_csv(out_csv + ".tmp", index=False)
+    os.replace(out_csv + ".tmp", out_csv)                 # atomic: a crashed run never leaves a partial CSV
     model.close()
 
 

@@ -136,3 +136,28 @@ def test_lpt_partition_and_costs():
     loads = [sum(costs[i] for i in p) for p in parts]
     assert max(loads) / (sum(loads) / 8) < 1.05
     assert abs(pdist.forward_flops(288) / 0.389e12 - 1) < 0.01  # 0.389 TFLOP per forward
+
+
+def test_tranception_cli_input_resolution(tmp_path):
+    """score_tranception_proteingym mirror: reference-file mode and manual mode resolve to the same inputs the
+    reference computes (score_tranception_proteingym.py:49-85: MSA_start made 0-indexed, weight path optional)."""
+    import pandas as pd
+    from proteingym_amd import score_tranception_proteingym as st
+    ref = tmp_path / "ref.csv"
+    pd.DataFrame([{"DMS_id": "A1", "DMS_filename": "A1.csv", "target_seq": "mkvla", "MSA_filename": "A1.a2m",
+                   "MSA_start": 2, "MSA_end": 5, "weight_file_name": "A1.npy"},
+                  {"DMS_id": "B2", "DMS_filename": "B2.csv", "target_seq": "ACDE", "MSA_filename": "B2.a2m",
+                   "MSA_start": 1, "MSA_end": 4, "weight_file_name": "B2.npy"}]).to_csv(ref, index=False)
+    p = st.create_parser()
+    a = p.parse_args(["--DMS_reference_file_path", str(ref), "--DMS_index", "0", "--inference_time_retrieval",
+                      "--MSA_folder", "msas", "--MSA_weights_folder", "w"])
+    assert st.resolve_inputs(a) == ("A1", "MKVLA", "A1.csv", ("msas/A1.a2m", "w/A1.npy", 1, 5))
+    a = p.parse_args(["--DMS_reference_file_path", str(ref), "--DMS_index", "1", "--inference_time_retrieval", "--MSA_folder", "m"])
+    assert st.resolve_inputs(a) == ("B2", "ACDE", "B2.csv", ("m/B2.a2m", None, 0, 4))
+    a = p.parse_args(["--DMS_reference_file_path", str(ref), "--DMS_index", "1"])
+    assert st.resolve_inputs(a) == ("B2", "ACDE", "B2.csv", None)
+    a = p.parse_args(["--target_seq", "MKV", "--DMS_file_name", "X9.csv", "--inference_time_retrieval", "--MSA_folder", "m",
+                      "--MSA_filename", "X9.a2m", "--MSA_start", "1", "--MSA_end", "3"])
+    assert st.resolve_inputs(a) == ("X9", "MKV", "X9.csv", ("m/X9.a2m", None, 0, 3))
+    with pytest.raises(NotImplementedError):
+        st.main(p.parse_args(["--model_framework", "JAX"]))
