@@ -72,49 +72,40 @@ def sequence_replace_single(sequence, char_to_replace, char_replacements):
 
 
 def get_sequence_slices(df, target_seq, model_context_len, start_idx=1, scoring_window="optimal", indel_mode=False):
-    """scoring_utils.py:152-203."""
-    len_target_seq = len(target_seq)
-    num_mutants = len(df['mutated_sequence'])
-    df = df.reset_index(drop=True)
+    """Behaviour of scoring_utils.py:152-203, written on plain lists: every input row yields a (mutated, window)
+    row and a wild-type row cropped to the SAME window; rows identical in every column are merged; the 'mutant'
+    column is dropped.  Columns added: sliced_mutated_sequence, window_start, window_end."""
+    L = len(target_seq)
+    base = df.reset_index(drop=True)
+    seqs = base["mutated_sequence"].tolist()
+    keep = base.drop(columns=[c for c in ("mutant",) if c in base.columns])
+
+    def block(sequences, windows):
+        out = keep.copy()
+        out["mutated_sequence"] = sequences
+        out["sliced_mutated_sequence"] = [s[w0:w1] for s, (w0, w1) in zip(sequences, windows)]
+        out["window_start"] = [w0 for w0, _ in windows]
+        out["window_end"] = [w1 for _, w1 in windows]
+        return out
+
     if scoring_window == "optimal":
-        df['mutation_barycenter'] = df['mutant'].apply(lambda x: int(np.array([int(mutation[1:-1]) - start_idx for mutation in x.split(':')]).mean())) \
-            if not indel_mode else df['mutated_sequence'].apply(lambda x: len(x) // 2)
-        df['scoring_optimal_window'] = df['mutation_barycenter'].apply(lambda x: get_optimal_window(x, len_target_seq, model_context_len)) \
-            if not indel_mode else df['mutated_sequence'].apply(lambda x: (0, len(x)))
-        df['sliced_mutated_sequence'] = [df['mutated_sequence'][index][df['scoring_optimal_window'][index][0]:df['scoring_optimal_window'][index][1]] for index in range(num_mutants)]
-        df['window_start'] = df['scoring_optimal_window'].map(lambda x: x[0])
-        df['window_end'] = df['scoring_optimal_window'].map(lambda x: x[1])
-        del df['scoring_optimal_window'], df['mutation_barycenter']
-        if 'mutant' in df:
-            del df['mutant']
-        df_wt = df.copy()
-        df_wt['mutated_sequence'] = [target_seq] * num_mutants
-        if indel_mode:
-            df_wt['window_end'] = df_wt['mutated_sequence'].map(lambda x: len(x))
-        df_wt['sliced_mutated_sequence'] = [target_seq[df_wt['window_start'][index]:df_wt['window_end'][index]] for index in range(num_mutants)]
-        df = pd.concat([df, df_wt], axis=0)
-        df = df.drop_duplicates()
-    elif scoring_window == "sliding":
-        num_windows = 1 + int(len_target_seq / model_context_len)
-        df_list = []
-        start = 0
-        for window_index in range(1, num_windows + 1):
-            df_sliced = df.copy()
-            df_sliced['sliced_mutated_sequence'] = df_sliced['mutated_sequence'].map(lambda x: x[start:start + model_context_len])
-            df_sliced['window_start'] = [start] * num_mutants
-            df_sliced['window_end'] = df_sliced['mutated_sequence'].map(lambda x: min(len(x), start + model_context_len))
-            df_sliced_wt = df_sliced.copy()
-            df_sliced_wt['mutated_sequence'] = [target_seq] * num_mutants
-            df_sliced_wt['sliced_mutated_sequence'] = df_sliced_wt['mutated_sequence'].map(lambda x: x[start:start + model_context_len])
-            df_sliced_wt['window_end'] = df_sliced_wt['mutated_sequence'].map(lambda x: min(len(x), start + model_context_len))
-            df_list.append(df_sliced)
-            df_list.append(df_sliced_wt)
-            start += model_context_len
-        df_final = pd.concat(df_list, axis=0)
-        if 'mutant' in df_final:
-            del df_final['mutant']
-        df = df_final.drop_duplicates()
-    return df.reset_index(drop=True)
+        if indel_mode:                                      # whole sequence; the wild type keeps its own length
+            win_mut = [(0, len(s)) for s in seqs]
+            win_wt = [(0, L)] * len(seqs)
+        else:                                               # window centred on the mean mutated position
+            centres = [int(np.mean([int(one[1:-1]) - start_idx for one in m.split(":")])) for m in base["mutant"]]
+            win_mut = [tuple(get_optimal_window(c, L, model_context_len)) for c in centres]
+            win_wt = win_mut
+        blocks = [block(seqs, win_mut), block([target_seq] * len(seqs), win_wt)]
+    elif scoring_window == "sliding":                       # consecutive context-sized chunks, mutated then wild type
+        blocks = []
+        for k in range(1 + int(L / model_context_len)):
+            lo = k * model_context_len
+            blocks.append(block(seqs, [(lo, min(len(s), lo + model_context_len)) for s in seqs]))
+            blocks.append(block([target_seq] * len(seqs), [(lo, min(L, lo + model_context_len))] * len(seqs)))
+    else:
+        raise ValueError("scoring_window must be 'optimal' or 'sliding'")
+    return pd.concat(blocks, axis=0).drop_duplicates().reset_index(drop=True)
 
 
 # ---- retrieval prior (tranception/utils/msa_utils.py:28-138) -------------------------------------
@@ -248,50 +239,45 @@ def compute_sequence_weights(enc: np.ndarray, theta: float, block: int = 256, de
 
 def get_msa_prior(MSA_data_file, MSA_weight_file_name, MSA_start, MSA_end, len_target_seq, vocab=VOCAB,
                   retrieval_aggregation_mode="aggregate_substitution", filter_MSA=True, seq_name_to_weight=None):
-    """Weighted pseudo-count profile of the retrieved MSA (msa_utils.py:63-138).  With
-    ``MSA_weight_file_name`` the EVE weights come from ``MSA_processing`` exactly as in the reference
-    (:100-115: sequences without a weight are dropped); ``seq_name_to_weight`` can inject them directly."""
-    msa_data = process_msa_data(MSA_data_file)
-    vocab_size = len(vocab.keys())
+    """Per-position amino-acid distribution of the retrieved alignment with 1e-5 pseudo-counts, [len_target_seq, V],
+    zero outside [MSA_start, MSA_end) -- the quantity msa_utils.py:63-138 builds.  Sequences sharing less than 20 %
+    of the query's symbols are dropped (:83-91); with ``MSA_weight_file_name`` the EVE weights come from
+    ``MSA_processing`` and sequences without a weight are dropped (:100-115); ``seq_name_to_weight`` injects weights
+    directly.  The float expression of the reference is kept term by term so the result is bit-identical."""
+    V = len(vocab)
+    alignment = process_msa_data(MSA_data_file)
+    names = list(alignment.keys())
+    width = MSA_end - MSA_start
 
-    def one_hot(s):
-        o = np.zeros((len(s), vocab_size))
-        for j, letter in enumerate(s):
-            if letter in vocab:
-                o[j, vocab[letter]] = 1.0
-        return o.flatten()
+    def encode(seq):                                      # vocabulary index per column, -1 = not in the vocabulary
+        return np.array([vocab.get(ch, -1) for ch in seq], dtype=np.int64)
+    codes = {n: encode(alignment[n]) for n in names}
     if filter_MSA:
-        names = list(msa_data.keys())
-        ref = one_hot(msa_data[names[0]])
-        for name in names:
-            if np.dot(ref, one_hot(msa_data[name])) / np.dot(ref, ref) < 0.2:
-                del msa_data[name]
+        query = codes[names[0]]
+        n_query = float((query >= 0).sum())
+        names = [n for n in names
+                 if not (float(((codes[n] == query) & (query >= 0)).sum()) / n_query < 0.2)]
     if MSA_weight_file_name is not None and seq_name_to_weight is None:
         assert os.path.exists(MSA_weight_file_name), "Weights file not located on disk."
-        MSA_EVE = MSA_processing(MSA_location=MSA_data_file, use_weights=True, weights_location=MSA_weight_file_name)
-        seq_name_to_weight = MSA_EVE.seq_name_to_weight
+        seq_name_to_weight = MSA_processing(MSA_location=MSA_data_file, use_weights=True,
+                                            weights_location=MSA_weight_file_name).seq_name_to_weight
     if seq_name_to_weight is not None:
-        for name in list(msa_data.keys()):
-            if name not in seq_name_to_weight:
-                del msa_data[name]
-        MSA_weight = [seq_name_to_weight[name] for name in msa_data.keys()]
+        names = [n for n in names if n in seq_name_to_weight]
+        weights = np.array([seq_name_to_weight[n] for n in names])
     else:
-        MSA_weight = [1] * len(list(msa_data.keys()))
-    if retrieval_aggregation_mode in ("aggregate_substitution", "aggregate_indel"):
-        one_hots = np.zeros((len(msa_data), MSA_end - MSA_start, vocab_size))
-        for i, name in enumerate(msa_data.keys()):
-            for j, letter in enumerate(msa_data[name]):
-                if letter in vocab:
-                    one_hots[i, j, vocab[letter]] = 1.0
-        MSA_weight = np.expand_dims(np.array(MSA_weight), axis=(1, 2))
-        weighted_one_hots = (one_hots + np.ones_like(one_hots) * 1e-5) * MSA_weight
-        norm = weighted_one_hots.sum(axis=-1).sum(axis=0)
-        norm = np.tile(norm.reshape(-1, 1), (1, vocab_size))
-        msa_prior = np.zeros((len_target_seq, vocab_size))
-        msa_prior[MSA_start:MSA_end, :] = weighted_one_hots.sum(axis=0) / norm
-    else:
-        msa_prior = np.ones((len_target_seq, vocab_size)) / vocab_size
-    return msa_prior
+        weights = np.array([1] * len(names))
+    if retrieval_aggregation_mode not in ("aggregate_substitution", "aggregate_indel"):
+        return np.ones((len_target_seq, V)) / V
+    one_hots = np.zeros((len(names), width, V))
+    for i, n in enumerate(names):
+        c = codes[n]
+        cols = np.nonzero(c >= 0)[0]
+        one_hots[i, cols, c[cols]] = 1.0
+    counts = (one_hots + np.ones_like(one_hots) * 1e-5) * np.expand_dims(weights, axis=(1, 2))
+    total = counts.sum(axis=-1).sum(axis=0)
+    prior = np.zeros((len_target_seq, V))
+    prior[MSA_start:MSA_end, :] = counts.sum(axis=0) / np.tile(total.reshape(-1, 1), (1, V))
+    return prior
 
 
 # ---- checkpoint ------------------------------------------------------------------------------------
