@@ -26,64 +26,50 @@ import pandas as pd
 from . import esm as pesm
 
 
+# Flag names, types and defaults are the reference's CLI contract (compute_fitness.py:100-238) so that the launchers
+# under scripts/scoring_DMS_zero_shot/ keep working; help texts are ours.  Last three entries are additive.
+_FLAGS = [
+    ("--model_type", dict(type=str, nargs="+", default="MSA_transformer", help="ESM1v | ESM1b | ESM2 | MSA_transformer")),
+    ("--model-location", dict(type=str, nargs="+", help="one or more local .pt checkpoints (fair-esm v1/v2 layout)")),
+    ("--sequence", dict(type=str, help="unused (kept for compatibility)")),
+    ("--dms-input", dict(type=pathlib.Path, help="assay CSV, or with --dms_index the folder holding the assay CSVs")),
+    ("--dms_index", dict(type=int, help="row of --dms_mapping to score")),
+    ("--dms_mapping", dict(type=str, help="reference CSV (DMS_id, target_seq, DMS_filename, MSA_* ...)")),
+    ("--mutation-col", dict(type=str, default="mutant", help="column holding the substitutions, e.g. 'A42G:L77P'")),
+    ("--dms-output", dict(type=pathlib.Path, help="output folder; one <DMS_id>.csv per assay")),
+    ("--offset-idx", dict(type=int, default=1, help="position of the first residue in the mutation strings")),
+    ("--scoring-strategy", dict(type=str, default="wt-marginals", choices=["wt-marginals", "pseudo-ppl", "masked-marginals"],
+                                help="how a mutant is scored from the language model")),
+    ("--msa-path", dict(type=pathlib.Path, help="alignment file, or with --dms_index the folder of alignments (MSA Transformer)")),
+    ("--msa-sampling-strategy", dict(type=str, default="sequence-reweighting", help="sequence-reweighting | random | first_x_rows")),
+    ("--msa-samples", dict(type=int, default=400, help="rows sampled from the alignment per seed")),
+    ("--msa-weights-folder", dict(type=str, default=None, help="folder of sequence-weight .npy files (sequence-reweighting)")),
+    ("--seeds", dict(type=int, nargs="+", default=1, help="one sampled alignment and one score column per seed")),
+    ("--filter-msa", dict(action="store_true", help="hhfilter pre-filtering (external binary: not available here)")),
+    ("--hhfilter-min-cov", dict(type=int, default=75, help="hhfilter -cov")),
+    ("--hhfilter-max-seq-id", dict(type=int, default=90, help="hhfilter -id")),
+    ("--hhfilter-min-seq-id", dict(type=int, default=0, help="hhfilter -qid")),
+    ("--path-to-hhfilter", dict(type=str, default="/n/groups/marks/software/hhsuite/hhsuite-3.3.0", help="hhsuite root")),
+    ("--scoring-window", dict(type=str, default="optimal", help="sequences longer than the context: optimal | overlapping")),
+    ("--overwrite-prior-scores", dict(action="store_true", help="recompute columns already present in the output CSV")),
+    ("--target_seq", dict(type=str, default=None, help="wild-type sequence (manual mode, no --dms_mapping)")),
+    ("--weight_file_name", dict(type=str, default=None, help="sequence-weight file inside --msa-weights-folder (manual mode)")),
+    ("--MSA_start", dict(type=int, default=None, help="first target position covered by the alignment, 1-indexed (manual mode)")),
+    ("--MSA_end", dict(type=int, default=None, help="last target position covered by the alignment, 1-indexed (manual mode)")),
+    ("--nogpu", dict(action="store_true", help="rejected: this scorer has no CPU path")),
+    ("--device", dict(type=int, default=int(os.environ.get("LOCAL_RANK", "0")), help="[additive] GPU index (default LOCAL_RANK or 0)")),
+    ("--precision", dict(type=str, default="f16x3", choices=sorted(pesm._lib.PRECISIONS),
+                         help="[additive] f16x3 (default: split-fp16, 3 MFMAs per product, fp32-class accuracy, parity-gated), "
+                              "fp32 (fp32 MFMA, parity-gated, slower), bf16 (fast, NOT parity-gated)")),
+    ("--all-positions", dict(action="store_true", help="[additive] forward every token position as the reference does "
+                                                       "(default: only positions some mutant reads; same outputs)")),
+]
+
+
 def create_parser():
-    parser = argparse.ArgumentParser(
-        description="Label a deep mutational scan with predictions from an ensemble of ESM-1v models."  # noqa
-    )
-    parser.add_argument("--model_type", type=str, help="MSA_transformer Vs ESM1v Vs ESM1b",
-                        default="MSA_transformer", nargs="+")
-    parser.add_argument("--model-location", type=str, nargs="+",
-                        help="PyTorch model file OR name of pretrained model to download (see README for models)")
-    parser.add_argument("--sequence", type=str, help="Base sequence to which mutations were applied")
-    parser.add_argument("--dms-input", type=pathlib.Path, help="CSV file containing the deep mutational scan")
-    parser.add_argument("--dms_index", type=int, help="Index of DMS in mapping file")
-    parser.add_argument("--dms_mapping", type=str, help="Location of DMS_mapping")
-    parser.add_argument("--mutation-col", type=str, default="mutant",
-                        help="column in the deep mutational scan labeling the mutation as 'AiB'")
-    parser.add_argument("--dms-output", type=pathlib.Path,
-                        help="Output file containing the deep mutational scan along with predictions")
-    parser.add_argument("--offset-idx", type=int, default=1,
-                        help="Offset of the mutation positions in `--mutation-col`")
-    parser.add_argument("--scoring-strategy", type=str, default="wt-marginals",
-                        choices=["wt-marginals", "pseudo-ppl", "masked-marginals"], help="")
-    parser.add_argument("--msa-path", type=pathlib.Path, help="path to MSA (required for MSA Transformer)")
-    parser.add_argument("--msa-sampling-strategy", type=str, default='sequence-reweighting',
-                        help="Strategy to sample sequences from MSA [sequence-reweighting|random|first_x_rows]")
-    parser.add_argument("--msa-samples", type=int, default=400,
-                        help="number of sequences to randomly sample from the MSA")
-    parser.add_argument("--msa-weights-folder", type=str, default=None,
-                        help="Folder with weights to sample MSA sequences in 'sequence-reweighting' scheme")
-    parser.add_argument('--seeds', type=int, default=1, help='Random seed used during training', nargs="+")
-    parser.add_argument('--filter-msa', action='store_true',
-                        help='Whether to use hhfilter to filter input MSA before sampling')
-    parser.add_argument('--hhfilter-min-cov', type=int, default=75, help='minimum coverage with query (%%)')
-    parser.add_argument('--hhfilter-max-seq-id', type=int, default=90, help='maximum pairwise identity (%%)')
-    parser.add_argument('--hhfilter-min-seq-id', type=int, default=0,
-                        help='minimum sequence identity with query (%%)')
-    parser.add_argument('--path-to-hhfilter', type=str,
-                        default='/n/groups/marks/software/hhsuite/hhsuite-3.3.0', help='Path to hhfilter binaries')
-    parser.add_argument('--scoring-window', type=str, default='optimal',
-                        help='Approach to handle long sequences [optimal|overlapping]')
-    parser.add_argument('--overwrite-prior-scores', action='store_true',
-                        help='Whether to overwrite prior scores in the dataframe')
-    # No ref file provided
-    parser.add_argument('--target_seq', default=None, type=str, help='WT sequence mutated in the assay')
-    parser.add_argument('--weight_file_name', default=None, type=str,
-                        help='Wild type sequence mutated in the assay (to be provided if not using a reference file)')
-    parser.add_argument('--MSA_start', default=None, type=int,
-                        help='Index of first AA covered by the MSA relative to target_seq coordinates (1-indexing)')
-    parser.add_argument('--MSA_end', default=None, type=int,
-                        help='Index of last AA covered by the MSA relative to target_seq coordinates (1-indexing)')
-    parser.add_argument("--nogpu", action="store_true", help="Do not use GPU even if available")
-    # additive
-    parser.add_argument("--device", type=int, default=int(os.environ.get("LOCAL_RANK", "0")),
-                        help="[pgmi] GPU index (default LOCAL_RANK or 0)")
-    parser.add_argument("--precision", type=str, default="f16x3", choices=sorted(pesm._lib.PRECISIONS),
-                        help="[pgmi] GEMM arithmetic: f16x3 (default; split-fp16 3-pass, fp32-class accuracy, parity-gated), "
-                             "fp32 (fp32 MFMA, parity-gated, slower), bf16 (fast, NOT parity-gated)")
-    parser.add_argument("--all-positions", action="store_true",
-                        help="[pgmi] forward every token position like the reference does (default: only "
-                             "positions some mutant reads; outputs are identical)")
+    parser = argparse.ArgumentParser(description="Zero-shot scoring of a deep mutational scan with ESM models on MI355X")
+    for flag, kw in _FLAGS:
+        parser.add_argument(flag, **kw)
     return parser
 
 
@@ -168,164 +154,163 @@ def wt_marginals_table(model, alphabet, sequence, scoring_window):
     return token_probs
 
 
-def main(args):
-    if not os.path.exists(args.dms_output):
-        os.mkdir(args.dms_output)
-    print("Arguments:", args)
+def _cell(row, name, default):
+    """Value of an optional reference-file column ("" / NaN / missing column -> default)."""
+    if name not in row.index:
+        return default
+    v = row[name]
+    return default if (isinstance(v, float) and np.isnan(v)) or v == "" else v
 
-    mutant_col = args.mutation_col
+
+def resolve_assay(args):
+    """Everything main() needs about the assay, from the reference-file row (--dms_index) or from the manual flags:
+    the rules of compute_fitness.py:286-340.  With the MSA Transformer the target sequence is cropped to the span the
+    alignment covers and mutation positions are read relative to MSA_start (:318-325, :361).  Side effects kept from
+    the reference: args.sequence / args.dms_input / args.dms_output / args.msa_path are rewritten."""
+    wants_msa = "MSA_transformer" in args.model_type
+    info = dict(mutant_col=args.mutation_col, msa_start=1, weight_file=None)
     if args.dms_index is not None:
-        mapping_protein_seq_DMS = pd.read_csv(args.dms_mapping)
-        DMS_id = mapping_protein_seq_DMS["DMS_id"][args.dms_index]
-        print("Compute scores for DMS: " + str(DMS_id))
-        row = mapping_protein_seq_DMS[mapping_protein_seq_DMS["DMS_id"] == DMS_id]
-        if len(row) == 0:
-            raise ValueError("No mappings found for DMS: " + str(DMS_id))
-        elif len(row) > 1:
-            raise ValueError("Multiple mappings found for DMS: " + str(DMS_id))
-        row = row.iloc[0]
-        row = row.replace(np.nan, "")
-        args.sequence = row["target_seq"].upper()
+        table = pd.read_csv(args.dms_mapping)
+        dms_id = table["DMS_id"][args.dms_index]
+        print("Compute scores for DMS: " + str(dms_id))
+        hits = table[table["DMS_id"] == dms_id]
+        if len(hits) != 1:
+            raise ValueError(("No mappings found for DMS: " if len(hits) == 0 else "Multiple mappings found for DMS: ") + str(dms_id))
+        row = hits.iloc[0]
+        sequence = str(row["target_seq"]).upper()
         args.dms_input = str(args.dms_input) + os.sep + row["DMS_filename"]
-        mutant_col = row["DMS_mutant_column"] if "DMS_mutant_column" in mapping_protein_seq_DMS.columns else mutant_col
-        args.dms_output = str(args.dms_output) + os.sep + DMS_id + '.csv'
-        target_seq_start_index = row["start_idx"] if "start_idx" in mapping_protein_seq_DMS.columns and row["start_idx"] != "" else 1
-        target_seq_end_index = target_seq_start_index + len(args.sequence)
-        if "MSA_transformer" in args.model_type:                       # compute_fitness.py:310-325
-            msa_filename = row["MSA_filename"]
-            if msa_filename == "":
-                raise ValueError("No MSA found for DMS: " + str(DMS_id))
-            args.msa_path = str(args.msa_path) + os.sep + msa_filename
-            msa_start_index = int(row["MSA_start"]) if "MSA_start" in mapping_protein_seq_DMS.columns else 1
-            msa_end_index = int(row["MSA_end"]) if "MSA_end" in mapping_protein_seq_DMS.columns else len(args.sequence)
-            MSA_weight_file_name = args.msa_weights_folder + os.sep + row["weight_file_name"] \
-                if ("weight_file_name" in mapping_protein_seq_DMS.columns and args.msa_weights_folder is not None) else None
-            if (target_seq_start_index != msa_start_index) or (target_seq_end_index != msa_end_index):
-                args.sequence = args.sequence[msa_start_index - 1:msa_end_index]
-                target_seq_start_index = msa_start_index
-                target_seq_end_index = msa_end_index
-        df = pd.read_csv(args.dms_input)
+        info["mutant_col"] = _cell(row, "DMS_mutant_column", args.mutation_col)
+        first = _cell(row, "start_idx", 1)
+        if wants_msa:
+            name = _cell(row, "MSA_filename", "")
+            if name == "":
+                raise ValueError("No MSA found for DMS: " + str(dms_id))
+            args.msa_path = str(args.msa_path) + os.sep + name       # --msa-path is the folder of alignments here
+            m0, m1 = int(_cell(row, "MSA_start", 1)), int(_cell(row, "MSA_end", len(sequence)))
+            if args.msa_weights_folder is not None and "weight_file_name" in row.index:
+                info["weight_file"] = args.msa_weights_folder + os.sep + row["weight_file_name"]
+            if first != m0 or first + len(sequence) != m1:            # the reference's (end-exclusive vs inclusive) test
+                sequence, first = sequence[m0 - 1:m1], m0
+            info["msa_start"] = m0
     else:
-        DMS_id = str(args.dms_input).split(os.sep)[-1].split('.csv')[0]
-        args.dms_output = str(args.dms_output) + os.sep + DMS_id + '.csv'
-        target_seq_start_index = args.offset_idx
-        args.sequence = args.target_seq.upper()
-        if (args.MSA_start is None) or (args.MSA_end is None):             # compute_fitness.py:333-339
+        dms_id = str(args.dms_input).split(os.sep)[-1].split(".csv")[0]
+        sequence = args.target_seq.upper()
+        first = args.offset_idx
+        if args.MSA_start is None or args.MSA_end is None:
             if args.msa_path:
                 print("MSA start and end not provided -- Assuming the MSA is covering the full WT sequence")
-            args.MSA_start = 1
-            args.MSA_end = len(args.target_seq)
-        msa_start_index = args.MSA_start
-        msa_end_index = args.MSA_end
-        MSA_weight_file_name = args.msa_weights_folder + os.sep + args.weight_file_name \
-            if (args.msa_weights_folder is not None and args.weight_file_name is not None) else None
-        df = pd.read_csv(args.dms_input)
+            args.MSA_start, args.MSA_end = 1, len(args.target_seq)
+        info["msa_start"] = args.MSA_start
+        if args.msa_weights_folder is not None and args.weight_file_name is not None:
+            info["weight_file"] = args.msa_weights_folder + os.sep + args.weight_file_name
+    args.sequence = sequence
+    args.dms_output = str(args.dms_output) + os.sep + str(dms_id) + ".csv"
+    info.update(dms_id=dms_id, first_position=first, frame=pd.read_csv(args.dms_input))
+    return info
 
+
+def checkpoint_stem(path):
+    return path.split("/")[-1].split(".")[0]
+
+
+def write_atomically(df, path):
+    tmp = str(path) + ".tmp"
+    df.to_csv(tmp, index=False)
+    os.replace(tmp, path)                      # a crashed shard never leaves a partial CSV
+
+
+def main(args):
+    os.makedirs(args.dms_output, exist_ok=True)
+    print("Arguments:", args)
+    info = resolve_assay(args)
+    df, mutant_col = info["frame"], info["mutant_col"]
     if len(df) == 0:
         raise ValueError("No rows found in the dataframe")
     print(f"df shape: {df.shape}", flush=True)
     if args.nogpu:
         raise RuntimeError("--nogpu: this scorer is GPU-only (libpgmi has no CPU path); "
                            "use the reference compute_fitness.py for CPU runs")
-
     print("Starting model scoring")
     if "MSA_transformer" in args.model_type:
-        return score_msa_transformer(args, df, mutant_col, msa_start_index, MSA_weight_file_name)
-    for model_location in args.model_location:
-        model, alphabet = pesm.load_model_and_alphabet(model_location, device=args.device,
-                                                       precision=args.precision)
-        model_location = model_location.split("/")[-1].split(".")[0]
+        return score_msa_transformer(args, df, mutant_col, info["msa_start"], info["weight_file"])
+    args.offset_idx = info["first_position"]
+    mutants = [str(m) for m in df[mutant_col]]
+    columns = []
+    for location in args.model_location:
+        model, alphabet = pesm.load_model_and_alphabet(location, device=args.device, precision=args.precision)
+        column = checkpoint_stem(location)
+        columns.append(column)
         print("Transferred model to GPU")
-        args.offset_idx = target_seq_start_index
-        mutants = [str(m) for m in df[mutant_col]]
-
-        if args.scoring_strategy == "wt-marginals":
-            token_probs = wt_marginals_table(model, alphabet, args.sequence, args.scoring_window)
-            df[model_location] = [label_row(m, args.sequence, token_probs, alphabet, args.offset_idx) for m in mutants]
-        elif args.scoring_strategy == "masked-marginals":
-            print("Scoring with masked-marginals and model {}".format(model_location))
+        if args.scoring_strategy == "wt-marginals":            # one forward (or blended windows), then table look-ups
+            table = wt_marginals_table(model, alphabet, args.sequence, args.scoring_window)
+            df[column] = [label_row(m, args.sequence, table, alphabet, args.offset_idx) for m in mutants]
+        elif args.scoring_strategy == "masked-marginals":      # the hot path: one device-resident assay
+            print("Scoring with masked-marginals and model {}".format(column))
             if len(args.sequence) + 2 > 1024 and args.scoring_window == "overlapping":
                 print("Overlapping not yet implemented for masked-marginals")
                 sys.exit(0)
             assay = pesm.Assay(model, args.sequence, mutants, offset_idx=args.offset_idx, alphabet=alphabet,
                                window=1024, all_positions=args.all_positions)
-            df[model_location] = assay.run()
+            df[column] = assay.run()
             assay.close()
-        elif args.scoring_strategy == "pseudo-ppl":
-            if 'mutated_sequence' not in df:
-                df['mutated_sequence'] = [get_mutated_sequence(m, args.sequence, args.offset_idx) for m in mutants]
-            df[model_location] = compute_pppl_batch(list(df['mutated_sequence']), model, alphabet)
+        else:                                                  # pseudo-ppl
+            if "mutated_sequence" not in df:
+                df["mutated_sequence"] = [get_mutated_sequence(m, args.sequence, args.offset_idx) for m in mutants]
+            df[column] = compute_pppl_batch(list(df["mutated_sequence"]), model, alphabet)
         model.close()
-
-    # compute_fitness.py:530-537: plain mean of the checkpoint columns
-    if "ESM1v" in args.model_type:
-        df["Ensemble_ESM1v"] = 0.0
-        for model_location in args.model_location:
-            model_location = model_location.split("/")[-1].split(".")[0]
-            df["Ensemble_ESM1v"] += df[model_location]
-        df["Ensemble_ESM1v"] /= len(args.model_location)
-    tmp = str(args.dms_output) + ".tmp"
-    df.to_csv(tmp, index=False)
-    os.replace(tmp, args.dms_output)            # atomic: a crashed shard never leaves a partial CSV
+    if "ESM1v" in args.model_type:                             # plain mean of the checkpoint columns (:530-537)
+        df["Ensemble_ESM1v"] = sum(df[c] for c in columns) / len(columns)
+    write_atomically(df, args.dms_output)
 
 
 def score_msa_transformer(args, df, mutant_col, msa_start_index, MSA_weight_file_name):
-    """compute_fitness.py:360-424 + 538-543: per seed sample the alignment, masked-marginals over the first
-    row, one ``<checkpoint>_seed<k>`` column per seed, then their mean in ``<checkpoint>_ensemble``."""
+    """MSA Transformer branch (compute_fitness.py:360-424, 538-543).  For every seed: sample ``--msa-samples`` rows of
+    the pre-processed alignment (the wild type always first), run masked-marginals over the first row, add the column
+    ``<checkpoint>_seed<k>``; finally ``<checkpoint>_ensemble`` = mean over the seeds.  Like the reference, the CSV is
+    rewritten after every seed and seeds whose column already exists are skipped unless --overwrite-prior-scores."""
     from . import msa_transformer as pmsa
-    seeds = args.seeds if isinstance(args.seeds, (list, tuple)) else [args.seeds]
+    seeds = list(args.seeds) if isinstance(args.seeds, (list, tuple)) else [args.seeds]
     assert args.scoring_strategy in ["masked-marginals", "pseudo-ppl"], "Zero-shot scoring strategy not supported with MSA Transformer"
     if args.scoring_strategy == "pseudo-ppl":
         raise NotImplementedError("pseudo-ppl with the MSA Transformer is not built (the reference launcher uses masked-marginals)")
-    for model_location in args.model_location:
-        max_rows = (min(args.msa_samples, 1024) + 31) // 32 * 32 * ((min(len(args.sequence) + 1, 1024) + 31) // 32 * 32)
-        model, alphabet = pmsa.load_model_and_alphabet(model_location, device=args.device, max_rows=max_rows)
-        model_location = model_location.split("/")[-1].split(".")[0]
+    out_csv = args.dms_output
+    args.offset_idx = msa_start_index
+    mutants = [str(m) for m in df[mutant_col]]
+    cells = sorted({1 + int(one[1:-1]) - args.offset_idx for m in mutants for one in m.split(":")})   # +1: <cls>
+    pad32 = lambda n: (n + 31) // 32 * 32
+    for location in args.model_location:
+        max_rows = pad32(min(args.msa_samples, 1024)) * pad32(min(len(args.sequence) + 1, 1024))
+        model, alphabet = pmsa.load_model_and_alphabet(location, device=args.device, max_rows=max_rows)
+        stem = checkpoint_stem(location)
         print("Transferred model to GPU")
-        batch_converter = alphabet.get_batch_converter()
-        args.offset_idx = msa_start_index
-        processed_msa = pmsa.process_msa(filename=str(args.msa_path), weight_filename=MSA_weight_file_name,
-                                         filter_msa=args.filter_msa, device=args.device)
-        mutants = [str(m) for m in df[mutant_col]]
+        to_tokens = alphabet.get_batch_converter()
+        alignment = pmsa.process_msa(filename=str(args.msa_path), weight_filename=MSA_weight_file_name,
+                                     filter_msa=args.filter_msa, device=args.device)
         for seed in seeds:
-            if os.path.exists(args.dms_output):
-                prior_score_df = pd.read_csv(args.dms_output)
-                if f"{model_location}_seed{seed}" in prior_score_df.columns and not args.overwrite_prior_scores:
-                    print(f"Skipping seed {seed} as it is already in the dataframe")
-                    df = prior_score_df
-                    continue
-            data = [pmsa.sample_msa(sampling_strategy=args.msa_sampling_strategy, filename=str(args.msa_path), nseq=args.msa_samples,
-                                    weight_filename=MSA_weight_file_name, processed_msa=processed_msa, random_seed=seed,
-                                    device=args.device)]
-            _, _, batch_tokens = batch_converter(data)
-            print(f"Batch sizes: {batch_tokens.shape}")
-            T = batch_tokens.shape[2]
-            # the reference forwards every column; only the cells some mutant reads are needed (--all-positions restores it)
-            if args.all_positions:
-                positions = list(range(T))
-            else:
-                positions = sorted({1 + int(mu[1:-1]) - args.offset_idx for m in mutants for mu in m.split(":")})
-            rows = model.masked_logprobs(batch_tokens[0], positions, seq_len=len(args.sequence))
-            token_probs = np.full((T, 33), np.nan, dtype=np.float32)
-            token_probs[positions] = rows
-            df[f"{model_location}_seed{seed}"] = [label_row(m, args.sequence, token_probs, alphabet, args.offset_idx) for m in mutants]
-            if os.path.exists(args.dms_output) and not args.overwrite_prior_scores:
-                prior_score_df = pd.read_csv(args.dms_output)
-                assert f"{model_location}_seed{seed}" not in prior_score_df.columns, \
-                    f"Column {model_location}_seed{seed} already exists in {args.dms_output}"
-                prior_score_df = prior_score_df.merge(df[[f"{model_location}_seed{seed}", "mutant"]], on="mutant")
-                prior_score_df.to_csv(args.dms_output, index=False)
-                df = prior_score_df
-            else:
-                df.to_csv(args.dms_output, index=False)
+            column = f"{stem}_seed{seed}"
+            on_disk = pd.read_csv(out_csv) if os.path.exists(out_csv) else None
+            if on_disk is not None and column in on_disk.columns and not args.overwrite_prior_scores:
+                print(f"Skipping seed {seed} as it is already in the dataframe")
+                df = on_disk
+                continue
+            rows = pmsa.sample_msa(filename=str(args.msa_path), nseq=args.msa_samples, sampling_strategy=args.msa_sampling_strategy,
+                                   random_seed=seed, weight_filename=MSA_weight_file_name, processed_msa=alignment,
+                                   device=args.device)
+            tokens = to_tokens([rows])[2][0]                      # [R, L+1]
+            print(f"Batch sizes: {(1,) + tokens.shape}")
+            T = tokens.shape[1]
+            # the reference forwards every column; only cells some mutant reads are needed (--all-positions restores it)
+            positions = list(range(T)) if args.all_positions else cells
+            table = np.full((T, 33), np.nan, dtype=np.float32)
+            table[positions] = model.masked_logprobs(tokens, positions, seq_len=len(args.sequence))
+            df[column] = [label_row(m, args.sequence, table, alphabet, args.offset_idx) for m in mutants]
+            if on_disk is not None and not args.overwrite_prior_scores:
+                assert column not in on_disk.columns, f"Column {column} already exists in {out_csv}"
+                df = on_disk.merge(df[[column, "mutant"]], on="mutant")
+            df.to_csv(out_csv, index=False)
         model.close()
-    df[f"{model_location}_ensemble"] = 0.0
-    for seed in seeds:
-        df[f"{model_location}_ensemble"] += df[f"{model_location}_seed{seed}"]
-    df[f"{model_location}_ensemble"] /= len(seeds)
-    tmp = str(args.dms_output) + ".tmp"
-    df.to_csv(tmp, index=False)
-    os.replace(tmp, args.dms_output)
+    df[f"{stem}_ensemble"] = sum(df[f"{stem}_seed{seed}"] for seed in seeds) / len(seeds)
+    write_atomically(df, out_csv)
 
 
 if __name__ == "__main__":

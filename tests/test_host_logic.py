@@ -161,3 +161,29 @@ def test_tranception_cli_input_resolution(tmp_path):
     assert st.resolve_inputs(a) == ("X9", "MKV", "X9.csv", ("m/X9.a2m", None, 0, 3))
     with pytest.raises(NotImplementedError):
         st.main(p.parse_args(["--model_framework", "JAX"]))
+
+
+def test_esm_cli_assay_resolution(tmp_path):
+    """compute_fitness mirror, input resolution (compute_fitness.py:286-340): reference-file mode incl. the MSA
+    Transformer's cropping of the target sequence to the alignment span, and manual mode."""
+    import pandas as pd
+    from proteingym_amd import compute_fitness as cf
+    seq = "MKVLAAGIVGLTACDEFGHIK"
+    pd.DataFrame({"mutant": ["K2A", "V3L:L4M"], "DMS_score": [0.1, -0.2]}).to_csv(tmp_path / "A1.csv", index=False)
+    pd.DataFrame([{"DMS_id": "A1", "DMS_filename": "A1.csv", "target_seq": seq.lower(), "MSA_filename": "A1.a2m",
+                   "MSA_start": 3, "MSA_end": 12, "weight_file_name": "A1.npy"}]).to_csv(tmp_path / "map.csv", index=False)
+    p = cf.create_parser()
+    common = ["--model-location", "x.pt", "--dms_index", "0", "--dms_mapping", str(tmp_path / "map.csv"),
+              "--dms-input", str(tmp_path), "--dms-output", str(tmp_path / "out")]
+    a = p.parse_args(common + ["--model_type", "ESM1v"])
+    info = cf.resolve_assay(a)
+    assert a.sequence == seq and info["first_position"] == 1 and info["mutant_col"] == "mutant"
+    assert str(a.dms_output).endswith("out/A1.csv") and len(info["frame"]) == 2 and info["weight_file"] is None
+    a = p.parse_args(common + ["--model_type", "MSA_transformer", "--msa-path", "msas", "--msa-weights-folder", "w"])
+    info = cf.resolve_assay(a)
+    assert a.sequence == seq[2:12] and info["msa_start"] == 3 and info["first_position"] == 3
+    assert str(a.msa_path) == "msas/A1.a2m" and info["weight_file"] == "w/A1.npy"
+    a = p.parse_args(["--model-location", "x.pt", "--model_type", "MSA_transformer", "--dms-input", str(tmp_path / "A1.csv"),
+                      "--dms-output", str(tmp_path / "o2"), "--target_seq", seq, "--msa-path", "q.a2m"])
+    info = cf.resolve_assay(a)
+    assert a.sequence == seq and info["msa_start"] == 1 and (a.MSA_start, a.MSA_end) == (1, len(seq)) and info["dms_id"] == "A1"
