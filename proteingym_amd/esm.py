@@ -101,6 +101,16 @@ class BatchConverter:
 
 
 # ---- checkpoint -> flat weight blob ------------------------------------------------------------
+def strip_fairseq_prefixes(key: str) -> str:
+    """fair-esm v1 files keep fairseq's module path in the key: ``encoder.sentence_encoder.<name>`` for the body and
+    ``encoder.<name>`` for the LM head.  Drop everything up to the innermost of those prefixes (the renaming that
+    pretrained.py:91-96 applies before ``load_state_dict``)."""
+    for marker in ("sentence_encoder.", "encoder."):
+        if marker.rstrip(".") in key:
+            key = "".join(key.split(marker)[1:])
+    return key
+
+
 def _upgrade_state_dict(path: str):
     """esm/pretrained.py:67-99 (v1) and :162-181 (v2).  torch is used only to unpickle the .pt."""
     import torch
@@ -119,9 +129,7 @@ def _upgrade_state_dict(path: str):
         a = data["args"]
         if a.arch != "roberta_large":
             raise ValueError("Unknown architecture selected")           # only ESM-1b/1v v1 + ESM2
-        prs1 = lambda s: "".join(s.split("encoder.")[1:] if "encoder" in s else s)
-        prs2 = lambda s: "".join(s.split("sentence_encoder.")[1:] if "sentence_encoder" in s else s)
-        sd = {prs1(prs2(k)): v for k, v in data["model"].items()}
+        sd = {strip_fairseq_prefixes(k): v for k, v in data["model"].items()}
         sd["embed_tokens.weight"][32].zero_()      # in place, "For token drop" (pretrained.py:97)
         cfg = dict(arch=_lib.ARCH_ESM1B, layers=int(a.encoder_layers),
                    embed_dim=int(a.encoder_embed_dim), heads=int(a.encoder_attention_heads),

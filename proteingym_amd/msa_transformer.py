@@ -76,10 +76,9 @@ def _upgrade_state_dict(path: str):
     a = data["args"]
     if a.arch != "msa_transformer":
         raise ValueError("Unknown architecture selected")
-    prs1 = lambda s: "".join(s.split("encoder.")[1:] if "encoder" in s else s)
-    prs2 = lambda s: "".join(s.split("sentence_encoder.")[1:] if "sentence_encoder" in s else s)
-    prs3 = lambda s: s.replace("row", "column") if "row" in s else s.replace("column", "row")   # pretrained.py:114
-    sd = {prs1(prs2(prs3(k))): v for k, v in data["model"].items()}
+    def swap_axes_names(key):          # the released file names the two attention blocks the other way round (pretrained.py:114)
+        return key.replace("row", "column") if "row" in key else key.replace("column", "row")
+    sd = {pesm.strip_fairseq_prefixes(swap_axes_names(k)): v for k, v in data["model"].items()}
     sd = {k: v for k, v in sd.items() if not k.startswith("contact_head")}
     if "lm_head.weight" in sd:                                      # tied parameter, entry copied last wins
         sd["embed_tokens.weight"] = sd["lm_head.weight"]
