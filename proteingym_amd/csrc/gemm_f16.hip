@@ -338,11 +338,18 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 2) void gemm16_k
         const int nb = n0 + wn * 64;                       // first column of this wave's head
         if (nb >= N) return;
         const int which = nb / Dm, hcol = nb - which * Dm, hh = hcol >> 6;
+        // q|k rows leave through the same per-wave LDS transpose as the split-plane epilogue below (one head =
+        // 64 columns = one 128-byte segment per row); V^T is already written as 64-byte runs along the key axis.
+        constexpr int SPQ = 144;
+        unsigned char* patch_q = reinterpret_cast<unsigned char*>(lds) + wave * (2 * 32 * SPQ);
+        const bool staged_q = which < 2 && !(qo.dbg_flags & 128);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
             const int m = m0 + (wm * TM + i) * 32 + r;
-            if (m >= M) continue;
+            const bool row_ok = m < M;
+            if (!staged_q && !row_ok) continue;
             const int bb = m / qo.T, t = m - bb * qo.T;
+            if (row_ok)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d0 = 8 * g + 4 * kh;             // dims d0..d0+3 (x0) and d0+32.. (x1) of the head
@@ -376,10 +383,18 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 2) void gemm16_k
                         split_act(x0[e], a, b2); hi0[e] = a; lo0[e] = b2;
                         split_act(x1[e], a, b2); hi1[e] = a; lo1[e] = b2;
                     }
-                    *reinterpret_cast<h4*>(dst) = hi0;
-                    *reinterpret_cast<h4*>(dst + c_plane) = lo0;
-                    *reinterpret_cast<h4*>(dst + 32) = hi1;
-                    *reinterpret_cast<h4*>(dst + c_plane + 32) = lo1;
+                    if (staged_q) {
+                        unsigned char* cell = patch_q + r * SPQ + d0 * 2;
+                        *reinterpret_cast<h4*>(cell) = hi0;
+                        *reinterpret_cast<h4*>(cell + 32 * SPQ) = lo0;
+                        *reinterpret_cast<h4*>(cell + 64) = hi1;
+                        *reinterpret_cast<h4*>(cell + 32 * SPQ + 64) = lo1;
+                    } else {
+                        *reinterpret_cast<h4*>(dst) = hi0;
+                        *reinterpret_cast<h4*>(dst + c_plane) = lo0;
+                        *reinterpret_cast<h4*>(dst + 32) = hi1;
+                        *reinterpret_cast<h4*>(dst + c_plane + 32) = lo1;
+                    }
                 } else {
                     const int tk = t & 31;
                     const int pos = (t & ~31) + ((tk & 0x13) | ((tk & 4) << 1) | ((tk & 8) >> 1));   // swap key bits 2,3
@@ -397,6 +412,22 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 2) void gemm16_k
                         c1p[qo.vt_plane] = __builtin_bit_cast(unsigned short, l1);
                     }
                 }
+            }
+            if (staged_q) {
+                __builtin_amdgcn_wave_barrier();
+                const int m_base = m0 + (wm * TM + i) * 32;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int q = lane + 64 * k, row = q >> 3, cc = q & 7;
+                    const u32x4 vh = *reinterpret_cast<const u32x4*>(patch_q + row * SPQ + cc * 16);
+                    const u32x4 vl = *reinterpret_cast<const u32x4*>(patch_q + (32 + row) * SPQ + cc * 16);
+                    if (m_base + row < M) {
+                        unsigned short* dst = Ch + (size_t)(m_base + row) * (2 * Dm) + (size_t)which * Dm + hcol + cc * 8;
+                        *reinterpret_cast<u32x4*>(dst) = vh;
+                        *reinterpret_cast<u32x4*>(dst + c_plane) = vl;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
             }
         }
         return;
