@@ -43,6 +43,56 @@ def lpt_partition(costs: Sequence[float], n_ranks: int) -> List[List[int]]:
     return out
 
 
+def plan_position_chunks(seq_lens: Sequence[int], positions: Sequence[np.ndarray], n_ranks: int,
+                         chunk_forwards: int = 64, window: int = 1024, **model_dims):
+    """Work list of (assay index, positions array) items for sharding INSIDE assays ("chunk = up to B
+    positions of one assay at one T"): every assay's masked positions are cut into chunks of <= chunk_forwards
+    forwards, the chunks are LPT-balanced over the ranks by algorithmic FLOPs.  Needed when assays are few and
+    unequal (config 3: ten assays on eight GPUs); by-assay LPT is enough for the 217-assay benchmark.
+    Returns (items, assignment): items[k] = (assay, positions), assignment[r] = item indices of rank r."""
+    items, costs = [], []
+    for a, (L, pos) in enumerate(zip(seq_lens, positions)):
+        pos = np.asarray(pos, dtype=np.int32)
+        per = forward_flops(min(L + 2, window), **model_dims)
+        for c0 in range(0, len(pos), chunk_forwards):
+            chunk = pos[c0:c0 + chunk_forwards]
+            items.append((a, chunk))
+            costs.append(per * len(chunk))
+    return items, lpt_partition(costs, n_ranks)
+
+
+def merge_tables(parts: Sequence[np.ndarray]) -> np.ndarray:
+    """Rows of a log-prob table computed by different ranks (NaN = not computed here) -> one table."""
+    out = np.array(parts[0], dtype=np.float32, copy=True)
+    for p in parts[1:]:
+        fill = np.isnan(out[:, 0]) & ~np.isnan(p[:, 0])
+        out[fill] = p[fill]
+    return out
+
+
+def gather_tables(local: Dict[int, np.ndarray], n_toks: Sequence[int], vocab: int = 33, device=None) -> Dict[int, np.ndarray]:
+    """Every rank passes {assay -> partial table [n_tok, vocab] with NaN rows it did not compute} for ALL assays
+    (all-NaN where it had no chunk); one all_gather of the concatenated tables (sum(n_tok) * vocab floats per rank:
+    11 MB for the whole 217-assay benchmark), then a NaN-merge.  Every rank returns the complete tables."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    order = sorted(range(len(n_toks)))
+    if world == 1:
+        return {a: np.asarray(local[a], dtype=np.float32) for a in order}
+    flat = np.concatenate([np.asarray(local[a], dtype=np.float32).ravel() for a in order])
+    buf = torch.from_numpy(flat).to(device) if device else torch.from_numpy(flat)
+    out = torch.empty(world * flat.size, dtype=torch.float32, device=device)
+    dist.all_gather_into_tensor(out, buf)
+    host = out.cpu().numpy().reshape(world, flat.size)
+    res, o = {}, 0
+    for a in order:
+        n = int(n_toks[a]) * vocab
+        res[a] = merge_tables([host[r, o:o + n].reshape(int(n_toks[a]), vocab) for r in range(world)])
+        o += n
+    return res
+
+
 def gather_score_vectors(local: Dict[int, np.ndarray], sizes: Sequence[int], assignment: List[List[int]],
                          device=None) -> Dict[int, np.ndarray]:
     """All ranks call this with their {item index -> float64 scores}.  One fixed-stride

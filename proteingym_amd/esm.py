@@ -283,7 +283,8 @@ class Assay:
     mask, and the flattened substitutions of every mutant."""
 
     def __init__(self, model: EsmModel, sequence: str, mutants: Sequence[str], offset_idx: int = 1,
-                 alphabet: Optional[Alphabet] = None, window: int = 1024, all_positions: bool = False):
+                 alphabet: Optional[Alphabet] = None, window: int = 1024, all_positions: bool = False,
+                 positions: Optional[Sequence[int]] = None):
         lib = _lib.load()
         self.model = model
         alphabet = alphabet or Alphabet()
@@ -292,7 +293,11 @@ class Assay:
         self.n_tok = int(self.wt_tokens.size)
         sub_pos, sub_wt, sub_mt, mut_off = parse_mutants(mutants, sequence, offset_idx)
         self.n_mut = len(mutants)
-        if all_positions:
+        if positions is not None:                               # an explicit shard of the token positions (dist.py)
+            positions = np.unique(np.asarray(positions, dtype=np.int32))
+            if positions.size and (positions[0] < 0 or positions[-1] >= self.n_tok):
+                raise ValueError("positions outside the token range")
+        elif all_positions:
             positions = np.arange(self.n_tok, dtype=np.int32)   # what the reference runs (:489)
         else:
             positions = np.unique(sub_pos).astype(np.int32)     # rows some mutant reads
@@ -355,6 +360,29 @@ def parse_mutants(mutants: Sequence[str], sequence: str, offset_idx: int):
                                 _lib.ptr(sub_mt, _lib._i32p), _lib.ptr(mut_off, _lib._i64p), C.byref(n_sub))
     _raise_parse(rc)
     return sub_pos, sub_wt, sub_mt, mut_off
+
+
+def positions_read(mutants: Sequence[str], sequence: str, offset_idx: int = 1) -> np.ndarray:
+    """Token positions (1 + residue index: <cls> is token 0) whose table rows some mutant reads."""
+    sub_pos, _, _, _ = parse_mutants(mutants, sequence, offset_idx)
+    return np.unique(sub_pos).astype(np.int32)
+
+
+def score_from_table(table: np.ndarray, mutants: Sequence[str], sequence: str, offset_idx: int = 1) -> np.ndarray:
+    """``label_row`` (compute_fitness.py:240-250) for a whole column on the host from a log-prob table: per
+    substitution an f32 difference table[pos, mt] - table[pos, wt], accumulated in double in the order of the
+    mutation string -- the arithmetic of the reference's ``.item()`` sum and of ``score_mutants_kernel``, so the
+    result is bit-identical to ``Assay.run()``.  Used when the table was assembled from position shards."""
+    sub_pos, sub_wt, sub_mt, mut_off = parse_mutants(mutants, sequence, offset_idx)
+    t = np.asarray(table, dtype=np.float32)
+    diff = (t[sub_pos, sub_mt] - t[sub_pos, sub_wt]).astype(np.float64)
+    out = np.zeros(len(mutants), dtype=np.float64)
+    start = np.asarray(mut_off[:-1], dtype=np.int64)
+    depth = np.asarray(mut_off[1:], dtype=np.int64) - start
+    for j in range(int(depth.max()) if len(depth) else 0):  # j-th substitution of every mutant that has one:
+        sel = depth > j                                     # left-to-right accumulation, as the reference sums
+        out[sel] += diff[start[sel] + j]
+    return out
 
 
 def _raise_parse(rc):

@@ -38,6 +38,11 @@ def create_parser():
     p.add_argument("--all-positions", action="store_true")
     p.add_argument("--overwrite-prior-scores", action="store_true")
     p.add_argument("--backend", type=str, default=None, help="torch.distributed backend (default nccl)")
+    p.add_argument("--shard", type=str, default="assay", choices=["assay", "positions"],
+                   help="unit of work given to a GPU: whole assays (default; enough for the 217-assay benchmark) or "
+                        "chunks of masked positions inside assays (few, unequal assays: the log-prob tables are "
+                        "gathered instead of the score vectors)")
+    p.add_argument("--chunk-forwards", type=int, default=64, help="positions per work item with --shard positions")
     return p
 
 
@@ -62,6 +67,8 @@ def main(args):
             if all(c in have for c in cols + ens_cols):
                 continue
         todo.append(i)
+    if args.shard == "positions":
+        return main_position_shards(args, mapping, todo, cols, ens_cols, rank, local_rank, world)
     costs = [pdist.assay_cost(len(str(mapping.iloc[i]["target_seq"]))) for i in todo]
     assignment = pdist.lpt_partition(costs, world)
     mine = [todo[k] for k in assignment[rank]]
@@ -133,6 +140,82 @@ def main(args):
         import torch.distributed as tdist
         tdist.barrier()
         tdist.destroy_process_group()
+
+
+def main_position_shards(args, mapping, todo, cols, ens_cols, rank, local_rank, world, make_model=None):
+    """--shard positions: every assay's masked positions are cut into chunks, chunks are LPT-balanced over the ranks,
+    each rank fills the table rows of its chunks, ONE all_gather moves the partial tables (NaN = not mine), every
+    rank merges them and rank 0 scores the mutants from the complete tables (bit-identical to Assay.run()) and
+    writes the CSVs.  ``make_model`` is a test seam: (location) -> object with table_rows(seq, positions, offset)."""
+    t0 = time.time()
+    frames = []
+    for i in todo:
+        row = mapping.iloc[i].replace(np.nan, "")
+        mutant_col = row["DMS_mutant_column"] if "DMS_mutant_column" in mapping.columns else args.mutation_col
+        df = pd.read_csv(os.path.join(args.dms_input, row["DMS_filename"]))
+        seq = str(row["target_seq"]).upper()
+        offset = int(row["start_idx"]) if "start_idx" in mapping.columns and row["start_idx"] != "" else 1
+        muts = [str(m) for m in df[mutant_col]]
+        pos = np.arange(len(seq) + 2, dtype=np.int32) if args.all_positions else pesm.positions_read(muts, seq, offset)
+        frames.append(dict(df=df, seq=seq, offset=offset, mutants=muts, positions=pos, dms_id=str(row["DMS_id"])))
+    items, assignment = pdist.plan_position_chunks([len(f["seq"]) for f in frames], [f["positions"] for f in frames],
+                                                   world, chunk_forwards=args.chunk_forwards)
+    n_toks = [len(f["seq"]) + 2 for f in frames]
+    dev = None
+    if world > 1:
+        import torch.distributed as tdist
+        dev = "cuda" if tdist.get_backend() == "nccl" else "cpu"
+    for ci, loc in enumerate(args.model_location):
+        if make_model is not None:
+            model = make_model(loc)
+        else:
+            model = _DeviceTables(loc, local_rank, args.precision)
+        local = {a: np.full((n_toks[a], 33), np.nan, dtype=np.float32) for a in range(len(frames))}
+        for k in assignment[rank]:
+            a, chunk = items[k]
+            rows = model.table_rows(frames[a]["seq"], chunk, frames[a]["offset"])
+            local[a][chunk] = rows
+        tables = pdist.gather_tables(local, n_toks, device=dev)
+        if hasattr(model, "close"):
+            model.close()
+        if rank == 0:
+            for a, f in enumerate(frames):
+                f["df"][cols[ci]] = pesm.score_from_table(tables[a], f["mutants"], f["seq"], f["offset"])
+    if rank == 0:
+        n_mut = 0
+        for f in frames:
+            df = f["df"]
+            if ens_cols:
+                df["Ensemble_ESM1v"] = sum(df[c] for c in cols) / len(cols)
+            out = os.path.join(args.dms_output, f["dms_id"] + ".csv")
+            df.to_csv(out + ".tmp", index=False)
+            os.replace(out + ".tmp", out)
+            n_mut += len(df)
+        dt = time.time() - t0
+        print(f"scored {len(frames)} assays / {n_mut} mutants x {len(cols)} checkpoint(s) on {world} GPU(s), "
+              f"{len(items)} position chunks, in {dt:.1f}s = {n_mut / max(dt, 1e-9):.1f} mutants/s (ensemble rate)")
+    if world > 1:
+        import torch.distributed as tdist
+        tdist.barrier()
+        tdist.destroy_process_group()
+
+
+class _DeviceTables:
+    """table_rows() on the GPU: an Assay restricted to the chunk's positions (the alignment of work items to
+    masked positions is the device path's own: windows, chunking and the head run as in pgmi_assay_run)."""
+
+    def __init__(self, location, device, precision):
+        self.model, self.alphabet = pesm.load_model_and_alphabet(location, device=device, precision=precision)
+
+    def table_rows(self, seq, positions, offset):
+        first = seq[0] + str(offset) + ("A" if seq[0] != "A" else "C")          # any valid mutant: only the table is read
+        a = pesm.Assay(self.model, seq, [first], offset_idx=offset, alphabet=self.alphabet, positions=positions)
+        _, table = a.run(want_table=True)
+        a.close()
+        return table[np.asarray(positions)]
+
+    def close(self):
+        self.model.close()
 
 
 if __name__ == "__main__":

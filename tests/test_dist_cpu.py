@@ -97,3 +97,73 @@ def test_run_sharded_world2_covers_every_assay_once(tmp_path):
     assert max(cost) / sum(cost) < 0.6
     with pytest.raises(SystemExit):
         run_sharded.main(["tranception", "--", "--DMS_index", "3", "--DMS_reference_file_path", csv])
+
+
+class _FakeTables:
+    """Stands in for the device: row p of an assay's table is a deterministic function of (sequence, p)."""
+
+    def __init__(self, location):
+        self.salt = sum(map(ord, location))
+
+    def table_rows(self, seq, positions, offset):
+        return np.stack([self.row(seq, int(p)) for p in positions])
+
+    def row(self, seq, p):
+        rng = np.random.default_rng(self.salt * 100003 + len(seq) * 1009 + p)
+        x = rng.standard_normal(33).astype(np.float32)
+        return (x - np.log(np.exp(x).sum())).astype(np.float32)
+
+
+def _position_worker(rank, world, port, workdir, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    import pandas as pd
+    from proteingym_amd import run_benchmark as rb
+    args = rb.create_parser().parse_args([
+        "--model-location", "ckA.pt", "ckB.pt", "--model_type", "ESM1v", "--dms_mapping", os.path.join(workdir, "map.csv"),
+        "--dms-input", workdir, "--dms-output", os.path.join(workdir, "out"), "--backend", "gloo", "--shard", "positions",
+        "--chunk-forwards", "5"])
+    r, lr, w = pdist.init_from_env("gloo")
+    mapping = pd.read_csv(args.dms_mapping)
+    os.makedirs(args.dms_output, exist_ok=True)
+    cols, ens = rb.column_names(args.model_location, args.model_type)
+    rb.main_position_shards(args, mapping, list(range(len(mapping))), cols, ens, r, lr, w, make_model=_FakeTables)
+    q.put(rank)
+
+
+def test_position_shards_world2_match_unsharded_scores(tmp_path):
+    """--shard positions: two gloo ranks each fill the table rows of their position chunks; after the table
+    all_gather + NaN-merge rank 0's CSVs equal the scores computed from the complete tables (bit-identical,
+    incl. the ensemble mean and multi-mutants whose rows came from different ranks)."""
+    import pandas as pd
+    from proteingym_amd import esm as pesm, synthetic
+    rows = []
+    assays = {}
+    for k, L in enumerate((23, 61, 40)):
+        seq, muts, score = synthetic.random_assay(seed=k, L=L, n_single=30, n_multi=12)
+        pd.DataFrame({"mutant": muts, "DMS_score": score}).to_csv(tmp_path / f"A{k}.csv", index=False)
+        rows.append({"DMS_id": f"A{k}", "DMS_filename": f"A{k}.csv", "target_seq": seq})
+        assays[f"A{k}"] = (seq, muts)
+    pd.DataFrame(rows).to_csv(tmp_path / "map.csv", index=False)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_position_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    done = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert done == [0, 1]
+    for name, (seq, muts) in assays.items():
+        got = pd.read_csv(tmp_path / "out" / f"{name}.csv", float_precision="round_trip")
+        cols = {}
+        for ck in ("ckA", "ckB"):
+            fake = _FakeTables(ck + ".pt")
+            table = np.full((len(seq) + 2, 33), np.nan, dtype=np.float32)
+            for p in pesm.positions_read(muts, seq, 1):
+                table[p] = fake.row(seq, int(p))
+            cols[ck] = pesm.score_from_table(table, muts, seq, 1)
+            assert np.array_equal(got[ck].to_numpy(), cols[ck])
+        assert np.array_equal(got["Ensemble_ESM1v"].to_numpy(), (cols["ckA"] + cols["ckB"]) / 2)

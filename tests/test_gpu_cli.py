@@ -90,3 +90,25 @@ def test_cli_dms_index_mapping_and_runner(lib, golden, golden_dir, tmp_path):
         assert list(df.columns) == list(golden["cli/columns"])
         for c in ("esm1v_toy_1", "esm1v_toy_2", "Ensemble_ESM1v"):
             assert np.abs(df[c].to_numpy() - golden[f"cli/{c}"]).max() < TOL
+
+
+def test_runner_position_shards_equal_assay_shards(lib, golden, golden_dir, tmp_path):
+    """run_benchmark --shard positions (tables assembled from chunks of masked positions, scored on the host) writes
+    the same numbers as the default --shard assay (device scoring), bit for bit, incl. a 1100-residue protein whose
+    chunks use different 1024-token windows."""
+    from proteingym_amd import run_benchmark as rb
+    mapping = pd.DataFrame({"DMS_id": ["TOY_A", "TOY_LONG"], "DMS_filename": ["TOY_DMS.csv", "TOY_LONG_DMS.csv"],
+                            "target_seq": [str(golden["seq"]), str(golden["seq_long"])]})
+    mapping.to_csv(tmp_path / "map.csv", index=False)
+    common = ["--model-location", os.path.join(golden_dir, "esm1v_toy_1.pt"), os.path.join(golden_dir, "esm1v_toy_2.pt"),
+              "--model_type", "ESM1v", "--dms_mapping", str(tmp_path / "map.csv"), "--dms-input", golden_dir]
+    rb.main(rb.create_parser().parse_args(common + ["--dms-output", str(tmp_path / "a")]))
+    rb.main(rb.create_parser().parse_args(common + ["--dms-output", str(tmp_path / "p"), "--shard", "positions",
+                                                    "--chunk-forwards", "7"]))
+    for name in ("TOY_A", "TOY_LONG"):
+        a = pd.read_csv(tmp_path / "a" / f"{name}.csv", float_precision="round_trip")
+        p = pd.read_csv(tmp_path / "p" / f"{name}.csv", float_precision="round_trip")
+        assert list(a.columns) == list(p.columns)
+        for c in ("esm1v_toy_1", "esm1v_toy_2", "Ensemble_ESM1v"):
+            assert np.array_equal(a[c].to_numpy(), p[c].to_numpy())
+    assert np.abs(p["esm1v_toy_1"].to_numpy() - golden["cli_long/esm1v_toy_1"]).max() < TOL
