@@ -187,3 +187,18 @@ def test_esm_cli_assay_resolution(tmp_path):
                       "--dms-output", str(tmp_path / "o2"), "--target_seq", seq, "--msa-path", "q.a2m"])
     info = cf.resolve_assay(a)
     assert a.sequence == seq and info["msa_start"] == 1 and (a.MSA_start, a.MSA_end) == (1, len(seq)) and info["dms_id"] == "A1"
+
+
+def test_esm_cli_rejects_empty_assay_and_nogpu(tmp_path):
+    """Error behaviour of the CLI mirror before any device work: an assay without rows raises the reference's
+    ValueError (compute_fitness.py:343-344); --nogpu is refused loudly (there is no CPU path to fall back to)."""
+    import pandas as pd
+    from proteingym_amd import compute_fitness as cf
+    pd.DataFrame({"mutant": [], "DMS_score": []}).to_csv(tmp_path / "E.csv", index=False)
+    pd.DataFrame({"mutant": ["M1A"], "DMS_score": [0.0]}).to_csv(tmp_path / "F.csv", index=False)
+    p = cf.create_parser()
+    base = ["--model-location", "x.pt", "--model_type", "ESM1v", "--target_seq", "MKV", "--dms-output", str(tmp_path / "o")]
+    with pytest.raises(ValueError, match="No rows found"):
+        cf.main(p.parse_args(base + ["--dms-input", str(tmp_path / "E.csv")]))
+    with pytest.raises(RuntimeError, match="GPU-only"):
+        cf.main(p.parse_args(base + ["--dms-input", str(tmp_path / "F.csv"), "--nogpu"]))
