@@ -43,6 +43,10 @@ def create_parser():
                         "chunks of masked positions inside assays (few, unequal assays: the log-prob tables are "
                         "gathered instead of the score vectors)")
     p.add_argument("--chunk-forwards", type=int, default=64, help="positions per work item with --shard positions")
+    p.add_argument("--write", type=str, default="owner", choices=["owner", "rank0"],
+                   help="--shard assay with N > 1: 'owner' = every rank writes the CSVs of the assays it scored (parallel "
+                        "I/O; rank 0 still receives every score vector through the all_gather and writes "
+                        "scores_summary.csv), 'rank0' = rank 0 writes every CSV from the gathered vectors")
     return p
 
 
@@ -51,7 +55,43 @@ def column_names(model_locations, model_type):
     return cols, (["Ensemble_ESM1v"] if "ESM1v" in model_type else [])
 
 
-def main(args):
+class _DeviceScorer:
+    """One checkpoint on this rank's GPU: score(seq, mutants, offset) = Assay.run()."""
+
+    def __init__(self, location, device, precision, all_positions):
+        self.model, self.alphabet = pesm.load_model_and_alphabet(location, device=device, precision=precision)
+        self.all_positions = all_positions
+
+    def score(self, seq, mutants, offset):
+        assay = pesm.Assay(self.model, seq, mutants, offset_idx=int(offset), alphabet=self.alphabet,
+                           all_positions=self.all_positions)
+        out = assay.run()
+        assay.close()
+        return out
+
+    def close(self):
+        self.model.close()
+
+
+def _finish_frame(df, cols, ens_cols, vectors):
+    """Add the checkpoint columns (+ the plain-mean ensemble, compute_fitness.py:532-537) to an assay's frame."""
+    for c, name in enumerate(cols):
+        df[name] = vectors[c]
+    if ens_cols:
+        df["Ensemble_ESM1v"] = 0.0
+        for name in cols:
+            df["Ensemble_ESM1v"] += df[name]
+        df["Ensemble_ESM1v"] /= len(cols)
+    return df
+
+
+def _write_csv(df, path):
+    df.to_csv(path + ".tmp", index=False)
+    os.replace(path + ".tmp", path)
+
+
+def main(args, make_model=None):
+    """``make_model`` is a test seam: (location) -> object with score(seq, mutants, offset) and close()."""
     rank, local_rank, world = pdist.init_from_env(args.backend)
     mapping = pd.read_csv(args.dms_mapping)
     indices = list(range(len(mapping))) if args.dms_indices is None else list(args.dms_indices)
@@ -82,14 +122,16 @@ def main(args):
                      str(row["target_seq"]).upper(),
                      row["start_idx"] if "start_idx" in mapping.columns and row["start_idx"] != "" else 1)
     for ci, loc in enumerate(args.model_location):
-        model, alphabet = pesm.load_model_and_alphabet(loc, device=local_rank, precision=args.precision)
+        model = make_model(loc) if make_model is not None else _DeviceScorer(loc, local_rank, args.precision, args.all_positions)
         for i in mine:
             df, mutant_col, seq, offset = frames[i]
-            assay = pesm.Assay(model, seq, [str(m) for m in df[mutant_col]], offset_idx=int(offset),
-                               alphabet=alphabet, all_positions=args.all_positions)
-            local.setdefault(i, []).append(assay.run())
-            assay.close()
+            local.setdefault(i, []).append(np.asarray(model.score(seq, [str(m) for m in df[mutant_col]], offset), dtype=np.float64))
         model.close()
+    owner_writes = world > 1 and args.write == "owner"
+    if owner_writes:                               # parallel I/O: 2.47 M rows of CSV are not rank 0's serial tail
+        for i in mine:
+            df = _finish_frame(frames[i][0], cols, ens_cols, local[i])
+            _write_csv(df, os.path.join(args.dms_output, str(mapping.iloc[i]["DMS_id"]) + ".csv"))
     # exchange: per item a [n_checkpoints * n_mut] vector
     sizes = []
     n_rows = {}
@@ -118,21 +160,18 @@ def main(args):
 
     if rank == 0:
         n_mut = 0
+        summary = []
         for k, i in enumerate(todo):
             row = mapping.iloc[i].replace(np.nan, "")
-            df = frames[i][0] if i in frames else pd.read_csv(os.path.join(args.dms_input, row["DMS_filename"]))
             v = allv[k].reshape(len(cols), -1)
-            for c, name in enumerate(cols):
-                df[name] = v[c]
-            if ens_cols:                                   # compute_fitness.py:532-537
-                df["Ensemble_ESM1v"] = 0.0
-                for name in cols:
-                    df["Ensemble_ESM1v"] += df[name]
-                df["Ensemble_ESM1v"] /= len(cols)
-            out = os.path.join(args.dms_output, str(row["DMS_id"]) + ".csv")
-            df.to_csv(out + ".tmp", index=False)
-            os.replace(out + ".tmp", out)
-            n_mut += len(df)
+            if not owner_writes:
+                df = frames[i][0] if i in frames else pd.read_csv(os.path.join(args.dms_input, row["DMS_filename"]))
+                _write_csv(_finish_frame(df, cols, ens_cols, v), os.path.join(args.dms_output, str(row["DMS_id"]) + ".csv"))
+            n_mut += v.shape[1]
+            summary.append({"DMS_id": str(row["DMS_id"]), "mutants": v.shape[1],
+                            **{f"mean_{name}": float(np.mean(v[c])) if v.shape[1] else float("nan") for c, name in enumerate(cols)}})
+        if world > 1:                              # what the gathered vectors are for when the owners write the CSVs
+            _write_csv(pd.DataFrame(summary), os.path.join(args.dms_output, "scores_summary.csv"))
         dt = time.time() - t0
         print(f"scored {len(todo)} assays / {n_mut} mutants x {len(cols)} checkpoint(s) on {world} GPU(s) "
               f"in {dt:.1f}s = {n_mut / max(dt, 1e-9):.1f} mutants/s (ensemble rate)")

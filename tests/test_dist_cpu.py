@@ -167,3 +167,60 @@ def test_position_shards_world2_match_unsharded_scores(tmp_path):
             cols[ck] = pesm.score_from_table(table, muts, seq, 1)
             assert np.array_equal(got[ck].to_numpy(), cols[ck])
         assert np.array_equal(got["Ensemble_ESM1v"].to_numpy(), (cols["ckA"] + cols["ckB"]) / 2)
+
+
+class _FakeScorer:
+    def __init__(self, location):
+        self.salt = sum(map(ord, location))
+
+    def score(self, seq, mutants, offset):
+        return np.array([((self.salt * 31 + len(seq) * 7 + sum(map(ord, m))) % 1000) / 37.0 for m in mutants])
+
+    def close(self):
+        pass
+
+
+def _assay_worker(rank, world, port, workdir, write, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    from proteingym_amd import run_benchmark as rb
+    args = rb.create_parser().parse_args([
+        "--model-location", "ckA.pt", "ckB.pt", "--model_type", "ESM1v", "--dms_mapping", os.path.join(workdir, "map.csv"),
+        "--dms-input", workdir, "--dms-output", os.path.join(workdir, "out_" + write), "--backend", "gloo", "--write", write])
+    rb.main(args, make_model=_FakeScorer)
+    q.put(rank)
+
+
+@pytest.mark.parametrize("write", ["owner", "rank0"])
+def test_assay_shards_world2_owner_and_rank0_writers(tmp_path, write):
+    """--shard assay on two gloo ranks: LPT split, all_gather of the score vectors; with --write owner every rank writes
+    its own assays' CSVs (rank 0 adds scores_summary.csv from the gathered vectors), with --write rank0 rank 0 writes
+    all of them.  Either way every CSV holds both checkpoint columns and their plain mean."""
+    import pandas as pd
+    from proteingym_amd import synthetic
+    rows, assays = [], {}
+    for k, L in enumerate((30, 90, 55, 41, 120)):
+        seq, muts, score = synthetic.random_assay(seed=10 + k, L=L, n_single=20 + k, n_multi=5)
+        pd.DataFrame({"mutant": muts, "DMS_score": score}).to_csv(tmp_path / f"B{k}.csv", index=False)
+        rows.append({"DMS_id": f"B{k}", "DMS_filename": f"B{k}.csv", "target_seq": seq})
+        assays[f"B{k}"] = (seq, muts)
+    pd.DataFrame(rows).to_csv(tmp_path / "map.csv", index=False)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_assay_worker, args=(r, 2, port, str(tmp_path), write, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    assert sorted(q.get(timeout=180) for _ in procs) == [0, 1]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    out = tmp_path / ("out_" + write)
+    for name, (seq, muts) in assays.items():
+        got = pd.read_csv(out / f"{name}.csv", float_precision="round_trip")
+        a, b = _FakeScorer("ckA.pt").score(seq, muts, 1), _FakeScorer("ckB.pt").score(seq, muts, 1)
+        assert np.array_equal(got["ckA"].to_numpy(), a) and np.array_equal(got["ckB"].to_numpy(), b)
+        assert np.array_equal(got["Ensemble_ESM1v"].to_numpy(), (a + b) / 2)
+        assert list(got["mutant"]) == muts
+    summary = pd.read_csv(out / "scores_summary.csv")
+    assert sorted(summary["DMS_id"]) == sorted(assays) and int(summary["mutants"].sum()) == sum(len(m) for _, m in assays.values())
