@@ -283,18 +283,44 @@ def get_optimal_window(p, n, w):
     return [max(0, p - h), min(n, p + h)]
 
 
-def get_sequence_slices(df, target_seq, model_context_len, start_idx=1):
-    """scoring_utils.py:152-183, scoring_window == 'optimal', substitutions."""
+def get_sequence_slices(df, target_seq, model_context_len, start_idx=1, scoring_window="optimal", indel_mode=False):
+    """scoring_utils.py:152-203: 'optimal' (:158-182; indels: window = whole sequence, :161-164,175-176) and
+    'sliding' (:183-201: 1 + len // ctx consecutive windows, mutated then wild type per window)."""
     df = df.reset_index(drop=True).copy()
     n = len(df)
-    bary = df["mutant"].apply(lambda x: int(np.array([int(m[1:-1]) - start_idx for m in x.split(":")]).mean()))
-    win = bary.apply(lambda x: get_optimal_window(x, len(target_seq), model_context_len))
+    L = len(target_seq)
+    if scoring_window == "sliding":
+        parts = []
+        start = 0
+        for _ in range(1 + int(L / model_context_len)):
+            m = df.copy()
+            m["sliced_mutated_sequence"] = m["mutated_sequence"].map(lambda x: x[start:start + model_context_len])
+            m["window_start"] = [start] * n
+            m["window_end"] = m["mutated_sequence"].map(lambda x: min(len(x), start + model_context_len))
+            w = m.copy()
+            w["mutated_sequence"] = [target_seq] * n
+            w["sliced_mutated_sequence"] = w["mutated_sequence"].map(lambda x: x[start:start + model_context_len])
+            w["window_end"] = w["mutated_sequence"].map(lambda x: min(len(x), start + model_context_len))
+            parts += [m, w]
+            start += model_context_len
+        out = pd.concat(parts, axis=0)
+        if "mutant" in out:
+            del out["mutant"]
+        return out.drop_duplicates()
+    if indel_mode:
+        win = df["mutated_sequence"].apply(lambda x: (0, len(x)))
+    else:
+        bary = df["mutant"].apply(lambda x: int(np.array([int(m[1:-1]) - start_idx for m in x.split(":")]).mean()))
+        win = bary.apply(lambda x: get_optimal_window(x, L, model_context_len))
     df["sliced_mutated_sequence"] = [df["mutated_sequence"][i][win[i][0]:win[i][1]] for i in range(n)]
     df["window_start"] = win.map(lambda x: x[0])
     df["window_end"] = win.map(lambda x: x[1])
-    del df["mutant"]
+    if "mutant" in df:
+        del df["mutant"]
     wt = df.copy()
     wt["mutated_sequence"] = [target_seq] * n
+    if indel_mode:
+        wt["window_end"] = wt["mutated_sequence"].map(len)
     wt["sliced_mutated_sequence"] = [target_seq[wt["window_start"][i]:wt["window_end"][i]] for i in range(n)]
     return pd.concat([df, wt], axis=0).drop_duplicates()
 
@@ -333,28 +359,36 @@ def sequence_scores(cfg, W, sliced, window_start, window_end, reverse=False, ret
     return np.array(out)
 
 
-def score_mutants(cfg, W, df, target_seq, scoring_mirror=True, retrieval=None):
-    """model_pytorch.py:878-928 for substitutions with scoring_window 'optimal'.  Returns a DataFrame
-    with mutated_sequence, avg_score_L_to_R, (avg_score_R_to_L), avg_score -- WT row appended with 0
-    when present in the input."""
+def score_mutants(cfg, W, df, target_seq, scoring_mirror=True, retrieval=None, scoring_window="optimal", indel_mode=False):
+    """model_pytorch.py:878-928.  Returns a DataFrame with mutated_sequence, avg_score_L_to_R, (avg_score_R_to_L),
+    avg_score; the zero-score WT row is appended when the WT is among the inputs -- in indel mode with the sequence
+    in column 'mutant' (:915-924), as the reference does.  'sliding' windows: per-window scores are summed per
+    sequence before the length normalisation, one WT reference (scoring_utils.py:136-147)."""
     d = df.copy()
     if "mutated_sequence" not in d:
         d["mutated_sequence"] = d["mutant"].apply(lambda x: get_mutated_sequence(target_seq, x))
     if "mutant" not in d:
         d["mutant"] = d["mutated_sequence"]
     d = d[["mutated_sequence", "mutant"]]
-    sl = get_sequence_slices(d, target_seq, cfg["n_ctx"] - 2).reset_index(drop=True)
+    sl = get_sequence_slices(d, target_seq, cfg["n_ctx"] - 2, scoring_window=scoring_window,
+                             indel_mode=indel_mode).reset_index(drop=True)
 
     def direction(name, rev):
         s = sl.copy()
         seqs = s["sliced_mutated_sequence"].apply(lambda x: x[::-1]) if rev else s["sliced_mutated_sequence"]
         s["score"] = sequence_scores(cfg, W, list(seqs), list(s["window_start"]), list(s["window_end"]), reverse=rev,
                                      retrieval=retrieval)
+        if scoring_window == "sliding":
+            s = s[["mutated_sequence", "score"]].groupby("mutated_sequence").sum().reset_index()
         s["score"] = s["score"] / s["mutated_sequence"].map(len)
         mut = s[s.mutated_sequence != target_seq]
         wt = s[s.mutated_sequence == target_seq]
-        dl = pd.merge(mut, wt, how="left", on=["window_start"], suffixes=("", "_wt"))
-        dl[name] = dl["score"] - dl["score_wt"]
+        if scoring_window == "sliding":
+            dl = mut.copy()
+            dl[name] = dl["score"] - list(wt["score"])[0]
+        else:
+            dl = pd.merge(mut, wt, how="left", on=["window_start"], suffixes=("", "_wt"))
+            dl[name] = dl["score"] - dl["score_wt"]
         return dl[["mutated_sequence", name]]
     out = direction("avg_score_L_to_R", False)
     if scoring_mirror:
@@ -363,8 +397,9 @@ def score_mutants(cfg, W, df, target_seq, scoring_mirror=True, retrieval=None):
         out["avg_score"] = (out["avg_score_L_to_R"] + out["avg_score_R_to_L"]) / 2.0
     else:
         out["avg_score"] = out["avg_score_L_to_R"]
-    if target_seq in df["mutated_sequence"].values if "mutated_sequence" in df else False:
-        cols = ["mutated_sequence", "avg_score_L_to_R"] + (["avg_score_R_to_L"] if scoring_mirror else []) + ["avg_score"]
+    key = "mutant" if indel_mode else "mutated_sequence"
+    if target_seq in df[key].values if key in df else False:
+        cols = [key, "avg_score_L_to_R"] + (["avg_score_R_to_L"] if scoring_mirror else []) + ["avg_score"]
         out = pd.concat([out, pd.DataFrame([[target_seq] + [0] * (len(cols) - 1)], columns=cols)], ignore_index=True)
     return out
 

@@ -83,6 +83,29 @@ def test_retrieval_with_eve_weights_vs_reference(lib, gold, golden_dir):
     m.close()
 
 
+def test_indel_and_sliding_modes_vs_reference(lib, gold, golden_dir):
+    """--indel_mode (variable-length mutated sequences in one padded device batch; the reference's WT row under
+    'mutant') and scoring_window='sliding' (per-window log-likelihoods summed per sequence) against the reference."""
+    g = np.load(os.path.join(golden_dir, "golden_tranception_modes.npz"))
+    seq, seql = str(gold["seq"]), str(gold["seq_long"])
+    indel = pd.read_csv(os.path.join(golden_dir, "TOY_TRANCEPTION_INDEL_DMS.csv"))
+    m = ptr.from_pretrained(os.path.join(golden_dir, "Tranception_toy"))
+    r = m.score_mutants(DMS_data=indel, target_seq=seq, scoring_mirror=True, indel_mode=True)
+    assert sorted(r.columns) == sorted(g["indel/columns"])
+    wt = r[r["mutated_sequence"].isna()]
+    assert len(wt) == 1 and wt["mutant"].iloc[0] == seq and float(wt["avg_score"].iloc[0]) == 0.0
+    rr = pd.merge(indel[["mutated_sequence"]].iloc[1:], r, on="mutated_sequence", how="left")
+    for c in ("avg_score_L_to_R", "avg_score_R_to_L", "avg_score"):
+        assert np.abs(rr[c].to_numpy() - g[f"indel/{c}"]).max() < TOL
+    m.close()
+    ms = ptr.from_pretrained(os.path.join(golden_dir, "Tranception_toy"), scoring_window="sliding")
+    dl = pd.read_csv(os.path.join(golden_dir, "TOY_TRANCEPTION_LONG_DMS.csv"))
+    rs = pd.merge(dl[["mutated_sequence"]], ms.score_mutants(DMS_data=dl, target_seq=seql, scoring_mirror=True), on="mutated_sequence", how="left")
+    for c in ("avg_score_L_to_R", "avg_score_R_to_L", "avg_score"):
+        assert np.abs(rs[c].to_numpy() - g[f"sliding/{c}"]).max() < TOL
+    ms.close()
+
+
 def test_wt_row_and_determinism(model, gold, golden_dir):
     seq = str(gold["seq"])
     df = pd.read_csv(os.path.join(golden_dir, "TOY_TRANCEPTION_DMS.csv")).iloc[:5]

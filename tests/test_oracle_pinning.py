@@ -277,3 +277,24 @@ def test_msa_transformer_host_logic_matches_reference(golden_dir, tmp_path):
     assert _lib.load().pgmi_weight_count(C.byref(c)) == blob.size
     with pytest.raises(RuntimeError, match="unaligned"):
         conv([("a", "MKV"), ("b", "MK")])
+
+
+def test_tranception_oracle_indel_and_sliding_modes(golden_dir):
+    """Indel scoring (variable-length sequences, WT row appended under 'mutant') and the 'sliding' window on a
+    1100-residue protein: oracle vs the reference outputs frozen by make_golden_tranception_modes.py."""
+    from oracle import tranception_oracle as to
+    g = np.load(os.path.join(golden_dir, "golden_tranception_modes.npz"))
+    gt = np.load(os.path.join(golden_dir, "golden_tranception.npz"))
+    seq, seql = str(gt["seq"]), str(gt["seq_long"])
+    cfg, W = to.load_checkpoint(os.path.join(golden_dir, "Tranception_toy"))
+    indel = pd.read_csv(os.path.join(golden_dir, "TOY_TRANCEPTION_INDEL_DMS.csv"))
+    r = to.score_mutants(cfg, W, indel, seq, indel_mode=True)
+    assert sorted(r.columns) == sorted(g["indel/columns"])
+    wt = r[r["mutated_sequence"].isna()]
+    assert len(wt) == 1 and wt["mutant"].iloc[0] == seq and float(wt["avg_score"].iloc[0]) == 0.0
+    rr = pd.merge(indel[["mutated_sequence"]].iloc[1:], r, on="mutated_sequence", how="left")
+    dl = pd.read_csv(os.path.join(golden_dir, "TOY_TRANCEPTION_LONG_DMS.csv"))
+    rs = pd.merge(dl[["mutated_sequence"]], to.score_mutants(cfg, W, dl, seql, scoring_window="sliding"), on="mutated_sequence", how="left")
+    for c in ("avg_score_L_to_R", "avg_score_R_to_L", "avg_score"):
+        assert np.abs(rr[c].to_numpy() - g[f"indel/{c}"]).max() < TOL
+        assert np.abs(rs[c].to_numpy() - g[f"sliding/{c}"]).max() < TOL
