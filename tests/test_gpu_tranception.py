@@ -83,6 +83,22 @@ def test_retrieval_with_eve_weights_vs_reference(lib, gold, golden_dir):
     m.close()
 
 
+def test_retrieval_on_long_protein_windows_vs_reference(lib, gold, golden_dir):
+    """Retrieval on a 1100-residue protein whose alignment covers residues 301..900 only: every scoring window
+    overlaps the alignment differently, in both directions (fusion index arithmetic of model_pytorch.py:806-830)."""
+    g = np.load(os.path.join(golden_dir, "golden_tranception_long_retrieval.npz"))
+    seql = str(gold["seq_long"])
+    ms, me = [int(v) for v in g["msa_start_end"]]
+    m = ptr.from_pretrained(os.path.join(golden_dir, "Tranception_toy"),
+                            retrieval=dict(MSA_filename=os.path.join(golden_dir, "TOY_MSA_LONGSPAN.a2m"), MSA_start=ms, MSA_end=me,
+                                           full_protein_length=len(seql), retrieval_inference_weight=0.6))
+    dl = pd.read_csv(os.path.join(golden_dir, "TOY_TRANCEPTION_LONG_DMS.csv"))
+    r = pd.merge(dl[["mutated_sequence"]], m.score_mutants(DMS_data=dl, target_seq=seql, scoring_mirror=True), on="mutated_sequence", how="left")
+    for c in ("avg_score_L_to_R", "avg_score_R_to_L", "avg_score"):
+        assert np.abs(r[c].to_numpy() - g[f"scores/{c}"]).max() < TOL
+    m.close()
+
+
 def test_indel_and_sliding_modes_vs_reference(lib, gold, golden_dir):
     """--indel_mode (variable-length mutated sequences in one padded device batch; the reference's WT row under
     'mutant') and scoring_window='sliding' (per-window log-likelihoods summed per sequence) against the reference."""

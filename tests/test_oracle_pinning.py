@@ -298,3 +298,18 @@ def test_tranception_oracle_indel_and_sliding_modes(golden_dir):
     for c in ("avg_score_L_to_R", "avg_score_R_to_L", "avg_score"):
         assert np.abs(rr[c].to_numpy() - g[f"indel/{c}"]).max() < TOL
         assert np.abs(rs[c].to_numpy() - g[f"sliding/{c}"]).max() < TOL
+
+
+def test_tranception_oracle_retrieval_on_long_protein(golden_dir):
+    """Retrieval with windows that overlap the alignment span differently (1100 residues, alignment 301..900)."""
+    from oracle import tranception_oracle as to
+    g = np.load(os.path.join(golden_dir, "golden_tranception_long_retrieval.npz"))
+    seql = str(np.load(os.path.join(golden_dir, "golden_tranception.npz"))["seq_long"])
+    ms, me = [int(v) for v in g["msa_start_end"]]
+    cfg, W = to.load_checkpoint(os.path.join(golden_dir, "Tranception_toy"))
+    prior = to.get_msa_prior(os.path.join(golden_dir, "TOY_MSA_LONGSPAN.a2m"), ms, me, len(seql))
+    retr = dict(log_prior=torch.log(torch.tensor(prior).float()).numpy(), MSA_start=ms, MSA_end=me, weight=0.6)
+    dl = pd.read_csv(os.path.join(golden_dir, "TOY_TRANCEPTION_LONG_DMS.csv"))
+    r = pd.merge(dl[["mutated_sequence"]], to.score_mutants(cfg, W, dl, seql, retrieval=retr), on="mutated_sequence", how="left")
+    for c in ("avg_score_L_to_R", "avg_score_R_to_L", "avg_score"):
+        assert np.abs(r[c].to_numpy() - g[f"scores/{c}"]).max() < TOL
