@@ -434,67 +434,69 @@ class TranceptionModel:
         return out
 
     # -- scoring (scoring_utils.py:77-150) ----------------------------------------------------------------
-    def _scores(self, mutated_sequence_df, score_var_name, target_seq, reverse=False):
-        df = mutated_sequence_df
-        ll = self.sequence_loglik(df['sliced_mutated_sequence'], df['window_start'].to_numpy(), df['window_end'].to_numpy(),
-                                  reverse=reverse)
-        scores = pd.DataFrame({'mutated_sequence': list(df['mutated_sequence']),
-                               'sliced_mutated_sequence': list(df['sliced_mutated_sequence']),
-                               'window_start': list(df['window_start']), 'window_end': list(df['window_end']),
-                               'score': ll.astype(np.float32)})
-        if self.scoring_window == "sliding":
-            scores = scores[['mutated_sequence', 'score']].groupby('mutated_sequence').sum().reset_index()
-        scores['score'] = scores['score'] / scores['mutated_sequence'].map(lambda x: len(x))
-        if target_seq is not None:
-            scores_mutated_seq = scores[scores.mutated_sequence != target_seq]
-            scores_wt = scores[scores.mutated_sequence == target_seq]
-            if self.scoring_window == "optimal":
-                delta_scores = pd.merge(scores_mutated_seq, scores_wt, how='left', on=['window_start'], suffixes=('', '_wt'))
-                delta_scores[score_var_name] = delta_scores['score'] - delta_scores['score_wt']
-            else:
-                delta_scores = scores_mutated_seq.copy()
-                delta_scores[score_var_name] = delta_scores['score'] - list(scores_wt['score'])[0]
-            return delta_scores[['mutated_sequence', score_var_name]]
-        scores[score_var_name] = scores['score']
-        return scores[['mutated_sequence', score_var_name]]
+    def _scores(self, slices, column, target_seq, reverse=False):
+        """Per-sequence score of one reading direction (scoring_utils.py:129-150): window log-likelihoods from the
+        device, summed per sequence in 'sliding' mode, divided by the FULL sequence length, then (with a target)
+        the wild type's value for the same window start (optimal) / the single wild-type total (sliding) subtracted."""
+        loglik = self.sequence_loglik(slices['sliced_mutated_sequence'], slices['window_start'].to_numpy(),
+                                      slices['window_end'].to_numpy(), reverse=reverse)
+        per = pd.DataFrame({'mutated_sequence': list(slices['mutated_sequence']),
+                            'sliced_mutated_sequence': list(slices['sliced_mutated_sequence']),
+                            'window_start': list(slices['window_start']), 'window_end': list(slices['window_end']),
+                            'score': loglik.astype(np.float32)})
+        sliding = self.scoring_window == "sliding"
+        if sliding:
+            per = per[['mutated_sequence', 'score']].groupby('mutated_sequence').sum().reset_index()
+        per['score'] = per['score'] / per['mutated_sequence'].map(len)
+        if target_seq is None:
+            per[column] = per['score']
+            return per[['mutated_sequence', column]]
+        is_wt = per.mutated_sequence == target_seq
+        variants, wild = per[~is_wt], per[is_wt]
+        if sliding:
+            out = variants.copy()
+            out[column] = out['score'] - list(wild['score'])[0]
+        else:
+            out = pd.merge(variants, wild, how='left', on=['window_start'], suffixes=('', '_wt'))
+            out[column] = out['score'] - out['score_wt']
+        return out[['mutated_sequence', column]]
 
     def score_mutants(self, DMS_data, target_seq=None, scoring_mirror=True, batch_size_inference=10, num_workers=10,
                       indel_mode=False):
-        """model_pytorch.py:878-928 (batch_size_inference / num_workers are accepted and ignored: batching
-        is done on the device side)."""
-        df = DMS_data.copy()
-        if ('mutated_sequence' not in df) and (not indel_mode):
-            df['mutated_sequence'] = df['mutant'].apply(lambda x: get_mutated_sequence(target_seq, x))
-        assert ('mutated_sequence' in df), "DMS file to score does not have mutated_sequence column"
-        if 'mutant' not in df:
-            df['mutant'] = df['mutated_sequence']
-        df = df[['mutated_sequence', 'mutant']]
+        """Same contract as the reference method (model_pytorch.py:878-928): returns mutated_sequence,
+        avg_score_L_to_R, [avg_score_R_to_L,] avg_score; a zero row for the wild type when it is among the inputs
+        (under column 'mutant' in indel mode, as the reference writes it).  batch_size_inference / num_workers are
+        accepted and ignored: batching happens on the device side."""
+        frame = DMS_data.copy()
+        if 'mutated_sequence' not in frame and not indel_mode:
+            frame['mutated_sequence'] = [get_mutated_sequence(target_seq, m) for m in frame['mutant']]
+        assert ('mutated_sequence' in frame), "DMS file to score does not have mutated_sequence column"
+        if 'mutant' not in frame:
+            frame['mutant'] = frame['mutated_sequence']
+        frame = frame[['mutated_sequence', 'mutant']]
+        context = self.n_ctx - 2                                         # [CLS] and [SEP]
         if target_seq is not None:
-            slices = get_sequence_slices(df, target_seq=target_seq, model_context_len=self.n_ctx - 2, indel_mode=indel_mode,
+            slices = get_sequence_slices(frame, target_seq=target_seq, model_context_len=context, indel_mode=indel_mode,
                                          scoring_window=self.scoring_window)
-        else:
-            slices = get_sequence_slices(df, target_seq=list(df['mutated_sequence'])[0], model_context_len=self.n_ctx - 2,
+        else:                                                            # no reference: raw log-likelihoods, sliding windows
+            slices = get_sequence_slices(frame, target_seq=list(frame['mutated_sequence'])[0], model_context_len=context,
                                          indel_mode=indel_mode, scoring_window='sliding')
         print("Scoring sequences from left to right")
-        scores_L_to_R = self._scores(slices, 'avg_score_L_to_R', target_seq)
+        result = self._scores(slices, 'avg_score_L_to_R', target_seq)
         if scoring_mirror:
             print("Scoring sequences from right to left")
-            rl = slices.copy()
-            rl['sliced_mutated_sequence'] = rl['sliced_mutated_sequence'].apply(lambda x: x[::-1])
-            scores_R_to_L = self._scores(rl, 'avg_score_R_to_L', target_seq, reverse=True)
-            all_scores = pd.merge(scores_L_to_R, scores_R_to_L, on='mutated_sequence', how='left', suffixes=('', '_R_to_L'))
-            all_scores['avg_score'] = (all_scores['avg_score_L_to_R'] + all_scores['avg_score_R_to_L']) / 2.0
+            mirrored = slices.copy()
+            mirrored['sliced_mutated_sequence'] = [x[::-1] for x in mirrored['sliced_mutated_sequence']]
+            backward = self._scores(mirrored, 'avg_score_R_to_L', target_seq, reverse=True)
+            result = pd.merge(result, backward, on='mutated_sequence', how='left', suffixes=('', '_R_to_L'))
+            result['avg_score'] = (result['avg_score_L_to_R'] + result['avg_score_R_to_L']) / 2.0
         else:
-            all_scores = scores_L_to_R
-            all_scores['avg_score'] = all_scores['avg_score_L_to_R']
-        mutant_column = "mutant" if indel_mode else "mutated_sequence"
-        if target_seq in DMS_data[mutant_column].values:
-            if scoring_mirror:
-                wt_row = pd.DataFrame([[target_seq, 0, 0, 0]], columns=[mutant_column, 'avg_score_L_to_R', 'avg_score_R_to_L', 'avg_score'])
-            else:
-                wt_row = pd.DataFrame([[target_seq, 0, 0]], columns=[mutant_column, 'avg_score_L_to_R', 'avg_score'])
-            all_scores = pd.concat([all_scores, wt_row], ignore_index=True)
-        return all_scores
+            result['avg_score'] = result['avg_score_L_to_R']
+        key = "mutant" if indel_mode else "mutated_sequence"
+        if target_seq in DMS_data[key].values:                           # the scorer drops the wild type: add it back, score 0
+            names = [key, 'avg_score_L_to_R'] + (['avg_score_R_to_L'] if scoring_mirror else []) + ['avg_score']
+            result = pd.concat([result, pd.DataFrame([[target_seq] + [0] * (len(names) - 1)], columns=names)], ignore_index=True)
+        return result
 
 
 def from_pretrained(checkpoint_dir: str, device: int = 0, scoring_window: str = "optimal", retrieval: Optional[dict] = None,

@@ -313,3 +313,57 @@ def test_tranception_oracle_retrieval_on_long_protein(golden_dir):
     r = pd.merge(dl[["mutated_sequence"]], to.score_mutants(cfg, W, dl, seql, retrieval=retr), on="mutated_sequence", how="left")
     for c in ("avg_score_L_to_R", "avg_score_R_to_L", "avg_score"):
         assert np.abs(r[c].to_numpy() - g[f"scores/{c}"]).max() < TOL
+
+
+class _OracleBackedTranception:
+    """The product's host scoring logic (TranceptionModel.score_mutants / _scores: slicing, length normalisation,
+    WT delta per window, sliding aggregation, mirror averaging, WT row) with the ORACLE standing in for the device
+    call ``sequence_loglik`` -- checks the host half of the product on CPU against the reference goldens."""
+
+    def __new__(cls, cfg, W, scoring_window="optimal", retrieval=None):
+        from oracle import tranception_oracle as to
+        from proteingym_amd import tranception as ptr
+        obj = object.__new__(ptr.TranceptionModel)
+        obj._h = None
+        obj.n_ctx = cfg["n_ctx"]
+        obj.scoring_window = scoring_window
+        obj.retrieval = retrieval
+
+        def sequence_loglik(seqs, window_start=None, window_end=None, reverse=False):
+            return np.asarray(to.sequence_scores(cfg, W, list(seqs), list(window_start), list(window_end), reverse=reverse,
+                                                 retrieval=retrieval), dtype=np.float32)
+        obj.sequence_loglik = sequence_loglik
+        return obj
+
+
+def test_tranception_product_host_logic_on_cpu(golden_dir):
+    from oracle import tranception_oracle as to
+    g = np.load(os.path.join(golden_dir, "golden_tranception.npz"))
+    gm = np.load(os.path.join(golden_dir, "golden_tranception_modes.npz"))
+    gl = np.load(os.path.join(golden_dir, "golden_tranception_long_retrieval.npz"))
+    seq, seql = str(g["seq"]), str(g["seq_long"])
+    cfg, W = to.load_checkpoint(os.path.join(golden_dir, "Tranception_toy"))
+    tol = 2e-5                                                        # oracle fp32 vs reference fp32, scores O(0.1..1)
+
+    def check(model, df, target, gold, prefix, **kw):
+        r = model.score_mutants(DMS_data=df, target_seq=target, scoring_mirror=True, **kw)
+        r = pd.merge(df[["mutated_sequence"]] if "mutated_sequence" in df else
+                     pd.DataFrame({"mutated_sequence": [to.get_mutated_sequence(target, m) for m in df["mutant"]]}),
+                     r, on="mutated_sequence", how="left")
+        for c in ("avg_score_L_to_R", "avg_score_R_to_L", "avg_score"):
+            assert np.abs(r[c].to_numpy() - gold[f"{prefix}/{c}"]).max() < tol, (prefix, c)
+
+    dms = pd.read_csv(os.path.join(golden_dir, "TOY_TRANCEPTION_DMS.csv"))
+    dml = pd.read_csv(os.path.join(golden_dir, "TOY_TRANCEPTION_LONG_DMS.csv"))
+    check(_OracleBackedTranception(cfg, W), dms, seq, g, "scores")
+    check(_OracleBackedTranception(cfg, W), dml, seql, g, "scores_long")
+    check(_OracleBackedTranception(cfg, W, scoring_window="sliding"), dml, seql, gm, "sliding")
+    indel = pd.read_csv(os.path.join(golden_dir, "TOY_TRANCEPTION_INDEL_DMS.csv"))
+    r = _OracleBackedTranception(cfg, W).score_mutants(DMS_data=indel, target_seq=seq, scoring_mirror=True, indel_mode=True)
+    rr = pd.merge(indel[["mutated_sequence"]].iloc[1:], r, on="mutated_sequence", how="left")
+    assert np.abs(rr["avg_score"].to_numpy() - gm["indel/avg_score"]).max() < tol
+    assert sorted(r.columns) == sorted(gm["indel/columns"])
+    ms, me = [int(v) for v in gl["msa_start_end"]]
+    prior = to.get_msa_prior(os.path.join(golden_dir, "TOY_MSA_LONGSPAN.a2m"), ms, me, len(seql))
+    retr = dict(log_prior=torch.log(torch.tensor(prior).float()).numpy(), MSA_start=ms, MSA_end=me, weight=0.6)
+    check(_OracleBackedTranception(cfg, W, retrieval=retr), dml, seql, gl, "scores")
