@@ -367,3 +367,48 @@ def test_tranception_product_host_logic_on_cpu(golden_dir):
     prior = to.get_msa_prior(os.path.join(golden_dir, "TOY_MSA_LONGSPAN.a2m"), ms, me, len(seql))
     retr = dict(log_prior=torch.log(torch.tensor(prior).float()).numpy(), MSA_start=ms, MSA_end=me, weight=0.6)
     check(_OracleBackedTranception(cfg, W, retrieval=retr), dml, seql, gl, "scores")
+
+
+class _OracleBackedEsm:
+    """token_logprobs / masked_logprobs of the product's EsmModel served by the oracle: lets the CLI mirror's host
+    logic (window blending of wt-marginals, pseudo-ppl batching, label_row) run on CPU against the reference goldens."""
+
+    def __init__(self, path):
+        self.cfg, self.W = eo.load_checkpoint(path)
+
+    def token_logprobs(self, tokens):
+        with torch.no_grad():
+            return torch.log_softmax(eo.forward_logits(self.cfg, self.W, np.asarray(tokens)), -1).numpy()
+
+    def masked_logprobs(self, tokens, mask_pos):
+        t = np.array(tokens, copy=True)
+        t[np.arange(len(t)), np.asarray(mask_pos)] = eo.MASK
+        out = []
+        with torch.no_grad():
+            for b0 in range(0, len(t), 64):
+                lp = torch.log_softmax(eo.forward_logits(self.cfg, self.W, t[b0:b0 + 64]), -1).numpy()
+                out.append(lp[np.arange(len(lp)), np.asarray(mask_pos)[b0:b0 + 64]])
+        return np.concatenate(out)
+
+
+def test_esm_cli_host_logic_on_cpu(golden, golden_dir):
+    """wt-marginals (short and the overlapping-window blend of a 1100-residue protein) and pseudo-ppl through the
+    product's host functions with oracle-backed forwards, against the reference CLI's score columns."""
+    from proteingym_amd import compute_fitness as cf, esm as pesm
+    alphabet = pesm.Alphabet()
+    seq, seql = str(golden["seq"]), str(golden["seq_long"])
+    df = pd.read_csv(os.path.join(golden_dir, "TOY_DMS.csv"))
+    dfl = pd.read_csv(os.path.join(golden_dir, "TOY_LONG_DMS.csv"))
+    m = _OracleBackedEsm(os.path.join(golden_dir, "esm1b_toy_lnb.pt"))
+    table = cf.wt_marginals_table(m, alphabet, seq, "optimal")
+    got = np.array([cf.label_row(x, seq, table, alphabet, 1) for x in df["mutant"]])
+    assert np.abs(got - golden["cli_wt/esm1b_toy_lnb"]).max() < 2e-5
+    m = _OracleBackedEsm(os.path.join(golden_dir, "esm1v_toy_1.pt"))
+    table = cf.wt_marginals_table(m, alphabet, seql, "overlapping")
+    got = np.array([cf.label_row(x, seql, table, alphabet, 1) for x in dfl["mutant"]])
+    assert np.abs(got - golden["cli_wt_long/esm1v_toy_1"]).max() < 2e-5
+    m = _OracleBackedEsm(os.path.join(golden_dir, "esm2_toy.pt"))
+    muts = list(df["mutant"][:6])
+    seqs = [cf.get_mutated_sequence(x, seq, 1) for x in muts]
+    got = cf.compute_pppl_batch(seqs, m, alphabet)
+    assert np.abs(got - golden["cli_pppl/esm2_toy"]).max() < 5e-4          # sum of 68 terms
