@@ -412,3 +412,77 @@ def test_esm_cli_host_logic_on_cpu(golden, golden_dir):
     seqs = [cf.get_mutated_sequence(x, seq, 1) for x in muts]
     got = cf.compute_pppl_batch(seqs, m, alphabet)
     assert np.abs(got - golden["cli_pppl/esm2_toy"]).max() < 5e-4          # sum of 68 terms
+
+
+def test_msa_transformer_cli_host_logic_on_cpu(golden_dir, tmp_path, monkeypatch):
+    """The whole MSA Transformer branch of the CLI mirror (alignment pre-processing, per-seed sampling, masked cells,
+    label_row, per-seed columns, ensemble, CSV layout, skip-existing-seed resume) with the oracle standing in for the
+    device model, against the reference CLI's columns."""
+    from oracle import msa_transformer_oracle as mo
+    from proteingym_amd import compute_fitness as cf, msa_transformer as pmsa
+    g = np.load(os.path.join(golden_dir, "golden_msa_transformer.npz"))
+    calls = []
+
+    class Fake:
+        def __init__(self, path):
+            self.cfg, self.W = mo.load_checkpoint(path)
+
+        def masked_logprobs(self, tokens, positions, seq_len, window=1024):
+            calls.append(len(positions))
+            table = mo.masked_marginals_table(self.cfg, self.W, np.asarray(tokens, dtype=np.int64), seq_len, positions=list(positions))
+            return table[list(positions)]
+
+        def close(self):
+            pass
+
+    monkeypatch.setattr(pmsa, "load_model_and_alphabet", lambda loc, device=0, max_rows=0: (Fake(loc), pmsa.MsaAlphabet()))
+    out = tmp_path / "o"
+    argv = ["--model-location", os.path.join(golden_dir, "msa_toy.pt"), "--model_type", "MSA_transformer", "--dms_index", "0",
+            "--dms_mapping", os.path.join(golden_dir, "TOY_MSA_MAPPING.csv"), "--dms-input", golden_dir, "--dms-output", str(out),
+            "--scoring-strategy", "masked-marginals", "--scoring-window", "optimal", "--msa-path", golden_dir,
+            "--msa-weights-folder", golden_dir, "--msa-samples", "12", "--seeds", "1", "2"]
+    cf.main(cf.create_parser().parse_args(argv))
+    df = pd.read_csv(out / "TOY_MSA_DMS.csv")
+    assert list(df.columns) == list(g["cli/columns"])
+    for c in ("msa_toy_seed1", "msa_toy_seed2", "msa_toy_ensemble"):
+        assert np.abs(df[c].to_numpy() - g[f"cli/{c}"]).max() < 2e-5
+    n_calls = len(calls)
+    cf.main(cf.create_parser().parse_args(argv))                      # both seed columns exist: nothing is recomputed
+    assert len(calls) == n_calls
+    again = pd.read_csv(out / "TOY_MSA_DMS.csv")
+    assert np.allclose(again["msa_toy_ensemble"], df["msa_toy_ensemble"], rtol=0, atol=1e-12)
+
+
+def test_esm_cli_main_masked_marginals_on_cpu(golden, golden_dir, tmp_path, monkeypatch):
+    """compute_fitness.main() for the ESM-1v ensemble (two checkpoints): argument resolution, column naming from the
+    checkpoint stems, plain-mean ensemble and CSV layout, with the oracle standing in for the device (model + Assay)."""
+    from proteingym_amd import compute_fitness as cf, esm as pesm
+
+    class FakeModel(_OracleBackedEsm):
+        def close(self):
+            pass
+
+    class FakeAssay:
+        def __init__(self, model, sequence, mutants, offset_idx=1, alphabet=None, window=1024, all_positions=False, positions=None):
+            self.args = (model, sequence, list(mutants), offset_idx)
+
+        def run(self):
+            model, sequence, mutants, offset = self.args
+            pos = pesm.positions_read(mutants, sequence, offset)
+            table = eo.masked_marginals_table(model.cfg, model.W, sequence, positions=[int(p) for p in pos], batch=16)
+            return pesm.score_from_table(table, mutants, sequence, offset)
+
+        def close(self):
+            pass
+
+    monkeypatch.setattr(pesm, "load_model_and_alphabet", lambda loc, device=0, precision="f16x3", max_rows=0: (FakeModel(loc), pesm.Alphabet()))
+    monkeypatch.setattr(pesm, "Assay", FakeAssay)
+    out = tmp_path / "o"
+    cf.main(cf.create_parser().parse_args([
+        "--model-location", os.path.join(golden_dir, "esm1v_toy_1.pt"), os.path.join(golden_dir, "esm1v_toy_2.pt"),
+        "--model_type", "ESM1v", "--dms-input", os.path.join(golden_dir, "TOY_DMS.csv"), "--dms-output", str(out),
+        "--target_seq", str(golden["seq"]), "--scoring-strategy", "masked-marginals", "--scoring-window", "optimal"]))
+    df = pd.read_csv(out / "TOY_DMS.csv")
+    assert list(df.columns) == list(golden["cli/columns"])
+    for c in ("esm1v_toy_1", "esm1v_toy_2", "Ensemble_ESM1v"):
+        assert np.abs(df[c].to_numpy() - golden[f"cli/{c}"]).max() < 2e-5
