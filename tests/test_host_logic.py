@@ -202,3 +202,28 @@ def test_esm_cli_rejects_empty_assay_and_nogpu(tmp_path):
         cf.main(p.parse_args(base + ["--dms-input", str(tmp_path / "E.csv")]))
     with pytest.raises(RuntimeError, match="GPU-only"):
         cf.main(p.parse_args(base + ["--dms-input", str(tmp_path / "F.csv"), "--nogpu"]))
+
+
+def test_bench_cpu_baseline_leg_and_parity_field():
+    """bench.py's CPU leg (the oracle timed on the host cores, bounded) on a tiny configuration: the returned object
+    has the contract's fields, and the live parity check compares exactly the rows the baseline computed."""
+    import importlib.util
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("pgmi_bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    sys.modules["pgmi_bench"] = bench
+    spec.loader.exec_module(bench)
+    assert 1 <= bench.usable_cores() <= (os.cpu_count() or 1)
+    cfg = dict(synthetic.ESM1V_650M, layers=2, embed_dim=128, heads=2, ffn_dim=256)
+    blob = synthetic.random_weights(cfg, seed=3)
+    seq, muts, _ = synthetic.random_assay(seed=1, L=24, n_single=30, n_multi=0)
+    ocfg, W = eo.from_arrays(arrays=synthetic.blob_to_arrays(cfg, blob), **cfg)
+    table = eo.masked_marginals_table(ocfg, W, seq, positions=[4, 5, 6], batch=3)
+    fake_gpu = np.full((len(seq) + 2, 33), np.nan, dtype=np.float32)
+    fake_gpu[[4, 5, 6]] = table[[4, 5, 6]]
+    fake_gpu[5, 7] += 3e-5
+    base, parity = bench.cpu_baseline(cfg, blob, seq, len(muts), budget_s=2.0, gpu_table=fake_gpu)
+    assert base["kind"] == "port" and base["unit"] == "mutants/s" and base["value"] > 0 and base["cores"] >= 1
+    assert "2 of 2 layers" in base["sample"]
+    assert parity["rows_compared"] == 3 and abs(parity["max_abs_err_vs_oracle"] - 3e-5) < 5e-6 and parity["tolerance"] == 1e-4
