@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PGMI_ABI_VERSION 2
+#define PGMI_ABI_VERSION 3
 
 /* error codes */
 #define PGMI_OK 0
@@ -78,6 +78,7 @@ typedef struct pgmi_config {
 
 typedef struct pgmi_model pgmi_model;
 typedef struct pgmi_assay pgmi_assay;
+typedef struct pgmi_pppl pgmi_pppl;
 
 /* ---- library ---------------------------------------------------------------------------- */
 int pgmi_abi_version(void);
@@ -138,6 +139,34 @@ int pgmi_assay_create(pgmi_model* m, const int32_t* wt_tokens, int n_tok,
 int pgmi_assay_run(pgmi_model* m, pgmi_assay* a, double* scores_host, float* table_host,
                    double* scores_dev);
 void pgmi_assay_destroy(pgmi_assay* a);
+
+/* ---- pseudo-perplexity over variable-length sequences, library resident in HBM (BASELINE config 5) ----
+ * Replaces the `--scoring-strategy pseudo-ppl` driver (compute_fitness.py:515-529: one compute_pppl call per
+ * row of the `mutated_sequence` column) and compute_pppl itself (:258-279).
+ * pgmi_pppl_create uploads a whole library ONCE:
+ *   tokens   uint8 [seq_off[n_seq]]  every sequence as BatchConverter writes it: <cls> + residues + <eos>
+ *                                    (esm/data.py:286-295), concatenated; no <pad>
+ *   seq_off  int64 [n_seq+1]         seq_off[0] = 0
+ * pgmi_pppl_run scores the sequences [first, first+count) (a shard of the library: ranks take disjoint
+ * ranges).  For a sequence of L residues the reference loops i in range(1, L-1), masks TOKEN i and reads
+ * log p(sequence[i]) = log-prob of token i+1's identity at position i (its off-by-one; residues 0 and L-1
+ * are never scored, residue L-2's identity is scored at residue L-3's position, L <= 2 gives 0.0): all of it
+ * is reproduced.  The (sequence, i) rows are enumerated on the device from the resident tokens; sequences of
+ * DIFFERENT lengths share a batch: the run is ordered by length, a batch's T is its longest member, shorter
+ * members are <pad>-filled and masked per sequence (key mask, position count and token-dropout ratio over the
+ * non-pad tokens, exactly what the reference computes for a sequence alone).  No windowing, like the
+ * reference: ESM-1b/1v fail above max_positions tokens ("Sequence length ... above maximum sequence length").
+ *   scores_host double [count]  sum(log_probs): left-to-right double sum of the f32 terms (python's sum)
+ *   terms_host  float  [pgmi_pppl_rows(first,count)]  optional: the terms, sequence by sequence in library order
+ *   scores_dev  device double [count], optional
+ * pgmi_pppl_rows: number of masked forwards (rows) the range needs.  pgmi_pppl_stats: rows, batches, real and
+ * padded token counts of the last run (packing efficiency = tokens / padded_tokens). */
+int pgmi_pppl_create(pgmi_model* m, const uint8_t* tokens, const int64_t* seq_off, int64_t n_seq, pgmi_pppl** out);
+int pgmi_pppl_run(pgmi_model* m, pgmi_pppl* lib, int64_t first, int64_t count, double* scores_host,
+                  float* terms_host, double* scores_dev);
+int64_t pgmi_pppl_rows(const pgmi_pppl* lib, int64_t first, int64_t count);
+int pgmi_pppl_stats(const pgmi_pppl* lib, int64_t* rows, int64_t* batches, int64_t* tokens, int64_t* padded_tokens);
+void pgmi_pppl_destroy(pgmi_pppl* lib);
 
 /* ---- host-side mutant parsing (label_row's string handling, compute_fitness.py:240-250) -----
  * text: n_mut NUL-free mutant strings ("A25G:L30P") concatenated, str_off int64 [n_mut+1].

@@ -11,7 +11,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libpgmi.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 ARCH_ESM1B, ARCH_ESM2, ARCH_TRANCEPTION = 1, 2, 3
 PREC_FP32, PREC_BF16, PREC_F16X3 = 0, 1, 2
 PRECISIONS = {"fp32": PREC_FP32, "bf16": PREC_BF16, "f16x3": PREC_F16X3}
@@ -51,6 +51,11 @@ SIGNATURES = [
                                     _i32p, _i32p, _i32p, _i64p, C.c_int64, C.POINTER(C.c_void_p)]),
     ("pgmi_assay_run", C.c_int, [C.c_void_p, C.c_void_p, _f64p, _f32p, C.c_void_p]),
     ("pgmi_assay_destroy", None, [C.c_void_p]),
+    ("pgmi_pppl_create", C.c_int, [C.c_void_p, C.POINTER(C.c_uint8), _i64p, C.c_int64, C.POINTER(C.c_void_p)]),
+    ("pgmi_pppl_run", C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, _f64p, _f32p, C.c_void_p]),
+    ("pgmi_pppl_rows", C.c_int64, [C.c_void_p, C.c_int64, C.c_int64]),
+    ("pgmi_pppl_stats", C.c_int, [C.c_void_p, _i64p, _i64p, _i64p, _i64p]),
+    ("pgmi_pppl_destroy", None, [C.c_void_p]),
     ("pgmi_parse_mutants", C.c_int, [C.c_char_p, _i64p, C.c_int64, C.c_char_p, C.c_int, C.c_int,
                                      _i32p, _i32p, _i32p, _i64p, _i64p]),
     ("pgmi_optimal_window", None, [C.c_int, C.c_int, C.c_int, _i32p, _i32p]),

@@ -10,7 +10,8 @@ here, and ``proteingym/merge.py`` + ``performance_DMS_benchmarks.py`` consume th
 Reference: /root/reference/proteingym/baselines/esm/compute_fitness.py
   create_parser :100-238   main :282-543   label_row :240-250   compute_pppl :258-279
 Additive flags (not in the reference): --device, --precision, --all-positions.
-The MSA-Transformer branch (:358-425) is out of scope and raises.
+The MSA-Transformer branch (:358-425) is score_msa_transformer below (masked-marginals; its pseudo-ppl variant is
+not built and raises NotImplementedError -- listed in INTEGRATION.md).
 """
 from __future__ import annotations
 
@@ -93,28 +94,15 @@ def get_mutated_sequence(row, wt_sequence, offset_idx):
 
 
 def compute_pppl_batch(sequences, model, alphabet):
-    """compute_fitness.py:258-279 for many sequences: for i in range(1, len(seq)-1) mask *token* i
-    and read log p(sequence[i]) there (the reference's off-by-one and the two never-scored
-    trailing residues are reproduced; no windowing, so ESM-1b raises above 1024 tokens).
-    All (sequence, i) rows of equal length go through pgmi_masked_logprobs in large batches."""
-    out = np.zeros(len(sequences), dtype=np.float64)
-    by_len = {}
-    for n, s in enumerate(sequences):
-        by_len.setdefault(len(s), []).append(n)
-    conv = alphabet.get_batch_converter()
-    for L, idxs in by_len.items():
-        if L < 3:
-            continue
-        pos = np.arange(1, L - 1)
-        _, _, toks = conv([("protein1", sequences[n]) for n in idxs])
-        rows = np.repeat(toks, len(pos), axis=0)
-        mpos = np.tile(pos, len(idxs))
-        lp = model.masked_logprobs(rows, mpos).reshape(len(idxs), len(pos), -1)
-        for j, n in enumerate(idxs):
-            tgt = np.array([alphabet.get_idx(sequences[n][i]) for i in pos])
-            vals = lp[j, np.arange(len(pos)), tgt]
-            out[n] = sum(float(v) for v in vals)          # python float sum, like sum(log_probs)
-    return out
+    """compute_fitness.py:258-279 for a whole ``mutated_sequence`` column: for i in range(1, len(seq)-1) mask *token* i
+    and read log p(sequence[i]) there (the reference's off-by-one and never-scored end residues are reproduced; no
+    windowing, so ESM-1b raises above 1024 tokens).  The sequences are uploaded once (one byte per token) and every
+    (sequence, i) row is enumerated on the device; mixed lengths (indels) share batches.  Host memory: O(total residues)."""
+    library = pesm.SequenceLibrary(model, [str(s) for s in sequences], alphabet)
+    try:
+        return library.score()
+    finally:
+        library.close()
 
 
 def wt_marginals_table(model, alphabet, sequence, scoring_window):
@@ -180,7 +168,7 @@ def resolve_assay(args):
         sequence = str(row["target_seq"]).upper()
         args.dms_input = str(args.dms_input) + os.sep + row["DMS_filename"]
         info["mutant_col"] = _cell(row, "DMS_mutant_column", args.mutation_col)
-        first = _cell(row, "start_idx", 1)
+        first = int(_cell(row, "start_idx", 1))
         if wants_msa:
             name = _cell(row, "MSA_filename", "")
             if name == "":
@@ -233,8 +221,9 @@ def main(args):
     print("Starting model scoring")
     if "MSA_transformer" in args.model_type:
         return score_msa_transformer(args, df, mutant_col, info["msa_start"], info["weight_file"])
-    args.offset_idx = info["first_position"]
-    mutants = [str(m) for m in df[mutant_col]]
+    args.offset_idx = int(info["first_position"])
+    needs_mutants = not (args.scoring_strategy == "pseudo-ppl" and "mutated_sequence" in df)
+    mutants = [str(m) for m in df[mutant_col]] if needs_mutants else None
     columns = []
     for location in args.model_location:
         model, alphabet = pesm.load_model_and_alphabet(location, device=args.device, precision=args.precision)

@@ -52,6 +52,7 @@ struct ProfEvent {
 using namespace pgmi;
 
 struct pgmi_assay;
+struct pgmi_pppl;
 
 struct pgmi_model {
     pgmi_config cfg;
@@ -59,6 +60,7 @@ struct pgmi_model {
     hipStream_t stream = nullptr;
     std::vector<void*> allocs;          // everything to hipFree
     std::vector<pgmi_assay*> assays;    // live assays created on this model (orphaned on destroy)
+    std::vector<pgmi_pppl*> pppls;      // live pseudo-ppl libraries (same rule)
     // weights
     float *embed_tokens = nullptr, *embed_positions = nullptr;
     float *lnb_w = nullptr, *lnb_b = nullptr, *lna_w = nullptr, *lna_b = nullptr;
@@ -113,6 +115,17 @@ struct pgmi_assay {
     int64_t* mut_off = nullptr;
     float* table = nullptr;
     double* scores = nullptr;
+};
+
+// A library of variable-length sequences resident in HBM for pseudo-perplexity scoring (config 5).
+struct pgmi_pppl {
+    pgmi_model* m = nullptr;
+    int64_t N = 0;
+    std::vector<int64_t> off;           // host copy of seq_off [N+1]
+    std::vector<void*> allocs;
+    uint8_t* tok8 = nullptr;            // all tokens, one byte each
+    int64_t* off_dev = nullptr;
+    int64_t last_rows = 0, last_chunks = 0, last_tokens = 0, last_padded = 0;   // statistics of the last run
 };
 
 namespace {
@@ -885,6 +898,12 @@ void pgmi_model_destroy(pgmi_model* m) {
         a->m = nullptr;
     }
     m->assays.clear();
+    for (pgmi_pppl* q : m->pppls) {
+        for (void* p : q->allocs) hipFree(p);
+        q->allocs.clear();
+        q->m = nullptr;
+    }
+    m->pppls.clear();
     for (auto& e : m->events) { hipEventDestroy(e.start); hipEventDestroy(e.stop); }
     for (void* p : m->allocs) hipFree(p);
     if (m->stream) hipStreamDestroy(m->stream);
@@ -1099,6 +1118,137 @@ int pgmi_assay_run(pgmi_model* m, pgmi_assay* a, double* scores_host, float* tab
     if (table_host) PGMI_HIP(hipMemcpyAsync(table_host, a->table, (size_t)a->n_tok * V * 4, hipMemcpyDeviceToHost, s));
     PGMI_HIP(hipStreamSynchronize(s));
     return check_nonfinite(m);
+}
+
+// ---- pseudo-perplexity over a resident library of variable-length sequences (BASELINE config 5) --------
+int pgmi_pppl_create(pgmi_model* m, const uint8_t* tokens, const int64_t* seq_off, int64_t n_seq, pgmi_pppl** out) {
+    if (!out) { set_error("null out"); return PGMI_EINVAL; }
+    *out = nullptr;
+    if (!m || !tokens || !seq_off || n_seq <= 0 || n_seq > 0x7fffffff) { set_error("bad argument"); return PGMI_EINVAL; }
+    if (m->cfg.arch != PGMI_ARCH_ESM1B && m->cfg.arch != PGMI_ARCH_ESM2) { set_error("pseudo-ppl needs an ESM-1b/1v/ESM2 model"); return PGMI_EINVAL; }
+    if (seq_off[0] != 0) { set_error("seq_off[0] must be 0"); return PGMI_EINVAL; }
+    for (int64_t n = 0; n < n_seq; ++n) {
+        const int64_t len = seq_off[n + 1] - seq_off[n];
+        // BatchConverter output: <cls> + residues + <eos> (esm/data.py:286-295); an empty sequence still has 2 tokens
+        if (len < 2 || len > (1 << 24)) { set_error("sequence %lld has %lld tokens", (long long)n, (long long)len); return PGMI_EINVAL; }
+        const uint8_t* t = tokens + seq_off[n];
+        for (int64_t i = 0; i < len; ++i)
+            if (t[i] >= PGMI_VOCAB || t[i] == PGMI_TOK_PAD) { set_error("token id %d invalid at sequence %lld, position %lld", (int)t[i], (long long)n, (long long)i); return PGMI_EINVAL; }
+    }
+    PGMI_HIP(hipSetDevice(m->device));
+    pgmi_pppl* q = new pgmi_pppl();
+    q->m = m;
+    q->N = n_seq;
+    q->off.assign(seq_off, seq_off + n_seq + 1);
+    int rc = dev_upload(q->allocs, &q->tok8, tokens, (size_t)seq_off[n_seq]);
+    if (!rc) rc = dev_upload(q->allocs, &q->off_dev, seq_off, (size_t)n_seq + 1);
+    if (rc) { for (void* p : q->allocs) hipFree(p); delete q; return rc; }
+    m->pppls.push_back(q);
+    *out = q;
+    return PGMI_OK;
+}
+
+void pgmi_pppl_destroy(pgmi_pppl* q) {
+    if (!q) return;
+    if (q->m) {
+        hipSetDevice(q->m->device);
+        hipStreamSynchronize(q->m->stream);
+        auto& v = q->m->pppls;
+        v.erase(std::remove(v.begin(), v.end(), q), v.end());
+    }
+    for (void* p : q->allocs) hipFree(p);
+    delete q;
+}
+
+int64_t pgmi_pppl_rows(const pgmi_pppl* q, int64_t first, int64_t count) {
+    if (!q || first < 0 || count < 0 || first + count > q->N) return -1;
+    int64_t r = 0;
+    for (int64_t n = first; n < first + count; ++n) r += std::max<int64_t>(0, q->off[n + 1] - q->off[n] - 4);
+    return r;
+}
+
+int pgmi_pppl_run(pgmi_model* m, pgmi_pppl* q, int64_t first, int64_t count, double* scores_host, float* terms_host,
+                  double* scores_dev) {
+    if (!m || !q || q->m != m) { set_error("bad model/library handle (library belongs to another or a destroyed model)"); return PGMI_EINVAL; }
+    if (first < 0 || count <= 0 || first + count > q->N) { set_error("sequence range [%lld, %lld) outside the library of %lld", (long long)first, (long long)(first + count), (long long)q->N); return PGMI_EINVAL; }
+    PGMI_HIP(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    const int J = (int)count, V = m->cfg.vocab;
+    // sequences of the run in descending token length (stable): every chunk's T is its first row's length, and the
+    // rows that share a chunk differ by the few residues an indel library's lengths differ by
+    std::vector<int32_t> sid(J);
+    for (int j = 0; j < J; ++j) sid[j] = (int32_t)(first + j);
+    auto len_of = [&](int32_t n) { return q->off[n + 1] - q->off[n]; };
+    std::stable_sort(sid.begin(), sid.end(), [&](int32_t a, int32_t b) { return len_of(a) > len_of(b); });
+    std::vector<int64_t> rp((size_t)J + 1);
+    rp[0] = 0;
+    for (int j = 0; j < J; ++j) rp[j + 1] = rp[j] + std::max<int64_t>(0, len_of(sid[j]) - 4);   // i in range(1, L-1): L-2 rows
+    const int64_t R = rp[J];
+    const int64_t Tmax = len_of(sid[0]);
+    if (R > 0 && Tmax + 31 > m->max_rows) { set_error("T=%lld exceeds workspace rows %d", (long long)Tmax, m->max_rows); return PGMI_EINVAL; }
+    if (R > 0 && m->cfg.arch == PGMI_ARCH_ESM1B && Tmax > m->cfg.max_positions) {
+        set_error("Sequence length %lld above maximum sequence length of %d", (long long)Tmax, m->cfg.max_positions);   // modules.py:256-260 (no windowing in compute_pppl)
+        return PGMI_EINVAL;
+    }
+    std::vector<void*> pool;
+    auto cleanup = [&]() { for (void* p : pool) hipFree(p); };
+    int32_t* d_sid = nullptr;
+    int64_t* d_rp = nullptr;
+    float* d_terms = nullptr;
+    double* d_out = nullptr;
+    int rc = dev_upload(pool, &d_sid, sid.data(), (size_t)J);
+    if (!rc) rc = dev_upload(pool, &d_rp, rp.data(), (size_t)J + 1);
+    if (!rc) rc = dev_alloc(pool, &d_terms, (size_t)R);
+    if (!rc) rc = dev_alloc(pool, &d_out, (size_t)J);
+    if (rc) { cleanup(); return rc; }
+    q->last_rows = R; q->last_chunks = 0; q->last_tokens = 0; q->last_padded = 0;
+    int j0 = 0;
+    for (int64_t g0 = 0; g0 < R;) {
+        while (rp[j0 + 1] <= g0) ++j0;                       // sequence holding row g0: the longest one left
+        const int T = (int)len_of(sid[j0]);
+        const int per = std::max(1, m->max_rows / ((T + 31) / 32 * 32));
+        const int bc = (int)std::min<int64_t>(per, R - g0);
+        launch_make_pppl_rows(q->tok8, q->off_dev, d_sid, d_rp, J, g0, bc, T, m->tokens, m->row_idx, m->aux_i, s);
+        rc = run_encoder(m, bc, T);
+        if (!rc) rc = run_head(m, bc, m->row_idx);
+        if (rc) { hipStreamSynchronize(s); cleanup(); return rc; }
+        launch_pppl_pick(m->lp, m->aux_i, bc, V, d_terms + g0, s);
+        q->last_chunks += 1;
+        q->last_padded += (int64_t)bc * T;
+        g0 += bc;
+    }
+    for (int j = 0; j < J; ++j) q->last_tokens += (rp[j + 1] - rp[j]) * len_of(sid[j]);
+    {
+        ProfScope p(m, PGMI_K_SCORE, 0, (double)R * 4);
+        launch_pppl_sum(d_terms, d_rp, d_sid, J, first, d_out, s);
+    }
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && scores_dev) e = hipMemcpyAsync(scores_dev, d_out, (size_t)J * 8, hipMemcpyDeviceToDevice, s);
+    if (e == hipSuccess && scores_host) e = hipMemcpyAsync(scores_host, d_out, (size_t)J * 8, hipMemcpyDeviceToHost, s);
+    std::vector<float> sorted_terms;
+    if (e == hipSuccess && terms_host && R > 0) {
+        sorted_terms.resize((size_t)R);
+        e = hipMemcpyAsync(sorted_terms.data(), d_terms, (size_t)R * 4, hipMemcpyDeviceToHost, s);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    cleanup();
+    if (e != hipSuccess) { set_error("pseudo-ppl run failed: %s", hipGetErrorString(e)); return PGMI_EHIP; }
+    if (terms_host && R > 0) {                               // caller order: sequence first, first+1, ... each with its rows in order
+        std::vector<int64_t> dst((size_t)J + 1, 0);
+        for (int k = 0; k < J; ++k) dst[k + 1] = dst[k] + std::max<int64_t>(0, len_of((int32_t)(first + k)) - 4);
+        for (int j = 0; j < J; ++j)
+            std::copy(sorted_terms.begin() + rp[j], sorted_terms.begin() + rp[j + 1], terms_host + dst[sid[j] - first]);
+    }
+    return check_nonfinite(m);
+}
+
+int pgmi_pppl_stats(const pgmi_pppl* q, int64_t* rows, int64_t* chunks, int64_t* tokens, int64_t* padded_tokens) {
+    if (!q) { set_error("null library"); return PGMI_EINVAL; }
+    if (rows) *rows = q->last_rows;
+    if (chunks) *chunks = q->last_chunks;
+    if (tokens) *tokens = q->last_tokens;
+    if (padded_tokens) *padded_tokens = q->last_padded;
+    return PGMI_OK;
 }
 
 int pgmi_parse_mutants(const char* text, const int64_t* str_off, int64_t n_mut, const char* sequence,

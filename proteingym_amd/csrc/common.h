@@ -78,6 +78,11 @@ void launch_score_mutants(const float* table, int V, const int32_t* sub_pos, con
                           double* scores, hipStream_t s);
 void launch_rotary(float* qkv, const float* cos_t, const float* sin_t, int rows, int T, int H,
                    hipStream_t s);
+// pseudo-perplexity (compute_fitness.py:258-279): rows enumerated on the device from a resident sequence library
+void launch_make_pppl_rows(const uint8_t* tok8, const int64_t* seq_off, const int32_t* sid, const int64_t* rp, int J,
+                           int64_t g0, int bc, int T, int32_t* tokens, int32_t* row_idx, int32_t* target, hipStream_t s);
+void launch_pppl_pick(const float* lp, const int32_t* target, int bc, int V, float* terms, hipStream_t s);
+void launch_pppl_sum(const float* terms, const int64_t* rp, const int32_t* sid, int J, int64_t first, double* out, hipStream_t s);
 
 // ---- gemm_f32.hip ------------------------------------------------------------------------
 // C[M,N] = epi(A[M,K] W[N,K]^T + bias[N]) (+ residual[M,N]); K % 32 == 0.

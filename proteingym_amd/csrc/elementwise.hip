@@ -394,4 +394,68 @@ void launch_score_mutants(const float* table, int V, const int32_t* sub_pos, con
                        sub_pos, sub_wt, sub_mt, mut_off, n_mut, scores);
 }
 
+
+// ---- pseudo-perplexity rows (compute_fitness.py:258-279), enumerated on the device ----------------------
+// A library of variable-length sequences is resident as one byte string tok8 (cls + residues + eos per
+// sequence, seq_off[n] .. seq_off[n+1]).  sid[j] lists the sequences of a run in descending token length,
+// rp[j] is the number of (sequence, masked position) rows before sid[j] in that order: sequence n with `len`
+// tokens (L = len-2 residues) contributes the rows i = 1 .. L-2 (the reference loops i in range(1, len(seq)-1)
+// and masks TOKEN i).  Row g of the run = (sid[j], i = 1 + g - rp[j]) with rp[j] <= g < rp[j+1]: one wave per row
+// finds j by bisection, then writes the T tokens of the row (<pad> beyond the sequence, <mask> at i), the
+// flat index of the masked token and the target token: the reference scores alphabet.get_idx(sequence[i]) =
+// token i+1 at masked token i (its off-by-one, reproduced).
+__global__ __launch_bounds__(256) void make_pppl_rows_kernel(const uint8_t* __restrict__ tok8, const int64_t* __restrict__ seq_off,
+                                                             const int32_t* __restrict__ sid, const int64_t* __restrict__ rp, int J,
+                                                             int64_t g0, int bc, int T, int32_t* __restrict__ tokens,
+                                                             int32_t* __restrict__ row_idx, int32_t* __restrict__ target) {
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (b >= bc) return;
+    const int64_t g = g0 + b;
+    int lo = 0, hi = J;                                   // largest j with rp[j] <= g (rp[J] = total rows > g)
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (rp[mid] <= g) lo = mid; else hi = mid;
+    }
+    const int n = sid[lo];
+    const int i = 1 + (int)(g - rp[lo]);
+    const int64_t o = seq_off[n];
+    const int len = (int)(seq_off[n + 1] - o);
+    int32_t* out = tokens + (int64_t)b * T;
+    for (int t = lane; t < T; t += 64) out[t] = (t == i) ? PGMI_TOK_MASK : (t < len ? (int32_t)tok8[o + t] : PGMI_TOK_PAD);
+    if (lane == 0) {
+        row_idx[b] = b * T + i;
+        target[b] = (int32_t)tok8[o + i + 1];
+    }
+}
+void launch_make_pppl_rows(const uint8_t* tok8, const int64_t* seq_off, const int32_t* sid, const int64_t* rp, int J,
+                           int64_t g0, int bc, int T, int32_t* tokens, int32_t* row_idx, int32_t* target, hipStream_t s) {
+    hipLaunchKernelGGL(make_pppl_rows_kernel, dim3((bc + 3) / 4), dim3(256), 0, s, tok8, seq_off, sid, rp, J, g0, bc, T,
+                       tokens, row_idx, target);
+}
+
+// terms[g0 + b] = lp[b, target[b]]   (token_probs[0, i, alphabet.get_idx(sequence[i])], compute_fitness.py:275)
+__global__ void pppl_pick_kernel(const float* __restrict__ lp, const int32_t* __restrict__ target, int bc, int V,
+                                 float* __restrict__ terms) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < bc) terms[b] = lp[(size_t)b * V + target[b]];
+}
+void launch_pppl_pick(const float* lp, const int32_t* target, int bc, int V, float* terms, hipStream_t s) {
+    hipLaunchKernelGGL(pppl_pick_kernel, dim3((bc + 255) / 256), dim3(256), 0, s, lp, target, bc, V, terms);
+}
+
+// out[sid[j] - first] = sum(log_probs): python's left-to-right sum of the f32 terms' double values (:279)
+__global__ void pppl_sum_kernel(const float* __restrict__ terms, const int64_t* __restrict__ rp, const int32_t* __restrict__ sid,
+                                int J, int64_t first, double* __restrict__ out) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= J) return;
+    double acc = 0.0;
+    for (int64_t g = rp[j]; g < rp[j + 1]; ++g) acc += (double)terms[g];
+    out[sid[j] - first] = acc;
+}
+void launch_pppl_sum(const float* terms, const int64_t* rp, const int32_t* sid, int J, int64_t first, double* out, hipStream_t s) {
+    if (J <= 0) return;
+    hipLaunchKernelGGL(pppl_sum_kernel, dim3((J + 127) / 128), dim3(128), 0, s, terms, rp, sid, J, first, out);
+}
+
 }  // namespace pgmi

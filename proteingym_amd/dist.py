@@ -30,14 +30,16 @@ def assay_cost(seq_len: int, n_positions: int = None, window: int = 1024, **mode
 
 
 def lpt_partition(costs: Sequence[float], n_ranks: int) -> List[List[int]]:
-    """Longest-processing-time-first: deterministic, every rank computes the same assignment."""
+    """Longest-processing-time-first: deterministic, every rank computes the same assignment.
+    (heap of (load, rank): ties go to the lower rank; O(n log n) -- the indel pool has ~3e5 items)"""
+    import heapq
     order = sorted(range(len(costs)), key=lambda i: (-costs[i], i))
-    loads = [0.0] * n_ranks
+    heap = [(0.0, r) for r in range(n_ranks)]
     out: List[List[int]] = [[] for _ in range(n_ranks)]
     for i in order:
-        r = min(range(n_ranks), key=lambda k: (loads[k], k))
+        load, r = heapq.heappop(heap)
         out[r].append(i)
-        loads[r] += costs[i]
+        heapq.heappush(heap, (load + costs[i], r))
     for r in out:
         r.sort()
     return out

@@ -339,6 +339,92 @@ class Assay:
             pass
 
 
+def pack_sequences(sequences: Sequence[str], alphabet: Optional[Alphabet] = None):
+    """BatchConverter (esm/data.py:262-297) for a whole column without padding: every sequence as <cls> + one token
+    per residue letter (unknown letters -> <unk>) + <eos>, concatenated, one byte per token.
+    Returns (tokens uint8 [sum(len)+2N], seq_off int64 [N+1])."""
+    alphabet = alphabet or Alphabet()
+    n = len(sequences)
+    lut = np.full(256, alphabet.unk_idx, dtype=np.uint8)              # Alphabet.get_idx per residue letter
+    for tok, i in alphabet.tok_to_idx.items():
+        if len(tok) == 1:
+            lut[ord(tok)] = i
+    lens = np.fromiter((len(s) for s in sequences), dtype=np.int64, count=n)
+    seq_off = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens + 2, out=seq_off[1:])
+    toks = np.empty(int(seq_off[-1]), dtype=np.uint8)
+    body = np.ones(toks.size, dtype=bool)
+    body[seq_off[:-1]] = False
+    body[seq_off[1:] - 1] = False
+    toks[seq_off[:-1]] = alphabet.cls_idx
+    toks[seq_off[1:] - 1] = alphabet.eos_idx
+    toks[body] = lut[np.frombuffer("".join(sequences).encode("latin-1", "replace"), dtype=np.uint8)]
+    return toks, seq_off
+
+
+class SequenceLibrary:
+    """A library of variable-length sequences resident on the device for pseudo-perplexity scoring
+    (pgmi_pppl_*; compute_fitness.py:258-279,515-529).  Tokens are uploaded once, one byte each; every
+    (sequence, masked position) row is built on the device, mixed lengths share a batch."""
+
+    MAX_ROWS_PER_CALL = 1 << 24          # bounds the per-call device term buffer (64 MB) and the time of one C call
+
+    def __init__(self, model: "EsmModel", sequences: Sequence[str], alphabet: Optional[Alphabet] = None):
+        lib = _lib.load()
+        alphabet = alphabet or Alphabet()
+        self.model = model
+        self.n = len(sequences)
+        toks, self.seq_off = pack_sequences(sequences, alphabet)
+        lens = np.diff(self.seq_off) - 2
+        self.rows = np.maximum(lens - 2, 0)                            # masked forwards per sequence: range(1, L-1)
+        h = C.c_void_p()
+        _lib.check(lib.pgmi_pppl_create(model._h, toks.ctypes.data_as(C.POINTER(C.c_uint8)), _lib.ptr(self.seq_off, _lib._i64p),
+                                        self.n, C.byref(h)))
+        self._h = h
+
+    def score(self, first: int = 0, count: Optional[int] = None, want_terms: bool = False, scores_dev_ptr: int = 0):
+        """Scores of sequences [first, first+count) (float64), optionally with the per-position terms
+        (list of float32 arrays).  Long ranges are cut into calls of at most MAX_ROWS_PER_CALL rows."""
+        lib = _lib.load()
+        count = self.n - first if count is None else count
+        out = np.empty(count, dtype=np.float64)
+        terms = [] if want_terms else None
+        a = first
+        csum = np.concatenate([[0], np.cumsum(self.rows[first:first + count])])
+        while a < first + count:
+            b = int(np.searchsorted(csum, csum[a - first] + self.MAX_ROWS_PER_CALL, side="right")) - 1 + first
+            b = min(max(b, a + 1), first + count)
+            nrow = int(csum[b - first] - csum[a - first])
+            tbuf = np.empty(max(nrow, 1), dtype=np.float32) if want_terms else None
+            dev = C.c_void_p(scores_dev_ptr + 8 * (a - first)) if scores_dev_ptr else None
+            _lib.check(lib.pgmi_pppl_run(self.model._h, self._h, a, b - a, _lib.ptr(out[a - first:b - first], _lib._f64p),
+                                         _lib.ptr(tbuf, _lib._f32p) if want_terms else None, dev))
+            if want_terms:
+                o = 0
+                for n in range(a, b):
+                    terms.append(tbuf[o:o + int(self.rows[n])].copy())
+                    o += int(self.rows[n])
+            a = b
+        return (out, terms) if want_terms else out
+
+    def stats(self) -> dict:
+        v = [C.c_int64() for _ in range(4)]
+        _lib.check(_lib.load().pgmi_pppl_stats(self._h, *[C.byref(x) for x in v]))
+        r, c, t, p = (x.value for x in v)
+        return dict(rows=r, batches=c, tokens=t, padded_tokens=p, packing_efficiency=(t / p if p else 1.0))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.load().pgmi_pppl_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def parse_mutants(mutants: Sequence[str], sequence: str, offset_idx: int):
     """label_row's string handling (compute_fitness.py:240-250) for a whole column at once, in
     C++ (pgmi_parse_mutants).  Raises AssertionError on a wild-type mismatch like the reference."""
