@@ -159,6 +159,32 @@ def dms_shapes():
                      n_multi=int(r["DMS_number_multiple_mutants"])) for i, r in enumerate(csv.DictReader(f))]
 
 
+def indel_shapes():
+    """seq_len and mutant count of the 66 indel assays (reference_files/DMS_indels.csv; 287 207 mutants)."""
+    import csv
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "dms_indels_shapes.csv")
+    with open(path) as f:
+        return [dict(DMS_index=i, DMS_id=r["DMS_id"], seq_len=int(r["seq_len"]), n_total=int(r["DMS_total_number_mutants"]))
+                for i, r in enumerate(csv.DictReader(f))]
+
+
+def random_indel_library(seed: int, L: int, n: int, max_edit: int = 3):
+    """(wild type, n mutated sequences): each member deletes or inserts 1..max_edit residues at a random site, like the
+    single-event indel libraries of DMS_indels.csv; lengths spread over L-max_edit .. L+max_edit."""
+    rng = np.random.default_rng(seed)
+    wt = random_sequence(rng, L)
+    out = []
+    for _ in range(n):
+        k = int(rng.integers(1, max_edit + 1))
+        if rng.random() < 0.5 and L - k > 4:
+            p = int(rng.integers(0, L - k + 1))
+            out.append(wt[:p] + wt[p + k:])
+        else:
+            p = int(rng.integers(0, L + 1))
+            out.append(wt[:p] + random_sequence(rng, k) + wt[p:])
+    return wt, out
+
+
 # ---- Tranception ------------------------------------------------------------------------------------
 TRANCEPTION_L = dict(arch=_lib.ARCH_TRANCEPTION, layers=36, embed_dim=1280, heads=20, ffn_dim=5120, vocab=25,
                      max_positions=1024, ln_eps=1e-5)     # paper "Large"; real dims come from the checkpoint's config.json

@@ -224,3 +224,69 @@ def test_assay_shards_world2_owner_and_rank0_writers(tmp_path, write):
         assert list(got["mutant"]) == muts
     summary = pd.read_csv(out / "scores_summary.csv")
     assert sorted(summary["DMS_id"]) == sorted(assays) and int(summary["mutants"].sum()) == sum(len(m) for _, m in assays.values())
+
+
+# ---- config 5: pseudo-ppl over pooled indel libraries, mutants sharded over the ranks -------------------
+class _FakePppl:
+    """Stands in for the device library: a deterministic score per (checkpoint, sequence)."""
+
+    def __init__(self, location):
+        self.salt = sum(map(ord, location))
+
+    def score(self, sequences):
+        return np.array([-((self.salt * 17 + sum(map(ord, s)) * 13 + len(s)) % 100003) / 97.0 for s in sequences])
+
+    def close(self):
+        pass
+
+
+def _indel_worker(rank, world, port, workdir, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    from proteingym_amd import run_indels as ri
+    args = ri.create_parser().parse_args([
+        "--model-location", "esm2_a.pt", "esm2_b.pt", "--model_type", "ESM2", "--dms_mapping", os.path.join(workdir, "map.csv"),
+        "--dms-input", workdir, "--dms-output", os.path.join(workdir, "out"), "--backend", "gloo"])
+    ri.main(args, make_model=_FakePppl)
+    q.put(rank)
+
+
+def test_run_indels_world2_pools_mutants_across_assays(tmp_path):
+    """Two gloo ranks: the mutated sequences of three indel assays (one of them holding most of the work, like
+    CAPSD_AAV2S) form ONE pool that is cost-balanced over the ranks; after the fixed-stride all_gather rank 0 writes
+    every assay's CSV with every sequence's score in its own row."""
+    import pandas as pd
+    from proteingym_amd import run_indels as ri, synthetic
+    rng = np.random.default_rng(3)
+    rows, truth = [], {}
+    for k, (L, n) in enumerate(((60, 25), (735, 400), (220, 40))):
+        wt = synthetic.random_sequence(rng, L)
+        seqs = []
+        for _ in range(n):
+            p, d = int(rng.integers(1, L - 4)), int(rng.integers(-3, 4))
+            seqs.append(wt[:p] + (synthetic.random_sequence(rng, d) if d > 0 else "") + wt[p - min(d, 0):])
+        pd.DataFrame({"mutant": seqs, "mutated_sequence": seqs, "DMS_score": rng.standard_normal(n)}).to_csv(tmp_path / f"I{k}.csv", index=False)
+        rows.append({"DMS_id": f"I{k}", "DMS_filename": f"I{k}.csv", "target_seq": wt})
+        truth[f"I{k}"] = seqs
+    pd.DataFrame(rows).to_csv(tmp_path / "map.csv", index=False)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_indel_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    assert sorted(q.get(timeout=180) for _ in procs) == [0, 1]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for name, seqs in truth.items():
+        got = pd.read_csv(tmp_path / "out" / f"{name}.csv", float_precision="round_trip")
+        assert list(got.columns) == ["mutant", "mutated_sequence", "DMS_score", "esm2_a", "esm2_b"]     # ESM2: no ensemble column
+        for ck in ("esm2_a", "esm2_b"):
+            assert np.array_equal(got[ck].to_numpy(), _FakePppl(ck + ".pt").score(seqs))
+    # the planner: identical on every rank, every sequence exactly once, FLOP-balanced although one assay dominates
+    lengths = [len(s) for seqs in truth.values() for s in seqs]
+    for world in (2, 8):
+        a, loads = ri.partition_pool(lengths, world)
+        assert sorted(k for part in a for k in part) == list(range(len(lengths)))
+        assert loads.max() / loads.mean() < 1.02

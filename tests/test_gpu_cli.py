@@ -63,7 +63,7 @@ def test_cli_pseudo_ppl(lib, golden, golden_dir, tmp_path):
               "--target_seq", str(golden["seq"]), "--scoring-strategy", "pseudo-ppl"])
     df = pd.read_csv(out / "TOY_PPPL.csv")
     assert "mutated_sequence" in df.columns
-    assert np.abs(df["esm2_toy"].to_numpy() - golden["cli_pppl/esm2_toy"]).max() < 5e-4   # sum of 68 terms
+    assert np.abs(df["esm2_toy"].to_numpy() - golden["cli_pppl/esm2_toy"]).max() < 1e-4 * np.sqrt(68)   # sums of 68 terms, each term held to 1e-4 (tests/test_gpu_pppl.py)
 
 
 def test_cli_dms_index_mapping_and_runner(lib, golden, golden_dir, tmp_path):

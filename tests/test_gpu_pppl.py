@@ -1,0 +1,95 @@
+"""BASELINE config 5 on the GPU: pseudo-perplexity of variable-length (indel) sequences through the device-resident
+library (pgmi_pppl_*), against goldens the unmodified reference produced (tests/golden/make_golden_pppl_indels.py).
+
+Bars: every per-position TERM within 1e-4 of the reference model's term (the north-star's per-score tolerance applied
+to what a pseudo-ppl score is made of); the SUM of a sequence's terms is reported and held to 1e-4 x sqrt(#terms)
+(independent rounding of the terms), which for these ~70-term sums is still < 1e-3 abs on values of ~ -200."""
+import os
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from proteingym_amd import esm as pesm
+
+pytestmark = pytest.mark.gpu
+TERM_TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def gp(golden_dir):
+    return np.load(os.path.join(golden_dir, "golden_pppl_indels.npz")), pd.read_csv(os.path.join(golden_dir, "TOY_INDELS.csv"))
+
+
+def _check(name, precision, gp, golden_dir, max_rows=0):
+    g, df = gp
+    seqs = list(df["mutated_sequence"])
+    model, alphabet = pesm.load_model_and_alphabet(os.path.join(golden_dir, name + ".pt"), precision=precision, max_rows=max_rows)
+    lib = pesm.SequenceLibrary(model, seqs, alphabet)
+    scores, terms = lib.score(want_terms=True)
+    st = lib.stats()
+    worst_term, worst_sum = 0.0, 0.0
+    for r, s in enumerate(seqs):
+        ref = g[f"terms/{name}/{r}"]
+        assert len(terms[r]) == len(ref) == max(0, len(s) - 2)
+        if len(ref):
+            worst_term = max(worst_term, float(np.abs(terms[r].astype(np.float64) - ref).max()))
+        assert scores[r] == sum(float(v) for v in terms[r])              # python's left-to-right double sum of the f32 terms
+        err = abs(scores[r] - g[f"cli/{name}"][r])
+        worst_sum = max(worst_sum, err)
+        assert err < TERM_TOL * max(1.0, np.sqrt(len(ref)))
+    print(f"[{name} {precision} max_rows={max_rows}] per-term max|err| {worst_term:.2e}; per-sequence sum max|err| {worst_sum:.2e} "
+          f"(up to {max(len(t) for t in terms)} terms); batches {st['batches']}, packing {st['packing_efficiency']:.3f}")
+    assert worst_term < TERM_TOL
+    assert scores[list(df["mutant"]).index("len2")] == 0.0
+    assert st["rows"] == sum(max(0, len(s) - 2) for s in seqs)
+    # any sub-range of the library (a rank's shard) gives the same numbers for its members: batches differ, bits may
+    # differ in the last place through the GEMM tile a row lands in -- held to the per-term bar's order
+    part = lib.score(first=3, count=5)
+    assert np.abs(part - scores[3:8]).max() < 2e-4
+    lib.close()
+    model.close()
+    return scores
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
+@pytest.mark.parametrize("name", ["esm2_toy", "esm1v_toy_1"])
+def test_pppl_indels_vs_reference(lib, gp, golden_dir, name, precision):
+    _check(name, precision, gp, golden_dir)
+
+
+def test_pppl_mixed_lengths_share_batches(lib, gp, golden_dir):
+    """A small workspace forces many batches that each hold sequences of several lengths (77 ... 35 residues in one
+    run): same goldens, so padding + per-sequence masks are exact for every member."""
+    a = _check("esm2_toy", "f16x3", gp, golden_dir, max_rows=2048)
+    b = _check("esm2_toy", "f16x3", gp, golden_dir, max_rows=0)
+    assert np.abs(a - b).max() < 2e-4
+
+
+def test_pppl_esm1b_rejects_sequences_above_max_positions(lib, golden_dir):
+    """No windowing in compute_pppl: the reference's learned-position table fails above max_positions tokens."""
+    model, alphabet = pesm.load_model_and_alphabet(os.path.join(golden_dir, "esm1v_toy_1.pt"))
+    libr = pesm.SequenceLibrary(model, ["A" * 1100, "ACD" * 10], alphabet)
+    with pytest.raises(pesm.PgmiError, match="above maximum sequence length"):
+        libr.score()
+    assert libr.score(first=1, count=1).shape == (1,)                     # the short member alone is fine
+    libr.close()
+    model.close()
+
+
+def test_cli_pseudo_ppl_on_indel_file(lib, gp, golden_dir, tmp_path):
+    """The drop-in CLI on an indel file (mutated_sequence column, `mutant` is a label): same header as the reference's
+    output, score column within the sum bar, input columns preserved."""
+    from proteingym_amd import compute_fitness as cf
+    g, src = gp
+    out = tmp_path / "o"
+    cf.main(cf.create_parser().parse_args(
+        ["--model-location", os.path.join(golden_dir, "esm1v_toy_1.pt"), "--model_type", "ESM1v",
+         "--dms-input", os.path.join(golden_dir, "TOY_INDELS.csv"), "--dms-output", str(out),
+         "--target_seq", str(src["mutated_sequence"][0]), "--scoring-strategy", "pseudo-ppl"]))
+    df = pd.read_csv(out / "TOY_INDELS.csv")
+    assert list(df.columns) == list(g["cli/esm1v_toy_1/columns"])
+    n = np.array([max(1, len(s) - 2) for s in src["mutated_sequence"]])
+    assert (np.abs(df["esm1v_toy_1"].to_numpy() - g["cli/esm1v_toy_1"]) < TERM_TOL * np.sqrt(n)).all()
+    assert np.array_equal(df["Ensemble_ESM1v"].to_numpy(), df["esm1v_toy_1"].to_numpy())
+    assert df[list(src.columns)].equals(src)
