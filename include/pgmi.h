@@ -241,6 +241,10 @@ int pgmi_tr_sequence_loglik(pgmi_model* m, const int32_t* tokens, const int32_t*
  * Writes the mean milliseconds per launch. */
 int pgmi_bench_gemm(int device, int precision, int M, int N, int K, int epilogue, int split_out,
                     int variant, int iters, double* ms_per_launch);
+/* The same for several variants on ONE set of operands, timed in `rounds` interleaved rounds of `iters` launches
+ * each (within-process A/B); ms_out[v] = median over the rounds of the mean milliseconds per launch. */
+int pgmi_bench_gemm_ab(int device, int precision, int M, int N, int K, int epilogue, int split_out,
+                       const int* variants, int n_variants, int rounds, int iters, double* ms_out);
 
 /* ---- MSA Transformer (arch PGMI_ARCH_MSA; vocab 33, head_dim 64, precision f16x3) --------------------
  * Replaces MSATransformer.forward (proteingym/baselines/esm/esm/model/msa_transformer.py:146-205; tied

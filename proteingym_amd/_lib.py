@@ -69,6 +69,7 @@ SIGNATURES = [
     ("pgmi_tr_sequence_loglik", C.c_int, [C.c_void_p, _i32p, _i32p, C.c_int, C.c_int, _f32p, C.c_int,
                                           _i32p, _i32p, _i32p, _i32p, C.c_float, _f32p]),
     ("pgmi_bench_gemm", C.c_int, [C.c_int] * 9 + [_f64p]),
+    ("pgmi_bench_gemm_ab", C.c_int, [C.c_int] * 7 + [_i32p, C.c_int, C.c_int, C.c_int, _f64p]),
     ("pgmi_op_attention", C.c_int, [C.c_int, C.c_int, _f32p, _i32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
     ("pgmi_msa_token_logprobs", C.c_int, [C.c_void_p, _i32p, C.c_int, C.c_int, _f32p]),
     ("pgmi_msa_masked_logprobs", C.c_int, [C.c_void_p, _i32p, C.c_int, C.c_int, C.c_int, _i32p, _i32p, C.c_int, _f32p]),

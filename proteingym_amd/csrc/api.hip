@@ -1464,9 +1464,9 @@ int pgmi_tr_sequence_loglik(pgmi_model* m, const int32_t* tokens, const int32_t*
     return check_nonfinite(m);
 }
 
-int pgmi_bench_gemm(int device, int precision, int M, int N, int K, int epilogue, int split_out, int variant,
-                    int iters, double* ms_per_launch) {
-    if (M <= 0 || N <= 0 || K <= 0 || iters <= 0 || !ms_per_launch) { set_error("bad argument"); return PGMI_EINVAL; }
+int pgmi_bench_gemm_ab(int device, int precision, int M, int N, int K, int epilogue, int split_out, const int* variants,
+                       int n_variants, int rounds, int iters, double* ms_out) {
+    if (M <= 0 || N <= 0 || K <= 0 || iters <= 0 || rounds <= 0 || n_variants <= 0 || !variants || !ms_out) { set_error("bad argument"); return PGMI_EINVAL; }
     if (pgmi_device_count() <= 0) { set_error("no HIP device visible"); return PGMI_ENODEV; }
     PGMI_HIP(hipSetDevice(device));
     std::vector<void*> pool;
@@ -1498,27 +1498,39 @@ int pgmi_bench_gemm(int device, int precision, int M, int N, int K, int epilogue
         else rc = dev_alloc(pool, &dC, (size_t)M * N);
         if (rc) { cleanup(); return rc; }
     }
-    const int var = variant >= 0 ? variant : env_int("PGMI_GEMM_VARIANT", 7);
-    auto run = [&]() -> int {
+    auto run = [&](int var) -> int {
         if (f32) return launch_gemm_f32(dA, dW, dB, nullptr, dC, M, N, K, epilogue, nullptr);
         return launch_gemm16(a16, (size_t)M * K, w16.p, w16.plane, dB, nullptr, split_out ? nullptr : dC,
                              split_out ? c16 : nullptr, (size_t)M * N, M, N, K, epilogue, w16.out_scale, planes, bf, var, nullptr);
     };
-    for (int i = 0; i < 2 && !rc; ++i) rc = run();
-    if (!rc) {
-        hipEventRecord(e0, nullptr);
-        for (int i = 0; i < iters && !rc; ++i) rc = run();
-        hipEventRecord(e1, nullptr);
-        hipError_t e = hipEventSynchronize(e1);
-        float ms = 0.f;
-        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
-        if (e != hipSuccess) { set_error("bench failed: %s", hipGetErrorString(e)); rc = PGMI_EHIP; }
-        *ms_per_launch = ms / iters;
-    }
+    std::vector<std::vector<double>> samples(n_variants);
+    for (int v = 0; v < n_variants && !rc; ++v) rc = run(variants[v] >= 0 ? variants[v] : env_int("PGMI_GEMM_VARIANT", 7));   // warm-up
+    for (int r = 0; r < rounds && !rc; ++r)
+        for (int v = 0; v < n_variants && !rc; ++v) {              // interleaved rounds: variants see the same clocks / temperature
+            const int var = variants[v] >= 0 ? variants[v] : env_int("PGMI_GEMM_VARIANT", 7);
+            hipEventRecord(e0, nullptr);
+            for (int i = 0; i < iters && !rc; ++i) rc = run(var);
+            hipEventRecord(e1, nullptr);
+            hipError_t e = hipEventSynchronize(e1);
+            float ms = 0.f;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+            if (e != hipSuccess) { set_error("bench failed: %s", hipGetErrorString(e)); rc = PGMI_EHIP; }
+            samples[v].push_back(ms / iters);
+        }
+    if (!rc)
+        for (int v = 0; v < n_variants; ++v) {
+            std::sort(samples[v].begin(), samples[v].end());
+            ms_out[v] = samples[v][samples[v].size() / 2];         // median over the rounds
+        }
     hipEventDestroy(e0);
     hipEventDestroy(e1);
     cleanup();
     return rc;
+}
+
+int pgmi_bench_gemm(int device, int precision, int M, int N, int K, int epilogue, int split_out, int variant,
+                    int iters, double* ms_per_launch) {
+    return pgmi_bench_gemm_ab(device, precision, M, N, K, epilogue, split_out, &variant, 1, 1, iters, ms_per_launch);
 }
 
 int pgmi_op_attention(int device, int precision, const float* qkv, const int32_t* kv_len, int B, int T, int H,

@@ -25,7 +25,10 @@
 // flight during the MFMAs of tile t; one barrier per K tile.
 // Roofline: MFMA-bound; peak 2.5 PFLOP/s of 16-bit MFMA = 833 TFLOP/s of fp32-equivalent
 // algorithmic FLOPs in f16x3.
+#include <stdio.h>
 #include <stdlib.h>
+#include <algorithm>
+#include <vector>
 
 #include "common.h"
 
@@ -745,6 +748,618 @@ static int launch_cfg_p(const unsigned short* A, size_t a_plane, const unsigned 
     return PGMI_OK;
 }
 
+
+// =================================================================================================
+// Persistent ping-pong kernel (f16x3, 256 x 256 x 32 tile, 8 waves = 2(M) x 4(N), wave tile 128 x 64).
+// One workgroup per CU walks a list of work items; per item the K loop is the ping-pong schedule of
+// gemm16_kernel<PP> (the two waves of a SIMD run one phase apart: one issues its 24 MFMAs while the other reads
+// fragments / stages the next K tile).  What the persistent form adds:
+//   * no workgroup launch/retire gap between tiles, the output stores of tile i drain under the prologue and
+//     main loop of tile i+1, and (STG 0) the first K tile of item i+1 is loaded into the staging registers
+//     BEFORE the epilogue of item i runs;
+//   * the tail of the launch is balanced: with T tiles on G workgroups the last partial round (T mod G tiles,
+//     1610 tiles on 256 CUs = 6.29 rounds for the N = 1280 GEMMs) is cut into `split` K slices per tile, so every
+//     CU gets a slice instead of 29 % of the chip working a full round.  Sliced items leave their raw fp32
+//     accumulators in a workspace (fully coalesced 16-byte stores in accumulator order); splitk_fix_kernel adds
+//     the slices in a fixed order (deterministic) and applies scale, bias and the residual.  Only the fp32-output
+//     GEMMs (out-projection, FC2) use slices; their N = D gives the few tiles that make the tail matter.
+// STG 0: global -> VGPR -> LDS staging (swizzle on the LDS address).  STG 1: global -> LDS DMA (swizzle on the
+// source chunk); the wave's share of tile kt+1 is issued in the first memory phase of tile kt and waited for at
+// the LAST barrier of tile kt (two to three phases of latency cover instead of one).
+// =================================================================================================
+struct TilePlan {
+    int tiles_m, tiles_n;
+    int n_main;       // tiles [0, n_main) in launch order: one full-K item each
+    int split;        // every later tile is cut into `split` K slices (<= 1: none)
+    int n_items;      // n_main + (tiles - n_main) * split
+    float* ws;        // raw accumulators of the sliced items
+    unsigned long long* diag;   // DIAG instantiation only: [2 waves][kDiagSamples][2] shader-clock stamps (barrier arrival, release)
+    int diag_flags;             // DIAG instantiation only (ablations): 1 no global loads in the loop, 2 no ds_write staging,
+                                // 4 loads issued in memory phase 1 instead of 2, 8 no fragment reads after the first K tile
+};
+constexpr int kDiagSamples = 1024;
+
+constexpr int XBM = 256, XBN = 256, XNT = 512, XCPR = 4;
+constexpr int X_OP_CH = XBM * XCPR * 2;                    // 16-byte chunks of one operand tile (two planes)
+constexpr int X_STAGE = 2 * X_OP_CH;                       // chunks per stage = 64 KB
+
+__device__ __forceinline__ void x_tile_coords(int wgid, int tiles_m, int tiles_n, int& tm, int& tn) {
+    constexpr int GROUP_M = 8;
+    const int width = GROUP_M * tiles_n;
+    const int group = wgid / width, first_m = group * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    tm = first_m + (wgid % width) % gsz;
+    tn = (wgid % width) / gsz;
+}
+
+template <int EPI, int OUT, int STG, bool DIAG = false>
+__global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
+    const unsigned short* __restrict__ A, size_t a_plane, const unsigned short* __restrict__ W,
+    size_t w_plane, const float* __restrict__ bias, const float* residual, float* Cf,
+    unsigned short* Ch, size_t c_plane, int M, int N, int K, float out_scale, TilePlan tp, QkvOut qo) {
+    constexpr int WN = 4, TM = 4, TN = 2, LD = 4;
+    extern __shared__ __attribute__((aligned(16))) u32x4 lds[];  // [2][X_STAGE]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // provably wave-uniform: scalar branches, SGPR LDS bases
+    const int wm = wave / WN, wn = wave % WN;
+    const int r = lane & 31, kh = lane >> 5;
+    const bool late = wave >= 4;                                  // the second wave of every SIMD
+    auto swz = [](int row, int c) -> int { return c ^ ((row >> 2) & 3); };
+
+    // staging geometry (the same for both operands: 256 rows x 4 chunks x 2 planes over 512 threads).  Slot
+    // f = tid + 512 i is (plane i >> 1, row (tid >> 2) + 128 (i & 1), chunk tid & 3): one LDS index + 512 i, and per
+    // operand two 32-bit byte offsets (the planes are reached through wave-uniform base pointers).
+    const int row_lo = tid >> 2, cch = tid & 3;
+    const int dst0 = (STG == 1) ? tid : row_lo * XCPR + swz(row_lo, cch);     // (row + 128) has the same swizzle
+    const int csrc = (STG == 1) ? swz(row_lo, cch) : cch;                      // DMA: lane-linear slot, swizzled SOURCE chunk
+    const char* const Ap[2] = {reinterpret_cast<const char*>(A), reinterpret_cast<const char*>(A + a_plane)};
+    const char* const Wp[2] = {reinterpret_cast<const char*>(W), reinterpret_cast<const char*>(W + w_plane)};
+    unsigned int a_off[2], w_off[2];
+    unsigned int a_offd[DIAG ? LD : 1], w_offd[DIAG ? LD : 1];
+    u32x4 a_st[LD], w_st[LD];
+    int m0 = 0, n0 = 0, kt0 = 0, kt1 = 0, slice_item = -1;
+    auto decode = [&](int item) {                                 // sets m0, n0, [kt0, kt1), slice_item and the source offsets
+        const int nk = K / 32;
+        int wgid;
+        if (item < tp.n_main) {
+            // XCD-aware order: item i runs on XCD i % 8 (grid size is a multiple of 8); every XCD walks a contiguous
+            // run of the grouped tile order so that its L2 keeps the live A panels and W tiles
+            const int nwg = tp.n_main, xcd = item & 7, q = nwg >> 3, r8 = nwg & 7;
+            wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (item >> 3);
+            kt0 = 0; kt1 = nk; slice_item = -1;
+        } else {
+            const int rel = item - tp.n_main, ks = rel % tp.split;
+            wgid = tp.n_main + rel / tp.split;
+            kt0 = (int)((long long)nk * ks / tp.split);
+            kt1 = (int)((long long)nk * (ks + 1) / tp.split);
+            slice_item = rel;
+        }
+        int tm, tn;
+        x_tile_coords(wgid, tp.tiles_m, tp.tiles_n, tm, tn);
+        m0 = __builtin_amdgcn_readfirstlane(tm * XBM); n0 = __builtin_amdgcn_readfirstlane(tn * XBN);
+        kt0 = __builtin_amdgcn_readfirstlane(kt0); kt1 = __builtin_amdgcn_readfirstlane(kt1);
+        slice_item = __builtin_amdgcn_readfirstlane(slice_item);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                             // the launcher guarantees rows * K * 2 bytes < 4 GiB
+            a_off[h] = ((unsigned int)min(m0 + row_lo + 128 * h, M - 1) * (unsigned int)K + (unsigned int)csrc * 8u) * 2u;
+            w_off[h] = ((unsigned int)min(n0 + row_lo + 128 * h, N - 1) * (unsigned int)K + (unsigned int)csrc * 8u) * 2u;
+        }
+        if constexpr (DIAG) {
+#pragma unroll
+            for (int i = 0; i < LD; ++i) {
+                a_offd[i] = (unsigned int)min(m0 + (tid >> 3) + 64 * i, M - 1) * (unsigned int)K * 2u + (unsigned int)(tid & 7) * 16u;
+                w_offd[i] = (unsigned int)min(n0 + (tid >> 3) + 64 * i, N - 1) * (unsigned int)K * 2u + (unsigned int)(tid & 7) * 16u;
+            }
+        }
+    };
+    // DIAG flag 16 (timing only, wrong numbers): the access pattern of a K-interleaved plane layout -- 8 consecutive lanes
+    // read one full 128-byte line of a row per K tile instead of 4 lanes reading 64 bytes of each of two planes
+    auto src_a = [&](int i, int kt) {
+        if (DIAG && (tp.diag_flags & 16)) return reinterpret_cast<const u32x4*>(Ap[0] + (size_t)(kt & 31) * 128 + a_offd[i]);
+        return reinterpret_cast<const u32x4*>(Ap[i >> 1] + (size_t)kt * 64 + a_off[i & 1]);
+    };
+    auto src_w = [&](int i, int kt) {
+        if (DIAG && (tp.diag_flags & 16)) return reinterpret_cast<const u32x4*>(Wp[0] + (size_t)(kt & 31) * 128 + w_offd[i]);
+        return reinterpret_cast<const u32x4*>(Wp[i >> 1] + (size_t)kt * 64 + w_off[i & 1]);
+    };
+    auto stage_load = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < LD; ++i) a_st[i] = *src_a(i, kt);
+#pragma unroll
+        for (int i = 0; i < LD; ++i) w_st[i] = *src_w(i, kt);
+    };
+    auto stage_store = [&](int buf) {
+        u32x4* base = lds + buf * X_STAGE + dst0;
+#pragma unroll
+        for (int i = 0; i < LD; ++i) base[XNT * i] = a_st[i];
+#pragma unroll
+        for (int i = 0; i < LD; ++i) base[X_OP_CH + XNT * i] = w_st[i];
+    };
+    auto issue_tile = [&](int kt, int buf) {                      // STG 1: 1 KiB per wave-instruction, wave-uniform LDS base
+        u32x4* base = lds + buf * X_STAGE + wave * 64;
+#pragma unroll
+        for (int i = 0; i < LD; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_a(i, kt),
+                                             (__attribute__((address_space(3))) void*)(base + XNT * i), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < LD; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_w(i, kt),
+                                             (__attribute__((address_space(3))) void*)(base + X_OP_CH + XNT * i), 16, 0, 0);
+    };
+    // phase boundary: everything issued before stays before, this wave's LDS traffic has landed; VMEM stays in flight
+    // DIAG (tuning-only instantiation): waves 0 and 4 of workgroup 0 stamp the shader clock when they reach and when
+    // they leave every phase barrier; a pair is written out at the NEXT boundary, so the stamps cost two SMEM reads
+    // and one 16-byte store per phase and no extra wait.
+    const bool diag_on = DIAG && blockIdx.x == 0 && (wave == 0 || wave == 4);
+    unsigned long long d_arr = 0, d_rel = 0;
+    int d_n = 0;
+    auto phase = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        if (DIAG && diag_on) {
+            if (d_n > 0 && d_n <= kDiagSamples && lane == 0) {
+                unsigned long long* q = tp.diag + ((size_t)(wave >> 2) * kDiagSamples + (d_n - 1)) * 2;
+                q[0] = d_arr; q[1] = d_rel;
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0)
+        if (DIAG && diag_on) d_arr = __builtin_readcyclecounter();   // after the wait: the SMEM read returns under the barrier
+        __builtin_amdgcn_s_barrier();
+        if (DIAG && diag_on) { d_rel = __builtin_readcyclecounter(); ++d_n; }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto phase_vm = [&]() {                                       // the same, plus this wave's DMA has landed (STG 1)
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0070);                      // vmcnt(0) lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    f32x16 acc[TN][TM];
+    u32x4 af[2][TM], wf[2][TN], whs[TN];
+    auto read_frags = [&](const u32x4* Ab, const u32x4* Wb, int ks) {
+        const int c = ks * 2 + kh;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = (wm * TM + i) * 32 + r;
+                af[p][i] = Ab[(p * XBM + row) * XCPR + swz(row, c)];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = (wn * TN + j) * 32 + r;
+                wf[p][j] = Wb[(p * XBN + row) * XCPR + swz(row, c)];
+            }
+        }
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const h2 sc = {(_Float16)(1.0f / kLoScale), (_Float16)(1.0f / kLoScale)};
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned int u = wf[0][j][e];
+                const h2 t = __builtin_bit_cast(h2, u) * sc;      // w_hi 2^-11: exact (weights are scaled to ~2^13)
+                whs[j][e] = __builtin_bit_cast(unsigned int, t);
+            }
+    };
+    auto mfmas = [&]() {
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                acc[j][i] = mfma16<false>(wf[1][j], af[0][i], acc[j][i]);    // w_lo a_hi
+                acc[j][i] = mfma16<false>(whs[j], af[1][i], acc[j][i]);      // (w_hi 2^-11)(a_lo 2^11)
+                acc[j][i] = mfma16<false>(wf[0][j], af[0][i], acc[j][i]);    // w_hi a_hi
+            }
+    };
+
+    int item = blockIdx.x;
+    if (item >= tp.n_items) return;
+    decode(item);
+    if constexpr (STG == 0) stage_load(kt0);
+    while (true) {
+        // ---- prologue: first K tile of the item into buffer 0 (the LDS patches of the previous epilogue are done:
+        //      every wave passed the barrier below only after finishing its own patch reads) ----
+        __syncthreads();
+        if constexpr (STG == 0) {
+            stage_store(0);
+            if (kt0 + 1 < kt1) stage_load(kt0 + 1);
+            __syncthreads();
+        } else {
+            issue_tile(kt0, 0);
+            phase_vm();
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[j][i][v] = 0.0f;
+        int cur = 0;
+        if (late) phase();
+        for (int kt = kt0; kt < kt1; ++kt) {
+            const u32x4* Ab = lds + cur * X_STAGE;
+            const u32x4* Wb = Ab + X_OP_CH;
+            // -- memory phase 1: fragments of the first k16 step (STG 1: DMA of tile kt+1 into the other buffer, last read
+            //    two phases ago by the other wave group) --
+            __builtin_amdgcn_s_setprio(0);
+            if (!(DIAG && (tp.diag_flags & 8) && kt > kt0)) read_frags(Ab, Wb, 0);
+            if (STG == 1 && kt + 1 < kt1) issue_tile(kt + 1, cur ^ 1);
+            if (DIAG && (tp.diag_flags & 4) && kt > kt0 && kt + 1 < kt1) stage_load(kt + 1);
+            phase();
+            // -- compute phase 1 --
+            __builtin_amdgcn_s_setprio(1);
+            mfmas();
+            phase();
+            // -- memory phase 2: fragments of the second k16 step; STG 0: tile kt+1 registers -> LDS, loads of kt+2 --
+            __builtin_amdgcn_s_setprio(0);
+            if (!(DIAG && (tp.diag_flags & 8) && kt > kt0)) read_frags(Ab, Wb, 1);
+            if (STG == 0 && kt + 1 < kt1) {
+                __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0); lgkmcnt / expcnt untouched
+                if (!(DIAG && (tp.diag_flags & 2))) stage_store(cur ^ 1);
+                if (kt + 2 < kt1 && !(DIAG && (tp.diag_flags & 5))) stage_load(kt + 2);
+            }
+            if (STG == 1 && late) phase_vm(); else phase();        // late waves close tile kt here: their DMA share must have landed
+            // -- compute phase 2 --
+            __builtin_amdgcn_s_setprio(1);
+            mfmas();
+            if (STG == 1 && !late) phase_vm(); else phase();       // early waves close tile kt here
+            cur ^= 1;
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (!late) phase();
+
+        // ---- the item just finished; fetch the next one's first K tile before the epilogue (STG 0) ----
+        const int em0 = m0, en0 = n0, eslice = slice_item;
+        item += gridDim.x;
+        const bool more = item < tp.n_items;
+        if (more) {
+            decode(item);
+            if constexpr (STG == 0) stage_load(kt0);
+        }
+
+        if (eslice >= 0) {
+            // raw accumulators, accumulator order: [item][wave][j][i][q][lane] f32x4 -> 1 KiB per store instruction
+            f32x4* dst = reinterpret_cast<f32x4*>(tp.ws) + ((size_t)eslice * 8 + wave) * (TN * TM * 4 * 64) + lane;
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4)
+                        dst[((j * TM + i) * 4 + q4) * 64] = f32x4{acc[j][i][4 * q4], acc[j][i][4 * q4 + 1], acc[j][i][4 * q4 + 2], acc[j][i][4 * q4 + 3]};
+        } else if constexpr (OUT == 2) {
+            const int Dm = N / 3;
+            const int nb = en0 + wn * 64;                      // first column of this wave's head
+            if (nb < N) {
+            const int which = nb / Dm, hcol = nb - which * Dm, hh = hcol >> 6;
+            constexpr int SPQ = 144;
+            unsigned char* patch_q = reinterpret_cast<unsigned char*>(lds) + wave * (2 * 32 * SPQ);
+            const bool staged_q = which < 2;
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = em0 + (wm * TM + i) * 32 + r;
+                const bool row_ok = m < M;
+                if (!staged_q && !row_ok) continue;
+                const int bb = m / qo.T, t = m - bb * qo.T;
+                if (row_ok)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int d0 = 8 * g + 4 * kh;             // dims d0..d0+3 (x0) and d0+32.. (x1) of the head
+                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + nb + d0);
+                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + nb + 32 + d0);
+                    float x0[4], x1[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        x0[e] = acc[0][i][4 * g + e] * out_scale + b0[e];
+                        x1[e] = acc[1][i][4 * g + e] * out_scale + b1[e];
+                    }
+                    if (which < 2) {
+                        if (qo.rotary) {                       // rotary_embedding.py:11-20
+                            const f32x4 c1 = *reinterpret_cast<const f32x4*>(qo.cos_t + t * 64 + d0);
+                            const f32x4 s1 = *reinterpret_cast<const f32x4*>(qo.sin_t + t * 64 + d0);
+                            const f32x4 c2 = *reinterpret_cast<const f32x4*>(qo.cos_t + t * 64 + 32 + d0);
+                            const f32x4 s2 = *reinterpret_cast<const f32x4*>(qo.sin_t + t * 64 + 32 + d0);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const float y0 = x0[e] * c1[e] + (-x1[e]) * s1[e];
+                                const float y1 = x1[e] * c2[e] + x0[e] * s2[e];
+                                x0[e] = y0;
+                                x1[e] = y1;
+                            }
+                        }
+                        h4 hi0, lo0, hi1, lo1;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            _Float16 a, b2;
+                            split_act(x0[e], a, b2); hi0[e] = a; lo0[e] = b2;
+                            split_act(x1[e], a, b2); hi1[e] = a; lo1[e] = b2;
+                        }
+                        unsigned char* cell = patch_q + r * SPQ + d0 * 2;
+                        *reinterpret_cast<h4*>(cell) = hi0;
+                        *reinterpret_cast<h4*>(cell + 32 * SPQ) = lo0;
+                        *reinterpret_cast<h4*>(cell + 64) = hi1;
+                        *reinterpret_cast<h4*>(cell + 32 * SPQ + 64) = lo1;
+                    } else {
+                        const int tk = t & 31;
+                        const int pos = (t & ~31) + ((tk & 0x13) | ((tk & 4) << 1) | ((tk & 8) >> 1));   // swap key bits 2,3
+                        unsigned short* col = qo.vt16 + (((size_t)bb * qo.H + hh) * kHeadDim + d0) * qo.Tp + pos;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            _Float16 a0, l0, a1, l1;
+                            split_act(x0[e], a0, l0);
+                            split_act(x1[e], a1, l1);
+                            unsigned short* c0 = col + (size_t)e * qo.Tp;
+                            unsigned short* c1p = c0 + (size_t)32 * qo.Tp;
+                            c0[0] = __builtin_bit_cast(unsigned short, a0);
+                            c0[qo.vt_plane] = __builtin_bit_cast(unsigned short, l0);
+                            c1p[0] = __builtin_bit_cast(unsigned short, a1);
+                            c1p[qo.vt_plane] = __builtin_bit_cast(unsigned short, l1);
+                        }
+                    }
+                }
+                if (staged_q) {
+                    __builtin_amdgcn_wave_barrier();
+                    const int m_base = em0 + (wm * TM + i) * 32;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int q = lane + 64 * k, row = q >> 3, cc = q & 7;
+                        const u32x4 vh = *reinterpret_cast<const u32x4*>(patch_q + row * SPQ + cc * 16);
+                        const u32x4 vl = *reinterpret_cast<const u32x4*>(patch_q + (32 + row) * SPQ + cc * 16);
+                        if (m_base + row < M) {
+                            unsigned short* dst = Ch + (size_t)(m_base + row) * (2 * Dm) + (size_t)which * Dm + hcol + cc * 8;
+                            *reinterpret_cast<u32x4*>(dst) = vh;
+                            *reinterpret_cast<u32x4*>(dst + c_plane) = vl;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+            }
+        } else {
+            // lane holds column m = m_base + r of C^T, rows n = (v&3) + 8(v>>2) + 4kh; split-plane output leaves through a
+            // per-wave LDS transpose as full 128-byte row segments (see gemm16_kernel)
+            constexpr int SP = 144;
+            const bool staged = (OUT == 1) && (N % 8 == 0) && (en0 + (wn * TN + TN) * 32 <= N);
+            unsigned char* patch = reinterpret_cast<unsigned char*>(lds) + wave * (2 * 32 * SP);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m = em0 + (wm * TM + i) * 32 + r;
+                const bool row_ok = m < M;
+                if (!staged && !row_ok) continue;
+                if (row_ok)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int n = en0 + (wn * TN + j) * 32 + 8 * g + 4 * kh;
+                        if (n >= N) continue;                    // N % 4 == 0 is required by the launcher
+                        const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        f32x4 val;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float t = acc[j][i][4 * g + e] * out_scale + bv[e];
+                            if (EPI == EPI_GELU) t = gelu_erf16(t);
+                            if (EPI == EPI_SQRELU) { t = fmaxf(t, 0.0f); t = t * t; }     // tranception/activations.py:79-84
+                            val[e] = t;
+                        }
+                        const size_t o = (size_t)m * N + n;
+                        if constexpr (OUT == 0) {
+                            if (residual) {
+                                const f32x4 rv = *reinterpret_cast<const f32x4*>(residual + o);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) val[e] = rv[e] + val[e];
+                            }
+                            *reinterpret_cast<f32x4*>(Cf + o) = val;
+                        } else {
+                            h4 hi, lo;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                _Float16 a, b;
+                                split_act(val[e], a, b);
+                                hi[e] = a;
+                                lo[e] = b;
+                            }
+                            if (staged) {
+                                unsigned char* cell = patch + r * SP + (j * 32 + 8 * g + 4 * kh) * 2;
+                                *reinterpret_cast<h4*>(cell) = hi;
+                                *reinterpret_cast<h4*>(cell + 32 * SP) = lo;
+                            } else {
+                                *reinterpret_cast<h4*>(Ch + o) = hi;
+                                *reinterpret_cast<h4*>(Ch + c_plane + o) = lo;
+                            }
+                        }
+                    }
+                }
+                if (OUT == 1 && staged) {
+                    __builtin_amdgcn_wave_barrier();
+                    const int m_base = em0 + (wm * TM + i) * 32;
+                    const size_t ncol0 = (size_t)en0 + (size_t)wn * TN * 32;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int q = lane + 64 * k;                 // 16-byte chunk: row q/8, chunk q%8 of the 128-byte row
+                        const int row = q >> 3, cc = q & 7;
+                        const u32x4 vh = *reinterpret_cast<const u32x4*>(patch + row * SP + cc * 16);
+                        const u32x4 vl = *reinterpret_cast<const u32x4*>(patch + (32 + row) * SP + cc * 16);
+                        if (m_base + row < M) {
+                            unsigned short* dst = Ch + (size_t)(m_base + row) * N + ncol0 + cc * 8;
+                            *reinterpret_cast<u32x4*>(dst) = vh;
+                            *reinterpret_cast<u32x4*>(dst + c_plane) = vl;
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+        if (!more) break;
+    }
+}
+
+// Sum of the K slices of the sliced tiles (fixed order: deterministic) + the fp32 epilogue of gemm16x_kernel<EPI_NONE, 0>:
+// C = residual + (sum acc) * out_scale + bias.  One workgroup per sliced tile, same thread <-> element map as the GEMM.
+__global__ __launch_bounds__(XNT) void splitk_fix_kernel(const float* __restrict__ ws, int split, int n_main, int tiles_m, int tiles_n,
+                                                         const float* __restrict__ bias, const float* residual, float* Cf,
+                                                         int M, int N, float out_scale) {
+    constexpr int WN = 4, TM = 4, TN = 2;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN, r = lane & 31, kh = lane >> 5;
+    int tm, tn;
+    x_tile_coords(n_main + blockIdx.x, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm * XBM, n0 = tn * XBN;
+    const f32x4* src = reinterpret_cast<const f32x4*>(ws) + ((size_t)blockIdx.x * split * 8 + wave) * (TN * TM * 4 * 64) + lane;
+    const size_t slice_stride = (size_t)8 * (TN * TM * 4 * 64);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int m = m0 + (wm * TM + i) * 32 + r;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + (wn * TN + j) * 32 + 8 * g + 4 * kh;
+                f32x4 a = src[((j * TM + i) * 4 + g) * 64];
+                for (int s = 1; s < split; ++s) {
+                    const f32x4 b = src[s * slice_stride + ((j * TM + i) * 4 + g) * 64];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[e] += b[e];
+                }
+                if (m >= M || n >= N) continue;
+                const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                const size_t o = (size_t)m * N + n;
+                f32x4 val;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) val[e] = a[e] * out_scale + bv[e];
+                if (residual) {
+                    const f32x4 rv = *reinterpret_cast<const f32x4*>(residual + o);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) val[e] = rv[e] + val[e];
+                }
+                *reinterpret_cast<f32x4*>(Cf + o) = val;
+            }
+        }
+}
+
+static int x_num_cus() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (n <= 0) n = 256;
+        n -= n % 8;                                              // the XCD-aware item order wants a multiple of 8
+        if (n <= 0) n = 8;
+    }
+    return n;
+}
+
+static float* g_splitk_ws = nullptr;                              // one per process and device in use (single-GPU ranks)
+static size_t g_splitk_ws_bytes = 0;
+static int g_splitk_ws_dev = -1;
+
+// stg: 0 register staging, 1 direct-to-LDS DMA.  splitk: allow K-sliced tail items (fp32-output GEMMs only).
+static int launch_gemm16x(const unsigned short* A, size_t a_plane, const unsigned short* W, size_t w_plane,
+                          const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
+                          int M, int N, int K, int epilogue, float out_scale, int stg, bool splitk, hipStream_t s,
+                          const QkvOut* qkv = nullptr) {
+    TilePlan tp{};
+    tp.tiles_m = (M + XBM - 1) / XBM;
+    tp.tiles_n = (N + XBN - 1) / XBN;
+    const int T = tp.tiles_m * tp.tiles_n, G = x_num_cus(), nk = K / 32;
+    tp.n_main = T; tp.split = 1; tp.n_items = T;
+    if ((unsigned long long)std::max(M, N) * (unsigned long long)K * 2ull >= (1ull << 32)) {
+        set_error("gemm16x: operand plane of %d x %d halfs exceeds the 32-bit offset range", std::max(M, N), K);
+        return PGMI_EINVAL;
+    }
+    const int rem = T % G;
+    static const int no_split = getenv("PGMI_GEMM_NO_SPLITK") ? atoi(getenv("PGMI_GEMM_NO_SPLITK")) : 0;
+    if (splitk && !no_split && Cf && !qkv && epilogue == EPI_NONE && rem > 0 && 4 * rem <= 3 * G) {
+        int split = std::min(std::min(G / rem, 8), nk / 4);       // every slice keeps >= 4 K tiles
+        if (split >= 2) {
+            const size_t need = (size_t)rem * split * XBM * XBN * sizeof(float);
+            int dev = 0;
+            hipGetDevice(&dev);
+            if (need > g_splitk_ws_bytes || dev != g_splitk_ws_dev) {
+                if (g_splitk_ws && dev == g_splitk_ws_dev) hipFree(g_splitk_ws);
+                g_splitk_ws = nullptr; g_splitk_ws_bytes = 0;
+                const size_t cap = std::max(need, (size_t)G * XBM * XBN * sizeof(float));
+                if (hipMalloc(reinterpret_cast<void**>(&g_splitk_ws), cap) == hipSuccess) { g_splitk_ws_bytes = cap; g_splitk_ws_dev = dev; }
+            }
+            if (g_splitk_ws) {
+                tp.n_main = T - rem; tp.split = split; tp.n_items = tp.n_main + rem * split; tp.ws = g_splitk_ws;
+            }
+        }
+    }
+    QkvOut qo{};
+    if (qkv) qo = *qkv;
+    const size_t lds_bytes = (size_t)2 * X_STAGE * 16;
+    const dim3 grid(std::min(G, tp.n_items)), block(XNT);
+    if (stg == 2) {                                               // tuning only: phase-timing instantiation (fp32-out GEMM)
+        if (!Cf || qkv || epilogue != EPI_NONE) { set_error("gemm16x diag: fp32-output GEMM without activation only"); return PGMI_EINVAL; }
+        static unsigned long long* dbuf = nullptr;
+        const size_t n = (size_t)2 * kDiagSamples * 2;
+        if (!dbuf && hipMalloc(reinterpret_cast<void**>(&dbuf), n * 8) != hipSuccess) { set_error("diag alloc failed"); return PGMI_ENOMEM; }
+        PGMI_HIP(hipMemsetAsync(dbuf, 0, n * 8, s));
+        tp.diag = dbuf;
+        tp.diag_flags = getenv("PGMI_GEMM_DIAG_FLAGS") ? atoi(getenv("PGMI_GEMM_DIAG_FLAGS")) : 0;
+        auto kfn = gemm16x_kernel<EPI_NONE, 0, 0, true>;
+        PGMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+        hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, out_scale, tp, qo);
+        if (tp.split > 1)
+            hipLaunchKernelGGL(splitk_fix_kernel, dim3(T - tp.n_main), dim3(XNT), 0, s, tp.ws, tp.split, tp.n_main, tp.tiles_m,
+                               tp.tiles_n, bias, residual, Cf, M, N, out_scale);
+        std::vector<unsigned long long> h(n);
+        PGMI_HIP(hipMemcpyAsync(h.data(), dbuf, n * 8, hipMemcpyDeviceToHost, s));
+        PGMI_HIP(hipStreamSynchronize(s));
+        // per wave group: work = release(k-1) -> arrival(k), wait = arrival(k) -> release(k); phases cycle mem1, cmp1, mem2, cmp2
+        static int printed = 0;
+        if (!printed++) {
+            fprintf(stderr, "[gemm16x diag] flags %d\n", tp.diag_flags);
+            for (int g = 0; g < 2; ++g) {
+                const unsigned long long* q = h.data() + (size_t)g * kDiagSamples * 2;
+                double work[4] = {0, 0, 0, 0}, wait[4] = {0, 0, 0, 0};
+                int cnt[4] = {0, 0, 0, 0};
+                // the late group passes one extra barrier before its first memory phase; skip the first 3 K tiles (pipeline fill)
+                const int first = 12 + g;
+                for (int k = first; k + 1 < kDiagSamples && q[2 * (k + 1)]; ++k) {
+                    const int ph = (k - g) & 3;                    // barrier k closes phase ph of its K tile: 0 mem1, 1 cmp1, 2 mem2, 3 cmp2
+                    work[ph] += (double)(q[2 * k] - q[2 * (k - 1) + 1]);
+                    wait[ph] += (double)(q[2 * k + 1] - q[2 * k]);
+                    cnt[ph]++;
+                }
+                fprintf(stderr, "[gemm16x diag] %s waves: ", g ? "late " : "early");
+                static const char* nm[4] = {"mem1", "cmp1", "mem2", "cmp2"};
+                for (int p = 0; p < 4; ++p)
+                    fprintf(stderr, "%s work %.0f wait %.0f | ", nm[p], cnt[p] ? work[p] / cnt[p] : 0.0, cnt[p] ? wait[p] / cnt[p] : 0.0);
+                fprintf(stderr, "(shader clocks, mean over %d K tiles)\n", cnt[0]);
+            }
+        }
+        return PGMI_OK;
+    }
+#define PGMI_LAUNCH16X(EPI_, OUT_, STG_)                                                                  \
+    do {                                                                                                 \
+        auto kfn = gemm16x_kernel<EPI_, OUT_, STG_>;                                                      \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                           \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);  \
+        if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PGMI_EHIP; } \
+        hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, A, a_plane, W, w_plane, bias, residual, Cf, Ch, \
+                           c_plane, M, N, K, out_scale, tp, qo);                                         \
+    } while (0)
+#define PGMI_LAUNCH16X_S(EPI_, OUT_) do { if (stg) PGMI_LAUNCH16X(EPI_, OUT_, 1); else PGMI_LAUNCH16X(EPI_, OUT_, 0); } while (0)
+    if (qkv) PGMI_LAUNCH16X_S(EPI_NONE, 2);
+    else {
+        const int out = Ch ? 1 : 0;
+        if (epilogue == EPI_GELU) { if (out) PGMI_LAUNCH16X_S(EPI_GELU, 1); else PGMI_LAUNCH16X_S(EPI_GELU, 0); }
+        else if (epilogue == EPI_SQRELU) { if (out) PGMI_LAUNCH16X_S(EPI_SQRELU, 1); else PGMI_LAUNCH16X_S(EPI_SQRELU, 0); }
+        else { if (out) PGMI_LAUNCH16X_S(EPI_NONE, 1); else PGMI_LAUNCH16X_S(EPI_NONE, 0); }
+    }
+#undef PGMI_LAUNCH16X_S
+#undef PGMI_LAUNCH16X
+    if (tp.split > 1)
+        hipLaunchKernelGGL(splitk_fix_kernel, dim3(T - tp.n_main), dim3(XNT), 0, s, tp.ws, tp.split, tp.n_main, tp.tiles_m,
+                           tp.tiles_n, bias, residual, Cf, M, N, out_scale);
+    PGMI_HIP(hipGetLastError());
+    return PGMI_OK;
+}
+
 template <int WM, int WN, int TM, int TN, int BK, int PLANES, bool BF, int PP = 0>
 static int launch_cfg(const unsigned short* A, size_t a_plane, const unsigned short* W, size_t w_plane,
                       const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
@@ -802,6 +1417,11 @@ int launch_gemm16(const unsigned short* A, size_t a_plane, const unsigned short*
             case 6: return launch_cfg_p<2, 2, 2, 2, 2, false>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);   // 128x128, 4 waves
             case 7: return launch_cfg<2, 4, 4, 2, 32, 2, false, 1>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);   // 256x256, ping-pong
             case 8: return launch_cfg<2, 4, 4, 2, 32, 2, false, 2>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);   // 256x256, ping-pong + direct-to-LDS tile loads
+            case 9: return launch_gemm16x(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 0, true, s);    // persistent ping-pong, register staging, K-sliced tail
+            case 10: return launch_gemm16x(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 1, true, s);   // persistent ping-pong, global->LDS DMA, K-sliced tail
+            case 11: return launch_gemm16x(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 0, false, s);  // persistent, no slicing
+            case 12: return launch_gemm16x(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 1, false, s);
+            case 13: return launch_gemm16x(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 2, false, s);  // phase-timing diagnostics
             default: return launch_cfg<2, 2, 2, 2, 32, 2, false>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);
         }
     }
@@ -832,6 +1452,8 @@ int launch_gemm16_qkv(const unsigned short* A, size_t a_plane, const unsigned sh
         case 3: return launch_cfg<4, 2, 2, 2, 32, 2, false>(A, a_plane, W, w_plane, bias, nullptr, nullptr, qk16, qk_plane, M, N, K, EPI_NONE, out_scale, s, &qo);
         case 7: return launch_cfg<2, 4, 4, 2, 32, 2, false, 1>(A, a_plane, W, w_plane, bias, nullptr, nullptr, qk16, qk_plane, M, N, K, EPI_NONE, out_scale, s, &qo);
         case 8: return launch_cfg<2, 4, 4, 2, 32, 2, false, 2>(A, a_plane, W, w_plane, bias, nullptr, nullptr, qk16, qk_plane, M, N, K, EPI_NONE, out_scale, s, &qo);
+        case 9: case 11: return launch_gemm16x(A, a_plane, W, w_plane, bias, nullptr, nullptr, qk16, qk_plane, M, N, K, EPI_NONE, out_scale, 0, false, s, &qo);
+        case 10: case 12: return launch_gemm16x(A, a_plane, W, w_plane, bias, nullptr, nullptr, qk16, qk_plane, M, N, K, EPI_NONE, out_scale, 1, false, s, &qo);
         default: return launch_cfg<2, 4, 4, 2, 32, 2, false>(A, a_plane, W, w_plane, bias, nullptr, nullptr, qk16, qk_plane, M, N, K, EPI_NONE, out_scale, s, &qo);
     }
 }
