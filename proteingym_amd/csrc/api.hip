@@ -25,8 +25,8 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-// 16-bit operand planes of one Linear weight: fp16 (hi, lo) of W*2^s for f16x3, one bf16 plane
-// for bf16; out_scale = 2^-s is applied in the GEMM epilogue.
+// 16-bit operand of one Linear weight [N,K]: f16x3 = fp16 (hi, lo) of W*2^s in the K-interleaved layout (common.h
+// ki_off: per row, groups of 32 hi halfs + 32 lo halfs), bf16 = one plane; out_scale = 2^-s is applied in the GEMM epilogue.
 struct W16 {
     unsigned short* p = nullptr;
     size_t plane = 0;
@@ -239,7 +239,7 @@ int env_int(const char* name, int dflt) {
 // Upload a Linear weight [n_elems] as 16-bit planes.  f16x3: W*2^s with 2^s chosen so that
 // max|W|*2^s lies in [8192, 16384): hi stays far below fp16's 65504 and lo = fp16(W' - hi) stays in
 // the normal range for every element within 2^-15 of the largest.  bf16: one plane, no scaling.
-int make_w16(std::vector<void*>& pool, const float* host, size_t n, int precision, hipStream_t s, W16* out) {
+int make_w16(std::vector<void*>& pool, const float* host, size_t n, size_t K, int precision, hipStream_t s, W16* out) {
     float mx = 0.f;
     for (size_t i = 0; i < n; ++i) mx = std::max(mx, fabsf(host[i]));
     float scale = 1.0f;
@@ -252,7 +252,7 @@ int make_w16(std::vector<void*>& pool, const float* host, size_t n, int precisio
     if (rc) { hipFree(tmp); return rc; }
     e = hipMemcpy(tmp, host, n * sizeof(float), hipMemcpyHostToDevice);
     if (e == hipSuccess) {
-        launch_split16(tmp, (int64_t)n, scale, precision == PGMI_PREC_BF16 ? 1 : 0, out->p, n, s);
+        launch_split16(tmp, (int64_t)n, scale, precision == PGMI_PREC_BF16 ? 1 : 0, (int)K, out->p, s);
         e = hipStreamSynchronize(s);
     }
     hipFree(tmp);
@@ -440,7 +440,7 @@ int create_tranception(pgmi_model* m, const pgmi_config* cfg, const float* w, in
         TRY(dev_upload(m->allocs, &L.ln1_w, p, D)); p += D;
         TRY(dev_upload(m->allocs, &L.ln1_b, p, D)); p += D;
         conv1d_to_linear(p, D, 3 * D, D, qscale, lin); p += D * 3 * D;
-        TRY(make_w16(m->allocs, lin.data(), lin.size(), cfg->precision, m->stream, &L.wqkv16));
+        TRY(make_w16(m->allocs, lin.data(), lin.size(), D, cfg->precision, m->stream, &L.wqkv16));
         for (size_t i = 0; i < 3 * D; ++i) bq[i] = p[i] * (i < D ? qscale : 1.0f);
         p += 3 * D;
         TRY(dev_upload(m->allocs, &L.bqkv, bq.data(), bq.size()));
@@ -460,15 +460,15 @@ int create_tranception(pgmi_model* m, const pgmi_config* cfg, const float* w, in
         }
         TRY(dev_upload(m->allocs, &L.conv, conv.data(), conv.size()));
         conv1d_to_linear(p, D, D, 0, 1.0f, lin); p += D * D;
-        TRY(make_w16(m->allocs, lin.data(), lin.size(), cfg->precision, m->stream, &L.wo16));
+        TRY(make_w16(m->allocs, lin.data(), lin.size(), D, cfg->precision, m->stream, &L.wo16));
         TRY(dev_upload(m->allocs, &L.bo, p, D)); p += D;
         TRY(dev_upload(m->allocs, &L.ln2_w, p, D)); p += D;
         TRY(dev_upload(m->allocs, &L.ln2_b, p, D)); p += D;
         conv1d_to_linear(p, D, F, 0, 1.0f, lin); p += D * F;
-        TRY(make_w16(m->allocs, lin.data(), lin.size(), cfg->precision, m->stream, &L.w116));
+        TRY(make_w16(m->allocs, lin.data(), lin.size(), D, cfg->precision, m->stream, &L.w116));
         TRY(dev_upload(m->allocs, &L.b1, p, F)); p += F;
         conv1d_to_linear(p, F, D, 0, 1.0f, lin); p += F * D;
-        TRY(make_w16(m->allocs, lin.data(), lin.size(), cfg->precision, m->stream, &L.w216));
+        TRY(make_w16(m->allocs, lin.data(), lin.size(), F, cfg->precision, m->stream, &L.w216));
         TRY(dev_upload(m->allocs, &L.b2, p, D)); p += D;
     }
     TRY(dev_upload(m->allocs, &m->lna_w, p, D)); p += D;
@@ -558,9 +558,9 @@ int create_msa(pgmi_model* m, const pgmi_config* cfg, const float* w, int64_t n_
             for (size_t i = 0; i < D; ++i) bq[k * D + i] = p[i] * sc;
             p += D;
         }
-        TRY(make_w16(m->allocs, wq.data(), wq.size(), cfg->precision, m->stream, wqkv));
+        TRY(make_w16(m->allocs, wq.data(), wq.size(), D, cfg->precision, m->stream, wqkv));
         TRY(dev_upload(m->allocs, bqkv, bq.data(), bq.size()));
-        TRY(make_w16(m->allocs, p, D * D, cfg->precision, m->stream, wo)); p += D * D;
+        TRY(make_w16(m->allocs, p, D * D, D, cfg->precision, m->stream, wo)); p += D * D;
         TRY(dev_upload(m->allocs, bo, p, D)); p += D;
         return PGMI_OK;
     };
@@ -570,14 +570,14 @@ int create_msa(pgmi_model* m, const pgmi_config* cfg, const float* w, int64_t n_
         TRY(attn(&L.c_ln_w, &L.c_ln_b, &L.c_wqkv16, &L.c_bqkv, &L.c_wo16, &L.c_bo));
         TRY(dev_upload(m->allocs, &L.ln2_w, p, D)); p += D;
         TRY(dev_upload(m->allocs, &L.ln2_b, p, D)); p += D;
-        TRY(make_w16(m->allocs, p, F * D, cfg->precision, m->stream, &L.w116)); p += F * D;
+        TRY(make_w16(m->allocs, p, F * D, D, cfg->precision, m->stream, &L.w116)); p += F * D;
         TRY(dev_upload(m->allocs, &L.b1, p, F)); p += F;
-        TRY(make_w16(m->allocs, p, D * F, cfg->precision, m->stream, &L.w216)); p += D * F;
+        TRY(make_w16(m->allocs, p, D * F, F, cfg->precision, m->stream, &L.w216)); p += D * F;
         TRY(dev_upload(m->allocs, &L.b2, p, D)); p += D;
     }
     TRY(dev_upload(m->allocs, &m->lna_w, p, D)); p += D;
     TRY(dev_upload(m->allocs, &m->lna_b, p, D)); p += D;
-    TRY(make_w16(m->allocs, p, D * D, cfg->precision, m->stream, &m->hd16)); p += D * D;
+    TRY(make_w16(m->allocs, p, D * D, D, cfg->precision, m->stream, &m->hd16)); p += D * D;
     TRY(dev_upload(m->allocs, &m->hd_b, p, D)); p += D;
     TRY(dev_upload(m->allocs, &m->hln_w, p, D)); p += D;
     TRY(dev_upload(m->allocs, &m->hln_b, p, D)); p += D;
@@ -662,7 +662,7 @@ int run_msa(pgmi_model* m, int R, int C) {
           g2.a_s0 = (int64_t)C * Cp; g2.w_s0 = (int64_t)R * 64 * Cp; g2.c_s0 = 64;
           rc = launch_gemm_f32_ex(m->tied_p, m->tied_vt, m->h, C, R * 64, Cp, g2, s);
           if (rc) return rc;
-          launch_split16(m->h, (int64_t)M * D, 1.0f, 2, m->h16, m->h16_plane, s); }
+          launch_split16(m->h, (int64_t)M * D, 1.0f, 2, D, m->h16, s); }
         { ProfScope p(m, PGMI_K_GEMM_OUT, 2.0 * M * D * D, 0);
           rc = linear(m, nullptr, m->h16, m->h16_plane, nullptr, L.wo16, L.bo, m->x, m->x, nullptr, 0, M, D, D, EPI_NONE);
           if (rc) return rc; }
@@ -813,29 +813,29 @@ int pgmi_model_create(const pgmi_config* cfg, const float* w, int64_t n_weights,
         }
         const bool f32w = cfg->precision == PGMI_PREC_FP32;
         if (f32w) TRY(dev_upload(m->allocs, &L.wqkv, wq.data(), wq.size()));
-        else TRY(make_w16(m->allocs, wq.data(), wq.size(), cfg->precision, m->stream, &L.wqkv16));
+        else TRY(make_w16(m->allocs, wq.data(), wq.size(), D, cfg->precision, m->stream, &L.wqkv16));
         TRY(dev_upload(m->allocs, &L.bqkv, bq.data(), bq.size()));
         for (size_t o = 0; o < D; ++o)           // out-proj [D, Da]: input columns follow the slot layout
             for (size_t i = 0; i < D; ++i) wo_r[o * Da + slot(i)] = p[o * D + i];
         if (f32w) TRY(dev_upload(m->allocs, &L.wo, wo_r.data(), wo_r.size()));
-        else TRY(make_w16(m->allocs, wo_r.data(), wo_r.size(), cfg->precision, m->stream, &L.wo16));
+        else TRY(make_w16(m->allocs, wo_r.data(), wo_r.size(), Da, cfg->precision, m->stream, &L.wo16));
         p += D * D;
         TRY(dev_upload(m->allocs, &L.bo, p, D)); p += D;
         TRY(dev_upload(m->allocs, &L.ln2_w, p, D)); p += D;
         TRY(dev_upload(m->allocs, &L.ln2_b, p, D)); p += D;
         if (f32w) TRY(dev_upload(m->allocs, &L.w1, p, F * D));
-        else TRY(make_w16(m->allocs, p, F * D, cfg->precision, m->stream, &L.w116));
+        else TRY(make_w16(m->allocs, p, F * D, D, cfg->precision, m->stream, &L.w116));
         p += F * D;
         TRY(dev_upload(m->allocs, &L.b1, p, F)); p += F;
         if (f32w) TRY(dev_upload(m->allocs, &L.w2, p, D * F));
-        else TRY(make_w16(m->allocs, p, D * F, cfg->precision, m->stream, &L.w216));
+        else TRY(make_w16(m->allocs, p, D * F, F, cfg->precision, m->stream, &L.w216));
         p += D * F;
         TRY(dev_upload(m->allocs, &L.b2, p, D)); p += D;
     }
     TRY(dev_upload(m->allocs, &m->lna_w, p, D)); p += D;
     TRY(dev_upload(m->allocs, &m->lna_b, p, D)); p += D;
     if (cfg->precision == PGMI_PREC_FP32) TRY(dev_upload(m->allocs, &m->hd_w, p, D * D));
-    else TRY(make_w16(m->allocs, p, D * D, cfg->precision, m->stream, &m->hd16));
+    else TRY(make_w16(m->allocs, p, D * D, D, cfg->precision, m->stream, &m->hd16));
     p += D * D;
     TRY(dev_upload(m->allocs, &m->hd_b, p, D)); p += D;
     TRY(dev_upload(m->allocs, &m->hln_w, p, D)); p += D;
@@ -870,7 +870,7 @@ int pgmi_model_create(const pgmi_config* cfg, const float* w, int64_t n_weights,
         TRY(dev_alloc(m->allocs, &m->vt16, m->vt16_plane * 2));
         PGMI_HIP(hipMemset(m->vt16, 0, m->vt16_plane * 2 * sizeof(unsigned short)));
     }
-    m->gemm_variant = env_int("PGMI_GEMM_VARIANT", 7);   // 256x256 tile, 8 waves, ping-pong schedule (fastest measured)
+    m->gemm_variant = env_int("PGMI_GEMM_VARIANT", 0);   // tuning only; 0 = persistent ping-pong kernel, register staging, K-sliced tail
     if (cfg->arch == PGMI_ARCH_MSA) {
         TRY(dev_alloc(m->allocs, &m->xt, R * D));
         TRY(dev_alloc(m->allocs, &m->msa_kv_len, (size_t)2048));
@@ -1373,12 +1373,12 @@ int pgmi_op_gemm(int device, int precision, const float* A, const float* W, cons
         const int planes = bf ? 1 : 2;
         W16 w16;
         unsigned short* a16 = nullptr;
-        rc = make_w16(pool, W, (size_t)N * K, precision, nullptr, &w16);
+        rc = make_w16(pool, W, (size_t)N * K, (size_t)K, precision, nullptr, &w16);
         if (!rc) rc = dev_alloc(pool, &a16, (size_t)M * K * planes);
         if (!rc) {
-            launch_split16(dA, (int64_t)M * K, 1.0f, bf ? 1 : 2, a16, (size_t)M * K, nullptr);
+            launch_split16(dA, (int64_t)M * K, 1.0f, bf ? 1 : 2, K, a16, nullptr);
             rc = launch_gemm16(a16, (size_t)M * K, w16.p, w16.plane, dB, dR, dC, nullptr, 0, M, N, K, epilogue,
-                               w16.out_scale, planes, bf, env_int("PGMI_GEMM_VARIANT", 7), nullptr);
+                               w16.out_scale, planes, bf, env_int("PGMI_GEMM_VARIANT", 0), nullptr);
         }
     }
     hipError_t e = hipMemcpy(C, dC, (size_t)M * N * 4, hipMemcpyDeviceToHost);
@@ -1491,9 +1491,9 @@ int pgmi_bench_gemm_ab(int device, int precision, int M, int N, int K, int epilo
     if (f32) {
         if ((rc = dev_upload(pool, &dW, hW.data(), hW.size())) || (rc = dev_alloc(pool, &dC, (size_t)M * N))) { cleanup(); return rc; }
     } else {
-        if ((rc = make_w16(pool, hW.data(), hW.size(), precision, nullptr, &w16)) ||
+        if ((rc = make_w16(pool, hW.data(), hW.size(), (size_t)K, precision, nullptr, &w16)) ||
             (rc = dev_alloc(pool, &a16, (size_t)M * K * planes))) { cleanup(); return rc; }
-        launch_split16(dA, (int64_t)M * K, 1.0f, bf ? 1 : 2, a16, (size_t)M * K, nullptr);
+        launch_split16(dA, (int64_t)M * K, 1.0f, bf ? 1 : 2, K, a16, nullptr);
         if (split_out) rc = dev_alloc(pool, &c16, (size_t)M * N * planes);
         else rc = dev_alloc(pool, &dC, (size_t)M * N);
         if (rc) { cleanup(); return rc; }
@@ -1504,10 +1504,10 @@ int pgmi_bench_gemm_ab(int device, int precision, int M, int N, int K, int epilo
                              split_out ? c16 : nullptr, (size_t)M * N, M, N, K, epilogue, w16.out_scale, planes, bf, var, nullptr);
     };
     std::vector<std::vector<double>> samples(n_variants);
-    for (int v = 0; v < n_variants && !rc; ++v) rc = run(variants[v] >= 0 ? variants[v] : env_int("PGMI_GEMM_VARIANT", 7));   // warm-up
+    for (int v = 0; v < n_variants && !rc; ++v) rc = run(variants[v] >= 0 ? variants[v] : env_int("PGMI_GEMM_VARIANT", 0));   // warm-up
     for (int r = 0; r < rounds && !rc; ++r)
         for (int v = 0; v < n_variants && !rc; ++v) {              // interleaved rounds: variants see the same clocks / temperature
-            const int var = variants[v] >= 0 ? variants[v] : env_int("PGMI_GEMM_VARIANT", 7);
+            const int var = variants[v] >= 0 ? variants[v] : env_int("PGMI_GEMM_VARIANT", 0);
             hipEventRecord(e0, nullptr);
             for (int i = 0; i < iters && !rc; ++i) rc = run(var);
             hipEventRecord(e1, nullptr);

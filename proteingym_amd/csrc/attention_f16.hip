@@ -247,8 +247,10 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_kernel(
                         _Float16 hh[4], ll[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) split_act(val[e], hh[e], ll[e]);
-                        *reinterpret_cast<u32x2*>(ctx16 + oo) = u32x2{pack_h2(hh[0], hh[1]), pack_h2(hh[2], hh[3])};
-                        *reinterpret_cast<u32x2*>(ctx16 + plane + oo) = u32x2{pack_h2(ll[0], ll[1]), pack_h2(ll[2], ll[3])};
+                        // K-interleaved GEMM operand (common.h ki_off): column h*64 + dt*32 + 8g + 4kh of a row of D
+                        unsigned short* dst = ctx16 + ((size_t)b * T + q0 + r) * (size_t)(2 * D) + (size_t)(2 * h + dt) * 64 + 8 * g + 4 * kh;
+                        *reinterpret_cast<u32x2*>(dst) = u32x2{pack_h2(hh[0], hh[1]), pack_h2(hh[2], hh[3])};
+                        *reinterpret_cast<u32x2*>(dst + 32) = u32x2{pack_h2(ll[0], ll[1]), pack_h2(ll[2], ll[3])};
                     }
                 }
         }
@@ -667,8 +669,10 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
                         _Float16 hh[4], ll[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) split_act(val[e], hh[e], ll[e]);
-                        *reinterpret_cast<u32x2*>(ctx16 + oo) = u32x2{pack_h2(hh[0], hh[1]), pack_h2(hh[2], hh[3])};
-                        *reinterpret_cast<u32x2*>(ctx16 + plane + oo) = u32x2{pack_h2(ll[0], ll[1]), pack_h2(ll[2], ll[3])};
+                        // K-interleaved GEMM operand (common.h ki_off): column h*64 + dt*32 + 8g + 4kh of a row of D
+                        unsigned short* dst = ctx16 + ((size_t)b * T + q0 + r) * (size_t)(2 * D) + (size_t)(2 * h + dt) * 64 + 8 * g + 4 * kh;
+                        *reinterpret_cast<u32x2*>(dst) = u32x2{pack_h2(hh[0], hh[1]), pack_h2(hh[2], hh[3])};
+                        *reinterpret_cast<u32x2*>(dst + 32) = u32x2{pack_h2(ll[0], ll[1]), pack_h2(ll[2], ll[3])};
                     }
                 }
         }

@@ -181,8 +181,10 @@ __global__ __launch_bounds__(WPB * 64) void attention_f32_kernel(
                             hi[e] = a;
                             lo[e] = b2;
                         }
-                        *reinterpret_cast<h4*>(ctx16 + oo) = hi;
-                        *reinterpret_cast<h4*>(ctx16 + plane + oo) = lo;
+                        // K-interleaved GEMM operand (common.h ki_off): column h*64 + dt*32 + 8g + 4kh of a row of D
+                        unsigned short* dst = ctx16 + ((size_t)b * T + q0 + r) * (size_t)(2 * D) + (size_t)(2 * h + dt) * 64 + 8 * g + 4 * kh;
+                        *reinterpret_cast<h4*>(dst) = hi;
+                        *reinterpret_cast<h4*>(dst + 32) = lo;
                     } else {                              // bf16
                         typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
                         unsigned short bb[4];

@@ -34,6 +34,13 @@ enum Epilogue { EPI_NONE = 0, EPI_GELU = 1, EPI_SQRELU = 2 };   // erf-GELU (ESM
 // subnormal ever reaches the MFMA inputs.  The GEMM multiplies lo by (w_hi * 2^-11), which is
 // exact because weights are pre-scaled to ~2^13.
 constexpr float kLoScale = 2048.0f;
+
+// K-interleaved layout of an f16x3 GEMM operand [rows][K] (K % 32 == 0): every group of 32 consecutive k is stored as the
+// 32 hi halfs (64 B) followed by the 32 lo halfs (64 B), so a row's share of a 32-deep K tile is ONE 128-byte line.
+// Returns the half index of the hi value of (row, k); its lo value sits 32 halfs further.  Row pitch: 2 K halfs.
+__host__ __device__ __forceinline__ size_t ki_off(size_t row, int k, int K) {
+    return row * (size_t)(2 * K) + (size_t)(k >> 5) * 64 + (size_t)(k & 31);
+}
 #if defined(__HIPCC__)
 __device__ __forceinline__ void split_act(float x, _Float16& hi, _Float16& lo) {
     hi = (fabsf(x) < 6.103515625e-05f) ? (_Float16)0.0f : (_Float16)x;
@@ -118,8 +125,9 @@ int launch_gemm16_qkv(const unsigned short* A, size_t a_plane, const unsigned sh
                       const float* bias, int M, int D, int K, float out_scale, unsigned short* qk16, size_t qk_plane,
                       unsigned short* vt16, size_t vt_plane, const float* cos_t, const float* sin_t, int rotary,
                       int T, int H, int variant, hipStream_t s);
-void launch_split16(const float* x, int64_t n, float scale, int mode, unsigned short* out, size_t plane,
-                    hipStream_t s);
+// x [n/K rows][K] fp32 -> mode 0: f16x3 weight (hi/lo of x*scale), 1: bf16 plane, 2: f16x3 activation split; the
+// f16x3 forms are written K-interleaved (ki_off)
+void launch_split16(const float* x, int64_t n, float scale, int mode, int K, unsigned short* out, hipStream_t s);
 
 // ---- attention_f32.hip -------------------------------------------------------------------
 // qkv [B*T, 3*H*64] (q pre-scaled by 1/8); kv_len[b] (nullable) = valid keys.  Output: ctx fp32

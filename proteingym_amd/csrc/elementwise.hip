@@ -139,7 +139,7 @@ void launch_zero_pad_rows(const int32_t* tokens, int rows, int D, float* x, hipS
 // ---- LayerNorm (torch.nn.LayerNorm, modules.py:80-81): biased variance, eps inside sqrt ----
 // One wave per row, the row held in registers (D <= 64*4*NV), two-pass mean / variance.
 // Algorithmic bytes: 2*D*4 per row (read + write); HBM-bound.
-// OUTMODE 0: fp32 y;  1: fp16 hi/lo planes (f16x3 GEMM operand);  2: bf16 plane
+// OUTMODE 0: fp32 y;  1: fp16 hi/lo, K-interleaved (f16x3 GEMM operand; `plane` unused);  2: bf16 plane
 template <int NV, int OUTMODE>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* x,   // may alias y (in place)
                                                         const float* __restrict__ w,
@@ -195,8 +195,9 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x,   // may
                     hi[k] = a;
                     lo[k] = b2;
                 }
-                reinterpret_cast<h4*>(y16 + (size_t)row * D)[c] = hi;
-                reinterpret_cast<h4*>(y16 + plane + (size_t)row * D)[c] = lo;
+                unsigned short* dst = y16 + ki_off((size_t)row, 4 * c, D);      // K-interleaved GEMM operand (common.h)
+                *reinterpret_cast<h4*>(dst) = hi;
+                *reinterpret_cast<h4*>(dst + 32) = lo;
             } else {
                 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
                 unsigned short b[4];

@@ -1,30 +1,26 @@
-// Split-precision GEMM on the 16-bit matrix cores: C = epi(A W^T * 2^-s + bias) (+ residual).
+// GEMMs on the 16-bit matrix cores: C = epi(A W^T * 2^-s + bias) (+ residual).
 //
-// Replaces nn.Linear on the ESM hot path (modules.py:134-140, multihead_attention.py:258-261,
-// 394) in the f16x3 and bf16 modes.
+// Replaces nn.Linear on the ESM hot path (modules.py:134-140, multihead_attention.py:258-261, 394) in the f16x3
+// (default, parity-gated) and bf16 (throughput, not parity-gated) modes.
 //
-// f16x3 (PLANES = 2): every fp32 operand x is carried as two fp16 planes, hi = fp16(x) and a
-// low part (weights: lo = fp16(x - hi); activations: lo = fp16((x - hi) 2^11), common.h
-// split_act); the kernel accumulates  a_hi w_hi + a_hi w_lo + (a_lo 2^11)(w_hi 2^-11)  in the fp32
-// MFMA accumulator (the dropped a_lo w_lo term is 2^-22 relative).  fp16 x fp16 products are
-// exact in fp32, so the result has ~22 mantissa bits -- measured fp32-class on the full
-// 33-layer model (1.9e-5 vs 2.5e-5 for fp32 itself against fp64) -- at 3 MFMAs of
-// the 2.5 PFLOP/s pipe per product block instead of 1 MFMA of the 157 TFLOP/s fp32 pipe.
-// Weights are pre-scaled by a per-tensor power of two 2^s (exact) so that their lo plane stays
-// in fp16's normal range; 2^-s is applied in the epilogue.  Activations arrive already split
-// (the producing LayerNorm / GELU / attention epilogue writes the two planes: same 4 bytes
-// per element as fp32).
-// bf16 (PLANES = 1): plain bf16 operands, one MFMA per block (throughput mode, not parity-gated).
+// f16x3: every fp32 operand x is carried as two fp16 planes, hi = fp16(x) and a low part (weights:
+// lo = fp16(x - hi); activations: lo = fp16((x - hi) 2^11), common.h split_act); the kernel accumulates
+//     a_hi w_hi + a_hi w_lo + (a_lo 2^11)(w_hi 2^-11)
+// in the fp32 MFMA accumulator (the dropped a_lo w_lo term is 2^-22 relative).  fp16 x fp16 products are exact in
+// fp32, so the result has ~22 mantissa bits -- measured fp32-class on the full 33- and 36-layer models --
+// at 3 MFMAs of the 2.5 PFLOP/s pipe per product block instead of 1 MFMA of the 157 TFLOP/s fp32 pipe.  Weights are
+// pre-scaled by a per-tensor power of two 2^s (exact) so that their lo plane stays in fp16's normal range; 2^-s is
+// applied in the epilogue.  Activations arrive already split (the producing LayerNorm / GELU / attention epilogue
+// writes both planes: the same 4 bytes per element as fp32).
 //
-// Tiling (wave64): workgroup (WM*TM*32) x (WN*TN*32) x BK, WM*WN waves, each wave TM x TN MFMA
-// tiles of 32x32 (v_mfma_f32_32x32x16_{f16,bf16}).  Operands are swapped (MFMA "A" = weight
-// rows, "B" = activation rows) so that the accumulator puts 4 consecutive output columns in a
-// lane: epilogue loads/stores are 8/16-byte vectors.  LDS tiles are K-contiguous rows of BK
-// elements with an XOR swizzle on the 16-byte chunk index (conflict-free ds_read_b128 for the
-// 16-lane groups), double buffered, global->VGPR->LDS staging with the loads of tile t+1 in
-// flight during the MFMAs of tile t; one barrier per K tile.
-// Roofline: MFMA-bound; peak 2.5 PFLOP/s of 16-bit MFMA = 833 TFLOP/s of fp32-equivalent
-// algorithmic FLOPs in f16x3.
+// Operand layout in HBM ("K-interleaved planes", common.h ki_off): a row of K elements is stored as K/32 groups of
+// 128 bytes = 32 hi halfs followed by the 32 lo halfs of the same k.  One row's share of a 32-deep K tile is then ONE
+// full 128-byte line: 8 consecutive lanes fetch it with one dwordx4 each.  With two separate planes (round 1) the same
+// data was two 64-byte half lines, every line was requested twice (the other half one K tile later, long evicted from
+// the 32 KB L1) and the texture-address unit handled twice the lines: measured with the phase-timing instantiation,
+// 288 -> 325 TFLOP/s on the FC2 shape from the access pattern alone.
+//
+// Roofline: MFMA-bound; peak 2.5 PFLOP/s of 16-bit MFMA = 833 TFLOP/s of fp32-equivalent algorithmic FLOPs in f16x3.
 #include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>
@@ -60,14 +56,15 @@ __device__ __forceinline__ float gelu_erf16(float x) {
     return fmaf(-0.5f * ax, t * q * e, fmaxf(x, 0.0f));
 }
 
+// Attention operands straight from the fused QKV projection (OUT 2): q|k as split planes qk16 [2][M][2D] (ESM2 rotary
+// applied here, rotary_embedding.py:11-20), v as the transposed, key-permuted planes vt16 [2][B*H*64][Tp] that
+// attention_f16.hip consumes.
 struct QkvOut {
     unsigned short* vt16;
     size_t vt_plane;
     const float* cos_t;
     const float* sin_t;
     int T, H, Tp, rotary;
-    int dbg_row_mod;      // tuning experiments only: wrap activation rows (keeps the A operand cache-resident)
-    int dbg_flags;        // tuning experiments only: 1 = skip global->LDS staging after tile 0, 2 = also skip ds_reads
 };
 
 template <bool BF>
@@ -85,26 +82,23 @@ __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
     return (unsigned short)(u >> 16);
 }
 
-// OUT: 0 = fp32 [M,N];  1 = 16-bit planes [PLANES][M,N] (split for f16x3, bf16 for PLANES==1);
-//      2 = attention operands straight from the fused QKV projection (f16x3 only): q|k as split
-//          planes qk16 [2][M][2D] (ESM2 rotary applied here, rotary_embedding.py:11-20), v as the
-//          transposed, key-permuted planes vt16 [2][B*H*64][Tp] that attention_f16.hip consumes.
-// PP = "ping-pong" schedule (8-wave tiles only): the two waves that share a SIMD run half a K-substep
-// out of phase, separated by workgroup barriers, so that one is always in its MFMA phase while the other
-// does its LDS fragment reads / global->LDS staging.  Without it both waves leave the tile barrier
-// together, read fragments together (matrix pipe idle) and then compete for the pipe.
-template <int WM, int WN, int TM, int TN, int BK, int PLANES, bool BF, int EPI, int OUT, int PP = 0>
-__global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 2) void gemm16_kernel(
-    const unsigned short* __restrict__ A, size_t a_plane, const unsigned short* __restrict__ W,
-    size_t w_plane, const float* __restrict__ bias, const float* residual, float* Cf,
-    unsigned short* Ch, size_t c_plane, int M, int N, int K, float out_scale, int tiles_m, int tiles_n,
-    QkvOut qo) {
+// ---- bf16 (throughput mode, NOT parity-gated): plain bf16 operands, one MFMA per product block ----------------------
+// Tiling (wave64): workgroup (WM*TM*32) x (WN*TN*32) x 32, WM*WN waves, each wave TM x TN MFMA tiles of 32x32
+// (v_mfma_f32_32x32x16_bf16).  Operands are swapped (MFMA "A" = weight rows, "B" = activation rows) so that the
+// accumulator puts 4 consecutive output columns in a lane: epilogue loads/stores are 8/16-byte vectors.  LDS tiles are
+// K-contiguous 64-byte rows with an XOR swizzle on the 16-byte chunk (conflict-free ds_read_b128), double buffered,
+// global -> VGPR -> LDS staging with the loads of tile t+1 in flight during the MFMAs of tile t; one barrier per K tile.
+// OUT: 0 = fp32 [M,N]; 1 = one bf16 plane [M,N].
+template <int WM, int WN, int TM, int TN, int EPI, int OUT>
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(
+    const unsigned short* __restrict__ A, const unsigned short* __restrict__ W, const float* __restrict__ bias,
+    const float* residual, float* Cf, unsigned short* Ch, int M, int N, int K, int tiles_m, int tiles_n) {
+    constexpr int BK = 32, CPR = 4;
     constexpr int NT = WM * WN * 64;
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int CPR = BK / 8;                                  // 16-byte chunks per row
-    constexpr int A_CH = BM * CPR * PLANES, W_CH = BN * CPR * PLANES;
+    constexpr int A_CH = BM * CPR, W_CH = BN * CPR;
     constexpr int A_LD = (A_CH + NT - 1) / NT, W_LD = (W_CH + NT - 1) / NT;
-    constexpr int STAGE = (BM + BN) * CPR * PLANES;              // chunks per stage
+    constexpr int STAGE = A_CH + W_CH;
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];  // [2][STAGE]
 
     // XCD-aware grouped tile order (see gemm_f32.hip)
@@ -121,32 +115,22 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 2) void gemm16_k
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, kh = lane >> 5;
+    auto swz = [](int row, int c) -> int { return c ^ ((row >> 2) & 3); };
 
-    auto swz = [](int row, int c) -> int {
-        return (CPR == 4) ? (c ^ ((row >> 2) & 3)) : (c ^ ((row >> 1) & (CPR - 1)));
-    };
-
-    // ---- staging maps -------------------------------------------------------------------
     const u32x4* a_src[A_LD];
     const u32x4* w_src[W_LD];
     int a_dst[A_LD], w_dst[W_LD];
 #pragma unroll
     for (int i = 0; i < A_LD; ++i) {
-        const int f = tid + NT * i;
-        const int p = f / (BM * CPR), g = f % (BM * CPR), row = g / CPR, c = g % CPR;
-        int am = min(m0 + row, M - 1);
-        if (qo.dbg_row_mod) am %= qo.dbg_row_mod;
-        // PP == 2 (direct-to-LDS): the DMA destination is lane-linear (slot f), so the swizzle picks the SOURCE chunk
-        a_src[i] = reinterpret_cast<const u32x4*>(A + (size_t)p * a_plane + (size_t)am * K) + (PP == 2 ? swz(row, c) : c);
-        a_dst[i] = (p * BM + row) * CPR + swz(row, c);
+        const int f = tid + NT * i, row = (f % A_CH) / CPR, c = f % CPR;
+        a_src[i] = reinterpret_cast<const u32x4*>(A + (size_t)min(m0 + row, M - 1) * K) + c;
+        a_dst[i] = row * CPR + swz(row, c);
     }
 #pragma unroll
     for (int i = 0; i < W_LD; ++i) {
-        const int f = tid + NT * i;
-        const int p = f / (BN * CPR), g = f % (BN * CPR), row = g / CPR, c = g % CPR;
-        const int wr = min(n0 + row, N - 1);
-        w_src[i] = reinterpret_cast<const u32x4*>(W + (size_t)p * w_plane + (size_t)wr * K) + (PP == 2 ? swz(row, c) : c);
-        w_dst[i] = A_CH + (p * BN + row) * CPR + swz(row, c);
+        const int f = tid + NT * i, row = (f % W_CH) / CPR, c = f % CPR;
+        w_src[i] = reinterpret_cast<const u32x4*>(W + (size_t)min(n0 + row, N - 1) * K) + c;
+        w_dst[i] = A_CH + row * CPR + swz(row, c);
     }
     u32x4 a_st[A_LD], w_st[W_LD];
     auto stage_load = [&](int kt) {
@@ -166,25 +150,8 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 2) void gemm16_k
         for (int i = 0; i < W_LD; ++i)
             if (W_CH % NT == 0 || tid + NT * i < W_CH) base[w_dst[i]] = w_st[i];
     };
-
-    auto issue_tile = [&](int kt, int buf) {                     // PP == 2: global -> LDS DMA, 1 KiB per wave-instruction
-        u32x4* base = lds + buf * STAGE + wave * 64;             // wave-uniform; the DMA adds lane * 16 B
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + kt * CPR),
-                                             (__attribute__((address_space(3))) void*)(base + NT * i), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < W_LD; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + kt * CPR),
-                                             (__attribute__((address_space(3))) void*)(base + A_CH + NT * i), 16, 0, 0);
-    };
-    if constexpr (PP == 2) {
-        static_assert(A_CH % NT == 0 && W_CH % NT == 0, "tile must split evenly over the waves");
-        issue_tile(0, 0);
-    } else {
-        stage_load(0);
-        stage_store(0);
-    }
+    stage_load(0);
+    stage_store(0);
     __syncthreads();
 
     f32x16 acc[TN][TM];
@@ -197,260 +164,39 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 2) void gemm16_k
 
     const int nk = K / BK;
     int cur = 0;
-    const bool dbg_nostage = qo.dbg_flags & 1, dbg_noread = qo.dbg_flags & 2;
-    u32x4 af[PLANES][TM], wf[PLANES][TN];
-    if constexpr (PP != 0) {
-        static_assert(PLANES == 2 && BK == 32 && WM * WN == 8, "ping-pong schedule: f16x3, BK 32, 8 waves");
-        u32x4 whs[TN];
-        auto read_frags = [&](const u32x4* Ab, const u32x4* Wb, int ks) {
-            const int c = ks * 2 + kh;
-#pragma unroll
-            for (int p = 0; p < PLANES; ++p) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int row = (wm * TM + i) * 32 + r;
-                    af[p][i] = Ab[(p * BM + row) * CPR + swz(row, c)];
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int row = (wn * TN + j) * 32 + r;
-                    wf[p][j] = Wb[(p * BN + row) * CPR + swz(row, c)];
-                }
-            }
-        };
-        auto scale_whi = [&]() {
-            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-            const h2 sc = {(_Float16)(1.0f / kLoScale), (_Float16)(1.0f / kLoScale)};
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const unsigned int u = wf[0][j][e];
-                    const h2 t = __builtin_bit_cast(h2, u) * sc;
-                    whs[j][e] = __builtin_bit_cast(unsigned int, t);
-                }
-        };
-        auto mfmas = [&]() {
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    acc[j][i] = mfma16<BF>(wf[1][j], af[0][i], acc[j][i]);
-                    acc[j][i] = mfma16<BF>(whs[j], af[1][i], acc[j][i]);
-                    acc[j][i] = mfma16<BF>(wf[0][j], af[0][i], acc[j][i]);
-                }
-        };
-        // phase boundary: everything issued before stays before, LDS traffic of this wave has landed
-        auto phase = [&]() {
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0); vmcnt / expcnt untouched
-            __builtin_amdgcn_s_barrier();
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        const bool late = wave >= (WM * WN) / 2;            // waves 4..7: the second wave of every SIMD
-        const bool pp_noprio = qo.dbg_flags & 16, pp_early_g = qo.dbg_flags & 32;
-        if (PP == 1 && nk > 1) stage_load(1);
-        if (late) phase();
-        for (int kt = 0; kt < nk; ++kt) {
-            const u32x4* Ab = lds + cur * STAGE;
-            const u32x4* Wb = Ab + A_CH;
-            // -- memory phase 1 --
-            __builtin_amdgcn_s_setprio(0);
-            if (PP == 1 && pp_early_g && kt > 0 && kt + 1 < nk) stage_load(kt + 1);
-            if (!(dbg_noread && kt > 0)) { read_frags(Ab, Wb, 0); scale_whi(); }
-            if (PP == 2 && kt + 1 < nk && !dbg_nostage) issue_tile(kt + 1, cur ^ 1);   // the other buffer was last read two phases ago
-            phase();
-            // -- compute phase 1 --
-            if (!pp_noprio) __builtin_amdgcn_s_setprio(1);
-            mfmas();
-            phase();
-            // -- memory phase 2: fragments of the second substep, tile kt+1 into the other buffer, loads of kt+2 --
-            __builtin_amdgcn_s_setprio(0);
-            if (!(dbg_noread && kt > 0)) { read_frags(Ab, Wb, 1); scale_whi(); }
-            if (PP == 2) {
-                __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): this wave's share of tile kt+1 has landed
-            } else if (kt + 1 < nk && !dbg_nostage) {
-                __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0); lgkmcnt / expcnt untouched
-                if (!(qo.dbg_flags & 4)) stage_store(cur ^ 1);
-                if (!pp_early_g && kt + 2 < nk && !(qo.dbg_flags & 8)) stage_load(kt + 2);
-            }
-            phase();
-            // -- compute phase 2 --
-            if (!pp_noprio) __builtin_amdgcn_s_setprio(1);
-            mfmas();
-            phase();
-            cur ^= 1;
-        }
-        __builtin_amdgcn_s_setprio(0);
-        if (!late) phase();
-    } else
     for (int kt = 0; kt < nk; ++kt) {
-        const bool more = (kt + 1 < nk) && !dbg_nostage;
-        if (more && !(qo.dbg_flags & 8)) stage_load(kt + 1);
+        const bool more = kt + 1 < nk;
+        if (more) stage_load(kt + 1);
         const u32x4* Ab = lds + cur * STAGE;
         const u32x4* Wb = Ab + A_CH;
 #pragma unroll
         for (int ks = 0; ks < BK / 16; ++ks) {
             const int c = ks * 2 + kh;
-            if (!(dbg_noread && kt > 0))
+            u32x4 af[TM], wf[TN];
 #pragma unroll
-            for (int p = 0; p < PLANES; ++p) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int row = (wm * TM + i) * 32 + r;
-                    af[p][i] = Ab[(p * BM + row) * CPR + swz(row, c)];
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int row = (wn * TN + j) * 32 + r;
-                    wf[p][j] = Wb[(p * BN + row) * CPR + swz(row, c)];
-                }
+            for (int i = 0; i < TM; ++i) {
+                const int row = (wm * TM + i) * 32 + r;
+                af[i] = Ab[row * CPR + swz(row, c)];
             }
-            u32x4 whs[TN];
-            if constexpr (PLANES == 2) {                // w_hi * 2^-11: exact (weights are scaled to ~2^13)
-                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-                const h2 sc = {(_Float16)(1.0f / kLoScale), (_Float16)(1.0f / kLoScale)};
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const unsigned int u = wf[0][j][e];   // (bit_cast straight from a vector-element
-                        const h2 t = __builtin_bit_cast(h2, u) * sc;   //  lvalue reads element 0: keep the copy)
-                        whs[j][e] = __builtin_bit_cast(unsigned int, t);
-                    }
+            for (int j = 0; j < TN; ++j) {
+                const int row = (wn * TN + j) * 32 + r;
+                wf[j] = Wb[row * CPR + swz(row, c)];
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    if constexpr (PLANES == 2) {        // small terms first, then the main product
-                        acc[j][i] = mfma16<BF>(wf[1][j], af[0][i], acc[j][i]);     // w_lo * a_hi
-                        acc[j][i] = mfma16<BF>(whs[j], af[1][i], acc[j][i]);       // (w_hi 2^-11) * (a_lo 2^11)
-                    }
-                    acc[j][i] = mfma16<BF>(wf[0][j], af[0][i], acc[j][i]);
-                }
+                for (int i = 0; i < TM; ++i) acc[j][i] = mfma16<true>(wf[j], af[i], acc[j][i]);
         }
-        if (more && !(qo.dbg_flags & 4)) stage_store(cur ^ 1);
+        if (more) stage_store(cur ^ 1);
         __syncthreads();
-        if (!dbg_nostage && !(qo.dbg_flags & 12)) cur ^= 1;
-    }
-
-    if constexpr (OUT == 2) {
-        static_assert(TN == 2 && PLANES == 2 && !BF, "QKV attention-operand epilogue needs one head (64 columns) per wave");
-        const int Dm = N / 3;
-        const int nb = n0 + wn * 64;                       // first column of this wave's head
-        if (nb >= N) return;
-        const int which = nb / Dm, hcol = nb - which * Dm, hh = hcol >> 6;
-        // q|k rows leave through the same per-wave LDS transpose as the split-plane epilogue below (one head =
-        // 64 columns = one 128-byte segment per row); V^T is already written as 64-byte runs along the key axis.
-        constexpr int SPQ = 144;
-        unsigned char* patch_q = reinterpret_cast<unsigned char*>(lds) + wave * (2 * 32 * SPQ);
-        const bool staged_q = which < 2 && !(qo.dbg_flags & 128);
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + (wm * TM + i) * 32 + r;
-            const bool row_ok = m < M;
-            if (!staged_q && !row_ok) continue;
-            const int bb = m / qo.T, t = m - bb * qo.T;
-            if (row_ok)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int d0 = 8 * g + 4 * kh;             // dims d0..d0+3 (x0) and d0+32.. (x1) of the head
-                const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + nb + d0);
-                const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + nb + 32 + d0);
-                float x0[4], x1[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    x0[e] = acc[0][i][4 * g + e] * out_scale + b0[e];
-                    x1[e] = acc[1][i][4 * g + e] * out_scale + b1[e];
-                }
-                if (which < 2) {
-                    if (qo.rotary) {
-                        const f32x4 c1 = *reinterpret_cast<const f32x4*>(qo.cos_t + t * 64 + d0);
-                        const f32x4 s1 = *reinterpret_cast<const f32x4*>(qo.sin_t + t * 64 + d0);
-                        const f32x4 c2 = *reinterpret_cast<const f32x4*>(qo.cos_t + t * 64 + 32 + d0);
-                        const f32x4 s2 = *reinterpret_cast<const f32x4*>(qo.sin_t + t * 64 + 32 + d0);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const float y0 = x0[e] * c1[e] + (-x1[e]) * s1[e];
-                            const float y1 = x1[e] * c2[e] + x0[e] * s2[e];
-                            x0[e] = y0;
-                            x1[e] = y1;
-                        }
-                    }
-                    unsigned short* dst = Ch + (size_t)m * (2 * Dm) + (size_t)which * Dm + hcol + d0;
-                    h4 hi0, lo0, hi1, lo1;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        _Float16 a, b2;
-                        split_act(x0[e], a, b2); hi0[e] = a; lo0[e] = b2;
-                        split_act(x1[e], a, b2); hi1[e] = a; lo1[e] = b2;
-                    }
-                    if (staged_q) {
-                        unsigned char* cell = patch_q + r * SPQ + d0 * 2;
-                        *reinterpret_cast<h4*>(cell) = hi0;
-                        *reinterpret_cast<h4*>(cell + 32 * SPQ) = lo0;
-                        *reinterpret_cast<h4*>(cell + 64) = hi1;
-                        *reinterpret_cast<h4*>(cell + 32 * SPQ + 64) = lo1;
-                    } else {
-                        *reinterpret_cast<h4*>(dst) = hi0;
-                        *reinterpret_cast<h4*>(dst + c_plane) = lo0;
-                        *reinterpret_cast<h4*>(dst + 32) = hi1;
-                        *reinterpret_cast<h4*>(dst + c_plane + 32) = lo1;
-                    }
-                } else {
-                    const int tk = t & 31;
-                    const int pos = (t & ~31) + ((tk & 0x13) | ((tk & 4) << 1) | ((tk & 8) >> 1));   // swap key bits 2,3
-                    unsigned short* col = qo.vt16 + (((size_t)bb * qo.H + hh) * kHeadDim + d0) * qo.Tp + pos;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        _Float16 a0, l0, a1, l1;
-                        split_act(x0[e], a0, l0);
-                        split_act(x1[e], a1, l1);
-                        unsigned short* c0 = col + (size_t)e * qo.Tp;
-                        unsigned short* c1p = c0 + (size_t)32 * qo.Tp;
-                        c0[0] = __builtin_bit_cast(unsigned short, a0);
-                        c0[qo.vt_plane] = __builtin_bit_cast(unsigned short, l0);
-                        c1p[0] = __builtin_bit_cast(unsigned short, a1);
-                        c1p[qo.vt_plane] = __builtin_bit_cast(unsigned short, l1);
-                    }
-                }
-            }
-            if (staged_q) {
-                __builtin_amdgcn_wave_barrier();
-                const int m_base = m0 + (wm * TM + i) * 32;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int q = lane + 64 * k, row = q >> 3, cc = q & 7;
-                    const u32x4 vh = *reinterpret_cast<const u32x4*>(patch_q + row * SPQ + cc * 16);
-                    const u32x4 vl = *reinterpret_cast<const u32x4*>(patch_q + (32 + row) * SPQ + cc * 16);
-                    if (m_base + row < M) {
-                        unsigned short* dst = Ch + (size_t)(m_base + row) * (2 * Dm) + (size_t)which * Dm + hcol + cc * 8;
-                        *reinterpret_cast<u32x4*>(dst) = vh;
-                        *reinterpret_cast<u32x4*>(dst + c_plane) = vl;
-                    }
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-        }
-        return;
+        cur ^= 1;
     }
     // ---- epilogue: lane holds column m = m_base + r of C^T, rows n = (v&3) + 8(v>>2) + 4kh ----
-    // Split-plane output (OUT == 1): a lane owns 4 columns (8 bytes of fp16) of ONE row, so direct stores are 64
-    // scattered 8-byte pieces per instruction; measured, they cost 17 % of FC1 and 2.4x write amplification at the
-    // fabric (WRITE_SIZE 4.05 GB for 1.69 GB of output).  Instead each wave transposes its 32 x 64 block through a
-    // private LDS patch (the K-tile buffers are free after the last barrier of the main loop) and stores full
-    // 128-byte row segments, 16 bytes per lane.
-    constexpr int SP = 144;                                   // patch row pitch in bytes: 128 + 16 (keeps 16-byte alignment for the b128 reads)
-    constexpr bool kCanStage = (OUT == 1) && PLANES == 2 && !BF && TN == 2;
-    const bool staged = kCanStage && (N % 8 == 0) && (n0 + (wn * TN + TN) * 32 <= N) && !(qo.dbg_flags & 128);
-    unsigned char* patch = reinterpret_cast<unsigned char*>(lds) + wave * (2 * 32 * SP);
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int m = m0 + (wm * TM + i) * 32 + r;
-        const bool row_ok = m < M;
-        if (!staged && !row_ok) continue;
-        if (row_ok)
+        if (m >= M) continue;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
 #pragma unroll
@@ -461,9 +207,9 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 2) void gemm16_k
                 f32x4 val;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float t = acc[j][i][4 * g + e] * out_scale + bv[e];
+                    float t = acc[j][i][4 * g + e] + bv[e];
                     if (EPI == EPI_GELU) t = gelu_erf16(t);
-                    if (EPI == EPI_SQRELU) { t = fmaxf(t, 0.0f); t = t * t; }     // tranception/activations.py:79-84
+                    if (EPI == EPI_SQRELU) { t = fmaxf(t, 0.0f); t = t * t; }
                     val[e] = t;
                 }
                 const size_t o = (size_t)m * N + n;
@@ -474,280 +220,42 @@ __global__ __launch_bounds__(WM * WN * 64, (WM * WN >= 8) ? 2 : 2) void gemm16_k
                 }
                 if constexpr (OUT == 0) {
                     *reinterpret_cast<f32x4*>(Cf + o) = val;
-                } else if constexpr (BF) {
+                } else {
                     u32x2 pk;
                     pk[0] = f32_to_bf16_rne(val[0]) | ((unsigned)f32_to_bf16_rne(val[1]) << 16);
                     pk[1] = f32_to_bf16_rne(val[2]) | ((unsigned)f32_to_bf16_rne(val[3]) << 16);
                     *reinterpret_cast<u32x2*>(Ch + o) = pk;
-                } else {
-                    h4 hi, lo;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        _Float16 a, b;
-                        split_act(val[e], a, b);
-                        hi[e] = a;
-                        lo[e] = b;
-                    }
-                    if (kCanStage && staged) {
-                        unsigned char* cell = patch + r * SP + (j * 32 + 8 * g + 4 * kh) * 2;
-                        *reinterpret_cast<h4*>(cell) = hi;
-                        *reinterpret_cast<h4*>(cell + 32 * SP) = lo;
-                    } else {
-                        *reinterpret_cast<h4*>(Ch + o) = hi;
-                        if constexpr (PLANES == 2) *reinterpret_cast<h4*>(Ch + c_plane + o) = lo;
-                    }
-                }
-            }
-        }
-        if (kCanStage && staged) {
-            // LDS executes one wave's instructions in order: the reads below see this wave's writes above, and the
-            // next iteration's writes come after these reads; the wave barriers only pin the compiler's ordering
-            __builtin_amdgcn_wave_barrier();
-            const int m_base = m0 + (wm * TM + i) * 32;
-            const size_t ncol0 = (size_t)n0 + (size_t)wn * TN * 32;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int q = lane + 64 * k;                 // 16-byte chunk: row q/8, chunk q%8 of the 128-byte row
-                const int row = q >> 3, cc = q & 7;
-                const u32x4 vh = *reinterpret_cast<const u32x4*>(patch + row * SP + cc * 16);
-                const u32x4 vl = *reinterpret_cast<const u32x4*>(patch + (32 + row) * SP + cc * 16);
-                if (m_base + row < M) {
-                    unsigned short* dst = Ch + (size_t)(m_base + row) * N + ncol0 + cc * 8;
-                    *reinterpret_cast<u32x4*>(dst) = vh;
-                    *reinterpret_cast<u32x4*>(dst + c_plane) = vl;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-}
-
-
-// ---- pipelined variant: direct-to-LDS tile loads + fragment prefetch ---------------------------
-// Same tiling/epilogue as gemm16_kernel, different data movement:
-//  * K tiles go global -> LDS with global_load_lds_dwordx4 (1 KiB per wave-instruction, no VGPR
-//    staging, no ds_write pass); the XOR swizzle is applied to the per-lane SOURCE chunk because the
-//    LDS destination of a DMA is lane-linear;
-//  * 3-deep LDS ring: at the single barrier of iteration t (placed between the two k16 steps of
-//    tile t) tile t+1 has landed (every wave drained its own DMA before the barrier), tile t-1's
-//    buffer is free and is immediately re-filled with tile t+2;
-//  * MFMA operand fragments are double-buffered in registers: the ds_read_b128s of the next k16
-//    step (same tile, or the first step of tile t+1 right after the barrier) are issued before the
-//    MFMAs of the current step, so LDS latency hides behind the matrix pipe.
-template <int WM, int WN, int TM, int TN, int PLANES, bool BF, int EPI, int OUT>
-__global__ __launch_bounds__(WM * WN * 64, 2) void gemm16p_kernel(
-    const unsigned short* __restrict__ A, size_t a_plane, const unsigned short* __restrict__ W,
-    size_t w_plane, const float* __restrict__ bias, const float* residual, float* Cf,
-    unsigned short* Ch, size_t c_plane, int M, int N, int K, float out_scale, int tiles_m, int tiles_n) {
-    constexpr int BK = 32, CPR = 4, NSTAGE = 3;
-    constexpr int NT = WM * WN * 64;
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int A_CH = BM * CPR * PLANES, W_CH = BN * CPR * PLANES;
-    constexpr int STAGE = A_CH + W_CH;
-    static_assert(A_CH % NT == 0 && W_CH % NT == 0, "tile must split evenly over the waves");
-    constexpr int A_LD = A_CH / NT, W_LD = W_CH / NT;
-    extern __shared__ __attribute__((aligned(16))) u32x4 lds[];  // [NSTAGE][STAGE]
-
-    const int nwg = gridDim.x, bid = blockIdx.x;
-    const int xcd = bid & 7, q = nwg >> 3, r8 = nwg & 7;
-    const int wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (bid >> 3);
-    constexpr int GROUP_M = 8;
-    const int width = GROUP_M * tiles_n;
-    const int group = wgid / width, first_m = group * GROUP_M;
-    const int gsz = min(tiles_m - first_m, GROUP_M);
-    const int tm = first_m + (wgid % width) % gsz, tn = (wgid % width) / gsz;
-    const int m0 = tm * BM, n0 = tn * BN;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN;
-    const int r = lane & 31, kh = lane >> 5;
-
-    // ---- DMA maps: LDS slot (tid + NT*i) <- global chunk (row, c' ^ swizzle(row)) -------------
-    const u32x4* a_src[A_LD];
-    const u32x4* w_src[W_LD];
-#pragma unroll
-    for (int i = 0; i < A_LD; ++i) {
-        const int f = tid + NT * i;
-        const int p = f / (BM * CPR), g = f % (BM * CPR), row = g / CPR, cs = g % CPR;
-        const int c = cs ^ ((row >> 2) & 3);
-        const int am = min(m0 + row, M - 1);
-        a_src[i] = reinterpret_cast<const u32x4*>(A + (size_t)p * a_plane + (size_t)am * K) + c;
-    }
-#pragma unroll
-    for (int i = 0; i < W_LD; ++i) {
-        const int f = tid + NT * i;
-        const int p = f / (BN * CPR), g = f % (BN * CPR), row = g / CPR, cs = g % CPR;
-        const int c = cs ^ ((row >> 2) & 3);
-        const int wr = min(n0 + row, N - 1);
-        w_src[i] = reinterpret_cast<const u32x4*>(W + (size_t)p * w_plane + (size_t)wr * K) + c;
-    }
-    auto issue_tile = [&](int kt, int buf) {
-        u32x4* base = lds + buf * STAGE + wave * 64;          // wave-uniform; the DMA adds lane*16 B
-#pragma unroll
-        for (int i = 0; i < A_LD; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + kt * CPR),
-                                             (__attribute__((address_space(3))) void*)(base + NT * i), 16, 0, 0);
-#pragma unroll
-        for (int i = 0; i < W_LD; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w_src[i] + kt * CPR),
-                                             (__attribute__((address_space(3))) void*)(base + A_CH + NT * i), 16, 0, 0);
-    };
-
-    // fragment addressing: row-dependent part is loop-invariant
-    int a_off[TM], w_off[TN], a_sw[TM], w_sw[TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int row = (wm * TM + i) * 32 + r;
-        a_off[i] = row * CPR;
-        a_sw[i] = (row >> 2) & 3;
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int row = (wn * TN + j) * 32 + r;
-        w_off[j] = A_CH + row * CPR;
-        w_sw[j] = (row >> 2) & 3;
-    }
-    auto load_frags = [&](u32x4 (&af)[PLANES][TM], u32x4 (&wf)[PLANES][TN], int buf, int ks) {
-        const u32x4* Sb = lds + buf * STAGE;
-        const int c = ks * 2 + kh;
-#pragma unroll
-        for (int p = 0; p < PLANES; ++p) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[p][i] = Sb[p * BM * CPR + a_off[i] + (c ^ a_sw[i])];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) wf[p][j] = Sb[p * BN * CPR + w_off[j] + (c ^ w_sw[j])];
-        }
-    };
-
-    f32x16 acc[TN][TM];
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) acc[j][i][v] = 0.0f;
-
-    auto mma_step = [&](const u32x4 (&af)[PLANES][TM], const u32x4 (&wf)[PLANES][TN]) {
-        u32x4 whs[TN];
-        if constexpr (PLANES == 2) {
-            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-            const h2 sc = {(_Float16)(1.0f / kLoScale), (_Float16)(1.0f / kLoScale)};
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const unsigned int u = wf[0][j][e];
-                    const h2 t = __builtin_bit_cast(h2, u) * sc;
-                    whs[j][e] = __builtin_bit_cast(unsigned int, t);
-                }
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                if constexpr (PLANES == 2) {
-                    acc[j][i] = mfma16<BF>(wf[1][j], af[0][i], acc[j][i]);
-                    acc[j][i] = mfma16<BF>(whs[j], af[1][i], acc[j][i]);
-                }
-                acc[j][i] = mfma16<BF>(wf[0][j], af[0][i], acc[j][i]);
-            }
-    };
-
-    const int nk = K / BK;
-    issue_tile(0, 0);
-    __syncthreads();                       // drains this wave's DMA (vmcnt(0)) and publishes tile 0
-    if (nk > 1) issue_tile(1, 1);
-    u32x4 af0[PLANES][TM], wf0[PLANES][TN], af1[PLANES][TM], wf1[PLANES][TN];
-    load_frags(af0, wf0, 0, 0);
-    int buf = 0;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int nbuf = (buf == NSTAGE - 1) ? 0 : buf + 1;
-        load_frags(af1, wf1, buf, 1);
-        mma_step(af0, wf0);
-        __syncthreads();                   // tile kt+1 landed + visible; tile kt-1's buffer is free
-        if (kt + 2 < nk) issue_tile(kt + 2, (nbuf == NSTAGE - 1) ? 0 : nbuf + 1);
-        if (kt + 1 < nk) load_frags(af0, wf0, nbuf, 0);
-        mma_step(af1, wf1);
-        buf = nbuf;
-    }
-
-    // ---- epilogue (identical to gemm16_kernel) ---------------------------------------------------
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int m = m0 + (wm * TM + i) * 32 + r;
-        if (m >= M) continue;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = n0 + (wn * TN + j) * 32 + 8 * g + 4 * kh;
-                if (n >= N) continue;
-                const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-                f32x4 val;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float t = acc[j][i][4 * g + e] * out_scale + bv[e];
-                    if (EPI == EPI_GELU) t = gelu_erf16(t);
-                    if (EPI == EPI_SQRELU) { t = fmaxf(t, 0.0f); t = t * t; }     // tranception/activations.py:79-84
-                    val[e] = t;
-                }
-                const size_t o = (size_t)m * N + n;
-                if (residual) {
-                    const f32x4 rv = *reinterpret_cast<const f32x4*>(residual + o);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) val[e] = rv[e] + val[e];
-                }
-                if constexpr (OUT == 0) {
-                    *reinterpret_cast<f32x4*>(Cf + o) = val;
-                } else if constexpr (BF) {
-                    u32x2 pk;
-                    pk[0] = f32_to_bf16_rne(val[0]) | ((unsigned)f32_to_bf16_rne(val[1]) << 16);
-                    pk[1] = f32_to_bf16_rne(val[2]) | ((unsigned)f32_to_bf16_rne(val[3]) << 16);
-                    *reinterpret_cast<u32x2*>(Ch + o) = pk;
-                } else {
-                    h4 hi, lo;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        _Float16 a, b;
-                        split_act(val[e], a, b);
-                        hi[e] = a;
-                        lo[e] = b;
-                    }
-                    *reinterpret_cast<h4*>(Ch + o) = hi;
-                    if constexpr (PLANES == 2) *reinterpret_cast<h4*>(Ch + c_plane + o) = lo;
                 }
             }
         }
     }
 }
 
-template <int WM, int WN, int TM, int TN, int PLANES, bool BF>
-static int launch_cfg_p(const unsigned short* A, size_t a_plane, const unsigned short* W, size_t w_plane,
-                        const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
-                        int M, int N, int K, int epilogue, float out_scale, hipStream_t s) {
+template <int WM, int WN, int TM, int TN>
+static int launch_bf16_cfg(const unsigned short* A, const unsigned short* W, const float* bias, const float* residual, float* Cf,
+                           unsigned short* Ch, int M, int N, int K, int epilogue, hipStream_t s) {
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr size_t lds_bytes = (size_t)3 * (BM + BN) * 4 * PLANES * 16;
+    constexpr size_t lds_bytes = (size_t)2 * (BM + BN) * 4 * 16;
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const dim3 grid(tiles_m * tiles_n), block(WM * WN * 64);
-#define PGMI_LAUNCH16P(EPI_, OUT_)                                                                       \
+#define PGMI_LAUNCH_BF16(EPI_, OUT_)                                                                     \
     do {                                                                                                 \
-        auto kfn = gemm16p_kernel<WM, WN, TM, TN, PLANES, BF, EPI_, OUT_>;                                \
+        auto kfn = gemm_bf16_kernel<WM, WN, TM, TN, EPI_, OUT_>;                                          \
         if (lds_bytes > 65536) {                                                                         \
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                       \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
             if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PGMI_EHIP; } \
         }                                                                                                \
-        hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, A, a_plane, W, w_plane, bias, residual, Cf, Ch, \
-                           c_plane, M, N, K, out_scale, tiles_m, tiles_n);                               \
+        hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, A, W, bias, residual, Cf, Ch, M, N, K, tiles_m, tiles_n); \
     } while (0)
     const int out = Ch ? 1 : 0;
-    if (epilogue == EPI_GELU) { if (out) PGMI_LAUNCH16P(EPI_GELU, 1); else PGMI_LAUNCH16P(EPI_GELU, 0); }
-    else { if (out) PGMI_LAUNCH16P(EPI_NONE, 1); else PGMI_LAUNCH16P(EPI_NONE, 0); }
-#undef PGMI_LAUNCH16P
+    if (epilogue == EPI_GELU) { if (out) PGMI_LAUNCH_BF16(EPI_GELU, 1); else PGMI_LAUNCH_BF16(EPI_GELU, 0); }
+    else if (epilogue == EPI_SQRELU) { if (out) PGMI_LAUNCH_BF16(EPI_SQRELU, 1); else PGMI_LAUNCH_BF16(EPI_SQRELU, 0); }
+    else { if (out) PGMI_LAUNCH_BF16(EPI_NONE, 1); else PGMI_LAUNCH_BF16(EPI_NONE, 0); }
+#undef PGMI_LAUNCH_BF16
     PGMI_HIP(hipGetLastError());
     return PGMI_OK;
 }
-
 
 // =================================================================================================
 // Persistent ping-pong kernel (f16x3, 256 x 256 x 32 tile, 8 waves = 2(M) x 4(N), wave tile 128 x 64).
@@ -763,9 +271,11 @@ static int launch_cfg_p(const unsigned short* A, size_t a_plane, const unsigned 
 //     accumulators in a workspace (fully coalesced 16-byte stores in accumulator order); splitk_fix_kernel adds
 //     the slices in a fixed order (deterministic) and applies scale, bias and the residual.  Only the fp32-output
 //     GEMMs (out-projection, FC2) use slices; their N = D gives the few tiles that make the tail matter.
-// STG 0: global -> VGPR -> LDS staging (swizzle on the LDS address).  STG 1: global -> LDS DMA (swizzle on the
-// source chunk); the wave's share of tile kt+1 is issued in the first memory phase of tile kt and waited for at
-// the LAST barrier of tile kt (two to three phases of latency cover instead of one).
+// LDS image of a K tile (per operand): [256 rows][8 chunks of 16 B] = the row's 128-byte line (4 hi chunks, 4 lo chunks)
+// with the chunk index XORed by (row >> 1) & 7: conflict-free ds_read_b128 fragment reads at a 128-byte row pitch, and
+// both staging forms write whole rows.  STG 0: global -> VGPR -> LDS staging.  STG 1: global -> LDS DMA (the swizzle
+// moves to the SOURCE chunk, which stays inside the row's line); the wave's share of tile kt+1 is issued in the first
+// memory phase of tile kt and waited for at the LAST barrier of tile kt (two to three phases of latency cover).
 // =================================================================================================
 struct TilePlan {
     int tiles_m, tiles_n;
@@ -774,13 +284,13 @@ struct TilePlan {
     int n_items;      // n_main + (tiles - n_main) * split
     float* ws;        // raw accumulators of the sliced items
     unsigned long long* diag;   // DIAG instantiation only: [2 waves][kDiagSamples][2] shader-clock stamps (barrier arrival, release)
-    int diag_flags;             // DIAG instantiation only (ablations): 1 no global loads in the loop, 2 no ds_write staging,
-                                // 4 loads issued in memory phase 1 instead of 2, 8 no fragment reads after the first K tile
+    int diag_flags;             // DIAG instantiation only (ablations, wrong numbers): 1 no global loads in the loop, 2 no
+                                // ds_write staging, 4 loads issued in memory phase 1, 8 no fragment reads after the first K tile
 };
 constexpr int kDiagSamples = 1024;
 
-constexpr int XBM = 256, XBN = 256, XNT = 512, XCPR = 4;
-constexpr int X_OP_CH = XBM * XCPR * 2;                    // 16-byte chunks of one operand tile (two planes)
+constexpr int XBM = 256, XBN = 256, XNT = 512, XCPR = 8;   // 8 chunks = one 128-byte line per row and K tile (hi | lo)
+constexpr int X_OP_CH = XBM * XCPR;                        // 16-byte chunks of one operand tile
 constexpr int X_STAGE = 2 * X_OP_CH;                       // chunks per stage = 64 KB
 
 __device__ __forceinline__ void x_tile_coords(int wgid, int tiles_m, int tiles_n, int& tm, int& tn) {
@@ -792,30 +302,30 @@ __device__ __forceinline__ void x_tile_coords(int wgid, int tiles_m, int tiles_n
     tn = (wgid % width) / gsz;
 }
 
-template <int EPI, int OUT, int STG, bool DIAG = false>
+template <int EPI, int OUT, int STG, int DFLAGS = -1>     // DFLAGS >= 0: tuning-only phase-timing instantiation with these ablation flags
 __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
-    const unsigned short* __restrict__ A, size_t a_plane, const unsigned short* __restrict__ W,
-    size_t w_plane, const float* __restrict__ bias, const float* residual, float* Cf,
-    unsigned short* Ch, size_t c_plane, int M, int N, int K, float out_scale, TilePlan tp, QkvOut qo) {
+    const unsigned short* __restrict__ A, const unsigned short* __restrict__ W, const float* __restrict__ bias,
+    const float* residual, float* Cf, unsigned short* Ch, size_t c_plane, int M, int N, int K, float out_scale,
+    TilePlan tp, QkvOut qo) {
     constexpr int WN = 4, TM = 4, TN = 2, LD = 4;
+    constexpr bool DIAG = DFLAGS >= 0;
+    constexpr int kFlags = DIAG ? DFLAGS : 0;
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];  // [2][X_STAGE]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // provably wave-uniform: scalar branches, SGPR LDS bases
     const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, kh = lane >> 5;
     const bool late = wave >= 4;                                  // the second wave of every SIMD
-    auto swz = [](int row, int c) -> int { return c ^ ((row >> 2) & 3); };
 
-    // staging geometry (the same for both operands: 256 rows x 4 chunks x 2 planes over 512 threads).  Slot
-    // f = tid + 512 i is (plane i >> 1, row (tid >> 2) + 128 (i & 1), chunk tid & 3): one LDS index + 512 i, and per
-    // operand two 32-bit byte offsets (the planes are reached through wave-uniform base pointers).
-    const int row_lo = tid >> 2, cch = tid & 3;
-    const int dst0 = (STG == 1) ? tid : row_lo * XCPR + swz(row_lo, cch);     // (row + 128) has the same swizzle
-    const int csrc = (STG == 1) ? swz(row_lo, cch) : cch;                      // DMA: lane-linear slot, swizzled SOURCE chunk
-    const char* const Ap[2] = {reinterpret_cast<const char*>(A), reinterpret_cast<const char*>(A + a_plane)};
-    const char* const Wp[2] = {reinterpret_cast<const char*>(W), reinterpret_cast<const char*>(W + w_plane)};
-    unsigned int a_off[2], w_off[2];
-    unsigned int a_offd[DIAG ? LD : 1], w_offd[DIAG ? LD : 1];
+    // staging geometry (the same for both operands): slot f = tid + 512 i is (row (tid >> 3) + 64 i, chunk tid & 7) -- 8
+    // consecutive lanes move one row's 128-byte line -- at LDS index row * 8 + (chunk ^ ((row >> 1) & 7)); the swizzle does
+    // not depend on i, so one LDS index + 512 i serves all four, plus one 32-bit byte offset per row and operand.
+    const int row_lo = tid >> 3, c8 = tid & 7, sw8 = (row_lo >> 1) & 7;
+    const int dst0 = (STG == 1) ? tid : row_lo * XCPR + (c8 ^ sw8);
+    const int csrc = (STG == 1) ? (c8 ^ sw8) : c8;               // DMA: lane-linear slot, swizzled SOURCE chunk
+    const char* const Ab8 = reinterpret_cast<const char*>(A);
+    const char* const Wb8 = reinterpret_cast<const char*>(W);
+    unsigned int a_off[LD], w_off[LD];
     u32x4 a_st[LD], w_st[LD];
     int m0 = 0, n0 = 0, kt0 = 0, kt1 = 0, slice_item = -1;
     auto decode = [&](int item) {                                 // sets m0, n0, [kt0, kt1), slice_item and the source offsets
@@ -840,28 +350,13 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
         kt0 = __builtin_amdgcn_readfirstlane(kt0); kt1 = __builtin_amdgcn_readfirstlane(kt1);
         slice_item = __builtin_amdgcn_readfirstlane(slice_item);
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {                             // the launcher guarantees rows * K * 2 bytes < 4 GiB
-            a_off[h] = ((unsigned int)min(m0 + row_lo + 128 * h, M - 1) * (unsigned int)K + (unsigned int)csrc * 8u) * 2u;
-            w_off[h] = ((unsigned int)min(n0 + row_lo + 128 * h, N - 1) * (unsigned int)K + (unsigned int)csrc * 8u) * 2u;
-        }
-        if constexpr (DIAG) {
-#pragma unroll
-            for (int i = 0; i < LD; ++i) {
-                a_offd[i] = (unsigned int)min(m0 + (tid >> 3) + 64 * i, M - 1) * (unsigned int)K * 2u + (unsigned int)(tid & 7) * 16u;
-                w_offd[i] = (unsigned int)min(n0 + (tid >> 3) + 64 * i, N - 1) * (unsigned int)K * 2u + (unsigned int)(tid & 7) * 16u;
-            }
+        for (int i = 0; i < LD; ++i) {                            // row pitch 4 K bytes; the launcher guarantees rows * 4 K < 4 GiB
+            a_off[i] = (unsigned int)min(m0 + row_lo + 64 * i, M - 1) * (unsigned int)K * 4u + (unsigned int)csrc * 16u;
+            w_off[i] = (unsigned int)min(n0 + row_lo + 64 * i, N - 1) * (unsigned int)K * 4u + (unsigned int)csrc * 16u;
         }
     };
-    // DIAG flag 16 (timing only, wrong numbers): the access pattern of a K-interleaved plane layout -- 8 consecutive lanes
-    // read one full 128-byte line of a row per K tile instead of 4 lanes reading 64 bytes of each of two planes
-    auto src_a = [&](int i, int kt) {
-        if (DIAG && (tp.diag_flags & 16)) return reinterpret_cast<const u32x4*>(Ap[0] + (size_t)(kt & 31) * 128 + a_offd[i]);
-        return reinterpret_cast<const u32x4*>(Ap[i >> 1] + (size_t)kt * 64 + a_off[i & 1]);
-    };
-    auto src_w = [&](int i, int kt) {
-        if (DIAG && (tp.diag_flags & 16)) return reinterpret_cast<const u32x4*>(Wp[0] + (size_t)(kt & 31) * 128 + w_offd[i]);
-        return reinterpret_cast<const u32x4*>(Wp[i >> 1] + (size_t)kt * 64 + w_off[i & 1]);
-    };
+    auto src_a = [&](int i, int kt) { return reinterpret_cast<const u32x4*>(Ab8 + (size_t)kt * 128 + a_off[i]); };
+    auto src_w = [&](int i, int kt) { return reinterpret_cast<const u32x4*>(Wb8 + (size_t)kt * 128 + w_off[i]); };
     auto stage_load = [&](int kt) {
 #pragma unroll
         for (int i = 0; i < LD; ++i) a_st[i] = *src_a(i, kt);
@@ -916,20 +411,15 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
 
     f32x16 acc[TN][TM];
     u32x4 af[2][TM], wf[2][TN], whs[TN];
+    const int fsw = (r >> 1) & 7;                                 // fragment rows are (multiple of 32) + r: the row swizzle is per lane
     auto read_frags = [&](const u32x4* Ab, const u32x4* Wb, int ks) {
-        const int c = ks * 2 + kh;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
+            const int c = (p * 4 + ks * 2 + kh) ^ fsw;            // chunk p*4 + (2 ks + kh) of the row's line, swizzled
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = (wm * TM + i) * 32 + r;
-                af[p][i] = Ab[(p * XBM + row) * XCPR + swz(row, c)];
-            }
+            for (int i = 0; i < TM; ++i) af[p][i] = Ab[((wm * TM + i) * 32 + r) * XCPR + c];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int row = (wn * TN + j) * 32 + r;
-                wf[p][j] = Wb[(p * XBN + row) * XCPR + swz(row, c)];
-            }
+            for (int j = 0; j < TN; ++j) wf[p][j] = Wb[((wn * TN + j) * 32 + r) * XCPR + c];
         }
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
         const h2 sc = {(_Float16)(1.0f / kLoScale), (_Float16)(1.0f / kLoScale)};
@@ -983,9 +473,9 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
             // -- memory phase 1: fragments of the first k16 step (STG 1: DMA of tile kt+1 into the other buffer, last read
             //    two phases ago by the other wave group) --
             __builtin_amdgcn_s_setprio(0);
-            if (!(DIAG && (tp.diag_flags & 8) && kt > kt0)) read_frags(Ab, Wb, 0);
+            if (!(DIAG && (kFlags & 8) && kt > kt0)) read_frags(Ab, Wb, 0);
             if (STG == 1 && kt + 1 < kt1) issue_tile(kt + 1, cur ^ 1);
-            if (DIAG && (tp.diag_flags & 4) && kt > kt0 && kt + 1 < kt1) stage_load(kt + 1);
+            if (DIAG && (kFlags & 4) && kt > kt0 && kt + 1 < kt1) stage_load(kt + 1);
             phase();
             // -- compute phase 1 --
             __builtin_amdgcn_s_setprio(1);
@@ -993,11 +483,11 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
             phase();
             // -- memory phase 2: fragments of the second k16 step; STG 0: tile kt+1 registers -> LDS, loads of kt+2 --
             __builtin_amdgcn_s_setprio(0);
-            if (!(DIAG && (tp.diag_flags & 8) && kt > kt0)) read_frags(Ab, Wb, 1);
+            if (!(DIAG && (kFlags & 8) && kt > kt0)) read_frags(Ab, Wb, 1);
             if (STG == 0 && kt + 1 < kt1) {
                 __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0); lgkmcnt / expcnt untouched
-                if (!(DIAG && (tp.diag_flags & 2))) stage_store(cur ^ 1);
-                if (kt + 2 < kt1 && !(DIAG && (tp.diag_flags & 5))) stage_load(kt + 2);
+                if (!(DIAG && (kFlags & 2))) stage_store(cur ^ 1);
+                if (kt + 2 < kt1 && !(DIAG && (kFlags & 5))) stage_load(kt + 2);
             }
             if (STG == 1 && late) phase_vm(); else phase();        // late waves close tile kt here: their DMA share must have landed
             // -- compute phase 2 --
@@ -1013,9 +503,12 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
         const int em0 = m0, en0 = n0, eslice = slice_item;
         item += gridDim.x;
         const bool more = item < tp.n_items;
+        // the fp32-output epilogue has the registers to spare for the next item's first K tile; the split-plane and
+        // attention-operand epilogues do not (the prefetch spilled 12-23 registers): they fetch after the epilogue
+        constexpr bool kPrefetchAcrossEpilogue = STG == 0 && OUT == 0;
         if (more) {
             decode(item);
-            if constexpr (STG == 0) stage_load(kt0);
+            if constexpr (kPrefetchAcrossEpilogue) stage_load(kt0);
         }
 
         if (eslice >= 0) {
@@ -1165,33 +658,34 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
                                 *reinterpret_cast<h4*>(cell) = hi;
                                 *reinterpret_cast<h4*>(cell + 32 * SP) = lo;
                             } else {
-                                *reinterpret_cast<h4*>(Ch + o) = hi;
-                                *reinterpret_cast<h4*>(Ch + c_plane + o) = lo;
+                                unsigned short* dst = Ch + ki_off((size_t)m, n, N);
+                                *reinterpret_cast<h4*>(dst) = hi;
+                                *reinterpret_cast<h4*>(dst + 32) = lo;
                             }
                         }
                     }
                 }
                 if (OUT == 1 && staged) {
+                    // K-interleaved output: the wave's 64 columns are two 32-column groups = 2 x (64 B hi | 64 B lo) = 256
+                    // contiguous bytes per row: 16 lanes write one row
                     __builtin_amdgcn_wave_barrier();
                     const int m_base = em0 + (wm * TM + i) * 32;
                     const size_t ncol0 = (size_t)en0 + (size_t)wn * TN * 32;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int q = lane + 64 * k;                 // 16-byte chunk: row q/8, chunk q%8 of the 128-byte row
-                        const int row = q >> 3, cc = q & 7;
-                        const u32x4 vh = *reinterpret_cast<const u32x4*>(patch + row * SP + cc * 16);
-                        const u32x4 vl = *reinterpret_cast<const u32x4*>(patch + (32 + row) * SP + cc * 16);
-                        if (m_base + row < M) {
-                            unsigned short* dst = Ch + (size_t)(m_base + row) * N + ncol0 + cc * 8;
-                            *reinterpret_cast<u32x4*>(dst) = vh;
-                            *reinterpret_cast<u32x4*>(dst + c_plane) = vl;
-                        }
+                    for (int k = 0; k < 8; ++k) {
+                        const int q = lane + 64 * k;                 // 16-byte chunk: row q/16, chunk q%16 of the 256-byte run
+                        const int row = q >> 4, cc = q & 15;
+                        const int grp = cc >> 3, pl = (cc >> 2) & 1, c4 = cc & 3;
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(patch + (pl * 32 + row) * SP + (grp * 4 + c4) * 16);
+                        if (m_base + row < M)
+                            *reinterpret_cast<u32x4*>(Ch + (size_t)(m_base + row) * (2 * (size_t)N) + ncol0 * 2 + cc * 8) = v;
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
             }
         }
         if (!more) break;
+        if constexpr (STG == 0 && !kPrefetchAcrossEpilogue) stage_load(kt0);
     }
 }
 
@@ -1256,7 +750,7 @@ static size_t g_splitk_ws_bytes = 0;
 static int g_splitk_ws_dev = -1;
 
 // stg: 0 register staging, 1 direct-to-LDS DMA.  splitk: allow K-sliced tail items (fp32-output GEMMs only).
-static int launch_gemm16x(const unsigned short* A, size_t a_plane, const unsigned short* W, size_t w_plane,
+static int launch_gemm16x(const unsigned short* A, const unsigned short* W,
                           const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
                           int M, int N, int K, int epilogue, float out_scale, int stg, bool splitk, hipStream_t s,
                           const QkvOut* qkv = nullptr) {
@@ -1265,8 +759,8 @@ static int launch_gemm16x(const unsigned short* A, size_t a_plane, const unsigne
     tp.tiles_n = (N + XBN - 1) / XBN;
     const int T = tp.tiles_m * tp.tiles_n, G = x_num_cus(), nk = K / 32;
     tp.n_main = T; tp.split = 1; tp.n_items = T;
-    if ((unsigned long long)std::max(M, N) * (unsigned long long)K * 2ull >= (1ull << 32)) {
-        set_error("gemm16x: operand plane of %d x %d halfs exceeds the 32-bit offset range", std::max(M, N), K);
+    if ((unsigned long long)std::max(M, N) * (unsigned long long)K * 4ull >= (1ull << 32)) {
+        set_error("gemm16x: operand of %d x %d split elements exceeds the 32-bit offset range", std::max(M, N), K);
         return PGMI_EINVAL;
     }
     const int rem = T % G;
@@ -1300,9 +794,17 @@ static int launch_gemm16x(const unsigned short* A, size_t a_plane, const unsigne
         PGMI_HIP(hipMemsetAsync(dbuf, 0, n * 8, s));
         tp.diag = dbuf;
         tp.diag_flags = getenv("PGMI_GEMM_DIAG_FLAGS") ? atoi(getenv("PGMI_GEMM_DIAG_FLAGS")) : 0;
-        auto kfn = gemm16x_kernel<EPI_NONE, 0, 0, true>;
-        PGMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
-        hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, out_scale, tp, qo);
+#define PGMI_DIAG_CASE(F_)                                                                                          \
+        case F_: {                                                                                                  \
+            auto kfn = gemm16x_kernel<EPI_NONE, 0, 0, F_>;                                                          \
+            PGMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
+            hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, A, W, bias, residual, Cf, Ch, c_plane, M, N, K, out_scale, tp, qo); \
+        } break;
+        switch (tp.diag_flags) {
+            PGMI_DIAG_CASE(0) PGMI_DIAG_CASE(1) PGMI_DIAG_CASE(2) PGMI_DIAG_CASE(3) PGMI_DIAG_CASE(8) PGMI_DIAG_CASE(11)
+            default: set_error("gemm16x diag: flags %d not instantiated", tp.diag_flags); return PGMI_EINVAL;
+        }
+#undef PGMI_DIAG_CASE
         if (tp.split > 1)
             hipLaunchKernelGGL(splitk_fix_kernel, dim3(T - tp.n_main), dim3(XNT), 0, s, tp.ws, tp.split, tp.n_main, tp.tiles_m,
                                tp.tiles_n, bias, residual, Cf, M, N, out_scale);
@@ -1340,8 +842,8 @@ static int launch_gemm16x(const unsigned short* A, size_t a_plane, const unsigne
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                           \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);  \
         if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PGMI_EHIP; } \
-        hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, A, a_plane, W, w_plane, bias, residual, Cf, Ch, \
-                           c_plane, M, N, K, out_scale, tp, qo);                                         \
+        hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, A, W, bias, residual, Cf, Ch, c_plane, M, N, K,  \
+                           out_scale, tp, qo);                                                           \
     } while (0)
 #define PGMI_LAUNCH16X_S(EPI_, OUT_) do { if (stg) PGMI_LAUNCH16X(EPI_, OUT_, 1); else PGMI_LAUNCH16X(EPI_, OUT_, 0); } while (0)
     if (qkv) PGMI_LAUNCH16X_S(EPI_NONE, 2);
@@ -1360,76 +862,31 @@ static int launch_gemm16x(const unsigned short* A, size_t a_plane, const unsigne
     return PGMI_OK;
 }
 
-template <int WM, int WN, int TM, int TN, int BK, int PLANES, bool BF, int PP = 0>
-static int launch_cfg(const unsigned short* A, size_t a_plane, const unsigned short* W, size_t w_plane,
-                      const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
-                      int M, int N, int K, int epilogue, float out_scale, hipStream_t s, const QkvOut* qkv = nullptr) {
-    QkvOut qo{};
-    static const int dbg_mod = getenv("PGMI_GEMM_DBG_ROWMOD") ? atoi(getenv("PGMI_GEMM_DBG_ROWMOD")) : 0;
-    static const int dbg_flags = getenv("PGMI_GEMM_DBG_FLAGS") ? atoi(getenv("PGMI_GEMM_DBG_FLAGS")) : 0;
-    qo.dbg_row_mod = dbg_mod;
-    qo.dbg_flags = dbg_flags;
-    constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int CPR = BK / 8;
-    constexpr size_t lds_bytes = (size_t)2 * (BM + BN) * CPR * PLANES * 16;
-    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-    const dim3 grid(tiles_m * tiles_n), block(WM * WN * 64);
-#define PGMI_LAUNCH16(EPI_, OUT_)                                                                        \
-    do {                                                                                                 \
-        auto kfn = gemm16_kernel<WM, WN, TM, TN, BK, PLANES, BF, EPI_, OUT_, PP>;                         \
-        if (lds_bytes > 65536) {                                                                         \
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                       \
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes); \
-            if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PGMI_EHIP; } \
-        }                                                                                                \
-        hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, A, a_plane, W, w_plane, bias, residual, Cf, Ch, \
-                           c_plane, M, N, K, out_scale, tiles_m, tiles_n, qo);                           \
-    } while (0)
-    if (qkv) {
-        if constexpr (PLANES == 2 && !BF && TN == 2) { qo = *qkv; PGMI_LAUNCH16(EPI_NONE, 2); }
-        else { set_error("gemm16: fused QKV epilogue unavailable for this configuration"); return PGMI_EINVAL; }
-    } else {
-        const int out = Ch ? 1 : 0;
-        if (epilogue == EPI_GELU) { if (out) PGMI_LAUNCH16(EPI_GELU, 1); else PGMI_LAUNCH16(EPI_GELU, 0); }
-        else if (epilogue == EPI_SQRELU) { if (out) PGMI_LAUNCH16(EPI_SQRELU, 1); else PGMI_LAUNCH16(EPI_SQRELU, 0); }
-        else { if (out) PGMI_LAUNCH16(EPI_NONE, 1); else PGMI_LAUNCH16(EPI_NONE, 0); }
-    }
-#undef PGMI_LAUNCH16
-    PGMI_HIP(hipGetLastError());
-    return PGMI_OK;
-}
-
+// f16x3 variants (tuning; 0 is the product's): 0 persistent ping-pong, register staging, K-sliced tail; 1 the same with
+// global->LDS DMA staging; 2 / 3 = 0 / 1 without tail slicing; 13 phase-timing diagnostics (PGMI_GEMM_DIAG_FLAGS).
 int launch_gemm16(const unsigned short* A, size_t a_plane, const unsigned short* W, size_t w_plane,
                   const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
                   int M, int N, int K, int epilogue, float out_scale, int planes, bool bf, int variant,
                   hipStream_t s) {
+    (void)a_plane; (void)w_plane;                 // f16x3 operands are K-interleaved (no plane stride); bf16 has one plane
     if (M <= 0 || N <= 0 || K <= 0 || (K % 64) != 0 || (N % 4) != 0 || (!Cf && !Ch) || (Cf && Ch)) {
         set_error("gemm16: unsupported shape/args M=%d N=%d K=%d (K %% 64 == 0, N %% 4 == 0 required)", M, N, K);
         return PGMI_EINVAL;
     }
     if (planes == 2 && !bf) {
+        if (Ch && (N % 32) != 0) { set_error("gemm16: split output needs N %% 32 == 0 (K-interleaved operand of the next GEMM), got %d", N); return PGMI_EINVAL; }
         switch (variant) {
-            case 1: return launch_cfg<2, 2, 2, 2, 64, 2, false>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);
-            case 2: return launch_cfg<2, 4, 4, 2, 32, 2, false>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);
-            case 3: return launch_cfg<4, 2, 2, 2, 32, 2, false>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);
-            case 4: return launch_cfg_p<4, 2, 2, 2, 2, false>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);   // 256x128, 8 waves
-            case 5: return launch_cfg_p<2, 4, 2, 2, 2, false>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);   // 128x256, 8 waves
-            case 6: return launch_cfg_p<2, 2, 2, 2, 2, false>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);   // 128x128, 4 waves
-            case 7: return launch_cfg<2, 4, 4, 2, 32, 2, false, 1>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);   // 256x256, ping-pong
-            case 8: return launch_cfg<2, 4, 4, 2, 32, 2, false, 2>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);   // 256x256, ping-pong + direct-to-LDS tile loads
-            case 9: return launch_gemm16x(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 0, true, s);    // persistent ping-pong, register staging, K-sliced tail
-            case 10: return launch_gemm16x(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 1, true, s);   // persistent ping-pong, global->LDS DMA, K-sliced tail
-            case 11: return launch_gemm16x(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 0, false, s);  // persistent, no slicing
-            case 12: return launch_gemm16x(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 1, false, s);
-            case 13: return launch_gemm16x(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 2, false, s);  // phase-timing diagnostics
-            default: return launch_cfg<2, 2, 2, 2, 32, 2, false>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);
+            case 1: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 1, true, s);
+            case 2: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 0, false, s);
+            case 3: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 1, false, s);
+            case 13: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 2, false, s);
+            default: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 0, true, s);
         }
     }
     if (planes == 1 && bf) {
-        switch (variant) {
-            case 2: return launch_cfg<2, 4, 4, 2, 32, 1, true>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);
-            default: return launch_cfg<2, 2, 2, 2, 32, 1, true>(A, a_plane, W, w_plane, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);
-        }
+        if (out_scale != 1.0f) { set_error("gemm16: bf16 weights are not pre-scaled"); return PGMI_EINVAL; }
+        if ((long long)M * N >= 1 << 22) return launch_bf16_cfg<2, 4, 4, 2>(A, W, bias, residual, Cf, Ch, M, N, K, epilogue, s);
+        return launch_bf16_cfg<2, 2, 2, 2>(A, W, bias, residual, Cf, Ch, M, N, K, epilogue, s);
     }
     set_error("gemm16: unsupported mode planes=%d bf=%d", planes, (int)bf);
     return PGMI_EINVAL;
@@ -1441,47 +898,42 @@ int launch_gemm16_qkv(const unsigned short* A, size_t a_plane, const unsigned sh
                       const float* bias, int M, int D, int K, float out_scale, unsigned short* qk16, size_t qk_plane,
                       unsigned short* vt16, size_t vt_plane, const float* cos_t, const float* sin_t, int rotary,
                       int T, int H, int variant, hipStream_t s) {
+    (void)a_plane; (void)w_plane;
     if (M <= 0 || D <= 0 || (K % 64) || (D % 64) || M % T) {
         set_error("gemm16_qkv: unsupported shape M=%d D=%d K=%d T=%d", M, D, K, T);
         return PGMI_EINVAL;
     }
     QkvOut qo{vt16, vt_plane, cos_t, sin_t, T, H, (T + 31) / 32 * 32, rotary};
-    const int N = 3 * D;
-    switch (variant) {
-        case 0: return launch_cfg<2, 2, 2, 2, 32, 2, false>(A, a_plane, W, w_plane, bias, nullptr, nullptr, qk16, qk_plane, M, N, K, EPI_NONE, out_scale, s, &qo);
-        case 3: return launch_cfg<4, 2, 2, 2, 32, 2, false>(A, a_plane, W, w_plane, bias, nullptr, nullptr, qk16, qk_plane, M, N, K, EPI_NONE, out_scale, s, &qo);
-        case 7: return launch_cfg<2, 4, 4, 2, 32, 2, false, 1>(A, a_plane, W, w_plane, bias, nullptr, nullptr, qk16, qk_plane, M, N, K, EPI_NONE, out_scale, s, &qo);
-        case 8: return launch_cfg<2, 4, 4, 2, 32, 2, false, 2>(A, a_plane, W, w_plane, bias, nullptr, nullptr, qk16, qk_plane, M, N, K, EPI_NONE, out_scale, s, &qo);
-        case 9: case 11: return launch_gemm16x(A, a_plane, W, w_plane, bias, nullptr, nullptr, qk16, qk_plane, M, N, K, EPI_NONE, out_scale, 0, false, s, &qo);
-        case 10: case 12: return launch_gemm16x(A, a_plane, W, w_plane, bias, nullptr, nullptr, qk16, qk_plane, M, N, K, EPI_NONE, out_scale, 1, false, s, &qo);
-        default: return launch_cfg<2, 4, 4, 2, 32, 2, false>(A, a_plane, W, w_plane, bias, nullptr, nullptr, qk16, qk_plane, M, N, K, EPI_NONE, out_scale, s, &qo);
-    }
+    return launch_gemm16x(A, W, bias, nullptr, nullptr, qk16, qk_plane, M, 3 * D, K, EPI_NONE, out_scale, (variant == 1 || variant == 3) ? 1 : 0,
+                          false, s, &qo);
 }
 
-// ---- fp32 -> 16-bit planes (used for weights at load time and by the op-level tests) ----------
-// mode 0: fp16 hi/lo planes of x*scale, lo unscaled (weights) ; mode 1: bf16 (single plane, RNE) ;
-// mode 2: activation split (lo scaled by 2^11, see split_act)
-__global__ void split16_kernel(const float* __restrict__ x, int64_t n, float scale, int mode,
-                               unsigned short* __restrict__ out, size_t plane) {
+// ---- fp32 -> 16-bit operands (weights at load time; activations in the op-level tests and the MSA tied-attention path) ----
+// mode 0: f16x3 weight: hi = fp16(x*scale), lo = fp16(x*scale - hi), K-interleaved rows of length K
+// mode 1: bf16 (single plane, RNE)
+// mode 2: f16x3 activation split (lo scaled by 2^11, see split_act), K-interleaved rows of length K
+__global__ void split16_kernel(const float* __restrict__ x, int64_t n, float scale, int mode, int K,
+                               unsigned short* __restrict__ out) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float v = x[i] * scale;
     if (mode == 1) {
         out[i] = f32_to_bf16_rne(v);
-    } else if (mode == 2) {
-        _Float16 hi, lo;
-        split_act(v, hi, lo);
-        out[i] = __builtin_bit_cast(unsigned short, hi);
-        out[plane + i] = __builtin_bit_cast(unsigned short, lo);
-    } else {
-        const _Float16 hi = (_Float16)v;
-        const _Float16 lo = (_Float16)(v - (float)hi);
-        out[i] = __builtin_bit_cast(unsigned short, hi);
-        out[plane + i] = __builtin_bit_cast(unsigned short, lo);
+        return;
     }
+    _Float16 hi, lo;
+    if (mode == 2) {
+        split_act(v, hi, lo);
+    } else {
+        hi = (_Float16)v;
+        lo = (_Float16)(v - (float)hi);
+    }
+    const size_t o = ki_off((size_t)(i / K), (int)(i % K), K);
+    out[o] = __builtin_bit_cast(unsigned short, hi);
+    out[o + 32] = __builtin_bit_cast(unsigned short, lo);
 }
-void launch_split16(const float* x, int64_t n, float scale, int mode, unsigned short* out, size_t plane, hipStream_t s) {
-    hipLaunchKernelGGL(split16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, scale, mode, out, plane);
+void launch_split16(const float* x, int64_t n, float scale, int mode, int K, unsigned short* out, hipStream_t s) {
+    hipLaunchKernelGGL(split16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, x, n, scale, mode, K, out);
 }
 
 }  // namespace pgmi

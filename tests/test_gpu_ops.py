@@ -96,10 +96,10 @@ def test_attention_rotary(lib, prec):
     assert np.abs(ctx - ref).max() < 3e-5
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("M,N,K,epi,res", [(300, 384, 128, 0, False), (257, 1280, 1280, 1, False),
                                             (513, 1280, 5120, 0, True), (1, 128, 256, 1, True),
-                                            (2300, 1280, 1280, 0, True),      # 45 tiles: every tile K-sliced (persistent variants)
+                                            (2300, 1280, 1280, 0, True),      # 45 tiles: every tile K-sliced (variants 0, 1)
                                             (4200, 5120, 128, 1, False),      # 340 tiles on 256 CUs: a second item per workgroup
                                             (15100, 1280, 256, 0, True)])     # 300 tiles: 256 full + 44 K-sliced x 2
 def test_gemm_f16x3(lib, monkeypatch, variant, M, N, K, epi, res):
