@@ -32,6 +32,32 @@ sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "f16x3": 2500.0}   # MI355X_MICROARCH.md, dense
 L_BLAT, N_MUT_BLAT = 286, 4996
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r2", "pmc_traffic.json")
+
+
+def ffn_traffic(precision, M, D, F):
+    """HBM-side bytes per FFN GEMM launch from the committed rocprofv3 --pmc passes of this same command
+    (scripts/pmc_profile.sh: FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md).
+    Counters cannot be read from inside the run; the summary is per launch and shape-specific, so it is only used when
+    it was taken on this precision's kernels."""
+    if precision != "f16x3" or not os.path.exists(PMC_TRAFFIC):
+        return None, None
+    k = json.load(open(PMC_TRAFFIC))["kernels"]
+    fc1 = next((v for n, v in k.items() if "gemm16x_kernel<1, 1," in n), None)          # FC1 + GELU, split output
+    fc2 = next((v for n, v in k.items() if "gemm16x_kernel<0, 0," in n), None)          # FC2 and out-projection share a kernel
+    if not fc1 or not fc2:
+        return None, None
+    algo = {"fc1": {"read": 4.0 * (M * D + F * D), "write": 4.0 * M * F}, "fc2_and_out_mean": {"read": 4.0 * (M * (F + D) / 2 + (D * F + D * D) / 2) + 4.0 * M * D, "write": 4.0 * M * D}}
+    detail = {"fc1": {"fetch_bytes": fc1["fetch_bytes"], "write_bytes": fc1["write_bytes"], "algorithmic_read": algo["fc1"]["read"],
+                      "algorithmic_write": algo["fc1"]["write"], "fetch_over_algorithmic": fc1["fetch_bytes"] / algo["fc1"]["read"],
+                      "l2_hit_rate": fc1["l2_hit_rate"]},
+              "fc2_and_out_projection_mean": {"fetch_bytes": fc2["fetch_bytes"], "write_bytes": fc2["write_bytes"],
+                                              "algorithmic_read": algo["fc2_and_out_mean"]["read"], "algorithmic_write": algo["fc2_and_out_mean"]["write"],
+                                              "fetch_over_algorithmic": fc2["fetch_bytes"] / algo["fc2_and_out_mean"]["read"],
+                                              "l2_hit_rate": fc2["l2_hit_rate"]},
+              "source": "profiles/r2/pmc_traffic.json (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes of `bench.py --layers 4`; "
+                        "bytes at the L2<->fabric boundary: requests served by the 256 MB Infinity Cache are counted)"}
+    return fc1["fetch_bytes"] + fc1["write_bytes"], detail
 
 
 def usable_cores() -> int:
@@ -99,6 +125,104 @@ def cpu_baseline(cfg, blob, seq, n_mut, budget_s, gpu_table=None):
     return out, parity
 
 
+def secondary(precision, budget_note="bounded: every leg is a few seconds of GPU time"):
+    """Other BASELINE.json configurations and the ensemble / end-to-end rates, measured on this GPU after the headline
+    (never inside its timed region).  Same synthetic conventions as the headline."""
+    import tempfile
+    import pandas as pd
+    from proteingym_amd import esm as pesm, synthetic, dist as pdist
+    out = {"note": budget_note}
+
+    def timed(fn, reps=2):
+        fn()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        return (time.perf_counter() - t0) / reps
+
+    seq, muts, _ = synthetic.random_assay(seed=23, L=L_BLAT, n_single=N_MUT_BLAT, n_multi=0)
+    # (1) ESM-1v ensemble rate: five checkpoints per assay, plain mean (compute_fitness.py:532-537)
+    cfg = dict(synthetic.ESM1V_650M)
+    blob = synthetic.random_weights(cfg, seed=2)
+    models = [pesm.EsmModel(cfg, blob, device=0, precision=precision) for _ in range(5)]
+    assays = [pesm.Assay(m, seq, muts) for m in models]
+    dt = timed(lambda: [a.run_device_only() for a in assays])
+    out["esm1v_5_checkpoint_ensemble"] = {"mutants_per_s": len(muts) / dt, "ms_per_assay": dt * 1e3,
+                                          "what": "BLAT-shaped assay scored with 5 resident ESM-1v-650M-shaped checkpoints"}
+    for a in assays:
+        a.close()
+    for m in models[1:]:
+        m.close()
+    # (2) end to end through the product runner incl. checkpoint read, assay upload and CSV writes: the first 8 assays of the
+    #     217-assay-shaped benchmark (DMS_substitutions.csv rows 0-7)
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import bench_217
+    from proteingym_amd import run_benchmark
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(os.path.join(d, "dms"))
+        shapes = synthetic.dms_shapes()[:8]
+        rows = []
+        for sh in shapes:
+            rng = np.random.default_rng(sh["DMS_index"])
+            sq, df = bench_217.make_assay(rng, sh["seq_len"], sh["n_single"], sh["n_total"] - sh["n_single"])
+            df.to_csv(os.path.join(d, "dms", sh["DMS_id"] + ".csv"), index=False)
+            rows.append({"DMS_id": sh["DMS_id"], "DMS_filename": sh["DMS_id"] + ".csv", "target_seq": sq, "DMS_total_number_mutants": len(df)})
+        pd.DataFrame(rows).to_csv(os.path.join(d, "map.csv"), index=False)
+        ck = synthetic.save_fair_esm_checkpoint(os.path.join(d, "esm1v_synth_1.pt"), cfg, blob)
+        a8 = run_benchmark.create_parser().parse_args(["--model-location", ck, "--model_type", "ESM1v", "--dms_mapping", os.path.join(d, "map.csv"),
+                                                       "--dms-input", os.path.join(d, "dms"), "--dms-output", os.path.join(d, "out"), "--precision", precision])
+        t0 = time.perf_counter()
+        run_benchmark.main(a8)
+        dt = time.perf_counter() - t0
+        n = sum(sh["n_total"] for sh in shapes)
+        out["run_benchmark_8_assays_end_to_end"] = {"mutants_per_s": n / dt, "seconds": dt, "mutants": n, "assays": len(shapes),
+                                                    "what": "checkpoint read + upload, 8 assay uploads, masked-marginals, CSVs written (1 checkpoint)"}
+    models[0].close()
+    # (3) BASELINE config 3's model: ESM2-3B (36 x 2560 x 40), one BLAT-shaped assay
+    cfg3 = dict(synthetic.ESM2_3B)
+    n3 = sum(int(np.prod(sh)) for _, sh in synthetic.key_shapes(cfg3))
+    block = (np.random.default_rng(3).random(1 << 24, dtype=np.float32) - 0.5) * 0.04      # timing only: a tiled random block
+    blob3 = np.tile(block, n3 // block.size + 1)[:n3]
+    m3 = pesm.EsmModel(cfg3, blob3, device=0, precision=precision)
+    del blob3
+    a3 = pesm.Assay(m3, seq, muts)
+    dt = timed(a3.run_device_only, reps=1)
+    fl = len(a3.positions) * pdist.forward_flops(a3.T, layers=36, D=2560, F=10240)
+    out["esm2_3b_one_assay"] = {"mutants_per_s": len(muts) / dt, "ms_per_assay": dt * 1e3, "algorithmic_tflops": fl / dt / 1e12,
+                                "what": "config 3 model shape, BLAT-shaped assay (286 positions x 288 tokens), 1 GPU"}
+    a3.close()
+    m3.close()
+    # (4) BASELINE config 5: pseudo-ppl on a CAPSD_AAV2S-shaped slice (variable-length members, ESM2-650M shape)
+    cfg5 = dict(synthetic.ESM2_650M)
+    m5 = pesm.EsmModel(cfg5, synthetic.random_weights(cfg5, seed=5), device=0, precision=precision)
+    lib5 = pesm.SequenceLibrary(m5, synthetic.random_indel_library(7, 735, 2)[1])
+    t0 = time.perf_counter()
+    lib5.score()
+    dt = time.perf_counter() - t0
+    st = lib5.stats()
+    out["esm2_650m_pseudo_ppl_capsd_shaped"] = {"mutants_per_s": 2 / dt, "masked_forwards_per_s": st["rows"] / dt, "tokens_per_s": st["tokens"] / dt,
+                                                "packing_efficiency": st["packing_efficiency"],
+                                                "what": "config 5: 2 members of a 735-residue indel library = 1 470 masked forwards of ~737 tokens"}
+    lib5.close()
+    m5.close()
+    # (5) BASELINE config 4's model: Tranception-L shape, both directions, no retrieval
+    from proteingym_amd import tranception as ptr
+    cfgt = dict(synthetic.TRANCEPTION_L)
+    mt = ptr.TranceptionModel(cfgt, synthetic.random_tranception_weights(cfgt, seed=3), device=0)
+    sq, mu, _ = synthetic.random_assay(seed=23, L=L_BLAT, n_single=512, n_multi=0)
+    df = pd.DataFrame({"mutant": mu})
+    df["mutated_sequence"] = df["mutant"].apply(lambda m: ptr.get_mutated_sequence(sq, m))
+    df = df.drop_duplicates("mutated_sequence")
+    mt.score_mutants(DMS_data=df.iloc[:32], target_seq=sq)
+    t0 = time.perf_counter()
+    mt.score_mutants(DMS_data=df, target_seq=sq, scoring_mirror=True)
+    dt = time.perf_counter() - t0
+    out["tranception_l_one_batch"] = {"mutants_per_s": len(df) / dt, "seconds": dt, "mutants": len(df),
+                                      "what": "config 4 model shape (36 x 1280 x 20), 286-residue protein, both directions, no retrieval"}
+    mt.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -111,6 +235,7 @@ def main():
     ap.add_argument("--checkpoints", type=int, default=1,
                     help="score with N checkpoints per step and average (ESM-1v ensemble rate; the headline is 1)")
     ap.add_argument("--variant", type=int, default=None, help="debug: PGMI_GEMM_VARIANT tile configuration")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` object (other configs; ~1 min after the headline)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -186,6 +311,7 @@ def main():
         peak = PEAK_TFLOPS[args.precision]
         passes = 3 if args.precision == "f16x3" else 1          # MFMA FLOPs executed per algorithmic FLOP
         total_fl = sum(v["flops"] for v in prof.values())
+        traffic, traffic_detail = ffn_traffic(args.precision, len(assay.positions) * assay.T, cfg["embed_dim"], cfg["ffn_dim"])
         kern = {k: {"ms_per_step": round(v["ms"] / args.steps, 3), "launches_per_step": v["launches"] // args.steps,
                     "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 and v["flops"] > 0 else None,
                     "gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 and v["bytes"] > 0 else None}
@@ -209,7 +335,7 @@ def main():
                        "positions_run": int(len(assay.positions)), "tokens_per_step": int(len(assay.positions) * assay.T)},
             "roofline": {"bound": "mfma", "kernel": "gemm (fc1+GELU, fc2+residual)", "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "avg_launch_ms": ffn_ms / max(ffn_n, 1), "traffic": None,
+                         "avg_launch_ms": ffn_ms / max(ffn_n, 1), "traffic": traffic, "traffic_detail": traffic_detail,
                          "mfma_passes": passes, "mfma_util": passes * achieved / peak,
                          "vs_fp32_mfma_peak": achieved / PEAK_TFLOPS["fp32"],
                          "note": "achieved = algorithmic FLOPs (2*M*N*K per GEMM) / HIP-event time of the FFN GEMM "
@@ -226,6 +352,17 @@ def main():
             assay.close()
             model.close()
             out["cpu_baseline"], out["parity"] = cpu_baseline(cfg, blob, seq, n_mut, args.cpu_seconds, gpu_table)
+            out["cpu_baseline"]["reference_vs_port"] = ("kind 'port': /root/reference does not exist on the GPU box; in the build container the "
+                                                        "unmodified reference model and this port were timed side by side on the same input "
+                                                        "(profiles/r2/cpu_reference_vs_port.json): same s/forward within noise")
+            if not args.no_secondary and args.layers == 33:
+                del blob
+                import contextlib
+                try:                                                 # the runner and scorer print progress: keep stdout to the ONE JSON line
+                    with contextlib.redirect_stdout(sys.stderr):
+                        out["secondary"] = secondary(args.precision)
+                except Exception as e:                               # a secondary leg must never take the headline line down
+                    out["secondary"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

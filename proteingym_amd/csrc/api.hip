@@ -87,7 +87,9 @@ struct pgmi_model {
     int gemm_variant = 0;
     int att16 = 3;        // f16x3 attention: 0 fp32 pipe, 1 in-kernel split, 2 prep pass + DMA ring, 3 QKV epilogue + DMA ring (default)
     int last_B = 0, last_T = 0;
-    int dh = kHeadDim;    // true head dim; heads are laid out in 64 slots: j < dh/2 -> j, else 32 + (j - dh/2)
+    int dh = kHeadDim;    // true head dim; heads are laid out in 64-lane slot groups (pgmi_model_create)
+    int rot_halves = 1;   // slot groups per head: 1, or 2 for head_dim 128
+    int Hs = 0;           // slot groups per token = heads * rot_halves
     int Da = 0;           // attention width = heads * 64 (== embed_dim when dh == 64)
     float *rot_cos = nullptr, *rot_sin = nullptr;
     int rot_len = 0;
@@ -192,11 +194,14 @@ int check_cfg(const pgmi_config* c) {
     if (c->arch != PGMI_ARCH_ESM1B && c->arch != PGMI_ARCH_ESM2 && c->arch != PGMI_ARCH_TRANCEPTION && c->arch != PGMI_ARCH_MSA) { set_error("unknown arch %d", c->arch); return PGMI_EINVAL; }
     if (c->layers <= 0 || c->embed_dim <= 0 || c->heads <= 0 || c->ffn_dim <= 0) { set_error("non-positive model dimension"); return PGMI_EINVAL; }
     {
-        // head_dim 64 natively; smaller head dims (ESM2 8M/35M/150M: 16/24/32) run zero-padded to 64
-        // lanes per head (see pgmi_model_create).  head_dim 128 (ESM2 15B) is not built.
+        // head_dim 64 natively; smaller head dims (ESM2 8M/35M/150M: 16/24/32) run zero-padded to 64 lanes per head;
+        // head_dim 128 (ESM2-15B: pretrained.py:387-394) as two 64-lane slot groups per head (see pgmi_model_create)
         const int dh = c->embed_dim / c->heads;
-        const bool ok = c->embed_dim % c->heads == 0 && (dh == kHeadDim || (dh < kHeadDim && dh % 2 == 0 && c->arch != PGMI_ARCH_TRANCEPTION));
-        if (!ok) { set_error("unsupported head_dim %d (embed_dim %d / heads %d): this build supports head_dim 64 and even head dims below 64 (ESM)", dh, c->embed_dim, c->heads); return PGMI_EINVAL; }
+        const bool esm = c->arch == PGMI_ARCH_ESM1B || c->arch == PGMI_ARCH_ESM2;
+        const bool ok = c->embed_dim % c->heads == 0 &&
+                        (dh == kHeadDim || (dh < kHeadDim && dh % 2 == 0 && esm) || (dh == 2 * kHeadDim && esm));
+        if (!ok) { set_error("unsupported head_dim %d (embed_dim %d / heads %d): this build supports head_dim 64, even head dims below 64 and head_dim 128 (ESM)", dh, c->embed_dim, c->heads); return PGMI_EINVAL; }
+        if (dh == 2 * kHeadDim && c->precision != PGMI_PREC_F16X3) { set_error("head_dim 128 (ESM2-15B class) is available in precision f16x3 only"); return PGMI_EINVAL; }
     }
     if (c->embed_dim % 32 || c->ffn_dim % 32) { set_error("embed_dim and ffn_dim must be multiples of 32"); return PGMI_EINVAL; }
     if (c->arch == PGMI_ARCH_TRANCEPTION) {
@@ -267,16 +272,21 @@ int ensure_rotary(pgmi_model* m, int T) {
     // rotary_embedding.py:40,52-58: inv_freq = 1/10000^(2i/d) in f32; freqs = t * inv_freq (f32);
     // emb = cat(freqs, freqs); cos/sin taken in f32.
     const int n = std::max(T, 1026);
-    std::vector<float> c((size_t)n * 64), s((size_t)n * 64);
-    float inv[32];
-    const int half = m->dh / 2;                            // slots i and 32+i hold dims i and i + dh/2
+    const int rh = m->rot_halves;                          // table rows per token: slot-group parity for head_dim 128
+    std::vector<float> c((size_t)n * rh * 64), s((size_t)n * rh * 64);
+    float inv[64];
+    const int half = m->dh / 2;                            // rotary pairs are (j, j + dh/2)
     for (int i = 0; i < half; ++i) inv[i] = 1.0f / powf(10000.0f, (float)(2 * i) / (float)m->dh);
+    // slots i and 32+i of slot group g hold dims j and j + dh/2 with j = i (dh <= 64) or 32 g + i (dh 128)
     for (int t = 0; t < n; ++t)
-        for (int i = 0; i < 32; ++i) {
-            const float f = i < half ? (float)t * inv[i] : 0.0f;       // padded slots: cos 1, sin 0
-            c[(size_t)t * 64 + i] = c[(size_t)t * 64 + 32 + i] = cosf(f);
-            s[(size_t)t * 64 + i] = s[(size_t)t * 64 + 32 + i] = sinf(f);
-        }
+        for (int g = 0; g < rh; ++g)
+            for (int i = 0; i < 32; ++i) {
+                const int j = (rh == 1) ? i : 32 * g + i;
+                const float f = j < half ? (float)t * inv[j] : 0.0f;       // padded slots (dh < 64): cos 1, sin 0
+                const size_t o = ((size_t)t * rh + g) * 64;
+                c[o + i] = c[o + 32 + i] = cosf(f);
+                s[o + i] = s[o + 32 + i] = sinf(f);
+            }
     int rc = dev_upload(m->allocs, &m->rot_cos, c.data(), c.size());
     if (rc) return rc;
     rc = dev_upload(m->allocs, &m->rot_sin, s.data(), s.size());
@@ -333,11 +343,12 @@ int run_encoder(pgmi_model* m, int B, int T) {
           if (prec == PGMI_PREC_FP32) launch_layernorm(m->x, L.ln1_w, L.ln1_b, M, D, 1e-5f, m->h, s);
           else launch_layernorm16(m->x, L.ln1_w, L.ln1_b, M, D, 1e-5f, m->h16, m->h16_plane, mode16, s); }
         const bool fused_qkv = prec == PGMI_PREC_F16X3 && m->att16 == 3;
+        if (m->rot_halves > 1 && !fused_qkv) { set_error("head_dim 128 needs the fused QKV + DMA-ring attention path (PGMI_ATT16=3)"); return PGMI_EINVAL; }
         { ProfScope p(m, PGMI_K_GEMM_QKV, 2.0 * M * 3 * D * D, 0);
           if (fused_qkv)
               rc = launch_gemm16_qkv(m->h16, m->h16_plane, L.wqkv16.p, L.wqkv16.plane, L.bqkv, M, Da, D, L.wqkv16.out_scale,
                                      m->qk16, m->qk16_plane, m->vt16, m->vt16_plane, m->rot_cos, m->rot_sin,
-                                     c.arch == PGMI_ARCH_ESM2, T, H, m->gemm_variant, s);
+                                     c.arch == PGMI_ARCH_ESM2, T, m->Hs, m->gemm_variant, s, m->rot_halves);
           else
               rc = linear(m, m->h, m->h16, m->h16_plane, L.wqkv, L.wqkv16, L.bqkv, nullptr, m->qkv, nullptr, 0, M, 3 * Da, D, EPI_NONE);
           if (rc) return rc; }
@@ -347,7 +358,7 @@ int run_encoder(pgmi_model* m, int B, int T) {
           if (v2)
               rc = launch_attention_f16x3_v2(fused_qkv ? nullptr : m->qkv, m->kv_len, m->rot_cos, m->rot_sin, c.arch == PGMI_ARCH_ESM2, B, T, H,
                                              m->qk16, m->qk16_plane, m->vt16, m->vt16_plane, nullptr, m->h16,
-                                             m->h16_plane, 1, s);
+                                             m->h16_plane, 1, s, nullptr, nullptr, m->rot_halves * kHeadDim);
           else if (prec == PGMI_PREC_F16X3 && m->att16 == 1)
               rc = launch_attention_f16x3(m->qkv, m->kv_len, B, T, H, m->h, m->h16, m->h16_plane, 1, s);
           else
@@ -766,7 +777,9 @@ int pgmi_model_create(const pgmi_config* cfg, const float* w, int64_t n_weights,
     if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { set_error("hipStreamCreate failed"); delete m; return PGMI_EHIP; }
     const size_t D = cfg->embed_dim, F = cfg->ffn_dim, V = cfg->vocab;
     m->dh = cfg->embed_dim / cfg->heads;
-    m->Da = cfg->heads * kHeadDim;
+    m->rot_halves = m->dh > kHeadDim ? 2 : 1;
+    m->Hs = cfg->heads * m->rot_halves;
+    m->Da = m->Hs * kHeadDim;
     m->ln_eps = cfg->ln_eps > 0.f ? cfg->ln_eps : 1e-5f;
     const float* p = w;
     if (cfg->arch == PGMI_ARCH_TRANCEPTION) {
@@ -792,7 +805,13 @@ int pgmi_model_create(const pgmi_config* cfg, const float* w, int64_t n_weights,
     // kernels' pairs (i, i + 32).  dh == 64 is the identity layout; smaller heads leave zero slots
     // (zero weight rows -> q,k,v slots exactly 0 -> scores and context unchanged).
     const size_t H = cfg->heads, dh = m->dh, Da = m->Da;
-    auto slot = [&](size_t col) { const size_t h = col / dh, j = col % dh; return h * 64 + (j < dh / 2 ? j : 32 + (j - dh / 2)); };
+    // head_dim 128: a head is two slot groups; group g in {0,1} holds dims 32 g + i (slots i < 32) and 64 + 32 g + i (slots 32 + i), so
+    // the rotary partners (j, j + 64) are again the kernels' pairs (i, i + 32) inside ONE 64-column wave tile of the QKV epilogue.
+    auto slot = [&](size_t col) -> size_t {
+        const size_t h = col / dh, j = col % dh;
+        if (dh > 64) return (2 * h + ((j >> 5) & 1)) * 64 + ((j >> 6) << 5) + (j & 31);
+        return h * 64 + (j < dh / 2 ? j : 32 + (j - dh / 2));
+    };
     const float qscale = 1.0f / sqrtf((float)dh);           // multihead_attention.py:261 (exact 1/8 for dh 64)
     m->layers.resize(cfg->layers);
     std::vector<float> wq(3 * Da * D, 0.0f), bq(3 * Da, 0.0f), wo_r(D * Da, 0.0f);

@@ -463,7 +463,9 @@ __global__ __launch_bounds__(256) void qkv_prep_conv_kernel(
     }
 }
 
-template <int WPB, int OUT, int NSTG>
+// DH = 64: one head = 64 lanes of the operand planes (head dims below 64 arrive zero-padded).  DH = 128 (ESM2-15B): a head is two
+// adjacent 64-lane slot groups of the planes; S sums 8 k16 steps instead of 4, O has 4 d tiles instead of 2.
+template <int WPB, int OUT, int NSTG, int DH = 64>
 __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
     const unsigned short* __restrict__ qk16, size_t qk_plane, const unsigned short* __restrict__ vt16,
     size_t vt_plane, const int32_t* __restrict__ kv_len, const float* __restrict__ slopes, int T, int H,
@@ -474,53 +476,60 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
     // A tile is 16 wave-instructions of 64 chunks (K hi, K lo, V^T hi, V^T lo: 1024 x 16 B).  Every
     // wave issues the same number NDMA of them (counted vmcnt needs a per-wave constant): when
     // 16 % WPB != 0 the surplus slots re-issue instruction (i - 16), i.e. write identical bytes twice.
-    constexpr int NDMA = (16 + WPB - 1) / WPB;
-    __shared__ __attribute__((aligned(16))) u32x4 lds[NSTG * A_STAGE];
+    constexpr int KCPR = DH / 8;                        // 16-byte chunks per key row of a K plane
+    constexpr int KCH = AKT * KCPR, VCH = DH * 4;       // chunks per K plane / V^T plane of a tile
+    constexpr int STG_CH = 2 * KCH + 2 * VCH;           // chunks per stage (16 KB at DH 64, 32 KB at DH 128)
+    constexpr int NWI = STG_CH / 64;                    // wave-instructions per tile
+    constexpr int NDMA = (NWI + WPB - 1) / WPB;
+    constexpr int NS = DH / 16, ND = DH / 32;
+    extern __shared__ __attribute__((aligned(16))) u32x4 lds[];   // [NSTG][STG_CH]
 
     const int b = blockIdx.z, h = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, kh = lane >> 5;
-    const int D = H * kHeadDim;
+    const int D = H * DH;
     const int Tk = kv_len ? kv_len[b] : T;
     const int q0 = (blockIdx.x * WPB + wave) * 32;
     const bool active = q0 < T;
 
     // Q fragments straight from the planes: lane (r,kh) holds Q[q0+r][16s + 8kh .. +7]
-    u32x4 qh[4], ql[4];
+    u32x4 qh[NS], ql[NS];
     {
         const int qrow = min(q0 + r, T - 1);
-        const unsigned short* qp = qk16 + ((size_t)b * T + qrow) * (2 * D) + h * kHeadDim + kh * 8;
+        const unsigned short* qp = qk16 + ((size_t)b * T + qrow) * (2 * D) + h * DH + kh * 8;
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < NS; ++s) {
             qh[s] = *reinterpret_cast<const u32x4*>(qp + s * 16);
             ql[s] = *reinterpret_cast<const u32x4*>(qp + qk_plane + s * 16);
         }
     }
 
-    // DMA map: LDS slot f (0..1023 within a stage) <- global chunk
-    //   f in [0,512):    K plane p=f>>8, key=(f>>3)&31, slot chunk c'=f&7, source chunk c = c' ^ ((key>>1)&7)
-    //   f in [512,1024): V^T plane p=(f-512)>>8, d=((f-512)>>2)&63, c'=f&3, source chunk c = c' ^ ((d>>2)&3)
+    // DMA map: LDS slot f (0 .. STG_CH-1 within a stage) <- global chunk
+    //   f in [0, 2 KCH):        K plane p = f / KCH, key = (f % KCH) / KCPR, slot chunk c' = f % KCPR, source chunk c = c' ^ swz(key)
+    //                           swz(key) = (key >> 1) & 7 for 128-byte rows (DH 64), key & 15 for 256-byte rows (DH 128)
+    //   f in [2 KCH, STG_CH):   V^T plane p, row d = (g >> 2) % DH, c' = g & 3, source chunk c = c' ^ ((d >> 2) & 3)
     const u32x4* src[NDMA];
     int step[NDMA];                                       // key index within the tile (K rows), -1 for V^T
     int slot0[NDMA];                                      // first LDS chunk of the wave-instruction
 #pragma unroll
     for (int i = 0; i < NDMA; ++i) {
-        int wi = wave + WPB * i;                          // wave-instruction index 0..15 (+ duplicates)
-        if (wi >= 16) wi -= 16;
+        int wi = wave + WPB * i;                          // wave-instruction index 0 .. NWI-1 (+ duplicates)
+        if (wi >= NWI) wi -= NWI;
         const int f = wi * 64 + lane;
         slot0[i] = wi * 64;
-        if (f < 512) {
-            const int p = f >> 8, key = (f >> 3) & 31, c = (f & 7) ^ ((key >> 1) & 7);
-            src[i] = reinterpret_cast<const u32x4*>(qk16 + (size_t)p * qk_plane + ((size_t)b * T) * (2 * D) + D + h * kHeadDim) + c;
+        if (f < 2 * KCH) {
+            const int p = f / KCH, key = (f % KCH) / KCPR;
+            const int c = (f % KCPR) ^ (DH == 64 ? ((key >> 1) & 7) : (key & 15));
+            src[i] = reinterpret_cast<const u32x4*>(qk16 + (size_t)p * qk_plane + ((size_t)b * T) * (2 * D) + D + h * DH) + c;
             step[i] = key;
         } else {
-            const int g = f - 512, p = g >> 8, d = (g >> 2) & 63, c = (g & 3) ^ ((d >> 2) & 3);
-            src[i] = reinterpret_cast<const u32x4*>(vt16 + (size_t)p * vt_plane + (((size_t)b * H + h) * kHeadDim + d) * Tp) + c;
+            const int g = f - 2 * KCH, p = g / VCH, d = (g >> 2) % DH, c = (g & 3) ^ ((d >> 2) & 3);
+            src[i] = reinterpret_cast<const u32x4*>(vt16 + (size_t)p * vt_plane + (((size_t)b * H + h) * DH + d) * Tp) + c;
             step[i] = -1;
         }
     }
     auto issue_tile = [&](int kt, int buf) {
-        u32x4* base = lds + buf * A_STAGE;
+        u32x4* base = lds + buf * STG_CH;
 #pragma unroll
         for (int i = 0; i < NDMA; ++i) {
             const u32x4* g;
@@ -546,9 +555,9 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
     for (int t = 0; t < NSTG - 1; ++t)
         if (t < nkt) issue_tile(t, t);
 
-    f32x16 om[2], oc[2];
+    f32x16 om[ND], oc[ND];
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
         for (int v = 0; v < 16; ++v) { om[dt][v] = 0.f; oc[dt][v] = 0.f; }
     // base-2 online softmax with P scaled by 2^10 (keeps every P hi in fp16's normal range; the
@@ -568,15 +577,15 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
         asm volatile("" ::: "memory");
         if (kt + NSTG - 1 < nkt) issue_tile(kt + NSTG - 1, (cur == 0) ? NSTG - 1 : cur - 1);
         if (active && !(causal && kt * AKT > q0 + 31)) {
-            const u32x4* Kb = lds + cur * A_STAGE;
-            const u32x4* Vb = Kb + 2 * K_CH;
+            const u32x4* Kb = lds + cur * STG_CH;
+            const u32x4* Vb = Kb + 2 * KCH;
             f32x16 sm, sc;
 #pragma unroll
             for (int v = 0; v < 16; ++v) { sm[v] = 0.f; sc[v] = 0.f; }
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int ci = r * 8 + ((2 * s + kh) ^ ((r >> 1) & 7));
-                const u32x4 kfh = Kb[ci], kfl = Kb[K_CH + ci];
+            for (int s = 0; s < NS; ++s) {
+                const int ci = r * KCPR + ((2 * s + kh) ^ (DH == 64 ? ((r >> 1) & 7) : (r & 15)));
+                const u32x4 kfh = Kb[ci], kfl = Kb[KCH + ci];
                 sc = mfma_h(kfh, ql[s], sc);
                 sc = mfma_h(kfl, qh[s], sc);
                 sm = mfma_h(kfh, qh[s], sm);
@@ -609,7 +618,7 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
                 const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
                 l_run *= alpha;
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
+                for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
                     for (int v = 0; v < 16; ++v) { om[dt][v] *= alpha; oc[dt][v] *= alpha; }
                 m_run = m_new;
@@ -637,10 +646,10 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
                     pl[e] = __builtin_bit_cast(unsigned int, lo2);
                 }
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
+                for (int dt = 0; dt < ND; ++dt) {
                     const int d = dt * 32 + r;
                     const int ci = d * 4 + ((2 * m + kh) ^ ((d >> 2) & 3));
-                    const u32x4 vfh = Vb[ci], vfl = Vb[V_CH + ci];
+                    const u32x4 vfh = Vb[ci], vfl = Vb[VCH + ci];
                     oc[dt] = mfma_h(vfh, pl, oc[dt]);
                     oc[dt] = mfma_h(vfl, ph, oc[dt]);
                     om[dt] = mfma_h(vfh, ph, om[dt]);
@@ -654,9 +663,9 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
         const float l_tot = l_run + __shfl_xor(l_run, 32);
         if (q0 + r < T) {
             const float inv = 1.0f / l_tot;
-            const size_t off = ((size_t)b * T + q0 + r) * D + (size_t)h * kHeadDim + 4 * kh;
+            const size_t off = ((size_t)b * T + q0 + r) * D + (size_t)h * DH + 4 * kh;
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
+            for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     float val[4];
@@ -669,8 +678,8 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
                         _Float16 hh[4], ll[4];
 #pragma unroll
                         for (int e = 0; e < 4; ++e) split_act(val[e], hh[e], ll[e]);
-                        // K-interleaved GEMM operand (common.h ki_off): column h*64 + dt*32 + 8g + 4kh of a row of D
-                        unsigned short* dst = ctx16 + ((size_t)b * T + q0 + r) * (size_t)(2 * D) + (size_t)(2 * h + dt) * 64 + 8 * g + 4 * kh;
+                        // K-interleaved GEMM operand (common.h ki_off): column h*DH + dt*32 + 8g + 4kh of a row of D
+                        unsigned short* dst = ctx16 + ((size_t)b * T + q0 + r) * (size_t)(2 * D) + (size_t)(ND * h + dt) * 64 + 8 * g + 4 * kh;
                         *reinterpret_cast<u32x2*>(dst) = u32x2{pack_h2(hh[0], hh[1]), pack_h2(hh[2], hh[3])};
                         *reinterpret_cast<u32x2*>(dst + 32) = u32x2{pack_h2(ll[0], ll[1]), pack_h2(ll[2], ll[3])};
                     }
@@ -679,16 +688,30 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
     }
 }
 
+template <int WPB, int OUT, int NSTG, int DH>
+static int launch_att16v2_one(dim3 grid, const unsigned short* qk16, size_t qk_plane, const unsigned short* vt16, size_t vt_plane,
+                              const int32_t* kv_len, const float* slopes, int T, int H, int Tp, float* ctx, unsigned short* ctx16,
+                              size_t plane, hipStream_t s) {
+    constexpr size_t lds_bytes = (size_t)NSTG * (DH * 16) * 16;          // stage = DH * 16 chunks of 16 B
+    auto kfn = attention_f16x3_v2_kernel<WPB, OUT, NSTG, DH>;
+    if (lds_bytes > 65536) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PGMI_EHIP; }
+    }
+    hipLaunchKernelGGL(kfn, grid, dim3(WPB * 64), lds_bytes, s, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane);
+    return PGMI_OK;
+}
+
 template <int OUT, int NSTG>
-static void launch_att16v2_mode(int wpb, dim3 grid, const unsigned short* qk16, size_t qk_plane,
-                                const unsigned short* vt16, size_t vt_plane, const int32_t* kv_len,
-                                const float* slopes, int T, int H, int Tp, float* ctx, unsigned short* ctx16,
-                                size_t plane, hipStream_t s) {
+static int launch_att16v2_mode(int wpb, dim3 grid, const unsigned short* qk16, size_t qk_plane,
+                               const unsigned short* vt16, size_t vt_plane, const int32_t* kv_len,
+                               const float* slopes, int T, int H, int Tp, float* ctx, unsigned short* ctx16,
+                               size_t plane, hipStream_t s) {
     switch (wpb) {
-        case 1: hipLaunchKernelGGL((attention_f16x3_v2_kernel<1, OUT, NSTG>), grid, dim3(64), 0, s, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane); break;
-        case 2: hipLaunchKernelGGL((attention_f16x3_v2_kernel<2, OUT, NSTG>), grid, dim3(128), 0, s, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane); break;
-        case 3: hipLaunchKernelGGL((attention_f16x3_v2_kernel<3, OUT, NSTG>), grid, dim3(192), 0, s, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane); break;
-        default: hipLaunchKernelGGL((attention_f16x3_v2_kernel<4, OUT, NSTG>), grid, dim3(256), 0, s, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane); break;
+        case 1: return launch_att16v2_one<1, OUT, NSTG, 64>(grid, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane, s);
+        case 2: return launch_att16v2_one<2, OUT, NSTG, 64>(grid, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane, s);
+        case 3: return launch_att16v2_one<3, OUT, NSTG, 64>(grid, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane, s);
+        default: return launch_att16v2_one<4, OUT, NSTG, 64>(grid, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane, s);
     }
 }
 
@@ -698,12 +721,25 @@ static void launch_att16v2_mode(int wpb, dim3 grid, const unsigned short* qk16, 
 int launch_attention_f16x3_v2(const float* qkv, const int32_t* kv_len, const float* cos_t, const float* sin_t,
                               int rotary, int B, int T, int H, unsigned short* qk16, size_t qk_plane,
                               unsigned short* vt16, size_t vt_plane, float* ctx, unsigned short* ctx16, size_t plane,
-                              int out_mode, hipStream_t s, const float* conv, const float* slopes) {
-    if (B <= 0 || T <= 0 || H <= 0 || out_mode < 0 || out_mode > 1) {
-        set_error("attention_f16x3_v2: bad arguments B=%d T=%d H=%d out=%d", B, T, H, out_mode);
+                              int out_mode, hipStream_t s, const float* conv, const float* slopes, int head_dim) {
+    if (B <= 0 || T <= 0 || H <= 0 || out_mode < 0 || out_mode > 1 || (head_dim != 64 && head_dim != 128)) {
+        set_error("attention_f16x3_v2: bad arguments B=%d T=%d H=%d out=%d head_dim=%d", B, T, H, out_mode, head_dim);
         return PGMI_EINVAL;
     }
     const int n32 = (T + 31) / 32, Tp = n32 * 32;
+    int rc = PGMI_OK;
+    if (head_dim == 128) {
+        // ESM2-15B class: H heads of 128 = 2 H slot groups of 64 in the operand planes; only the fused-QKV operand path
+        // (no prep pass), no causal / ALiBi flavour; 2-stage ring (2 x 32 KB) so that two workgroups share a CU
+        if (qkv || conv || slopes) { set_error("attention_f16x3_v2: head_dim 128 needs operands from the fused QKV projection"); return PGMI_EINVAL; }
+        const int nblk = (n32 + 3) / 4;
+        const dim3 grid(nblk, H, B);
+        if (out_mode == 0) rc = launch_att16v2_one<4, 0, 3, 128>(grid, qk16, qk_plane, vt16, vt_plane, kv_len, nullptr, T, H, Tp, ctx, ctx16, plane, s);
+        else rc = launch_att16v2_one<4, 1, 3, 128>(grid, qk16, qk_plane, vt16, vt_plane, kv_len, nullptr, T, H, Tp, ctx, ctx16, plane, s);
+        if (rc) return rc;
+        PGMI_HIP(hipGetLastError());
+        return PGMI_OK;
+    }
     static const bool old_prep = getenv("PGMI_PREP_OLD") != nullptr;
     if (qkv && conv && !rotary && !old_prep)      // Tranception: LDS-staged depth-wise conv + split
         hipLaunchKernelGGL(qkv_prep_conv_kernel, dim3(n32, H, B), dim3(256), 0, s, qkv, conv, T, H, Tp, qk16, qk_plane, vt16, vt_plane);
@@ -716,14 +752,9 @@ int launch_attention_f16x3_v2(const float* qkv, const int32_t* kv_len, const flo
     static const int wpb_env = getenv("PGMI_ATT_WPB") ? atoi(getenv("PGMI_ATT_WPB")) : 0;   // tuning only
     dim3 grid(nblk, H, B);
     if (wpb_env >= 1 && wpb_env <= 4) { wpb = wpb_env; grid.x = (n32 + wpb - 1) / wpb; }
-    static const int nstg = getenv("PGMI_ATT_STAGES") ? atoi(getenv("PGMI_ATT_STAGES")) : 3;
-    if (nstg == 4) {
-        if (out_mode == 0) launch_att16v2_mode<0, 4>(wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane, s);
-        else launch_att16v2_mode<1, 4>(wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane, s);
-    } else {
-        if (out_mode == 0) launch_att16v2_mode<0, 3>(wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane, s);
-        else launch_att16v2_mode<1, 3>(wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane, s);
-    }
+    if (out_mode == 0) rc = launch_att16v2_mode<0, 3>(wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane, s);
+    else rc = launch_att16v2_mode<1, 3>(wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane, s);
+    if (rc) return rc;
     PGMI_HIP(hipGetLastError());
     return PGMI_OK;
 }

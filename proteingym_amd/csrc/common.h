@@ -121,10 +121,12 @@ int launch_gemm16(const unsigned short* A, size_t a_plane, const unsigned short*
                   const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
                   int M, int N, int K, int epilogue, float out_scale, int planes, bool bf, int variant,
                   hipStream_t s);
+// H = number of 64-lane slot groups per token (= heads, or 2 x heads for head_dim 128); rot_halves = rotary table rows per
+// token (1, or 2 for head_dim 128: slot group parity selects the frequencies)
 int launch_gemm16_qkv(const unsigned short* A, size_t a_plane, const unsigned short* W, size_t w_plane,
                       const float* bias, int M, int D, int K, float out_scale, unsigned short* qk16, size_t qk_plane,
                       unsigned short* vt16, size_t vt_plane, const float* cos_t, const float* sin_t, int rotary,
-                      int T, int H, int variant, hipStream_t s);
+                      int T, int H, int variant, hipStream_t s, int rot_halves = 1);
 // x [n/K rows][K] fp32 -> mode 0: f16x3 weight (hi/lo of x*scale), 1: bf16 plane, 2: f16x3 activation split; the
 // f16x3 forms are written K-interleaved (ki_off)
 void launch_split16(const float* x, int64_t n, float scale, int mode, int K, unsigned short* out, hipStream_t s);
@@ -146,6 +148,7 @@ int launch_attention_f16x3(const float* qkv, const int32_t* kv_len, int B, int T
 int launch_attention_f16x3_v2(const float* qkv, const int32_t* kv_len, const float* cos_t, const float* sin_t,
                               int rotary, int B, int T, int H, unsigned short* qk16, size_t qk_plane,
                               unsigned short* vt16, size_t vt_plane, float* ctx, unsigned short* ctx16, size_t plane,
-                              int out_mode, hipStream_t s, const float* conv = nullptr, const float* slopes = nullptr);
+                              int out_mode, hipStream_t s, const float* conv = nullptr, const float* slopes = nullptr,
+                              int head_dim = 64);     // 128: H heads of two 64-lane slot groups (ESM2-15B), fused-QKV operands only
 
 }  // namespace pgmi

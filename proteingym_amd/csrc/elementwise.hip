@@ -195,9 +195,18 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* x,   // may
                     hi[k] = a;
                     lo[k] = b2;
                 }
-                unsigned short* dst = y16 + ki_off((size_t)row, 4 * c, D);      // K-interleaved GEMM operand (common.h)
-                *reinterpret_cast<h4*>(dst) = hi;
-                *reinterpret_cast<h4*>(dst + 32) = lo;
+                // K-interleaved GEMM operand (common.h ki_off).  Lanes (2m, 2m+1) hold k..k+3 and k+4..k+7 of one 8-group:
+                // the even lane stores the 16 bytes of hi values, the odd lane the 16 bytes of lo values (one exchange of
+                // 8 bytes with the neighbour), so 8 lanes write one full 128-byte line with a single store each.
+                typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+                typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+                const u32x2 H = __builtin_bit_cast(u32x2, hi), L = __builtin_bit_cast(u32x2, lo);
+                const bool odd = lane & 1;
+                const unsigned int s0 = odd ? H[0] : L[0], s1 = odd ? H[1] : L[1];
+                const unsigned int r0 = __shfl_xor(s0, 1), r1 = __shfl_xor(s1, 1);
+                const u32x4 out = odd ? u32x4{r0, r1, L[0], L[1]} : u32x4{H[0], H[1], r0, r1};
+                unsigned short* dst = y16 + ki_off((size_t)row, 4 * (c & ~1), D) + (odd ? 32 : 0);
+                *reinterpret_cast<u32x4*>(dst) = out;
             } else {
                 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
                 unsigned short b[4];

@@ -65,6 +65,7 @@ struct QkvOut {
     const float* cos_t;
     const float* sin_t;
     int T, H, Tp, rotary;
+    int rot_halves;       // rotary table rows per token: 1, or 2 for head_dim 128 (row = slot-group parity)
 };
 
 template <bool BF>
@@ -285,7 +286,8 @@ struct TilePlan {
     float* ws;        // raw accumulators of the sliced items
     unsigned long long* diag;   // DIAG instantiation only: [2 waves][kDiagSamples][2] shader-clock stamps (barrier arrival, release)
     int diag_flags;             // DIAG instantiation only (ablations, wrong numbers): 1 no global loads in the loop, 2 no
-                                // ds_write staging, 4 loads issued in memory phase 1, 8 no fragment reads after the first K tile
+                                // ds_write staging, 4 loads issued in memory phase 1, 8 no fragment reads after the first K tile, 32 no s_setprio, 64 static
+                                // priority 1 for the late waves only
 };
 constexpr int kDiagSamples = 1024;
 
@@ -421,6 +423,12 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
 #pragma unroll
             for (int j = 0; j < TN; ++j) wf[p][j] = Wb[((wn * TN + j) * 32 + r) * XCPR + c];
         }
+    };
+    // w_hi 2^-11 (exact: weights are pre-scaled to ~2^13), the third operand of the split product.  Computed at the head of
+    // the wave's own COMPUTE phase, interleaved with the first MFMAs (which do not need it): in the memory phase the partner
+    // wave holds priority and these eight VALU ops sat on the critical path to the phase barrier (measured: a memory phase
+    // with nothing but them still took 600-700 clocks).
+    auto scale_whi = [&]() {
         typedef _Float16 h2 __attribute__((ext_vector_type(2)));
         const h2 sc = {(_Float16)(1.0f / kLoScale), (_Float16)(1.0f / kLoScale)};
 #pragma unroll
@@ -428,19 +436,31 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const unsigned int u = wf[0][j][e];
-                const h2 t = __builtin_bit_cast(h2, u) * sc;      // w_hi 2^-11: exact (weights are scaled to ~2^13)
+                const h2 t = __builtin_bit_cast(h2, u) * sc;
                 whs[j][e] = __builtin_bit_cast(unsigned int, t);
             }
     };
     auto mfmas = [&]() {
+        scale_whi();
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                acc[j][i] = mfma16<false>(wf[1][j], af[0][i], acc[j][i]);    // w_lo a_hi
-                acc[j][i] = mfma16<false>(whs[j], af[1][i], acc[j][i]);      // (w_hi 2^-11)(a_lo 2^11)
-                acc[j][i] = mfma16<false>(wf[0][j], af[0][i], acc[j][i]);    // w_hi a_hi
-            }
+            for (int i = 0; i < TM; ++i) acc[j][i] = mfma16<false>(wf[1][j], af[0][i], acc[j][i]);    // w_lo a_hi
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[j][i] = mfma16<false>(whs[j], af[1][i], acc[j][i]);      // (w_hi 2^-11)(a_lo 2^11)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) acc[j][i] = mfma16<false>(wf[0][j], af[0][i], acc[j][i]);    // w_hi a_hi
+        // one MFMA, one VALU: the eight scalings ride in the shadow of the first eight MFMAs
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
     };
 
     int item = blockIdx.x;
@@ -466,23 +486,24 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[j][i][v] = 0.0f;
         int cur = 0;
+        if (DIAG && (kFlags & 64) && late) __builtin_amdgcn_s_setprio(1);
         if (late) phase();
         for (int kt = kt0; kt < kt1; ++kt) {
             const u32x4* Ab = lds + cur * X_STAGE;
             const u32x4* Wb = Ab + X_OP_CH;
             // -- memory phase 1: fragments of the first k16 step (STG 1: DMA of tile kt+1 into the other buffer, last read
             //    two phases ago by the other wave group) --
-            __builtin_amdgcn_s_setprio(0);
+            if (!(DIAG && (kFlags & 96))) __builtin_amdgcn_s_setprio(0);
             if (!(DIAG && (kFlags & 8) && kt > kt0)) read_frags(Ab, Wb, 0);
             if (STG == 1 && kt + 1 < kt1) issue_tile(kt + 1, cur ^ 1);
             if (DIAG && (kFlags & 4) && kt > kt0 && kt + 1 < kt1) stage_load(kt + 1);
             phase();
             // -- compute phase 1 --
-            __builtin_amdgcn_s_setprio(1);
+            if (!(DIAG && (kFlags & 96))) __builtin_amdgcn_s_setprio(1);
             mfmas();
             phase();
             // -- memory phase 2: fragments of the second k16 step; STG 0: tile kt+1 registers -> LDS, loads of kt+2 --
-            __builtin_amdgcn_s_setprio(0);
+            if (!(DIAG && (kFlags & 96))) __builtin_amdgcn_s_setprio(0);
             if (!(DIAG && (kFlags & 8) && kt > kt0)) read_frags(Ab, Wb, 1);
             if (STG == 0 && kt + 1 < kt1) {
                 __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0); lgkmcnt / expcnt untouched
@@ -491,7 +512,7 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
             }
             if (STG == 1 && late) phase_vm(); else phase();        // late waves close tile kt here: their DMA share must have landed
             // -- compute phase 2 --
-            __builtin_amdgcn_s_setprio(1);
+            if (!(DIAG && (kFlags & 96))) __builtin_amdgcn_s_setprio(1);
             mfmas();
             if (STG == 1 && !late) phase_vm(); else phase();       // early waves close tile kt here
             cur ^= 1;
@@ -549,10 +570,11 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
                     }
                     if (which < 2) {
                         if (qo.rotary) {                       // rotary_embedding.py:11-20
-                            const f32x4 c1 = *reinterpret_cast<const f32x4*>(qo.cos_t + t * 64 + d0);
-                            const f32x4 s1 = *reinterpret_cast<const f32x4*>(qo.sin_t + t * 64 + d0);
-                            const f32x4 c2 = *reinterpret_cast<const f32x4*>(qo.cos_t + t * 64 + 32 + d0);
-                            const f32x4 s2 = *reinterpret_cast<const f32x4*>(qo.sin_t + t * 64 + 32 + d0);
+                            const int tr = (t * qo.rot_halves + (hh % qo.rot_halves)) * 64;
+                            const f32x4 c1 = *reinterpret_cast<const f32x4*>(qo.cos_t + tr + d0);
+                            const f32x4 s1 = *reinterpret_cast<const f32x4*>(qo.sin_t + tr + d0);
+                            const f32x4 c2 = *reinterpret_cast<const f32x4*>(qo.cos_t + tr + 32 + d0);
+                            const f32x4 s2 = *reinterpret_cast<const f32x4*>(qo.sin_t + tr + 32 + d0);
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const float y0 = x0[e] * c1[e] + (-x1[e]) * s1[e];
@@ -612,9 +634,10 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
         } else {
             // lane holds column m = m_base + r of C^T, rows n = (v&3) + 8(v>>2) + 4kh; split-plane output leaves through a
             // per-wave LDS transpose as full 128-byte row segments (see gemm16_kernel)
-            constexpr int SP = 144;
+            // per-wave LDS patch: 32 rows x (256 B in OUTPUT order: group 0 hi | group 0 lo | group 1 hi | group 1 lo) + 16 B pad
+            constexpr int SP = 272;
             const bool staged = (OUT == 1) && (N % 8 == 0) && (en0 + (wn * TN + TN) * 32 <= N);
-            unsigned char* patch = reinterpret_cast<unsigned char*>(lds) + wave * (2 * 32 * SP);
+            unsigned char* patch = reinterpret_cast<unsigned char*>(lds) + wave * (32 * SP);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int m = em0 + (wm * TM + i) * 32 + r;
@@ -654,9 +677,9 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
                                 lo[e] = b;
                             }
                             if (staged) {
-                                unsigned char* cell = patch + r * SP + (j * 32 + 8 * g + 4 * kh) * 2;
+                                unsigned char* cell = patch + r * SP + j * 128 + (8 * g + 4 * kh) * 2;
                                 *reinterpret_cast<h4*>(cell) = hi;
-                                *reinterpret_cast<h4*>(cell + 32 * SP) = lo;
+                                *reinterpret_cast<h4*>(cell + 64) = lo;
                             } else {
                                 unsigned short* dst = Ch + ki_off((size_t)m, n, N);
                                 *reinterpret_cast<h4*>(dst) = hi;
@@ -675,8 +698,7 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
                     for (int k = 0; k < 8; ++k) {
                         const int q = lane + 64 * k;                 // 16-byte chunk: row q/16, chunk q%16 of the 256-byte run
                         const int row = q >> 4, cc = q & 15;
-                        const int grp = cc >> 3, pl = (cc >> 2) & 1, c4 = cc & 3;
-                        const u32x4 v = *reinterpret_cast<const u32x4*>(patch + (pl * 32 + row) * SP + (grp * 4 + c4) * 16);
+                        const u32x4 v = *reinterpret_cast<const u32x4*>(patch + row * SP + cc * 16);
                         if (m_base + row < M)
                             *reinterpret_cast<u32x4*>(Ch + (size_t)(m_base + row) * (2 * (size_t)N) + ncol0 * 2 + cc * 8) = v;
                     }
@@ -764,8 +786,12 @@ static int launch_gemm16x(const unsigned short* A, const unsigned short* W,
         return PGMI_EINVAL;
     }
     const int rem = T % G;
-    static const int no_split = getenv("PGMI_GEMM_NO_SPLITK") ? atoi(getenv("PGMI_GEMM_NO_SPLITK")) : 0;
-    if (splitk && !no_split && Cf && !qkv && epilogue == EPI_NONE && rem > 0 && 4 * rem <= 3 * G) {
+    // K-sliced tails are OPT-IN (PGMI_GEMM_SPLITK=1): a sliced tile adds its K range in a different association than a full
+    // tile, so a row's bits would depend on how many rows travel with it -- and the scorer guarantees that every way of
+    // batching an assay (whole, position chunks, any number of GPUs) gives bit-identical scores (tests/test_gpu_cli.py).
+    // Measured gain when enabled: FC2 386 -> 402 TFLOP/s at the BLAT shape (6.29 -> 6.33 rounds of tiles), +1.2 % per step.
+    const int want_split = getenv("PGMI_GEMM_SPLITK") ? atoi(getenv("PGMI_GEMM_SPLITK")) : 0;
+    if (splitk && want_split && Cf && !qkv && epilogue == EPI_NONE && rem > 0 && 4 * rem <= 3 * G) {
         int split = std::min(std::min(G / rem, 8), nk / 4);       // every slice keeps >= 4 K tiles
         if (split >= 2) {
             const size_t need = (size_t)rem * split * XBM * XBN * sizeof(float);
@@ -801,7 +827,7 @@ static int launch_gemm16x(const unsigned short* A, const unsigned short* W,
             hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, A, W, bias, residual, Cf, Ch, c_plane, M, N, K, out_scale, tp, qo); \
         } break;
         switch (tp.diag_flags) {
-            PGMI_DIAG_CASE(0) PGMI_DIAG_CASE(1) PGMI_DIAG_CASE(2) PGMI_DIAG_CASE(3) PGMI_DIAG_CASE(8) PGMI_DIAG_CASE(11)
+            PGMI_DIAG_CASE(0) PGMI_DIAG_CASE(1) PGMI_DIAG_CASE(3) PGMI_DIAG_CASE(11) PGMI_DIAG_CASE(32) PGMI_DIAG_CASE(64)
             default: set_error("gemm16x diag: flags %d not instantiated", tp.diag_flags); return PGMI_EINVAL;
         }
 #undef PGMI_DIAG_CASE
@@ -862,8 +888,9 @@ static int launch_gemm16x(const unsigned short* A, const unsigned short* W,
     return PGMI_OK;
 }
 
-// f16x3 variants (tuning; 0 is the product's): 0 persistent ping-pong, register staging, K-sliced tail; 1 the same with
-// global->LDS DMA staging; 2 / 3 = 0 / 1 without tail slicing; 13 phase-timing diagnostics (PGMI_GEMM_DIAG_FLAGS).
+// f16x3 variants (tuning; 0 is the product's): 0 persistent ping-pong kernel, staging form chosen per output kind, K-sliced
+// tail; 1 register staging everywhere; 2 global->LDS DMA staging everywhere; 3 = 1 without tail slicing; 13 phase-timing
+// diagnostics (PGMI_GEMM_DIAG_FLAGS).
 int launch_gemm16(const unsigned short* A, size_t a_plane, const unsigned short* W, size_t w_plane,
                   const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
                   int M, int N, int K, int epilogue, float out_scale, int planes, bool bf, int variant,
@@ -876,11 +903,14 @@ int launch_gemm16(const unsigned short* A, size_t a_plane, const unsigned short*
     if (planes == 2 && !bf) {
         if (Ch && (N % 32) != 0) { set_error("gemm16: split output needs N %% 32 == 0 (K-interleaved operand of the next GEMM), got %d", N); return PGMI_EINVAL; }
         switch (variant) {
-            case 1: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 1, true, s);
-            case 2: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 0, false, s);
-            case 3: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 1, false, s);
+            case 1: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 0, true, s);
+            case 2: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 1, true, s);
+            case 3: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 0, false, s);
             case 13: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 2, false, s);
-            default: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 0, true, s);
+            // measured (profiles/r2): the fp32-output GEMMs (out-projection, FC2) are faster with register staging (and
+            // prefetch the next tile across the epilogue), the split-output ones (FC1+GELU, fused QKV) with the DMA form
+            // (fewer live registers next to their heavier epilogues)
+            default: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, Ch ? 1 : 0, true, s);
         }
     }
     if (planes == 1 && bf) {
@@ -897,14 +927,14 @@ int launch_gemm16(const unsigned short* A, size_t a_plane, const unsigned short*
 int launch_gemm16_qkv(const unsigned short* A, size_t a_plane, const unsigned short* W, size_t w_plane,
                       const float* bias, int M, int D, int K, float out_scale, unsigned short* qk16, size_t qk_plane,
                       unsigned short* vt16, size_t vt_plane, const float* cos_t, const float* sin_t, int rotary,
-                      int T, int H, int variant, hipStream_t s) {
+                      int T, int H, int variant, hipStream_t s, int rot_halves) {
     (void)a_plane; (void)w_plane;
-    if (M <= 0 || D <= 0 || (K % 64) || (D % 64) || M % T) {
+    if (M <= 0 || D <= 0 || (K % 64) || (D % 64) || M % T || rot_halves < 1) {
         set_error("gemm16_qkv: unsupported shape M=%d D=%d K=%d T=%d", M, D, K, T);
         return PGMI_EINVAL;
     }
-    QkvOut qo{vt16, vt_plane, cos_t, sin_t, T, H, (T + 31) / 32 * 32, rotary};
-    return launch_gemm16x(A, W, bias, nullptr, nullptr, qk16, qk_plane, M, 3 * D, K, EPI_NONE, out_scale, (variant == 1 || variant == 3) ? 1 : 0,
+    QkvOut qo{vt16, vt_plane, cos_t, sin_t, T, H, (T + 31) / 32 * 32, rotary, rot_halves};
+    return launch_gemm16x(A, W, bias, nullptr, nullptr, qk16, qk_plane, M, 3 * D, K, EPI_NONE, out_scale, (variant == 1 || variant == 3) ? 0 : 1,
                           false, s, &qo);
 }
 

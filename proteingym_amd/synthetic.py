@@ -27,6 +27,8 @@ ESM2_650M = dict(arch=_lib.ARCH_ESM2, layers=33, embed_dim=1280, heads=20, ffn_d
                  max_positions=0, token_dropout=1, emb_layer_norm_before=0)
 ESM2_3B = dict(arch=_lib.ARCH_ESM2, layers=36, embed_dim=2560, heads=40, ffn_dim=10240,
                max_positions=0, token_dropout=1, emb_layer_norm_before=0)
+ESM2_15B = dict(arch=_lib.ARCH_ESM2, layers=48, embed_dim=5120, heads=40, ffn_dim=20480,      # head_dim 128 (pretrained.py:387-394)
+                max_positions=0, token_dropout=1, emb_layer_norm_before=0)
 
 
 def key_shapes(cfg) -> List[Tuple[str, Tuple[int, ...]]]:

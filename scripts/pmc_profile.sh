@@ -18,5 +18,5 @@ pass fetch FETCH_SIZE
 pass write WRITE_SIZE
 pass lds SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS
 pass tcc TCC_HIT_sum TCC_MISS_sum
-python scripts/pmc_summarize.py $OUT > $OUT/summary.txt 2>&1
+python scripts/pmc_summarize.py $OUT $OUT/pmc_traffic.json > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

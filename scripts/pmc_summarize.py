@@ -1,11 +1,16 @@
-"""Summarise rocprofv3 --pmc CSV output per kernel name: mean counter value per dispatch."""
+"""Summarise rocprofv3 --pmc CSV output per kernel name: mean counter value per dispatch.
+    python scripts/pmc_summarize.py <dir> [traffic.json]
+With a second argument the per-kernel fabric traffic (FETCH_SIZE x 2 per the gfx950 note of MI355X_MICROARCH.md, WRITE_SIZE,
+both in bytes per dispatch) is also written as JSON: bench.py reads it to fill `roofline.traffic`."""
 import csv
 import glob
+import json
 import os
 import sys
 from collections import defaultdict
 
 root = sys.argv[1]
+traffic = {}
 agg = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
 dur = defaultdict(lambda: [0.0, 0])
 for f in glob.glob(os.path.join(root, "*", "**", "*counter_collection.csv"), recursive=True):
@@ -32,3 +37,11 @@ for k in sorted(agg, key=lambda k: -dur[k][0]):
         print(f"   -> HBM read  ~ {c['FETCH_SIZE'] * 1024 * 2 / 1e6:.1f} MB/dispatch (FETCH_SIZE KB x2 gfx950 correction)")
     if "WRITE_SIZE" in c:
         print(f"   -> HBM write ~ {c['WRITE_SIZE'] * 1024 / 1e6:.1f} MB/dispatch (uncalibrated)")
+    if "FETCH_SIZE" in c or "WRITE_SIZE" in c:
+        traffic[k] = {"dispatches": d[1], "avg_ns_under_pmc": d[0] / max(d[1], 1),
+                      "fetch_bytes": c.get("FETCH_SIZE", 0.0) * 1024 * 2, "write_bytes": c.get("WRITE_SIZE", 0.0) * 1024,
+                      "l2_hit_rate": (c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"])) if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c else None}
+if len(sys.argv) > 2:
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts "
+                         "128-byte requests as 64 bytes); bytes at the L2<->fabric boundary (Infinity Cache hits included)",
+               "kernels": traffic}, open(sys.argv[2], "w"), indent=1)

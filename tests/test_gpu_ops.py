@@ -1,5 +1,6 @@
 """GPU numerics of each HIP kernel against the torch fp32 op it replaces (through the C ABI)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -105,6 +106,7 @@ def test_attention_rotary(lib, prec):
 def test_gemm_f16x3(lib, monkeypatch, variant, M, N, K, epi, res):
     """Split-fp16 3-pass GEMM: fp32-class accuracy (same bound as the fp32 kernel)."""
     monkeypatch.setenv("PGMI_GEMM_VARIANT", str(variant))
+    monkeypatch.setenv("PGMI_GEMM_SPLITK", "1" if variant in (1, 2) else "0")      # K-sliced tails (opt-in) with variants 1, 2
     rng = np.random.default_rng(4)
     A = (rng.standard_normal((M, K)) * rng.choice([0.01, 1.0, 30.0], size=(M, 1))).astype(np.float32)
     W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)

@@ -486,3 +486,19 @@ def test_esm_cli_main_masked_marginals_on_cpu(golden, golden_dir, tmp_path, monk
     assert list(df.columns) == list(golden["cli/columns"])
     for c in ("esm1v_toy_1", "esm1v_toy_2", "Ensemble_ESM1v"):
         assert np.abs(df[c].to_numpy() - golden[f"cli/{c}"]).max() < 2e-5
+
+
+def test_oracle_head_dim_128_reproduces_reference(golden_dir, golden):
+    """ESM2 with head_dim 128 (the ESM2-15B class): oracle vs the reference-generated goldens of make_golden_h128.py."""
+    g = np.load(os.path.join(golden_dir, "golden_esm_h128.npz"))
+    seq = str(golden["seq"])
+    cfg, W = eo.load_checkpoint(os.path.join(golden_dir, "esm2_toy_h128.pt"))
+    assert cfg["embed_dim"] // cfg["heads"] == 128
+    with torch.no_grad():
+        lp = torch.log_softmax(eo.forward_logits(cfg, W, eo.tokenize(seq)[None]), -1)[0].numpy()
+    assert np.abs(lp - g["wt_logprobs"]).max() < 2e-5
+    table = eo.masked_marginals_table(cfg, W, seq, batch=8)
+    assert np.abs(table - g["mm_table"]).max() < 2e-5
+    df = pd.read_csv(os.path.join(golden_dir, "TOY_DMS.csv"))
+    got = np.array([eo.label_row(m, seq, table, 1) for m in df["mutant"]])
+    assert np.abs(got - g["cli"]).max() < 5e-5
