@@ -18,6 +18,10 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libpgmi.so")
 BUILD = os.path.join(HERE, "csrc", "_build")
 SOURCES = ["api.hip", "elementwise.hip", "gemm_f32.hip", "gemm_f16.hip", "attention_f32.hip", "attention_f16.hip", "msa_weights.hip", "msa_transformer.hip"]
+# attention_f16.hip: keep the MFMA accumulators in ArchVGPRs.  hipcc put the running O / S accumulators into AGPRs and then
+# paid 64 v_accvgpr_read + 64 v_accvgpr_write around every online-softmax rescale and around the S -> P conversion (VALU work
+# on accumulator data); the kernel fits 184 VGPRs at the same occupancy without them.
+EXTRA_FLAGS = {"attention_f16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 
@@ -37,6 +41,7 @@ def _digest() -> str:
                 h.update(fn.encode())
                 h.update(open(p, "rb").read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(EXTRA_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -50,7 +55,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     def compile_one(src):
         obj = os.path.join(BUILD, src.replace(".", "_") + ".o")
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")

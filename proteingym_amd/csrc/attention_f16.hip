@@ -324,6 +324,10 @@ __global__ __launch_bounds__(256) void qkv_prep_kernel(
                 x2 = y2;
             }
             unsigned short* dst = qk16 + ((size_t)b * T + t) * (2 * D) + (size_t)which * D + h * kHeadDim + 4 * c;
+            if (which == 0) {                        // base-2 softmax downstream: q carries log2(e) (common.h kQLog2e)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { x1[e] *= kQLog2e; x2[e] *= kQLog2e; }
+            }
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const f32x4 x = half ? x2 : x1;
@@ -426,6 +430,10 @@ __global__ __launch_bounds__(256) void qkv_prep_conv_kernel(
                 }
             }
             unsigned short* dst = qk16 + ((size_t)b * T + t) * (2 * D) + (size_t)which * D + h * kHeadDim + 4 * c;
+            if (which == 0) {                        // base-2 softmax downstream: q carries log2(e) (common.h kQLog2e)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { x1[e] *= kQLog2e; x2[e] *= kQLog2e; }
+            }
 #pragma unroll
             for (int half = 0; half < 2; ++half) {
                 const f32x4 x = half ? x2 : x1;
@@ -547,7 +555,8 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
     // NSTG-deep LDS ring, K/V tiles prefetched NSTG-1 ahead with counted vmcnt (the DMAs stay in
     // flight across the barrier; a __syncthreads() would drain them)
     const bool causal = slopes != nullptr;
-    const float slope = causal ? slopes[h] : 0.0f;
+    constexpr float kLog2e = 1.4426950408889634f;
+    const float slope2 = causal ? slopes[h] * kLog2e : 0.0f;      // the q planes carry log2(e) (kQLog2e), the ALiBi term must too
     // causal: keys beyond the block's last query tile are never needed (uniform bound for the block)
     const int last_q = min(T, (int)(blockIdx.x * WPB + WPB) * 32);
     const int nkt = causal ? (min(Tk, last_q) + AKT - 1) / AKT : (Tk + AKT - 1) / AKT;
@@ -564,7 +573,6 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
     // factor cancels in O / l because l accumulates the same scaled P)
     float m_run = -INFINITY, l_run = 0.f;
     constexpr float kInvLo = 1.0f / kLoScale;
-    constexpr float kLog2e = 1.4426950408889634f;
 
     int cur = 0;
     for (int kt = 0; kt < nkt; ++kt) {
@@ -595,12 +603,12 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
 #pragma unroll
                 for (int v = 0; v < 16; ++v) {
                     const int key = kt * AKT + (v & 3) + 8 * (v >> 2) + 4 * kh;
-                    const float sv = fmaf(sc[v], kInvLo, sm[v]) + slope * (float)key;
-                    st[v] = (key > q0 + r) ? -INFINITY : sv * kLog2e;
+                    const float sv = fmaf(sc[v], kInvLo, sm[v]) + slope2 * (float)key;
+                    st[v] = (key > q0 + r) ? -INFINITY : sv;
                 }
             } else {
 #pragma unroll
-                for (int v = 0; v < 16; ++v) st[v] = fmaf(sc[v], kInvLo, sm[v]) * kLog2e;
+                for (int v = 0; v < 16; ++v) st[v] = fmaf(sc[v], kInvLo, sm[v]);
             }
             if (kt * AKT + AKT > Tk) {
 #pragma unroll

@@ -34,6 +34,9 @@ enum Epilogue { EPI_NONE = 0, EPI_GELU = 1, EPI_SQRELU = 2 };   // erf-GELU (ESM
 // subnormal ever reaches the MFMA inputs.  The GEMM multiplies lo by (w_hi * 2^-11), which is
 // exact because weights are pre-scaled to ~2^13.
 constexpr float kLoScale = 2048.0f;
+// The split q planes consumed by attention_f16x3_v2_kernel are pre-multiplied by log2(e): its online softmax works in base 2
+// (v_exp_f32 is 2^x) and the scores come out of the MFMAs already in base-2 units -- 16 multiplies per 32 x 32 tile saved.
+constexpr float kQLog2e = 1.4426950408889634f;
 
 // K-interleaved layout of an f16x3 GEMM operand [rows][K] (K % 32 == 0): every group of 32 consecutive k is stored as the
 // 32 hi halfs (64 B) followed by the 32 lo halfs (64 B), so a row's share of a 32-deep K tile is ONE 128-byte line.

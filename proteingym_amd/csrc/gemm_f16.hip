@@ -325,8 +325,10 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
     const int row_lo = tid >> 3, c8 = tid & 7, sw8 = (row_lo >> 1) & 7;
     const int dst0 = (STG == 1) ? tid : row_lo * XCPR + (c8 ^ sw8);
     const int csrc = (STG == 1) ? (c8 ^ sw8) : c8;               // DMA: lane-linear slot, swizzled SOURCE chunk
-    const char* const Ab8 = reinterpret_cast<const char*>(A);
-    const char* const Wb8 = reinterpret_cast<const char*>(W);
+    // buffer descriptors built from kernel arguments only (provably wave-uniform): loads take a 32-bit per-lane byte offset
+    // and the K-tile offset as an SGPR -- no 64-bit address arithmetic in the memory phases
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(A), 0, (int)((unsigned int)M * (unsigned int)K * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(W), 0, (int)((unsigned int)N * (unsigned int)K * 4u), 0x00020000);
     unsigned int a_off[LD], w_off[LD];
     u32x4 a_st[LD], w_st[LD];
     int m0 = 0, n0 = 0, kt0 = 0, kt1 = 0, slice_item = -1;
@@ -357,13 +359,11 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
             w_off[i] = (unsigned int)min(n0 + row_lo + 64 * i, N - 1) * (unsigned int)K * 4u + (unsigned int)csrc * 16u;
         }
     };
-    auto src_a = [&](int i, int kt) { return reinterpret_cast<const u32x4*>(Ab8 + (size_t)kt * 128 + a_off[i]); };
-    auto src_w = [&](int i, int kt) { return reinterpret_cast<const u32x4*>(Wb8 + (size_t)kt * 128 + w_off[i]); };
     auto stage_load = [&](int kt) {
 #pragma unroll
-        for (int i = 0; i < LD; ++i) a_st[i] = *src_a(i, kt);
+        for (int i = 0; i < LD; ++i) a_st[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)a_off[i], kt * 128, 0));
 #pragma unroll
-        for (int i = 0; i < LD; ++i) w_st[i] = *src_w(i, kt);
+        for (int i = 0; i < LD; ++i) w_st[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)w_off[i], kt * 128, 0));
     };
     auto stage_store = [&](int buf) {
         u32x4* base = lds + buf * X_STAGE + dst0;
@@ -376,12 +376,10 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
         u32x4* base = lds + buf * X_STAGE + wave * 64;
 #pragma unroll
         for (int i = 0; i < LD; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_a(i, kt),
-                                             (__attribute__((address_space(3))) void*)(base + XNT * i), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(base + XNT * i), 16, (int)a_off[i], kt * 128, 0, 0);
 #pragma unroll
         for (int i = 0; i < LD; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_w(i, kt),
-                                             (__attribute__((address_space(3))) void*)(base + X_OP_CH + XNT * i), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(base + X_OP_CH + XNT * i), 16, (int)w_off[i], kt * 128, 0, 0);
     };
     // phase boundary: everything issued before stays before, this wave's LDS traffic has landed; VMEM stays in flight
     // DIAG (tuning-only instantiation): waves 0 and 4 of workgroup 0 stamp the shader clock when they reach and when
@@ -567,6 +565,10 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
                     for (int e = 0; e < 4; ++e) {
                         x0[e] = acc[0][i][4 * g + e] * out_scale + b0[e];
                         x1[e] = acc[1][i][4 * g + e] * out_scale + b1[e];
+                    }
+                    if (which == 0) {                          // attention's softmax is base 2: q carries log2(e) (common.h)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { x0[e] *= kQLog2e; x1[e] *= kQLog2e; }
                     }
                     if (which < 2) {
                         if (qo.rotary) {                       // rotary_embedding.py:11-20
@@ -888,9 +890,8 @@ static int launch_gemm16x(const unsigned short* A, const unsigned short* W,
     return PGMI_OK;
 }
 
-// f16x3 variants (tuning; 0 is the product's): 0 persistent ping-pong kernel, staging form chosen per output kind, K-sliced
-// tail; 1 register staging everywhere; 2 global->LDS DMA staging everywhere; 3 = 1 without tail slicing; 13 phase-timing
-// diagnostics (PGMI_GEMM_DIAG_FLAGS).
+// f16x3 variants (tuning; 0 is the product's): 0 / 2 persistent ping-pong kernel with global->LDS DMA staging; 1 / 3 register
+// staging; 13 phase-timing diagnostics (PGMI_GEMM_DIAG_FLAGS).  K-sliced tails only with PGMI_GEMM_SPLITK=1 (not with 3).
 int launch_gemm16(const unsigned short* A, size_t a_plane, const unsigned short* W, size_t w_plane,
                   const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
                   int M, int N, int K, int epilogue, float out_scale, int planes, bool bf, int variant,
@@ -907,10 +908,9 @@ int launch_gemm16(const unsigned short* A, size_t a_plane, const unsigned short*
             case 2: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 1, true, s);
             case 3: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 0, false, s);
             case 13: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 2, false, s);
-            // measured (profiles/r2): the fp32-output GEMMs (out-projection, FC2) are faster with register staging (and
-            // prefetch the next tile across the epilogue), the split-output ones (FC1+GELU, fused QKV) with the DMA form
-            // (fewer live registers next to their heavier epilogues)
-            default: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, Ch ? 1 : 0, true, s);
+            // measured (profiles/r2/README.md): with buffer loads the DMA form wins for every output kind (FFN 368 -> 379 TFLOP/s
+            // against register staging for the fp32-output GEMMs)
+            default: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 1, true, s);
         }
     }
     if (planes == 1 && bf) {
