@@ -9,7 +9,7 @@ here, and ``proteingym/merge.py`` + ``performance_DMS_benchmarks.py`` consume th
 
 Reference: /root/reference/proteingym/baselines/esm/compute_fitness.py
   create_parser :100-238   main :282-543   label_row :240-250   compute_pppl :258-279
-Additive flags (not in the reference): --device, --precision, --all-positions.
+Additive flags (not in the reference): --device, --precision, --all-positions, --shard-positions.
 The MSA-Transformer branch (:358-425) is score_msa_transformer below (masked-marginals; its pseudo-ppl variant is
 not built and raises NotImplementedError -- listed in INTEGRATION.md).
 """
@@ -64,6 +64,8 @@ _FLAGS = [
                               "fp32 (fp32 MFMA, parity-gated, slower), bf16 (fast, NOT parity-gated)")),
     ("--all-positions", dict(action="store_true", help="[additive] forward every token position as the reference does "
                                                        "(default: only positions some mutant reads; same outputs)")),
+    ("--shard-positions", dict(action="store_true", help="[additive] MSA Transformer under torchrun: every rank forwards its share of "
+                                                         "the masked positions of every seed, tables are all_gathered (see run_sharded)")),
 ]
 
 
@@ -263,6 +265,11 @@ def score_msa_transformer(args, df, mutant_col, msa_start_index, MSA_weight_file
     if args.scoring_strategy == "pseudo-ppl":
         raise NotImplementedError("pseudo-ppl with the MSA Transformer is not built (the reference launcher uses masked-marginals)")
     out_csv = args.dms_output
+    shard_rank, shard_world = 0, 1
+    if getattr(args, "shard_positions", False):
+        import torch.distributed as tdist
+        if tdist.is_available() and tdist.is_initialized():
+            shard_rank, shard_world = tdist.get_rank(), tdist.get_world_size()
     args.offset_idx = msa_start_index
     mutants = [str(m) for m in df[mutant_col]]
     cells = sorted({1 + int(one[1:-1]) - args.offset_idx for m in mutants for one in m.split(":")})   # +1: <cls>
@@ -291,15 +298,29 @@ def score_msa_transformer(args, df, mutant_col, msa_start_index, MSA_weight_file
             # the reference forwards every column; only cells some mutant reads are needed (--all-positions restores it)
             positions = list(range(T)) if args.all_positions else cells
             table = np.full((T, 33), np.nan, dtype=np.float32)
-            table[positions] = model.masked_logprobs(tokens, positions, seq_len=len(args.sequence))
+            # (seed, position) is the unit of work SURVEY 8e names for this path: with --shard-positions under torchrun every
+            # rank samples the SAME rows (python RNG seeded by `seed`), forwards positions[rank::world] -- one alignment-wide
+            # forward per masked column, all of equal cost -- and one all_gather + NaN-merge completes the table on every rank
+            mine = positions[shard_rank::shard_world]
+            if mine:
+                table[mine] = model.masked_logprobs(tokens, mine, seq_len=len(args.sequence))
+            if shard_world > 1:
+                from . import dist as pdist
+                import torch.distributed as tdist
+                table = pdist.gather_tables({0: table}, [T], device="cuda" if tdist.get_backend() == "nccl" else "cpu")[0]
             df[column] = [label_row(m, args.sequence, table, alphabet, args.offset_idx) for m in mutants]
             if on_disk is not None and not args.overwrite_prior_scores:
                 assert column not in on_disk.columns, f"Column {column} already exists in {out_csv}"
                 df = on_disk.merge(df[[column, "mutant"]], on="mutant")
-            df.to_csv(out_csv, index=False)
+            if shard_rank == 0:
+                df.to_csv(out_csv, index=False)
+            if shard_world > 1:
+                import torch.distributed as tdist
+                tdist.barrier()                           # the next seed re-reads the CSV rank 0 just wrote
         model.close()
     df[f"{stem}_ensemble"] = sum(df[f"{stem}_seed{seed}"] for seed in seeds) / len(seeds)
-    write_atomically(df, out_csv)
+    if shard_rank == 0:
+        write_atomically(df, out_csv)
 
 
 if __name__ == "__main__":

@@ -111,11 +111,42 @@ def strip_fairseq_prefixes(key: str) -> str:
     return key
 
 
-def _upgrade_state_dict(path: str):
-    """esm/pretrained.py:67-99 (v1) and :162-181 (v2).  torch is used only to unpickle the .pt."""
+def load_checkpoint_file(path):
+    """``torch.load`` restricted to tensors and plain containers plus ``argparse.Namespace`` (what fair-esm checkpoints hold,
+    esm/pretrained.py:70): a ``.pt`` is a pickle, and an unrestricted load runs whatever it names.  Files that need more are
+    refused unless the user opts in with PGMI_UNSAFE_TORCH_LOAD=1."""
     import torch
     torch.serialization.add_safe_globals([argparse.Namespace])
-    data = torch.load(str(path), map_location="cpu", weights_only=False)
+    try:
+        return torch.load(str(path), map_location="cpu", weights_only=True)
+    except Exception as e:
+        if os.environ.get("PGMI_UNSAFE_TORCH_LOAD") == "1":
+            return torch.load(str(path), map_location="cpu", weights_only=False)
+        raise RuntimeError(f"{path}: not loadable with weights_only=True ({type(e).__name__}: {e}); if the file is trusted, set "
+                           "PGMI_UNSAFE_TORCH_LOAD=1 to unpickle it without restrictions") from e
+
+
+def split_fused_in_proj(sd):
+    """Legacy fairseq attention blocks store q, k and v as one ``in_proj_weight`` / ``in_proj_bias``; cut them into the
+    three projections (the arithmetic of esm/multihead_attention.py:481-508).  The reference carries that hook but its
+    loader never calls it (esm/pretrained.py goes straight to ``load_state_dict``), so it rejects such a file with missing
+    keys; accepting it here is a superset.  Released ESM-1v/1b/ESM2 checkpoints do not use the fused form."""
+    out = {}
+    for k, v in sd.items():
+        for fused, leaf in (("in_proj_weight", "weight"), ("in_proj_bias", "bias")):
+            if k.endswith(fused):
+                stem, dim = k[: -len(fused)], v.shape[0] // 3
+                for j, name in enumerate(("q_proj", "k_proj", "v_proj")):
+                    out[f"{stem}{name}.{leaf}"] = v[j * dim:(j + 1) * dim]
+                break
+        else:
+            out[k] = v
+    return out
+
+
+def _upgrade_state_dict(path: str):
+    """esm/pretrained.py:67-99 (v1) and :162-181 (v2).  torch is used only to unpickle the .pt."""
+    data = load_checkpoint_file(path)
     model_name = Path(path).stem
     if model_name.startswith("esm2"):                                   # pretrained.py:187
         c = data["cfg"]["model"]
@@ -136,7 +167,7 @@ def _upgrade_state_dict(path: str):
                    ffn_dim=int(a.encoder_ffn_embed_dim), max_positions=int(a.max_positions),
                    token_dropout=int(bool(getattr(a, "token_dropout", False))),
                    emb_layer_norm_before=int(any(k.startswith("emb_layer_norm_before") for k in sd)))
-    sd = {k: v for k, v in sd.items() if not k.startswith("contact_head")}
+    sd = split_fused_in_proj({k: v for k, v in sd.items() if not k.startswith("contact_head")})
     # embed_tokens.weight and lm_head.weight are ONE tied parameter (esm1.py:101-105); load_state_dict
     # (pretrained.py:216) copies the entries in module order, so the value the model ends up with
     # is the lm_head.weight entry.  In real fair-esm files both entries share storage, so the

@@ -70,9 +70,7 @@ class MSABatchConverter:
 
 # ---- checkpoint -------------------------------------------------------------------------------------
 def _upgrade_state_dict(path: str):
-    import torch
-    torch.serialization.add_safe_globals([argparse.Namespace])
-    data = torch.load(str(path), map_location="cpu", weights_only=False)
+    data = pesm.load_checkpoint_file(path)              # weights_only=True + argparse.Namespace (see esm.load_checkpoint_file)
     a = data["args"]
     if a.arch != "msa_transformer":
         raise ValueError("Unknown architecture selected")

@@ -55,6 +55,22 @@ def column_names(model_locations, model_type):
     return cols, (["Ensemble_ESM1v"] if "ESM1v" in model_type else [])
 
 
+GPU_FLOPS_PER_S = 3.0e14          # planning constants only (ratios matter): sustained algorithmic rate of one GPU ...
+HOST_S_PER_ROW = 4.0e-6           # ... and parse + CSV seconds per mutant row on the rank that owns the assay
+
+
+def assay_seconds(seq_len: int, n_rows: int, n_checkpoints: int) -> float:
+    """Planned wall time of one assay on one rank: masked-marginals FLOPs for every checkpoint + the host work that
+    scales with the number of mutants (parsing, CSV): the 537k-row assay costs 2 s of host time against 0.3 s of GPU."""
+    return pdist.assay_cost(seq_len) * n_checkpoints / GPU_FLOPS_PER_S + n_rows * HOST_S_PER_ROW
+
+
+def plan_assays(mapping, todo, world, n_checkpoints):
+    rows = mapping["DMS_total_number_mutants"] if "DMS_total_number_mutants" in mapping.columns else None
+    costs = [assay_seconds(len(str(mapping.iloc[i]["target_seq"])), int(rows.iloc[i]) if rows is not None else 0, n_checkpoints) for i in todo]
+    return pdist.lpt_partition(costs, world)
+
+
 class _DeviceScorer:
     """One checkpoint on this rank's GPU: score(seq, mutants, offset) = Assay.run()."""
 
@@ -98,19 +114,26 @@ def main(args, make_model=None):
     cols, ens_cols = column_names(args.model_location, args.model_type)
     os.makedirs(args.dms_output, exist_ok=True)
 
+    # rank 0 decides what is left to do and broadcasts it: every collective below is shaped by this list, so it must not
+    # depend on each rank's own view of the output folder (NFS lag, an owner-writing rank finishing early)
     todo = []
-    for i in indices:
-        row = mapping.iloc[i]
-        out = os.path.join(args.dms_output, str(row["DMS_id"]) + ".csv")
-        if os.path.exists(out) and not args.overwrite_prior_scores:
-            have = pd.read_csv(out, nrows=0).columns
-            if all(c in have for c in cols + ens_cols):
-                continue
-        todo.append(i)
+    if rank == 0:
+        for i in indices:
+            row = mapping.iloc[i]
+            out = os.path.join(args.dms_output, str(row["DMS_id"]) + ".csv")
+            if os.path.exists(out) and not args.overwrite_prior_scores:
+                have = pd.read_csv(out, nrows=0).columns
+                if all(c in have for c in cols + ens_cols):
+                    continue
+            todo.append(i)
+    if world > 1:
+        import torch.distributed as tdist
+        box = [todo]
+        tdist.broadcast_object_list(box, src=0)
+        todo = box[0]
     if args.shard == "positions":
-        return main_position_shards(args, mapping, todo, cols, ens_cols, rank, local_rank, world)
-    costs = [pdist.assay_cost(len(str(mapping.iloc[i]["target_seq"]))) for i in todo]
-    assignment = pdist.lpt_partition(costs, world)
+        return main_position_shards(args, mapping, todo, cols, ens_cols, rank, local_rank, world, make_model=make_model)
+    assignment = plan_assays(mapping, todo, world, len(args.model_location))
     mine = [todo[k] for k in assignment[rank]]
 
     t0 = time.time()
@@ -121,17 +144,28 @@ def main(args, make_model=None):
         frames[i] = (pd.read_csv(os.path.join(args.dms_input, row["DMS_filename"])), mutant_col,
                      str(row["target_seq"]).upper(),
                      row["start_idx"] if "start_idx" in mapping.columns and row["start_idx"] != "" else 1)
+    owner_writes = world > 1 and args.write == "owner"
+    # the owner's CSVs are written by a background thread as soon as an assay has its last checkpoint column: pandas
+    # formatting (2.47 M rows over the benchmark) overlaps the scoring of the following assays (the C calls drop the GIL);
+    # in that last pass the assays with the most rows go first so that the un-overlapped tail is a small file
+    from concurrent.futures import ThreadPoolExecutor
+    writer = ThreadPoolExecutor(max_workers=2) if owner_writes else None
+    pending = []
     for ci, loc in enumerate(args.model_location):
         model = make_model(loc) if make_model is not None else _DeviceScorer(loc, local_rank, args.precision, args.all_positions)
-        for i in mine:
+        last = ci == len(args.model_location) - 1
+        order = sorted(mine, key=lambda i: -len(frames[i][0])) if last else mine
+        for i in order:
             df, mutant_col, seq, offset = frames[i]
             local.setdefault(i, []).append(np.asarray(model.score(seq, [str(m) for m in df[mutant_col]], offset), dtype=np.float64))
+            if last and writer is not None:
+                pending.append(writer.submit(_write_csv, _finish_frame(df, cols, ens_cols, local[i]),
+                                             os.path.join(args.dms_output, str(mapping.iloc[i]["DMS_id"]) + ".csv")))
         model.close()
-    owner_writes = world > 1 and args.write == "owner"
-    if owner_writes:                               # parallel I/O: 2.47 M rows of CSV are not rank 0's serial tail
-        for i in mine:
-            df = _finish_frame(frames[i][0], cols, ens_cols, local[i])
-            _write_csv(df, os.path.join(args.dms_output, str(mapping.iloc[i]["DMS_id"]) + ".csv"))
+    for f in pending:
+        f.result()                                 # re-raises a writer's exception
+    if writer is not None:
+        writer.shutdown()
     # exchange: per item a [n_checkpoints * n_mut] vector
     sizes = []
     n_rows = {}

@@ -66,6 +66,10 @@ def main(argv=None):
     ap.add_argument("baseline", choices=sorted(BASELINES))
     ap.add_argument("--indices", type=int, nargs="*", default=None, help="default: every row of the reference file")
     ap.add_argument("--dry-run", action="store_true", help="print this rank's assays and exit")
+    ap.add_argument("--shard", choices=["assay", "positions"], default="assay",
+                    help="msa_transformer only: 'positions' = every rank works on EVERY assay and forwards its share of the (seed, "
+                         "masked position) pairs; the log-prob tables are all_gathered (one BLAT-size assay x 5 seeds is ~190 s "
+                         "of serial work: sharding whole assays cannot balance a handful of them)")
     ap.add_argument("--backend", type=str, default=None)
     own = ap.parse_args(argv[:cut])
     rest = argv[cut + 1:]
@@ -75,20 +79,42 @@ def main(argv=None):
     rank, local_rank, world = pdist.init_from_env(own.backend)
     mapping = pd.read_csv(_value_after(rest, ref_flag))
     indices = list(range(len(mapping))) if own.indices is None else list(own.indices)
-    mine = plan(own.baseline, mapping, indices, world)[rank]
+    by_position = own.shard == "positions"
+    if by_position and own.baseline != "msa_transformer":
+        raise SystemExit("run_sharded: --shard positions is implemented for msa_transformer")
+    mine = list(indices) if by_position else plan(own.baseline, mapping, indices, world)[rank]
+    if by_position:
+        rest = rest + ["--shard-positions"]
     print(f"[rank {rank}/{world}] {own.baseline}: assays {mine}", flush=True)
     if not own.dry_run:
         import importlib
         mod = importlib.import_module(module)
         t0 = time.time()
+        failed = []
         for i in mine:
             args = mod.create_parser().parse_args(rest + [index_flag, str(i), device_flag, str(local_rank)])
-            mod.main(args)
-        print(f"[rank {rank}] {len(mine)} assays in {time.time() - t0:.1f}s", flush=True)
+            try:                                   # one assay's failure (a missing MSA, sys.exit in the single-assay CLI ...) must
+                mod.main(args)                     # neither skip this rank's other assays nor leave the peers in the barrier
+            except BaseException as e:
+                if isinstance(e, KeyboardInterrupt):
+                    raise
+                failed.append((i, f"{type(e).__name__}: {e}"))
+                print(f"[rank {rank}] assay {i} FAILED: {type(e).__name__}: {e}", flush=True)
+        print(f"[rank {rank}] {len(mine) - len(failed)} of {len(mine)} assays in {time.time() - t0:.1f}s", flush=True)
+    else:
+        failed = []
+    n_failed = len(failed)
     if world > 1:
+        import torch
         import torch.distributed as tdist
-        tdist.barrier()
+        cnt = torch.tensor([n_failed], dtype=torch.int64, device="cuda" if tdist.get_backend() == "nccl" else "cpu")
+        tdist.all_reduce(cnt)                      # doubles as the final barrier
+        n_failed = int(cnt.item())
         tdist.destroy_process_group()
+    if n_failed:
+        for i, why in failed:
+            print(f"[rank {rank}] failed assay {i}: {why}", file=sys.stderr, flush=True)
+        raise SystemExit(f"run_sharded: {n_failed} assay(s) failed (see the per-rank messages)")
     return mine
 
 

@@ -290,3 +290,134 @@ def test_run_indels_world2_pools_mutants_across_assays(tmp_path):
         a, loads = ri.partition_pool(lengths, world)
         assert sorted(k for part in a for k in part) == list(range(len(lengths)))
         assert loads.max() / loads.mean() < 1.02
+
+
+# ---- the 217-assay benchmark on 8 ranks: planned balance at the real shapes, and a world-8 gloo run of the runner ----
+def test_plan_of_the_217_assay_benchmark_on_8_ranks_balances_time_flops_and_rows():
+    """The assay-level plan for N = 8 over the REAL table (seq_len 37..3423, 2 465 767 mutants, one assay with 536 962):
+    planned seconds (GPU FLOPs for 5 checkpoints + host seconds per row) within 1 % of the mean on every rank; the
+    pure-FLOP and the row imbalance are reported and bounded."""
+    import pandas as pd
+    from proteingym_amd import run_benchmark as rb, synthetic
+    shapes = synthetic.dms_shapes()
+    assert len(shapes) == 217 and sum(s["n_total"] for s in shapes) == 2465767
+    mapping = pd.DataFrame({"target_seq": ["M" * s["seq_len"] for s in shapes], "DMS_total_number_mutants": [s["n_total"] for s in shapes]})
+    todo = list(range(217))
+    a = rb.plan_assays(mapping, todo, 8, 5)
+    assert sorted(k for part in a for k in part) == todo
+    secs = np.array([sum(rb.assay_seconds(shapes[k]["seq_len"], shapes[k]["n_total"], 5) for k in part) for part in a])
+    flops = np.array([sum(pdist.assay_cost(shapes[k]["seq_len"]) for k in part) for part in a])
+    rows = np.array([sum(shapes[k]["n_total"] for k in part) for part in a])
+    print("planned s/rank", np.round(secs, 1), "flop max/mean", flops.max() / flops.mean(), "rows/rank", rows)
+    assert secs.max() / secs.mean() < 1.01
+    assert flops.max() / flops.mean() < 1.05
+    # the rank that owns the 537k-row assay carries fewer FLOPs instead: host seconds are part of the plan
+    big = max(range(217), key=lambda k: shapes[k]["n_total"])
+    r_big = next(r for r, part in enumerate(a) if big in part)
+    assert flops[r_big] < flops.mean()
+
+
+def _world8_worker(rank, world, port, workdir, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    from proteingym_amd import run_benchmark as rb
+    args = rb.create_parser().parse_args([
+        "--model-location", "ckA.pt", "ckB.pt", "--model_type", "ESM1v", "--dms_mapping", os.path.join(workdir, "map.csv"),
+        "--dms-input", workdir, "--dms-output", os.path.join(workdir, "out"), "--backend", "gloo"])
+    rb.main(args, make_model=_FakeScorer)
+    q.put(rank)
+
+
+def test_assay_shards_world8_on_217_shaped_table(tmp_path):
+    """Eight gloo ranks over a 217-assay table with the benchmark's sequence lengths and 1/400 of its mutant counts:
+    todo list broadcast from rank 0, LPT by planned seconds, owners write their CSVs from a background thread, one
+    fixed-stride all_gather, rank 0's scores_summary.csv lists every assay."""
+    import pandas as pd
+    from proteingym_amd import synthetic
+    shapes = synthetic.dms_shapes()
+    rows, truth = [], {}
+    for s in shapes:
+        n = max(2, s["n_total"] // 400)
+        seq, muts, score = synthetic.random_assay(seed=s["DMS_index"], L=s["seq_len"], n_single=n, n_multi=0)
+        pd.DataFrame({"mutant": muts, "DMS_score": score}).to_csv(tmp_path / f"{s['DMS_id']}.csv", index=False)
+        rows.append({"DMS_id": s["DMS_id"], "DMS_filename": f"{s['DMS_id']}.csv", "target_seq": seq, "DMS_total_number_mutants": n})
+        truth[s["DMS_id"]] = (seq, muts)
+    pd.DataFrame(rows).to_csv(tmp_path / "map.csv", index=False)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_world8_worker, args=(r, 8, port, str(tmp_path), q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    assert sorted(q.get(timeout=600) for _ in procs) == list(range(8))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    summary = pd.read_csv(tmp_path / "out" / "scores_summary.csv")
+    assert sorted(summary["DMS_id"]) == sorted(truth) and int(summary["mutants"].sum()) == sum(len(m) for _, m in truth.values())
+    for name in list(truth)[::23]:
+        seq, muts = truth[name]
+        got = pd.read_csv(tmp_path / "out" / f"{name}.csv", float_precision="round_trip")
+        a, b = _FakeScorer("ckA.pt").score(seq, muts, 1), _FakeScorer("ckB.pt").score(seq, muts, 1)
+        assert np.array_equal(got["ckA"].to_numpy(), a) and np.array_equal(got["Ensemble_ESM1v"].to_numpy(), (a + b) / 2)
+
+
+# ---- MSA Transformer: (seed, position) pairs sharded over ranks ----------------------------------------
+def _msa_pos_worker(rank, world, port, golden_dir, outdir, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    from proteingym_amd import msa_transformer as pmsa, run_sharded
+
+    class Fake:                                   # a deterministic row per (sampled grid, masked column): no device, no oracle
+        calls = []
+
+        def __init__(self, path):
+            pass
+
+        def masked_logprobs(self, tokens, positions, seq_len, window=1024):
+            Fake.calls.append(list(positions))
+            t = np.asarray(tokens)
+            out = []
+            for p in positions:
+                rng = np.random.default_rng(int(t.sum()) * 1000003 + int(p))
+                x = rng.standard_normal(33).astype(np.float32)
+                out.append(x - np.log(np.exp(x).sum()))
+            return np.stack(out)
+
+        def close(self):
+            pass
+
+    pmsa.load_model_and_alphabet = lambda loc, device=0, max_rows=0: (Fake(loc), pmsa.MsaAlphabet())
+    run_sharded.main(["msa_transformer", "--shard", "positions", "--backend", "gloo", "--",
+                      "--model-location", os.path.join(golden_dir, "msa_toy.pt"), "--model_type", "MSA_transformer",
+                      "--dms_mapping", os.path.join(golden_dir, "TOY_MSA_MAPPING.csv"), "--dms-input", golden_dir, "--dms-output", outdir,
+                      "--scoring-strategy", "masked-marginals", "--msa-path", golden_dir, "--msa-weights-folder", golden_dir,
+                      "--msa-samples", "12", "--seeds", "1", "2"])
+    q.put((rank, Fake.calls))
+
+
+def test_msa_transformer_seed_position_pairs_shard_over_two_ranks(tmp_path):
+    """run_sharded msa_transformer --shard positions: both gloo ranks run the assay, each forwards every second masked
+    position of every seed, the tables are all_gathered; the CSV rank 0 writes equals the single-rank CSV bit for bit."""
+    import pandas as pd
+    golden_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    ctx = mp.get_context("spawn")
+    res = {}
+    for world, tag in ((1, "w1"), (2, "w2")):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_msa_pos_worker, args=(r, world, port, golden_dir, str(tmp_path / tag), q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        calls = dict(q.get(timeout=300) for _ in procs)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        res[tag] = (pd.read_csv(tmp_path / tag / "TOY_MSA_DMS.csv", float_precision="round_trip"), calls)
+    (d1, c1), (d2, c2) = res["w1"], res["w2"]
+    assert list(d1.columns) == list(d2.columns) and "msa_toy_ensemble" in d1.columns
+    for c in ("msa_toy_seed1", "msa_toy_seed2", "msa_toy_ensemble"):
+        assert np.array_equal(d1[c].to_numpy(), d2[c].to_numpy())
+    for seed_k in range(2):                       # per seed: the two ranks' positions are disjoint and together the single rank's
+        assert sorted(c2[0][seed_k] + c2[1][seed_k]) == sorted(c1[0][seed_k]) and not set(c2[0][seed_k]) & set(c2[1][seed_k])

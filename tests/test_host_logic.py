@@ -227,3 +227,37 @@ def test_bench_cpu_baseline_leg_and_parity_field():
     assert base["kind"] == "port" and base["unit"] == "mutants/s" and base["value"] > 0 and base["cores"] >= 1
     assert "2 of 2 layers" in base["sample"]
     assert parity["rows_compared"] == 3 and abs(parity["max_abs_err_vs_oracle"] - 3e-5) < 5e-6 and parity["tolerance"] == 1e-4
+
+
+def test_checkpoint_loading_is_restricted_and_accepts_fused_in_proj(tmp_path, golden_dir):
+    """(1) .pt files are unpickled with weights_only=True (+ argparse.Namespace): a file naming anything else is refused
+    with a message that names the opt-in; (2) a legacy checkpoint with fused in_proj_weight / in_proj_bias loads to the
+    same weight blob as its split twin (esm/multihead_attention.py:481-508)."""
+    import torch
+    from proteingym_amd import esm as pesm
+    cfg, sd = pesm._upgrade_state_dict(os.path.join(golden_dir, "esm1v_toy_1.pt"))
+    blob = pesm.pack_state_dict(cfg, sd)
+    raw = pesm.load_checkpoint_file(os.path.join(golden_dir, "esm1v_toy_1.pt"))
+    fused = {}
+    for k, v in raw["model"].items():
+        if ".self_attn.q_proj." in k:
+            leaf = k.split(".")[-1]
+            stem = k[: k.index("q_proj.")]
+            fused[stem + "in_proj_" + leaf] = torch.cat([raw["model"][stem + n + "_proj." + leaf] for n in ("q", "k", "v")], 0)
+        elif ".self_attn.k_proj." in k or ".self_attn.v_proj." in k:
+            continue
+        else:
+            fused[k] = v
+    assert any(k.endswith("in_proj_weight") for k in fused) and not any(".q_proj." in k for k in fused)
+    path = str(tmp_path / "esm1v_legacy.pt")
+    torch.save({"args": raw["args"], "model": fused}, path)
+    cfg2, sd2 = pesm._upgrade_state_dict(path)
+    assert cfg2 == cfg and np.array_equal(pesm.pack_state_dict(cfg2, sd2), blob)
+
+    class Evil:
+        def __reduce__(self):
+            return (print, ("arbitrary code ran",))
+    bad = str(tmp_path / "evil.pt")
+    torch.save({"args": raw["args"], "model": {"x": Evil()}}, bad)
+    with pytest.raises(RuntimeError, match="PGMI_UNSAFE_TORCH_LOAD"):
+        pesm.load_checkpoint_file(bad)
