@@ -69,6 +69,12 @@ def build(force: bool = False, verbose: bool = True) -> str:
                        capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    # a shared object links with unresolved symbols; resolve them now (RTLD_NOW) so a kernel whose host stub the
+    # compiler dropped fails the build instead of the first import on the GPU box
+    r = subprocess.run([sys.executable, "-c", f"import ctypes, os; ctypes.CDLL({OUT!r}, mode=os.RTLD_NOW)"],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"{OUT} does not load:\n{r.stderr}")
     open(stamp, "w").write(dig)
     if verbose:
         print(f"built {OUT}")

@@ -493,7 +493,8 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];   // [NSTG][STG_CH]
 
     const int b = blockIdx.z, h = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: scalar branches, SGPR DMA bases
     const int r = lane & 31, kh = lane >> 5;
     const int D = H * DH;
     const int Tk = kv_len ? kv_len[b] : T;
@@ -516,50 +517,56 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
     //   f in [0, 2 KCH):        K plane p = f / KCH, key = (f % KCH) / KCPR, slot chunk c' = f % KCPR, source chunk c = c' ^ swz(key)
     //                           swz(key) = (key >> 1) & 7 for 128-byte rows (DH 64), key & 15 for 256-byte rows (DH 128)
     //   f in [2 KCH, STG_CH):   V^T plane p, row d = (g >> 2) % DH, c' = g & 3, source chunk c = c' ^ ((d >> 2) & 3)
-    const u32x4* src[NDMA];
-    int step[NDMA];                                       // key index within the tile (K rows), -1 for V^T
-    int slot0[NDMA];                                      // first LDS chunk of the wave-instruction
+    // Every wave-instruction (64 slots) lies inside ONE plane of one tensor, so the tensor, the plane and the (sequence, head,
+    // tile) part of the address are wave-uniform: they go into the buffer descriptor and the SGPR offset, the lane keeps one
+    // 32-bit byte offset per instruction -- no per-tile address arithmetic.
+    const __amdgpu_buffer_rsrc_t rsQK = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(qk16), 0, (int)(unsigned int)(qk_plane * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsVT = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(vt16), 0, (int)(unsigned int)(vt_plane * 4), 0x00020000);
+    // causal: keys beyond the block's last query tile are never needed (uniform bound for the block)
+    const bool causal = slopes != nullptr;
+    const int last_q = min(T, (int)(blockIdx.x * WPB + WPB) * 32);
+    const int nkt = causal ? (min(Tk, last_q) + AKT - 1) / AKT : (Tk + AKT - 1) / AKT;
+    // voff_last: the same offsets for the LAST key tile with its K rows clamped to the sequence's last row (finite, masked by Tk) --
+    // the only tile that can reach past row T-1, i.e. into the next sequence or past the end of the operand
+    int voff[NDMA], voff_last[NDMA], sbase[NDMA], sstep[NDMA], slot0[NDMA];
+    bool is_k[NDMA];
 #pragma unroll
     for (int i = 0; i < NDMA; ++i) {
         int wi = wave + WPB * i;                          // wave-instruction index 0 .. NWI-1 (+ duplicates)
         if (wi >= NWI) wi -= NWI;
-        const int f = wi * 64 + lane;
         slot0[i] = wi * 64;
-        if (f < 2 * KCH) {
-            const int p = f / KCH, key = (f % KCH) / KCPR;
-            const int c = (f % KCPR) ^ (DH == 64 ? ((key >> 1) & 7) : (key & 15));
-            src[i] = reinterpret_cast<const u32x4*>(qk16 + (size_t)p * qk_plane + ((size_t)b * T) * (2 * D) + D + h * DH) + c;
-            step[i] = key;
+        is_k[i] = wi < 2 * KCH / 64;
+        if (is_k[i]) {
+            const int p = wi / (KCH / 64), key = ((wi % (KCH / 64)) * 64 + lane) / KCPR;
+            const int c = (lane % KCPR) ^ (DH == 64 ? ((key >> 1) & 7) : (key & 15));
+            voff[i] = key * (2 * D) * 2 + c * 16;
+            voff_last[i] = min(key, T - 1 - (nkt - 1) * AKT) * (2 * D) * 2 + c * 16;
+            sbase[i] = (int)((unsigned int)p * (unsigned int)qk_plane * 2u + ((unsigned int)b * T * (2 * D) + D + h * DH) * 2u);
+            sstep[i] = AKT * (2 * D) * 2;
         } else {
-            const int g = f - 2 * KCH, p = g / VCH, d = (g >> 2) % DH, c = (g & 3) ^ ((d >> 2) & 3);
-            src[i] = reinterpret_cast<const u32x4*>(vt16 + (size_t)p * vt_plane + (((size_t)b * H + h) * DH + d) * Tp) + c;
-            step[i] = -1;
+            const int wv = wi - 2 * KCH / 64, p = wv / (VCH / 64), g = (wv % (VCH / 64)) * 64 + lane;
+            const int d = g >> 2, c = (g & 3) ^ ((d >> 2) & 3);
+            voff[i] = voff_last[i] = d * Tp * 2 + c * 16;
+            sbase[i] = (int)((unsigned int)p * (unsigned int)vt_plane * 2u + (((unsigned int)b * H + h) * DH) * (unsigned int)Tp * 2u);
+            sstep[i] = (AKT / 8) * 16;
         }
     }
     auto issue_tile = [&](int kt, int buf) {
         u32x4* base = lds + buf * STG_CH;
 #pragma unroll
         for (int i = 0; i < NDMA; ++i) {
-            const u32x4* g;
-            if (step[i] >= 0) {
-                const int key = min(kt * AKT + step[i], T - 1);     // rows past the sequence: clamped (finite, masked by Tk)
-                g = src[i] + (size_t)key * (2 * D / 8);
-            } else {
-                g = src[i] + kt * (AKT / 8);
-            }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(base + slot0[i]), 16, 0, 0);
+            const int vo = (kt == nkt - 1) ? voff_last[i] : voff[i];
+            const int so = sbase[i] + kt * sstep[i];
+            // (soffset goes through a named local: with the array expression written in the call hipcc 7.2 silently drops the kernel's host stub)
+            if (is_k[i]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQK, (__attribute__((address_space(3))) void*)(base + slot0[i]), 16, vo, so, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsVT, (__attribute__((address_space(3))) void*)(base + slot0[i]), 16, vo, so, 0, 0);
         }
     };
 
     // NSTG-deep LDS ring, K/V tiles prefetched NSTG-1 ahead with counted vmcnt (the DMAs stay in
     // flight across the barrier; a __syncthreads() would drain them)
-    const bool causal = slopes != nullptr;
     constexpr float kLog2e = 1.4426950408889634f;
     const float slope2 = causal ? slopes[h] * kLog2e : 0.0f;      // the q planes carry log2(e) (kQLog2e), the ALiBi term must too
-    // causal: keys beyond the block's last query tile are never needed (uniform bound for the block)
-    const int last_q = min(T, (int)(blockIdx.x * WPB + WPB) * 32);
-    const int nkt = causal ? (min(Tk, last_q) + AKT - 1) / AKT : (Tk + AKT - 1) / AKT;
 #pragma unroll
     for (int t = 0; t < NSTG - 1; ++t)
         if (t < nkt) issue_tile(t, t);

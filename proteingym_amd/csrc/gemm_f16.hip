@@ -311,6 +311,7 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
     TilePlan tp, QkvOut qo) {
     constexpr int WN = 4, TM = 4, TN = 2, LD = 4;
     constexpr bool DIAG = DFLAGS >= 0;
+    constexpr bool DMA = STG == 1 || STG == 3;                    // 3 (tuning): DMA staging without the cross-item prefetch
     constexpr int kFlags = DIAG ? DFLAGS : 0;
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];  // [2][X_STAGE]
     const int tid = threadIdx.x, lane = tid & 63;
@@ -323,8 +324,8 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
     // consecutive lanes move one row's 128-byte line -- at LDS index row * 8 + (chunk ^ ((row >> 1) & 7)); the swizzle does
     // not depend on i, so one LDS index + 512 i serves all four, plus one 32-bit byte offset per row and operand.
     const int row_lo = tid >> 3, c8 = tid & 7, sw8 = (row_lo >> 1) & 7;
-    const int dst0 = (STG == 1) ? tid : row_lo * XCPR + (c8 ^ sw8);
-    const int csrc = (STG == 1) ? (c8 ^ sw8) : c8;               // DMA: lane-linear slot, swizzled SOURCE chunk
+    const int dst0 = DMA ? tid : row_lo * XCPR + (c8 ^ sw8);
+    const int csrc = DMA ? (c8 ^ sw8) : c8;               // DMA: lane-linear slot, swizzled SOURCE chunk
     // buffer descriptors built from kernel arguments only (provably wave-uniform): loads take a 32-bit per-lane byte offset
     // and the K-tile offset as an SGPR -- no 64-bit address arithmetic in the memory phases
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(A), 0, (int)((unsigned int)M * (unsigned int)K * 4u), 0x00020000);
@@ -463,6 +464,7 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
 
     int item = blockIdx.x;
     if (item >= tp.n_items) return;
+    bool dma_ahead = false;                                       // the item's first K tile was issued before the previous epilogue
     decode(item);
     if constexpr (STG == 0) stage_load(kt0);
     while (true) {
@@ -474,7 +476,7 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
             if (kt0 + 1 < kt1) stage_load(kt0 + 1);
             __syncthreads();
         } else {
-            issue_tile(kt0, 0);
+            if (!dma_ahead) issue_tile(kt0, 0);
             phase_vm();
         }
 #pragma unroll
@@ -493,7 +495,7 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
             //    two phases ago by the other wave group) --
             if (!(DIAG && (kFlags & 96))) __builtin_amdgcn_s_setprio(0);
             if (!(DIAG && (kFlags & 8) && kt > kt0)) read_frags(Ab, Wb, 0);
-            if (STG == 1 && kt + 1 < kt1) issue_tile(kt + 1, cur ^ 1);
+            if (DMA && kt + 1 < kt1) issue_tile(kt + 1, cur ^ 1);
             if (DIAG && (kFlags & 4) && kt > kt0 && kt + 1 < kt1) stage_load(kt + 1);
             phase();
             // -- compute phase 1 --
@@ -508,11 +510,11 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
                 if (!(DIAG && (kFlags & 2))) stage_store(cur ^ 1);
                 if (kt + 2 < kt1 && !(DIAG && (kFlags & 5))) stage_load(kt + 2);
             }
-            if (STG == 1 && late) phase_vm(); else phase();        // late waves close tile kt here: their DMA share must have landed
+            if (DMA && late) phase_vm(); else phase();        // late waves close tile kt here: their DMA share must have landed
             // -- compute phase 2 --
             if (!(DIAG && (kFlags & 96))) __builtin_amdgcn_s_setprio(1);
             mfmas();
-            if (STG == 1 && !late) phase_vm(); else phase();       // early waves close tile kt here
+            if (DMA && !late) phase_vm(); else phase();       // early waves close tile kt here
             cur ^= 1;
         }
         __builtin_amdgcn_s_setprio(0);
@@ -528,6 +530,9 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
         if (more) {
             decode(item);
             if constexpr (kPrefetchAcrossEpilogue) stage_load(kt0);
+            // DMA form: the fp32-output epilogue does not touch LDS and both K-tile buffers are free after the last phase barrier,
+            // so the next item's first K tile is already in flight while this item's epilogue runs
+            if constexpr (STG == 1 && OUT == 0) { issue_tile(kt0, 0); dma_ahead = true; }
         }
 
         if (eslice >= 0) {
@@ -773,7 +778,7 @@ static float* g_splitk_ws = nullptr;                              // one per pro
 static size_t g_splitk_ws_bytes = 0;
 static int g_splitk_ws_dev = -1;
 
-// stg: 0 register staging, 1 direct-to-LDS DMA.  splitk: allow K-sliced tail items (fp32-output GEMMs only).
+// stg: 0 register staging, 1 direct-to-LDS DMA, 3 the same without the cross-item prefetch (tuning).  splitk: allow K-sliced tail items (fp32-output GEMMs only).
 static int launch_gemm16x(const unsigned short* A, const unsigned short* W,
                           const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
                           int M, int N, int K, int epilogue, float out_scale, int stg, bool splitk, hipStream_t s,
@@ -873,7 +878,8 @@ static int launch_gemm16x(const unsigned short* A, const unsigned short* W,
         hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, A, W, bias, residual, Cf, Ch, c_plane, M, N, K,  \
                            out_scale, tp, qo);                                                           \
     } while (0)
-#define PGMI_LAUNCH16X_S(EPI_, OUT_) do { if (stg) PGMI_LAUNCH16X(EPI_, OUT_, 1); else PGMI_LAUNCH16X(EPI_, OUT_, 0); } while (0)
+#define PGMI_LAUNCH16X_S(EPI_, OUT_) do { if constexpr (OUT_ == 0) { if (stg == 3) { PGMI_LAUNCH16X(EPI_, OUT_, 3); break; } } \
+        if (stg) PGMI_LAUNCH16X(EPI_, OUT_, 1); else PGMI_LAUNCH16X(EPI_, OUT_, 0); } while (0)
     if (qkv) PGMI_LAUNCH16X_S(EPI_NONE, 2);
     else {
         const int out = Ch ? 1 : 0;
@@ -890,8 +896,8 @@ static int launch_gemm16x(const unsigned short* A, const unsigned short* W,
     return PGMI_OK;
 }
 
-// f16x3 variants (tuning; 0 is the product's): 0 / 2 persistent ping-pong kernel with global->LDS DMA staging; 1 / 3 register
-// staging; 13 phase-timing diagnostics (PGMI_GEMM_DIAG_FLAGS).  K-sliced tails only with PGMI_GEMM_SPLITK=1 (not with 3).
+// f16x3 variants (tuning; 0 is the product's): 0 persistent ping-pong kernel with global->LDS DMA staging; 2 the same without
+// the cross-item DMA prefetch; 1 / 3 register staging; 13 phase-timing diagnostics (PGMI_GEMM_DIAG_FLAGS).  K-sliced tails only with PGMI_GEMM_SPLITK=1 (not with 3).
 int launch_gemm16(const unsigned short* A, size_t a_plane, const unsigned short* W, size_t w_plane,
                   const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
                   int M, int N, int K, int epilogue, float out_scale, int planes, bool bf, int variant,
@@ -905,7 +911,7 @@ int launch_gemm16(const unsigned short* A, size_t a_plane, const unsigned short*
         if (Ch && (N % 32) != 0) { set_error("gemm16: split output needs N %% 32 == 0 (K-interleaved operand of the next GEMM), got %d", N); return PGMI_EINVAL; }
         switch (variant) {
             case 1: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 0, true, s);
-            case 2: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 1, true, s);
+            case 2: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 3, true, s);
             case 3: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 0, false, s);
             case 13: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 2, false, s);
             // measured (profiles/r2/README.md): with buffer loads the DMA form wins for every output kind (FFN 368 -> 379 TFLOP/s
