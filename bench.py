@@ -332,6 +332,9 @@ def main():
                                    f"{args.checkpoints} checkpoint{'s averaged (ensemble rate)' if args.checkpoints > 1 else ''}; "
                                    "assays shard over ranks + RCCL all_gather of score vectors",
                        "precision": args.precision, "layers": args.layers,
+                       "last_layer": ("after its attention the last layer runs on the masked row of every sequence only -- the one row "
+                                      "masked-marginals reads (class kept_rows); scores bit-identical to the full evaluation"
+                                      if os.environ.get("PGMI_KEEP_ROWS", "1") != "0" else "all rows (PGMI_KEEP_ROWS=0)"),
                        "positions_run": int(len(assay.positions)), "tokens_per_step": int(len(assay.positions) * assay.T)},
             "roofline": {"bound": "mfma", "kernel": "gemm (fc1+GELU, fc2+residual)", "achieved": achieved,
                          "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define PGMI_ABI_VERSION 3
+#define PGMI_ABI_VERSION 4
 
 /* error codes */
 #define PGMI_OK 0
@@ -194,7 +194,8 @@ void pgmi_optimal_window(int position, int seq_len_with_special, int model_windo
 #define PGMI_K_GEMM_FC2 6
 #define PGMI_K_HEAD 7
 #define PGMI_K_SCORE 8
-#define PGMI_K_COUNT 9
+#define PGMI_K_KEPT_ROWS 9   /* last layer after attention, on the kept (masked) rows only: gathers + out-projection + LN + FFN */
+#define PGMI_K_COUNT 10
 /* on != 0: every launch of the classes above is bracketed by hipEventRecord on the stream. */
 int pgmi_profile_enable(pgmi_model* m, int on);
 /* Sum of event-measured milliseconds, launch count and algorithmic FLOPs / bytes for a class

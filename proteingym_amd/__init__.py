@@ -12,4 +12,4 @@ Host-side mirrors of the reference's scoring entry points over a C-ABI library o
 There is no CPU fallback: every compute entry point raises ``PgmiError`` without the library or a GPU.
 """
 __version__ = "0.1.0"
-ABI_VERSION = 3
+ABI_VERSION = 4

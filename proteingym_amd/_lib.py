@@ -11,12 +11,12 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libpgmi.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 ARCH_ESM1B, ARCH_ESM2, ARCH_TRANCEPTION = 1, 2, 3
 PREC_FP32, PREC_BF16, PREC_F16X3 = 0, 1, 2
 PRECISIONS = {"fp32": PREC_FP32, "bf16": PREC_BF16, "f16x3": PREC_F16X3}
 K_NAMES = ["embed", "layernorm", "gemm_qkv", "attention", "gemm_out", "gemm_fc1", "gemm_fc2",
-           "head", "score"]
+           "head", "score", "kept_rows"]
 
 
 class PgmiError(RuntimeError):

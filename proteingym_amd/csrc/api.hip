@@ -85,6 +85,7 @@ struct pgmi_model {
     size_t qk16_plane = 0, vt16_plane = 0;
     int32_t* nonfinite = nullptr;
     int gemm_variant = 0;
+    int keep_rows = 1;                                 // last layer's row-local stages on the kept rows only (PGMI_KEEP_ROWS)
     int att16 = 3;        // f16x3 attention: 0 fp32 pipe, 1 in-kernel split, 2 prep pass + DMA ring, 3 QKV epilogue + DMA ring (default)
     int last_B = 0, last_T = 0;
     int dh = kHeadDim;    // true head dim; heads are laid out in 64-lane slot groups (pgmi_model_create)
@@ -308,7 +309,14 @@ int linear(pgmi_model* m, const float* in32, const unsigned short* in16, size_t 
 }
 
 // Runs the encoder on tokens already in m->tokens [B,T]; leaves the residual stream in m->x.
-int run_encoder(pgmi_model* m, int B, int T) {
+// keep != nullptr (device, n_keep row indices into [B*T]): the caller reads only these rows of the output (the masked
+// position of every sequence: compute_fitness.py:503 `token_probs[:, i]`, :274-276).  Everything after the last layer's
+// attention is row-local (out-projection, LayerNorm, FFN: modules.py:126-141), so the last layer gathers the kept rows
+// of the attention context and of the residual stream and runs those stages on n_keep rows; m->x then holds the kept
+// rows COMPACTED (row j = keep[j]) and *compacted is set.  The kept rows are bit-identical to the full evaluation: every
+// kernel on the way computes a row from that row's inputs only, in an order that does not depend on the row count
+// (tests/test_gpu_esm.py::test_last_layer_kept_rows_bit_identical).  PGMI_KEEP_ROWS=0 turns it off.
+int run_encoder(pgmi_model* m, int B, int T, const int32_t* keep = nullptr, int n_keep = 0, bool* compacted = nullptr) {
     const pgmi_config& c = m->cfg;
     const int M = B * T, D = c.embed_dim, F = c.ffn_dim, H = c.heads, Da = m->Da;
     hipStream_t s = m->stream;
@@ -365,6 +373,27 @@ int run_encoder(pgmi_model* m, int B, int T) {
               rc = launch_attention_f32(m->qkv, m->kv_len, B, T, H, m->h, m->h16, m->h16_plane,
                                         prec == PGMI_PREC_FP32 ? 0 : mode16, s);
           if (rc) return rc; }
+        if (keep && m->keep_rows && l == c.layers - 1) {
+            const int R = n_keep;
+            ProfScope p(m, PGMI_K_KEPT_ROWS, 2.0 * R * D * (Da + 2.0 * F), 0);
+            launch_gather_rows(m->x, keep, R, D, m->qkv, s);                       // residual rows (qkv is free after attention)
+            if (prec == PGMI_PREC_FP32) launch_gather_rows(m->h, keep, R, Da, m->g, s);
+            else        // a 16-bit context row is one contiguous run (K-interleaved hi|lo: 4 Da bytes; bf16: 2 Da bytes)
+                launch_gather_rows(reinterpret_cast<const float*>(m->h16), keep, R, prec == PGMI_PREC_F16X3 ? Da : Da / 2,
+                                   reinterpret_cast<float*>(m->g16), s);
+            rc = linear(m, m->g, m->g16, m->g16_plane, L.wo, L.wo16, L.bo, m->qkv, m->x, nullptr, 0, R, D, Da, EPI_NONE);
+            if (rc) return rc;
+            if (prec == PGMI_PREC_FP32) launch_layernorm(m->x, L.ln2_w, L.ln2_b, R, D, 1e-5f, m->h, s);
+            else launch_layernorm16(m->x, L.ln2_w, L.ln2_b, R, D, 1e-5f, m->h16, m->h16_plane, mode16, s);
+            rc = linear(m, m->h, m->h16, m->h16_plane, L.w1, L.w116, L.b1, nullptr,
+                        prec == PGMI_PREC_FP32 ? m->g : nullptr, prec == PGMI_PREC_FP32 ? nullptr : m->g16, m->g16_plane,
+                        R, F, D, EPI_GELU);
+            if (rc) return rc;
+            rc = linear(m, m->g, m->g16, m->g16_plane, L.w2, L.w216, L.b2, m->x, m->x, nullptr, 0, R, D, F, EPI_NONE);
+            if (rc) return rc;
+            if (compacted) *compacted = true;
+            break;
+        }
         { ProfScope p(m, PGMI_K_GEMM_OUT, 2.0 * M * D * D, 0);
           rc = linear(m, m->h, m->h16, m->h16_plane, L.wo, L.wo16, L.bo, m->x, m->x, nullptr, 0, M, D, Da, EPI_NONE);
           if (rc) return rc; }
@@ -408,6 +437,14 @@ int run_head(pgmi_model* m, int R, const int32_t* row_idx) {
     return PGMI_OK;
 }
 
+
+// Encoder + LM head where only the rows row_idx [R] (device) of the [B*T] outputs are read.  Result in m->lp [R,V].
+int run_rows(pgmi_model* m, int B, int T, int R, const int32_t* row_idx) {
+    bool compacted = false;
+    int rc = run_encoder(m, B, T, row_idx, R, &compacted);
+    if (rc) return rc;
+    return run_head(m, R, compacted ? nullptr : row_idx);
+}
 
 // ALiBi slopes, grouped: tranception/model_pytorch.py:50-71 (get_slopes(n, "grouped_alibi"))
 static void alibi_slopes_pow2(int n, std::vector<double>& out) {
@@ -889,6 +926,7 @@ int pgmi_model_create(const pgmi_config* cfg, const float* w, int64_t n_weights,
         TRY(dev_alloc(m->allocs, &m->vt16, m->vt16_plane * 2));
         PGMI_HIP(hipMemset(m->vt16, 0, m->vt16_plane * 2 * sizeof(unsigned short)));
     }
+    m->keep_rows = env_int("PGMI_KEEP_ROWS", 1);
     m->gemm_variant = env_int("PGMI_GEMM_VARIANT", 0);   // tuning only; 0 = persistent ping-pong kernel, register staging, K-sliced tail
     if (cfg->arch == PGMI_ARCH_MSA) {
         TRY(dev_alloc(m->allocs, &m->xt, R * D));
@@ -977,9 +1015,7 @@ int pgmi_masked_logprobs(pgmi_model* m, const int32_t* tokens, const int32_t* ma
         PGMI_HIP(hipMemcpyAsync(m->aux_i, mask_pos + b0, (size_t)bc * 4, hipMemcpyHostToDevice, m->stream));
         PGMI_HIP(hipMemcpyAsync(m->row_idx, ridx.data(), (size_t)bc * 4, hipMemcpyHostToDevice, m->stream));
         launch_apply_mask(m->tokens, m->aux_i, bc, T, m->stream);
-        rc = run_encoder(m, bc, T);
-        if (rc) return rc;
-        rc = run_head(m, bc, m->row_idx);
+        rc = run_rows(m, bc, T, bc, m->row_idx);
         if (rc) return rc;
         PGMI_HIP(hipMemcpyAsync(out + (size_t)b0 * V, m->lp, (size_t)bc * V * 4, hipMemcpyDeviceToHost, m->stream));
         PGMI_HIP(hipStreamSynchronize(m->stream));
@@ -1119,11 +1155,9 @@ int pgmi_assay_run(pgmi_model* m, pgmi_assay* a, double* scores_host, float* tab
     for (int p0 = 0; p0 < a->P; p0 += per) {
         const int bc = std::min(per, a->P - p0);
         launch_make_masked_windows(a->wt, a->win_start + p0, a->mask_rel + p0, bc, T, m->tokens, s);
-        int rc = run_encoder(m, bc, T);
-        if (rc) return rc;
         // rows to keep: b*T + mask_rel[b]  (compute_fitness.py:503: token_probs[:, i-start])
         launch_row_index(a->mask_rel + p0, bc, T, m->row_idx, s);
-        rc = run_head(m, bc, m->row_idx);
+        int rc = run_rows(m, bc, T, bc, m->row_idx);
         if (rc) return rc;
         launch_scatter_rows(m->lp, a->positions + p0, bc, V, a->table, s);
     }
@@ -1228,8 +1262,7 @@ int pgmi_pppl_run(pgmi_model* m, pgmi_pppl* q, int64_t first, int64_t count, dou
         const int per = std::max(1, m->max_rows / ((T + 31) / 32 * 32));
         const int bc = (int)std::min<int64_t>(per, R - g0);
         launch_make_pppl_rows(q->tok8, q->off_dev, d_sid, d_rp, J, g0, bc, T, m->tokens, m->row_idx, m->aux_i, s);
-        rc = run_encoder(m, bc, T);
-        if (!rc) rc = run_head(m, bc, m->row_idx);
+        rc = run_rows(m, bc, T, bc, m->row_idx);
         if (rc) { hipStreamSynchronize(s); cleanup(); return rc; }
         launch_pppl_pick(m->lp, m->aux_i, bc, V, d_terms + g0, s);
         q->last_chunks += 1;

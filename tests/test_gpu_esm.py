@@ -109,6 +109,30 @@ def test_determinism_and_chunking(lib, golden, golden_dir):
     assert np.array_equal(s1, s2)
 
 
+@pytest.mark.parametrize("precision", ["f16x3", "fp32", "bf16"])
+@pytest.mark.parametrize("name", ["esm1v_toy_1", "esm1b_toy_lnb", "esm2_toy", "esm2_toy_h128"])
+def test_last_layer_kept_rows_bit_identical(lib, golden, golden_dir, name, precision, monkeypatch):
+    """Masked-marginals and pseudo-ppl read ONE output row per forward (compute_fitness.py:503, :274-276); the last layer's
+    row-local stages run on those rows only.  Same bits as the full evaluation (PGMI_KEEP_ROWS=0)."""
+    if name == "esm2_toy_h128" and precision != "f16x3":
+        pytest.skip("head_dim 128 is f16x3-only")
+    seq = str(golden["seq"])
+    _, _, toks = pesm.Alphabet().get_batch_converter()([("p", seq)])
+    n = toks.shape[1]
+    rng = np.random.default_rng(5)
+    pos = rng.permutation(n)                                  # kept rows in no particular order
+    out = {}
+    for keep in ("1", "0"):
+        monkeypatch.setenv("PGMI_KEEP_ROWS", keep)
+        m = pesm.load_model_and_alphabet(os.path.join(golden_dir, name + ".pt"), precision=precision)[0]
+        out[keep] = m.masked_logprobs(np.repeat(toks, n, axis=0), pos)
+        a = pesm.Assay(m, seq, ["%s%d%s" % (seq[i], i + 1, "A" if seq[i] != "A" else "C") for i in range(0, len(seq), 3)], offset_idx=1)
+        out[keep + "s"] = a.run()
+        m.close()
+    assert np.array_equal(out["1"], out["0"])
+    assert np.array_equal(np.asarray(out["1s"]), np.asarray(out["0s"]))
+
+
 def test_esm1b_too_long_raises(models):
     toks = np.full((1, 1030), 5, np.int64)
     with pytest.raises(pesm.PgmiError, match="above maximum"):
