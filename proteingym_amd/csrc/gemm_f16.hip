@@ -24,6 +24,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 #include "common.h"
@@ -282,7 +283,8 @@ struct TilePlan {
     int tiles_m, tiles_n;
     int n_main;       // tiles [0, n_main) in launch order: one full-K item each
     int split;        // every later tile is cut into `split` K slices (<= 1: none)
-    int n_items;      // n_main + (tiles - n_main) * split
+    int n_items;      // n_main + (tiles - n_main) * split (or * 2 with half)
+    int half;         // 1: every later tile is cut into its upper and lower 128 rows instead (two items, full K each)
     float* ws;        // raw accumulators of the sliced items
     unsigned long long* diag;   // DIAG instantiation only: [2 waves][kDiagSamples][2] shader-clock stamps (barrier arrival, release)
     int diag_flags;             // DIAG instantiation only (ablations, wrong numbers): 1 no global loads in the loop, 2 no
@@ -309,10 +311,10 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
     const unsigned short* __restrict__ A, const unsigned short* __restrict__ W, const float* __restrict__ bias,
     const float* residual, float* Cf, unsigned short* Ch, size_t c_plane, int M, int N, int K, float out_scale,
     TilePlan tp, QkvOut qo) {
-    constexpr int WN = 4, TM = 4, TN = 2, LD = 4;
+    constexpr int WN = 4, TMX = 4, TN = 2, LD = 4;               // TMX: 32-row MFMA tiles per wave of a full item (a half item: 2)
     constexpr bool DIAG = DFLAGS >= 0;
-    constexpr bool DMA = STG == 1 || STG == 3;                    // 3 (tuning): DMA staging without the cross-item prefetch
-    constexpr int kFlags = DIAG ? DFLAGS : 0;
+    constexpr bool DMA = STG == 1 || STG == 3;                    // 3 (tuning): DMA issued after the fragment reads of memory phase 1
+    constexpr int kFlags = DIAG ? DFLAGS % 1000 : 0;              // DFLAGS >= 1000: the DMA form (launched with STG 1)
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];  // [2][X_STAGE]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // provably wave-uniform: scalar branches, SGPR LDS bases
@@ -332,7 +334,8 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(W), 0, (int)((unsigned int)N * (unsigned int)K * 4u), 0x00020000);
     unsigned int a_off[LD], w_off[LD];
     u32x4 a_st[LD], w_st[LD];
-    int m0 = 0, n0 = 0, kt0 = 0, kt1 = 0, slice_item = -1;
+    int m0 = 0, n0 = 0, kt0 = 0, kt1 = 0, slice_item = -1, a_ld = LD;
+    bool half_item = false;                                       // the upper or lower 128 rows of a tile (tail of the item list)
     auto decode = [&](int item) {                                 // sets m0, n0, [kt0, kt1), slice_item and the source offsets
         const int nk = K / 32;
         int wgid;
@@ -341,6 +344,9 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
             // run of the grouped tile order so that its L2 keeps the live A panels and W tiles
             const int nwg = tp.n_main, xcd = item & 7, q = nwg >> 3, r8 = nwg & 7;
             wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (item >> 3);
+            kt0 = 0; kt1 = nk; slice_item = -1;
+        } else if (tp.half) {
+            wgid = tp.n_main + ((item - tp.n_main) >> 1);
             kt0 = 0; kt1 = nk; slice_item = -1;
         } else {
             const int rel = item - tp.n_main, ks = rel % tp.split;
@@ -351,7 +357,10 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
         }
         int tm, tn;
         x_tile_coords(wgid, tp.tiles_m, tp.tiles_n, tm, tn);
-        m0 = __builtin_amdgcn_readfirstlane(tm * XBM); n0 = __builtin_amdgcn_readfirstlane(tn * XBN);
+        half_item = tp.half && item >= tp.n_main;
+        a_ld = half_item ? LD / 2 : LD;                           // A rows staged per K tile: 64 per instruction
+        m0 = __builtin_amdgcn_readfirstlane(tm * XBM + (half_item ? ((item - tp.n_main) & 1) * (XBM / 2) : 0));
+        n0 = __builtin_amdgcn_readfirstlane(tn * XBN);
         kt0 = __builtin_amdgcn_readfirstlane(kt0); kt1 = __builtin_amdgcn_readfirstlane(kt1);
         slice_item = __builtin_amdgcn_readfirstlane(slice_item);
 #pragma unroll
@@ -377,43 +386,44 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
         u32x4* base = lds + buf * X_STAGE + wave * 64;
 #pragma unroll
         for (int i = 0; i < LD; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(base + XNT * i), 16, (int)a_off[i], kt * 128, 0, 0);
+            if (i < a_ld)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(base + XNT * i), 16, (int)a_off[i], kt * 128, 0, 0);
 #pragma unroll
         for (int i = 0; i < LD; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(base + X_OP_CH + XNT * i), 16, (int)w_off[i], kt * 128, 0, 0);
     };
     // phase boundary: everything issued before stays before, this wave's LDS traffic has landed; VMEM stays in flight
-    // DIAG (tuning-only instantiation): waves 0 and 4 of workgroup 0 stamp the shader clock when they reach and when
-    // they leave every phase barrier; a pair is written out at the NEXT boundary, so the stamps cost two SMEM reads
-    // and one 16-byte store per phase and no extra wait.
+    // DIAG (tuning-only instantiation): waves 0 and 4 of workgroup 0 stamp the shader clock when they ARRIVE at every phase
+    // barrier, with a tag saying what the phase was (0 mem1, 1 cmp1, 3 mem2, 4 cmp2, 2 other).  The stamp is an SMEM read
+    // issued before the barrier and consumed at the next one: a wave that waits at the barrier pays nothing for it; the wave
+    // that arrives last (a computing wave) pays its latency at the start of its next -- memory -- phase.  (A second stamp
+    // after the barrier made every instrumented compute phase wait for the SMEM round trip: +200-350 clocks.)  The host
+    // takes release(k) = max over the two waves of arrival(k).
     const bool diag_on = DIAG && blockIdx.x == 0 && (wave == 0 || wave == 4);
-    unsigned long long d_arr = 0, d_rel = 0;
-    int d_n = 0;
-    auto phase = [&]() {
+    unsigned long long d_arr = 0;
+    int d_n = 0, d_tag = 0;
+    auto phase_impl = [&](bool vm, int tag) {
         __builtin_amdgcn_sched_barrier(0);
         if (DIAG && diag_on) {
             if (d_n > 0 && d_n <= kDiagSamples && lane == 0) {
                 unsigned long long* q = tp.diag + ((size_t)(wave >> 2) * kDiagSamples + (d_n - 1)) * 2;
-                q[0] = d_arr; q[1] = d_rel;
+                q[0] = d_arr; q[1] = (unsigned long long)d_tag + 1;
             }
         }
-        __builtin_amdgcn_s_waitcnt(0xC07F);                      // lgkmcnt(0)
-        if (DIAG && diag_on) d_arr = __builtin_readcyclecounter();   // after the wait: the SMEM read returns under the barrier
-        __builtin_amdgcn_s_barrier();
-        if (DIAG && diag_on) { d_rel = __builtin_readcyclecounter(); ++d_n; }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto phase_vm = [&]() {                                       // the same, plus this wave's DMA has landed (STG 1)
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_waitcnt(0x0070);                      // vmcnt(0) lgkmcnt(0)
+        if (vm && !(DIAG && (kFlags & 128))) __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
+        else __builtin_amdgcn_s_waitcnt(0xC07F);                                    // lgkmcnt(0)
+        if (DIAG && diag_on) { d_arr = __builtin_readcyclecounter(); d_tag = tag; ++d_n; }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
+    auto phase = [&](int tag = 2) { phase_impl(false, tag); };
+    auto phase_vm = [&](int tag = 2) { phase_impl(true, tag); };   // the same, plus this wave's DMA has landed (DMA form)
 
-    f32x16 acc[TN][TM];
-    u32x4 af[2][TM], wf[2][TN], whs[TN];
+    f32x16 acc[TN][TMX];
+    u32x4 af[2][TMX], wf[2][TN], whs[TN];
     const int fsw = (r >> 1) & 7;                                 // fragment rows are (multiple of 32) + r: the row swizzle is per lane
-    auto read_frags = [&](const u32x4* Ab, const u32x4* Wb, int ks) {
+    auto read_frags = [&](auto tmc, const u32x4* Ab, const u32x4* Wb, int ks) {
+        constexpr int TM = decltype(tmc)::value;
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int c = (p * 4 + ks * 2 + kh) ^ fsw;            // chunk p*4 + (2 ks + kh) of the row's line, swizzled
@@ -439,7 +449,8 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
                 whs[j][e] = __builtin_bit_cast(unsigned int, t);
             }
     };
-    auto mfmas = [&]() {
+    auto mfmas = [&](auto tmc) {
+        constexpr int TM = decltype(tmc)::value;
         scale_whi();
 #pragma unroll
         for (int j = 0; j < TN; ++j)
@@ -459,7 +470,7 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
         }
-        __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3 * TN * TM - 8, 0);
     };
 
     int item = blockIdx.x;
@@ -467,7 +478,12 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
     bool dma_ahead = false;                                       // the item's first K tile was issued before the previous epilogue
     decode(item);
     if constexpr (STG == 0) stage_load(kt0);
-    while (true) {
+    // the fp32-output epilogue has the registers to spare for the next item's first K tile; the split-plane and
+    // attention-operand epilogues do not (the prefetch spilled 12-23 registers): they fetch after the epilogue
+    constexpr bool kPrefetchAcrossEpilogue = STG == 0 && OUT == 0;
+    // one item, start to finish; TM (compile time) = 32-row MFMA tiles per wave: 4, or 2 for a half item.  Returns "more items".
+    auto run_item = [&](auto tmc) -> bool {
+        constexpr int TM = decltype(tmc)::value;
         // ---- prologue: first K tile of the item into buffer 0 (the LDS patches of the previous epilogue are done:
         //      every wave passed the barrier below only after finishing its own patch reads) ----
         __syncthreads();
@@ -494,27 +510,30 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
             // -- memory phase 1: fragments of the first k16 step (STG 1: DMA of tile kt+1 into the other buffer, last read
             //    two phases ago by the other wave group) --
             if (!(DIAG && (kFlags & 96))) __builtin_amdgcn_s_setprio(0);
-            if (!(DIAG && (kFlags & 8) && kt > kt0)) read_frags(Ab, Wb, 0);
-            if (DMA && kt + 1 < kt1) issue_tile(kt + 1, cur ^ 1);
+            // the DMA goes first: with the fragment reads ahead of it the memory phase outlasts the partner's 24 MFMAs
+            // (tools/mfma_phase.hip: 829 -> 797 clocks per phase on the bare loop); STG 3 keeps the old order for A/B
+            if (STG == 1 && kt + 1 < kt1 && !(DIAG && (kFlags & 16) && kt > kt0)) issue_tile(kt + 1, cur ^ 1);
+            if (!(DIAG && (kFlags & 8) && kt > kt0)) read_frags(tmc, Ab, Wb, 0);
+            if (STG == 3 && kt + 1 < kt1) issue_tile(kt + 1, cur ^ 1);
             if (DIAG && (kFlags & 4) && kt > kt0 && kt + 1 < kt1) stage_load(kt + 1);
-            phase();
+            phase(0);
             // -- compute phase 1 --
             if (!(DIAG && (kFlags & 96))) __builtin_amdgcn_s_setprio(1);
-            mfmas();
-            phase();
+            mfmas(tmc);
+            phase(1);
             // -- memory phase 2: fragments of the second k16 step; STG 0: tile kt+1 registers -> LDS, loads of kt+2 --
             if (!(DIAG && (kFlags & 96))) __builtin_amdgcn_s_setprio(0);
-            if (!(DIAG && (kFlags & 8) && kt > kt0)) read_frags(Ab, Wb, 1);
+            if (!(DIAG && (kFlags & 8) && kt > kt0)) read_frags(tmc, Ab, Wb, 1);
             if (STG == 0 && kt + 1 < kt1) {
                 __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0); lgkmcnt / expcnt untouched
                 if (!(DIAG && (kFlags & 2))) stage_store(cur ^ 1);
                 if (kt + 2 < kt1 && !(DIAG && (kFlags & 5))) stage_load(kt + 2);
             }
-            if (DMA && late) phase_vm(); else phase();        // late waves close tile kt here: their DMA share must have landed
+            if (DMA && late) phase_vm(3); else phase(3);        // late waves close tile kt here: their DMA share must have landed
             // -- compute phase 2 --
             if (!(DIAG && (kFlags & 96))) __builtin_amdgcn_s_setprio(1);
-            mfmas();
-            if (DMA && !late) phase_vm(); else phase();       // early waves close tile kt here
+            mfmas(tmc);
+            if (DMA && !late) phase_vm(4); else phase(4);       // early waves close tile kt here
             cur ^= 1;
         }
         __builtin_amdgcn_s_setprio(0);
@@ -524,15 +543,12 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
         const int em0 = m0, en0 = n0, eslice = slice_item;
         item += gridDim.x;
         const bool more = item < tp.n_items;
-        // the fp32-output epilogue has the registers to spare for the next item's first K tile; the split-plane and
-        // attention-operand epilogues do not (the prefetch spilled 12-23 registers): they fetch after the epilogue
-        constexpr bool kPrefetchAcrossEpilogue = STG == 0 && OUT == 0;
         if (more) {
             decode(item);
             if constexpr (kPrefetchAcrossEpilogue) stage_load(kt0);
             // DMA form: the fp32-output epilogue does not touch LDS and both K-tile buffers are free after the last phase barrier,
             // so the next item's first K tile is already in flight while this item's epilogue runs
-            if constexpr (STG == 1 && OUT == 0) { issue_tile(kt0, 0); dma_ahead = true; }
+            if constexpr (DMA && OUT == 0) { issue_tile(kt0, 0); dma_ahead = true; }
         }
 
         if (eslice >= 0) {
@@ -713,6 +729,14 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
                 }
             }
         }
+        return more;
+    };
+    using Full = std::integral_constant<int, TMX>;
+    using Half = std::integral_constant<int, TMX / 2>;
+    while (true) {
+        bool more;
+        if constexpr (OUT == 0 && DMA && !DIAG) more = half_item ? run_item(Half{}) : run_item(Full{});
+        else more = run_item(Full{});
         if (!more) break;
         if constexpr (STG == 0 && !kPrefetchAcrossEpilogue) stage_load(kt0);
     }
@@ -778,7 +802,7 @@ static float* g_splitk_ws = nullptr;                              // one per pro
 static size_t g_splitk_ws_bytes = 0;
 static int g_splitk_ws_dev = -1;
 
-// stg: 0 register staging, 1 direct-to-LDS DMA, 3 the same without the cross-item prefetch (tuning).  splitk: allow K-sliced tail items (fp32-output GEMMs only).
+// stg: 0 register staging, 1 direct-to-LDS DMA, 3 the same with the DMA issued after the fragment reads (tuning).  splitk: allow K-sliced tail items (fp32-output GEMMs only).
 static int launch_gemm16x(const unsigned short* A, const unsigned short* W,
                           const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
                           int M, int N, int K, int epilogue, float out_scale, int stg, bool splitk, hipStream_t s,
@@ -815,6 +839,14 @@ static int launch_gemm16x(const unsigned short* A, const unsigned short* W,
             }
         }
     }
+    // Half-height tail (fp32-output GEMMs, DMA form): the last, partial round of tiles leaves G - rem CUs idle for a whole tile
+    // time (N = 1280 at the BLAT shape: 6.29 rounds cost 7).  Its tiles are cut into their upper and lower 128 rows -- two
+    // items on two CUs, each over the full K range in the same order, so every output element is computed exactly as in a
+    // full tile (bit-identical; unlike the K slices above) -- when all the halves still fit one round.
+    static const int want_half = getenv("PGMI_GEMM_HALF_TAIL") ? atoi(getenv("PGMI_GEMM_HALF_TAIL")) : 1;
+    if (want_half && tp.split <= 1 && Cf && !qkv && (stg == 1 || stg == 3) && rem > 0 && 2 * rem <= G) {
+        tp.n_main = T - rem; tp.half = 1; tp.n_items = tp.n_main + 2 * rem;
+    }
     QkvOut qo{};
     if (qkv) qo = *qkv;
     const size_t lds_bytes = (size_t)2 * X_STAGE * 16;
@@ -829,12 +861,14 @@ static int launch_gemm16x(const unsigned short* A, const unsigned short* W,
         tp.diag_flags = getenv("PGMI_GEMM_DIAG_FLAGS") ? atoi(getenv("PGMI_GEMM_DIAG_FLAGS")) : 0;
 #define PGMI_DIAG_CASE(F_)                                                                                          \
         case F_: {                                                                                                  \
-            auto kfn = gemm16x_kernel<EPI_NONE, 0, 0, F_>;                                                          \
+            auto kfn = gemm16x_kernel<EPI_NONE, 0, (F_ >= 1000 ? 1 : 0), F_>;                                       \
             PGMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
             hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, A, W, bias, residual, Cf, Ch, c_plane, M, N, K, out_scale, tp, qo); \
         } break;
         switch (tp.diag_flags) {
-            PGMI_DIAG_CASE(0) PGMI_DIAG_CASE(1) PGMI_DIAG_CASE(3) PGMI_DIAG_CASE(11) PGMI_DIAG_CASE(32) PGMI_DIAG_CASE(64)
+            // register staging: 0 as shipped, 11 no loads / LDS writes / fragment reads.  DMA form (+1000): 1000 as shipped, 1016 no DMA
+            // after the first K tile, 1008 no fragment reads, 1024 neither, 1128 no wait for the DMA (wrong numbers, timing only)
+            PGMI_DIAG_CASE(0) PGMI_DIAG_CASE(11) PGMI_DIAG_CASE(1000) PGMI_DIAG_CASE(1016) PGMI_DIAG_CASE(1008) PGMI_DIAG_CASE(1024) PGMI_DIAG_CASE(1128)
             default: set_error("gemm16x diag: flags %d not instantiated", tp.diag_flags); return PGMI_EINVAL;
         }
 #undef PGMI_DIAG_CASE
@@ -844,25 +878,28 @@ static int launch_gemm16x(const unsigned short* A, const unsigned short* W,
         std::vector<unsigned long long> h(n);
         PGMI_HIP(hipMemcpyAsync(h.data(), dbuf, n * 8, hipMemcpyDeviceToHost, s));
         PGMI_HIP(hipStreamSynchronize(s));
-        // per wave group: work = release(k-1) -> arrival(k), wait = arrival(k) -> release(k); phases cycle mem1, cmp1, mem2, cmp2
+        // per wave: work = release(k-1) -> arrival(k), wait = arrival(k) -> release(k), release(k) = the later arrival of the two
         static int printed = 0;
         if (!printed++) {
             fprintf(stderr, "[gemm16x diag] flags %d\n", tp.diag_flags);
+            const unsigned long long* q0 = h.data();
+            const unsigned long long* q1 = h.data() + (size_t)kDiagSamples * 2;
             for (int g = 0; g < 2; ++g) {
-                const unsigned long long* q = h.data() + (size_t)g * kDiagSamples * 2;
-                double work[4] = {0, 0, 0, 0}, wait[4] = {0, 0, 0, 0};
-                int cnt[4] = {0, 0, 0, 0};
-                // the late group passes one extra barrier before its first memory phase; skip the first 3 K tiles (pipeline fill)
-                const int first = 12 + g;
-                for (int k = first; k + 1 < kDiagSamples && q[2 * (k + 1)]; ++k) {
-                    const int ph = (k - g) & 3;                    // barrier k closes phase ph of its K tile: 0 mem1, 1 cmp1, 2 mem2, 3 cmp2
-                    work[ph] += (double)(q[2 * k] - q[2 * (k - 1) + 1]);
-                    wait[ph] += (double)(q[2 * k + 1] - q[2 * k]);
-                    cnt[ph]++;
+                const unsigned long long* q = g ? q1 : q0;
+                double work[5] = {0, 0, 0, 0, 0}, wait[5] = {0, 0, 0, 0, 0};
+                int cnt[5] = {0, 0, 0, 0, 0};
+                for (int k = 16; k < kDiagSamples && q0[2 * k + 1] && q1[2 * k + 1]; ++k) {     // skip the pipeline fill
+                    const int tag = (int)q[2 * k + 1] - 1;
+                    const unsigned long long rel_prev = std::max(q0[2 * (k - 1)], q1[2 * (k - 1)]);
+                    const unsigned long long rel = std::max(q0[2 * k], q1[2 * k]);
+                    if (tag < 0 || tag > 4 || q[2 * k] < rel_prev) continue;
+                    work[tag] += (double)(q[2 * k] - rel_prev);
+                    wait[tag] += (double)(rel - q[2 * k]);
+                    cnt[tag]++;
                 }
                 fprintf(stderr, "[gemm16x diag] %s waves: ", g ? "late " : "early");
-                static const char* nm[4] = {"mem1", "cmp1", "mem2", "cmp2"};
-                for (int p = 0; p < 4; ++p)
+                static const char* nm[5] = {"mem1", "cmp1", "other", "mem2", "cmp2"};
+                for (int p : {0, 1, 3, 4})
                     fprintf(stderr, "%s work %.0f wait %.0f | ", nm[p], cnt[p] ? work[p] / cnt[p] : 0.0, cnt[p] ? wait[p] / cnt[p] : 0.0);
                 fprintf(stderr, "(shader clocks, mean over %d K tiles)\n", cnt[0]);
             }
@@ -896,8 +933,8 @@ static int launch_gemm16x(const unsigned short* A, const unsigned short* W,
     return PGMI_OK;
 }
 
-// f16x3 variants (tuning; 0 is the product's): 0 persistent ping-pong kernel with global->LDS DMA staging; 2 the same without
-// the cross-item DMA prefetch; 1 / 3 register staging; 13 phase-timing diagnostics (PGMI_GEMM_DIAG_FLAGS).  K-sliced tails only with PGMI_GEMM_SPLITK=1 (not with 3).
+// f16x3 variants (tuning; 0 is the product's): 0 persistent ping-pong kernel with global->LDS DMA staging; 2 the same with
+// the DMA issued after the fragment reads; 1 / 3 register staging; 13 phase-timing diagnostics (PGMI_GEMM_DIAG_FLAGS).  K-sliced tails only with PGMI_GEMM_SPLITK=1 (not with 3).
 int launch_gemm16(const unsigned short* A, size_t a_plane, const unsigned short* W, size_t w_plane,
                   const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
                   int M, int N, int K, int epilogue, float out_scale, int planes, bool bf, int variant,
