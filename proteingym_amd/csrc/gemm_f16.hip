@@ -735,7 +735,7 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
     using Half = std::integral_constant<int, TMX / 2>;
     while (true) {
         bool more;
-        if constexpr (OUT == 0 && DMA && !DIAG) more = half_item ? run_item(Half{}) : run_item(Full{});
+        if constexpr (OUT != 2 && DMA && !DIAG) more = half_item ? run_item(Half{}) : run_item(Full{});
         else more = run_item(Full{});
         if (!more) break;
         if constexpr (STG == 0 && !kPrefetchAcrossEpilogue) stage_load(kt0);
@@ -839,12 +839,12 @@ static int launch_gemm16x(const unsigned short* A, const unsigned short* W,
             }
         }
     }
-    // Half-height tail (fp32-output GEMMs, DMA form): the last, partial round of tiles leaves G - rem CUs idle for a whole tile
+    // Half-height tail (every output kind but the fused QKV, DMA form): the last, partial round of tiles leaves G - rem CUs idle for a whole tile
     // time (N = 1280 at the BLAT shape: 6.29 rounds cost 7).  Its tiles are cut into their upper and lower 128 rows -- two
     // items on two CUs, each over the full K range in the same order, so every output element is computed exactly as in a
     // full tile (bit-identical; unlike the K slices above) -- when all the halves still fit one round.
     static const int want_half = getenv("PGMI_GEMM_HALF_TAIL") ? atoi(getenv("PGMI_GEMM_HALF_TAIL")) : 1;
-    if (want_half && tp.split <= 1 && Cf && !qkv && (stg == 1 || stg == 3) && rem > 0 && 2 * rem <= G) {
+    if (want_half && tp.split <= 1 && !qkv && (stg == 1 || stg == 3) && rem > 0 && 2 * rem <= G) {
         tp.n_main = T - rem; tp.half = 1; tp.n_items = tp.n_main + 2 * rem;
     }
     QkvOut qo{};
