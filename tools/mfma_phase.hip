@@ -168,9 +168,17 @@ int main(int argc, char** argv) {
         h[i] = (unsigned short)(((rand() & 1) << 15) | (e << 10) | (rand() & 0x3ff));
     }
     for (size_t o = 0; o < in_bytes; o += (1 << 24)) hipMemcpy((char*)in + o, h, 1 << 24, hipMemcpyHostToDevice);
+    run<0>(in, in_bytes, out, clk, iters, reps);
+    run<1>(in, in_bytes, out, clk, iters, reps);
+    run<3>(in, in_bytes, out, clk, iters, reps);
     run<4>(in, in_bytes, out, clk, iters, reps);
     run<5>(in, in_bytes, out, clk, iters, reps);
     run<11>(in, in_bytes, out, clk, iters, reps);
     run<14>(in, in_bytes, out, clk, iters, reps);
+    run<7>(in, in_bytes, out, clk, iters, reps);
+    run<9>(in, in_bytes, out, clk, iters, reps);
+    run<10>(in, in_bytes, out, clk, iters, reps);
+    run<13>(in, in_bytes, out, clk, iters, reps);
+    run<6>(in, in_bytes, out, clk, iters, reps);
     return 0;
 }
