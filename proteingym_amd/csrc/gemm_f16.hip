@@ -843,7 +843,7 @@ static int launch_gemm16x(const unsigned short* A, const unsigned short* W,
     // time (N = 1280 at the BLAT shape: 6.29 rounds cost 7).  Its tiles are cut into their upper and lower 128 rows -- two
     // items on two CUs, each over the full K range in the same order, so every output element is computed exactly as in a
     // full tile (bit-identical; unlike the K slices above) -- when all the halves still fit one round.
-    static const int want_half = getenv("PGMI_GEMM_HALF_TAIL") ? atoi(getenv("PGMI_GEMM_HALF_TAIL")) : 1;
+    const int want_half = getenv("PGMI_GEMM_HALF_TAIL") ? atoi(getenv("PGMI_GEMM_HALF_TAIL")) : 1;   // read per launch: the tests toggle it
     if (want_half && tp.split <= 1 && !qkv && (stg == 1 || stg == 3) && rem > 0 && 2 * rem <= G) {
         tp.n_main = T - rem; tp.half = 1; tp.n_items = tp.n_main + 2 * rem;
     }

@@ -129,6 +129,29 @@ def test_gemm_f16x3(lib, monkeypatch, variant, M, N, K, epi, res):
     assert err < 2e-5 * np.sqrt(K / 128), err
 
 
+@pytest.mark.parametrize("M,N,K,epi,res", [(2300, 1280, 1280, 0, True),      # 45 tiles: every one of them as two half-height items
+                                            (15100, 1280, 256, 1, False),     # 300 tiles on 256 CUs: 256 full + 44 x 2 halves
+                                            (4300, 5120, 128, 0, True),       # 340 tiles: 256 + 84 x 2
+                                            (200, 1280, 384, 1, True)])       # one row of tiles, rows past M in the lower halves
+def test_gemm_f16x3_half_tail_bit_identical(lib, monkeypatch, M, N, K, epi, res):
+    """The half-height tail items (gemm_f16.hip: TilePlan.half) compute every element exactly as a full tile does."""
+    monkeypatch.setenv("PGMI_GEMM_VARIANT", "0")
+    monkeypatch.setenv("PGMI_GEMM_SPLITK", "0")
+    rng = np.random.default_rng(6)
+    A = (rng.standard_normal((M, K)) * rng.choice([0.01, 1.0, 30.0], size=(M, 1))).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    R = rng.standard_normal((M, N)).astype(np.float32) if res else None
+    out = {}
+    for half in ("1", "0"):
+        monkeypatch.setenv("PGMI_GEMM_HALF_TAIL", half)
+        C = np.full((M, N), np.nan, np.float32)
+        _lib.check(lib.pgmi_op_gemm(0, _lib.PREC_F16X3, _p(A), _p(W), _p(bias), _p(R), M, N, K, epi, _p(C)))
+        out[half] = C
+    assert np.isfinite(out["1"]).all()
+    assert np.array_equal(out["1"], out["0"])
+
+
 @pytest.mark.parametrize("M,N,K,epi,res", [(300, 384, 256, 0, False), (3600, 384, 128, 0, False),
                                             (3600, 256, 128, 1, False), (3600, 128, 256, 0, True), (70, 128, 128, 1, True)])
 def test_gemm_bf16(lib, M, N, K, epi, res):
