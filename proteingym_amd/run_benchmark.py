@@ -77,12 +77,17 @@ class _DeviceScorer:
     def __init__(self, location, device, precision, all_positions):
         self.model, self.alphabet = pesm.load_model_and_alphabet(location, device=device, precision=precision)
         self.all_positions = all_positions
+        self.create_s = self.run_s = 0.0            # wall clock in Assay() (parse + upload) / Assay.run() (GPU + 8 bytes per mutant back)
 
     def score(self, seq, mutants, offset):
+        t0 = time.time()
         assay = pesm.Assay(self.model, seq, mutants, offset_idx=int(offset), alphabet=self.alphabet,
                            all_positions=self.all_positions)
+        t1 = time.time()
         out = assay.run()
         assay.close()
+        self.create_s += t1 - t0
+        self.run_s += time.time() - t1
         return out
 
     def close(self):
@@ -137,35 +142,58 @@ def main(args, make_model=None):
     mine = [todo[k] for k in assignment[rank]]
 
     t0 = time.time()
-    frames, local = {}, {}
-    for i in mine:
+    from concurrent.futures import ThreadPoolExecutor
+    frames, local, reads = {}, {}, {}
+    clock = {"wait_read_s": 0.0, "score_s": 0.0, "wait_write_s": 0.0}
+
+    def read_frame(i):
         row = mapping.iloc[i].replace(np.nan, "")
         mutant_col = row["DMS_mutant_column"] if "DMS_mutant_column" in mapping.columns else args.mutation_col
-        frames[i] = (pd.read_csv(os.path.join(args.dms_input, row["DMS_filename"])), mutant_col,
-                     str(row["target_seq"]).upper(),
-                     row["start_idx"] if "start_idx" in mapping.columns and row["start_idx"] != "" else 1)
-    owner_writes = world > 1 and args.write == "owner"
+        return (pd.read_csv(os.path.join(args.dms_input, row["DMS_filename"])), mutant_col, str(row["target_seq"]).upper(),
+                row["start_idx"] if "start_idx" in mapping.columns and row["start_idx"] != "" else 1)
+
+    # the DMS files are read by a background thread in scoring order, ahead of the GPU (the C parser and the scoring calls
+    # both drop the GIL); every frame is kept: the checkpoint columns are added to it at the end
+    rows_of = {i: int(mapping.iloc[i]["DMS_total_number_mutants"]) if "DMS_total_number_mutants" in mapping.columns else 0 for i in mine}
+    order = sorted(mine, key=lambda i: -rows_of[i])      # most rows first: the CSV written last, un-overlapped, is a small one
+    reader = ThreadPoolExecutor(max_workers=1)
+    for i in order:
+        reads[i] = reader.submit(read_frame, i)
+
+    def frame(i):
+        if i not in frames:
+            t = time.time()
+            frames[i] = reads.pop(i).result()
+            clock["wait_read_s"] += time.time() - t
+        return frames[i]
+
+    owner_writes = args.write == "owner"
     # the owner's CSVs are written by a background thread as soon as an assay has its last checkpoint column: pandas
     # formatting (2.47 M rows over the benchmark) overlaps the scoring of the following assays (the C calls drop the GIL);
-    # in that last pass the assays with the most rows go first so that the un-overlapped tail is a small file
-    from concurrent.futures import ThreadPoolExecutor
     writer = ThreadPoolExecutor(max_workers=2) if owner_writes else None
     pending = []
     for ci, loc in enumerate(args.model_location):
         model = make_model(loc) if make_model is not None else _DeviceScorer(loc, local_rank, args.precision, args.all_positions)
         last = ci == len(args.model_location) - 1
-        order = sorted(mine, key=lambda i: -len(frames[i][0])) if last else mine
         for i in order:
-            df, mutant_col, seq, offset = frames[i]
+            df, mutant_col, seq, offset = frame(i)
+            t = time.time()
             local.setdefault(i, []).append(np.asarray(model.score(seq, [str(m) for m in df[mutant_col]], offset), dtype=np.float64))
+            clock["score_s"] += time.time() - t
             if last and writer is not None:
                 pending.append(writer.submit(_write_csv, _finish_frame(df, cols, ens_cols, local[i]),
                                              os.path.join(args.dms_output, str(mapping.iloc[i]["DMS_id"]) + ".csv")))
+        for k in ("create_s", "run_s"):
+            if hasattr(model, k):
+                clock["assay_" + k] = clock.get("assay_" + k, 0.0) + getattr(model, k)
         model.close()
+    t = time.time()
     for f in pending:
         f.result()                                 # re-raises a writer's exception
     if writer is not None:
         writer.shutdown()
+    reader.shutdown()
+    clock["wait_write_s"] = time.time() - t
     # exchange: per item a [n_checkpoints * n_mut] vector
     sizes = []
     n_rows = {}
@@ -209,6 +237,8 @@ def main(args, make_model=None):
         dt = time.time() - t0
         print(f"scored {len(todo)} assays / {n_mut} mutants x {len(cols)} checkpoint(s) on {world} GPU(s) "
               f"in {dt:.1f}s = {n_mut / max(dt, 1e-9):.1f} mutants/s (ensemble rate)")
+        print("rank 0 wall clock: " + ", ".join(f"{k} {v:.1f}" for k, v in clock.items())
+              + " (score_s = mutant parse + upload + GPU; checkpoint load and the rest are the difference)")
     if world > 1:
         import torch.distributed as tdist
         tdist.barrier()
