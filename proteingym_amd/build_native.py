@@ -49,8 +49,22 @@ def build(force: bool = False, verbose: bool = True) -> str:
     os.makedirs(BUILD, exist_ok=True)
     stamp = os.path.join(BUILD, "stamp")
     dig = _digest()
-    if not force and os.path.exists(OUT) and os.path.exists(stamp) and open(stamp).read() == dig:
+
+    def fresh():
+        return os.path.exists(OUT) and os.path.exists(stamp) and open(stamp).read() == dig
+    if not force and fresh():
         return OUT
+    # one builder at a time: the ranks of a multi-GPU launch all come through here, and on a box where the library was not
+    # built yet they must not write the same object files together -- the others wait for the lock and find the stamp
+    import fcntl
+    with open(os.path.join(BUILD, "lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and fresh():
+            return OUT
+        return _build_locked(dig, stamp, verbose)
+
+
+def _build_locked(dig: str, stamp: str, verbose: bool) -> str:
     hipcc = _hipcc()
 
     def compile_one(src):
