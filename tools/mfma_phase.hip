@@ -14,6 +14,7 @@
 //   mode 11: as 5 with the DMA issued BEFORE the fragment reads; mode 13: as 5 but the COMPUTING wave issues the DMA (two per
 //             four MFMAs in compute phase 1), the memory phases only read fragments
 //   mode 14: DMA first, 4 in memory phase 1 and 4 in memory phase 2
+//   mode 15: as 11, but every fourth K tile is the workgroup's own data (HBM): the GEMM's L2 miss ratio (~25 %)
 // Prints shader clocks per K tile / 4 (= per phase) from s_memtime at the loop ends, and raw MFMA TFLOP/s.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
@@ -82,7 +83,8 @@ __global__ __launch_bounds__(512, 1) void k(const u4* __restrict__ in, size_t in
     };
     auto issue = [&](int kt, int buf, int i0 = 0, int i1 = 8) {
         u4* base = lds + buf * 4096 + wave * 64;
-        const unsigned so = (MODE == 6 ? (unsigned)((blockIdx.x * 64 + (kt & 63)) * 65536u) : (unsigned)((kt & 1023) * 65536u)) + wave * 1024;
+        const bool own = MODE == 6 || (MODE == 15 && (kt & 3) == 0);
+        const unsigned so = (own ? (unsigned)((blockIdx.x * 64 + (kt & 63)) * 65536u) : (unsigned)((kt & 1023) * 65536u)) + wave * 1024;
 #pragma unroll
         for (int i = i0; i < i1; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(base + 512 * i), 16, voff, (int)(so + i * 8192), 0, 0);
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(512, 1) void k(const u4* __restrict__ in, size_t in
             const u4* Ab = lds + cur * 4096;
             const u4* Wb = Ab + 2048;
             if (MODE >= 3) __builtin_amdgcn_s_setprio(0);
-            if (MODE == 11 && kt + 1 < iters) issue(kt + 1, cur ^ 1);
+            if ((MODE == 11 || MODE == 15) && kt + 1 < iters) issue(kt + 1, cur ^ 1);
             if (MODE == 14 && kt + 1 < iters) issue(kt + 1, cur ^ 1, 0, 4);
             if (MODE >= 4 && MODE < 9 || MODE >= 11) read_frags(Ab, Wb, 0);
             if (MODE >= 5 && MODE < 11 && kt + 1 < iters) issue(kt + 1, cur ^ 1, 0, MODE == 7 ? 4 : 8);
@@ -174,6 +176,7 @@ int main(int argc, char** argv) {
     run<4>(in, in_bytes, out, clk, iters, reps);
     run<5>(in, in_bytes, out, clk, iters, reps);
     run<11>(in, in_bytes, out, clk, iters, reps);
+    run<15>(in, in_bytes, out, clk, iters, reps);
     run<14>(in, in_bytes, out, clk, iters, reps);
     run<7>(in, in_bytes, out, clk, iters, reps);
     run<9>(in, in_bytes, out, clk, iters, reps);
