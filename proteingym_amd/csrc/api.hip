@@ -650,7 +650,12 @@ static int ensure_cap(pgmi_model* m, T** p, size_t* cap, size_t need) {
 
 // MSA Transformer forward on the token grid in m->tokens [R, C] (one alignment); leaves the residual
 // stream (row-major token order) in m->x.  msa_transformer.py:146-205.
-int run_msa(pgmi_model* m, int R, int C) {
+// keep_col >= 0: the caller reads only token (row 0, column keep_col) of the output (masked-marginals: compute_fitness.py:418-423
+// `token_probs[:, 0, i]`).  In the LAST layer everything after the tied row attention's value update is then needed for the R
+// tokens of that column only -- out-projection of the row attention, the whole column attention (one column = one sequence of R
+// rows) -- and the feed-forward for the single token (0, keep_col); the same kernels on the same rows, so the kept token is
+// bit-identical to the full evaluation (tests/test_gpu_msa_transformer.py).  m->x row 0 then holds that token (*compacted = true).
+int run_msa(pgmi_model* m, int R, int C, int keep_col = -1, bool* compacted = nullptr) {
     const pgmi_config& c = m->cfg;
     const int M = R * C, D = c.embed_dim, F = c.ffn_dim, H = c.heads;
     hipStream_t s = m->stream;
@@ -711,6 +716,33 @@ int run_msa(pgmi_model* m, int R, int C) {
           rc = launch_gemm_f32_ex(m->tied_p, m->tied_vt, m->h, C, R * 64, Cp, g2, s);
           if (rc) return rc;
           launch_split16(m->h, (int64_t)M * D, 1.0f, 2, D, m->h16, s); }
+        if (keep_col >= 0 && m->keep_rows && l == c.layers - 1) {
+            ProfScope p(m, PGMI_K_KEPT_ROWS, 2.0 * R * D * (2.0 * D + 3.0 * D) + 4.0 * R * R * D + 4.0 * D * F, 0);
+            // the column's tokens (r, keep_col), r = 0 .. R-1: rows r * C + keep_col of the (r, c) order
+            launch_strided_index(keep_col, C, R, m->row_idx, s);
+            launch_gather_rows(m->x, m->row_idx, R, D, m->qkv, s);                                     // residual rows
+            launch_gather_rows(reinterpret_cast<const float*>(m->h16), m->row_idx, R, D, reinterpret_cast<float*>(m->g16), s);   // context rows (K-interleaved: 4 D bytes)
+            rc = linear(m, nullptr, m->g16, m->g16_plane, nullptr, L.wo16, L.bo, m->qkv, m->xt, nullptr, 0, R, D, D, EPI_NONE);
+            if (rc) return rc;
+            // column attention of this one column: a sequence of R rows (m->xt rows 0 .. R-1)
+            launch_layernorm16(m->xt, L.c_ln_w, L.c_ln_b, R, D, 1e-5f, m->h16, m->h16_plane, 1, s);
+            rc = launch_gemm16_qkv(m->h16, m->h16_plane, L.c_wqkv16.p, L.c_wqkv16.plane, L.c_bqkv, R, D, D, L.c_wqkv16.out_scale,
+                                   m->qk16, m->qk16_plane, m->vt16, m->vt16_plane, nullptr, nullptr, 0, R, H, m->gemm_variant, s);
+            if (rc) return rc;
+            rc = launch_attention_f16x3_v2(nullptr, m->msa_kv_len, nullptr, nullptr, 0, 1, R, H, m->qk16, m->qk16_plane, m->vt16,
+                                           m->vt16_plane, nullptr, m->h16, m->h16_plane, 1, s);
+            if (rc) return rc;
+            rc = linear(m, nullptr, m->h16, m->h16_plane, nullptr, L.c_wo16, L.c_bo, m->xt, m->xt, nullptr, 0, R, D, D, EPI_NONE);
+            if (rc) return rc;
+            // feed-forward for token (0, keep_col) = row 0 of the column
+            launch_layernorm16(m->xt, L.ln2_w, L.ln2_b, 1, D, 1e-5f, m->h16, m->h16_plane, 1, s);
+            rc = linear(m, nullptr, m->h16, m->h16_plane, nullptr, L.w116, L.b1, nullptr, nullptr, m->g16, m->g16_plane, 1, F, D, EPI_GELU);
+            if (rc) return rc;
+            rc = linear(m, nullptr, m->g16, m->g16_plane, nullptr, L.w216, L.b2, m->xt, m->x, nullptr, 0, 1, D, F, EPI_NONE);
+            if (rc) return rc;
+            if (compacted) *compacted = true;
+            break;
+        }
         { ProfScope p(m, PGMI_K_GEMM_OUT, 2.0 * M * D * D, 0);
           rc = linear(m, nullptr, m->h16, m->h16_plane, nullptr, L.wo16, L.bo, m->x, m->x, nullptr, 0, M, D, D, EPI_NONE);
           if (rc) return rc; }
@@ -1063,11 +1095,12 @@ int pgmi_msa_masked_logprobs(pgmi_model* m, const int32_t* tokens, int R, int T,
         const int Tw = std::min(window, T - st);             // python slicing [:, :, start:end] truncates at the end
         if (st < 0 || st >= T || pos < st || pos >= st + Tw) { set_error("position %d outside its window [%d,%d)", pos, st, st + Tw); return PGMI_EINVAL; }
         launch_msa_window_tokens(m->msa_full, R, T, st, Tw, pos, m->tokens, m->stream);
-        rc = run_msa(m, R, Tw);
-        if (rc) return rc;
         const int32_t row = pos - st;                        // row 0 of the grid, column pos - start
-        PGMI_HIP(hipMemcpyAsync(m->row_idx, &row, 4, hipMemcpyHostToDevice, m->stream));
-        rc = run_head(m, 1, m->row_idx);
+        bool compacted = false;
+        rc = run_msa(m, R, Tw, row, &compacted);
+        if (rc) return rc;
+        if (!compacted) PGMI_HIP(hipMemcpyAsync(m->row_idx, &row, 4, hipMemcpyHostToDevice, m->stream));
+        rc = run_head(m, 1, compacted ? nullptr : m->row_idx);
         if (rc) return rc;
         PGMI_HIP(hipMemcpyAsync(out + (size_t)i * V, m->lp, (size_t)V * 4, hipMemcpyDeviceToHost, m->stream));
         PGMI_HIP(hipStreamSynchronize(m->stream));

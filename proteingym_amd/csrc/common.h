@@ -68,6 +68,8 @@ void launch_layernorm(const float* x, const float* w, const float* b, int rows, 
                       float* y, hipStream_t s);
 // y[i,:] = x[row_idx[i],:]
 void launch_gather_rows(const float* x, const int32_t* row_idx, int n, int D, float* y, hipStream_t s);
+// idx[i] = first + i * stride, i < n
+void launch_strided_index(int first, int stride, int n, int32_t* idx, hipStream_t s);
 // out[r,:] = log_softmax(h[r,:] @ E^T + bias); E [V,D]
 void launch_vocab_logsoftmax(const float* h, const float* E, const float* bias, int rows, int D,
                              int V, float* out, int32_t* nonfinite, hipStream_t s);

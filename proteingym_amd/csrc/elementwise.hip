@@ -287,6 +287,14 @@ void launch_gather_rows(const float* x, const int32_t* idx, int n, int D, float*
     hipLaunchKernelGGL(gather_rows_kernel, dim3((n + 3) / 4), dim3(256), 0, s, x, idx, n, D, y);
 }
 
+__global__ void strided_index_kernel(int first, int stride, int n, int32_t* __restrict__ idx) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) idx[i] = first + i * stride;
+}
+void launch_strided_index(int first, int stride, int n, int32_t* idx, hipStream_t s) {
+    hipLaunchKernelGGL(strided_index_kernel, dim3((n + 255) / 256), dim3(256), 0, s, first, stride, n, idx);
+}
+
 __global__ void scatter_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ dst_row,
                                     int n, int V, float* __restrict__ table) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;

@@ -42,6 +42,33 @@ def test_masked_marginals_table_vs_reference(model, gold):
     assert np.array_equal(sub, rows[[3, 17, 40]])
 
 
+def test_last_layer_kept_column_bit_identical(lib, gold, golden_dir, monkeypatch):
+    """Masked-marginals reads token (row 0, masked column) only (compute_fitness.py:418-423): the last layer runs the row
+    attention's out-projection and the column attention on that column's tokens, the feed-forward on that one token.
+    Same bits as the full evaluation (PGMI_KEEP_ROWS=0), toy model and esm_msa1b's width at a ragged shape."""
+    from proteingym_amd import synthetic
+    tok = gold["sampled/seed1"]
+    out = {}
+    for keep in ("1", "0"):
+        monkeypatch.setenv("PGMI_KEEP_ROWS", keep)
+        m, _ = pmsa.load_model_and_alphabet(os.path.join(golden_dir, "msa_toy.pt"), max_rows=32 * 1056)
+        out[keep] = m.masked_logprobs(tok, np.arange(tok.shape[1]), seq_len=60)
+        m.close()
+    assert np.array_equal(out["1"], out["0"])
+    cfg = dict(arch=4, layers=2, embed_dim=768, heads=12, ffn_dim=3072, max_positions=1024, embed_positions_msa=True)
+    blob = pmsa.pack_state_dict(cfg, synthetic.random_msa_transformer_arrays(cfg, seed=3))
+    rng = np.random.default_rng(0)
+    wide = rng.integers(4, 30, size=(70, 45)).astype(np.int64)
+    wide[:, 0] = 0
+    for keep in ("1", "0"):
+        monkeypatch.setenv("PGMI_KEEP_ROWS", keep)
+        m = pmsa.MsaTransformerModel(cfg, blob, max_rows=96 * 64)
+        out[keep] = m.masked_logprobs(wide, [0, 1, 7, 31, 32, 44], seq_len=44)
+        m.close()
+    assert np.isfinite(out["1"]).all()
+    assert np.array_equal(out["1"], out["0"])
+
+
 def test_cli_matches_reference_columns(lib, gold, golden_dir, tmp_path):
     from proteingym_amd import compute_fitness as cf
     out = tmp_path / "o"
