@@ -654,8 +654,8 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
                     const float p0 = st[8 * m + 2 * e], p1 = st[8 * m + 2 * e + 1];
                     typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
                     const fp16x2 hi2 = __builtin_amdgcn_cvt_pkrtz(p0, p1);
-                    const float f0 = (float)hi2[0], f1 = (float)hi2[1];
-                    const float l0 = (p0 - f0) * kLoScale, l1 = (p1 - f1) * kLoScale;
+                    // (p - hi) 2^11 as one mixed-precision fma on the fp16 hi (v_fma_mix_f32): p 2^11 and the fma are both exact
+                    const float l0 = fmaf((float)hi2[0], -kLoScale, p0 * kLoScale), l1 = fmaf((float)hi2[1], -kLoScale, p1 * kLoScale);
                     const fp16x2 lo2 = __builtin_amdgcn_cvt_pkrtz(l0, l1);
                     ph[e] = __builtin_bit_cast(unsigned int, hi2);
                     pl[e] = __builtin_bit_cast(unsigned int, lo2);
