@@ -595,15 +595,14 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
             const u32x4* Kb = lds + cur * STG_CH;
             const u32x4* Vb = Kb + 2 * KCH;
             f32x16 sm, sc;
-#pragma unroll
-            for (int v = 0; v < 16; ++v) { sm[v] = 0.f; sc[v] = 0.f; }
+            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int s = 0; s < NS; ++s) {
                 const int ci = r * KCPR + ((2 * s + kh) ^ (DH == 64 ? ((r >> 1) & 7) : (r & 15)));
                 const u32x4 kfh = Kb[ci], kfl = Kb[KCH + ci];
-                sc = mfma_h(kfh, ql[s], sc);
+                sc = mfma_h(kfh, ql[s], s == 0 ? zero16 : sc);       // s == 0: the accumulator operand is the inline constant 0
                 sc = mfma_h(kfl, qh[s], sc);
-                sm = mfma_h(kfh, qh[s], sm);
+                sm = mfma_h(kfh, qh[s], s == 0 ? zero16 : sm);
             }
             float st[16];
             if (causal) {
@@ -639,11 +638,15 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
                 m_run = m_new;
             }
             const float mb = m_run - 10.0f;
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
             float psum = 0.f;
 #pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                st[v] = __builtin_amdgcn_exp2f(st[v] - mb);      // P * 2^10 in [0, 1024]
+            for (int v = 0; v < 16; v += 2) {                    // packed fp32 subtract (v_pk_add_f32): same values, half the issue slots
+                const f32x2 dlt = f32x2{st[v], st[v + 1]} - f32x2{mb, mb};
+                st[v] = __builtin_amdgcn_exp2f(dlt[0]);          // P * 2^10 in [0, 1024]
+                st[v + 1] = __builtin_amdgcn_exp2f(dlt[1]);
                 psum += st[v];
+                psum += st[v + 1];
             }
             l_run += psum;
 #pragma unroll
@@ -654,8 +657,11 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
                     const float p0 = st[8 * m + 2 * e], p1 = st[8 * m + 2 * e + 1];
                     typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
                     const fp16x2 hi2 = __builtin_amdgcn_cvt_pkrtz(p0, p1);
-                    // (p - hi) 2^11 as one mixed-precision fma on the fp16 hi (v_fma_mix_f32): p 2^11 and the fma are both exact
-                    const float l0 = fmaf((float)hi2[0], -kLoScale, p0 * kLoScale), l1 = fmaf((float)hi2[1], -kLoScale, p1 * kLoScale);
+                    // (p - hi) 2^11 as one mixed-precision fma on the fp16 hi (v_fma_mix_f32): p 2^11 (one packed multiply for
+                    // the pair) and the fma are both exact
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    const f32x2 ps = f32x2{p0, p1} * f32x2{kLoScale, kLoScale};
+                    const float l0 = fmaf((float)hi2[0], -kLoScale, ps[0]), l1 = fmaf((float)hi2[1], -kLoScale, ps[1]);
                     const fp16x2 lo2 = __builtin_amdgcn_cvt_pkrtz(l0, l1);
                     ph[e] = __builtin_bit_cast(unsigned int, hi2);
                     pl[e] = __builtin_bit_cast(unsigned int, lo2);
