@@ -60,8 +60,10 @@ def get_idx(tok: str) -> int:
 
 
 def tokenize(seq: str) -> np.ndarray:
-    """BatchConverter for one sequence (data.py:262-297): cls + residues + eos, int64."""
-    return np.array([CLS] + [get_idx(c) for c in seq] + [EOS], dtype=np.int64)
+    """BatchConverter for one sequence (data.py:262-297): cls + residues + eos, int64.  Alphabet.encode (data.py:253-254)
+    indexes tok_to_idx directly: a character outside the vocabulary raises KeyError (it is NOT mapped to <unk>; only
+    get_idx does that).  Residue letters only: literal special tokens inside the text are not handled here."""
+    return np.array([CLS] + [TOK_TO_IDX[c] for c in seq] + [EOS], dtype=np.int64)
 
 
 # --- checkpoint (esm/pretrained.py) ------------------------------------------------------

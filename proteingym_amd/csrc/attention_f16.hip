@@ -749,6 +749,14 @@ int launch_attention_f16x3_v2(const float* qkv, const int32_t* kv_len, const flo
     }
     const int n32 = (T + 31) / 32, Tp = n32 * 32;
     int rc = PGMI_OK;
+    // The K / V^T DMA addresses a plane pair through one buffer descriptor with 32-bit byte offsets (num_records = 2 planes =
+    // plane * 4 bytes): both operand arrays must stay below 4 GiB.  Every supported model fits at the default workspace
+    // (ESM2-15B is closest: 4.03e9 bytes of q|k planes at 98 304 rows); a larger max_rows is refused here instead of wrapping.
+    if ((unsigned long long)qk_plane * 4ull >= (1ull << 32) || (unsigned long long)vt_plane * 4ull >= (1ull << 32)) {
+        set_error("attention_f16x3_v2: operand planes of %zu / %zu halfs exceed the 32-bit offset range of the K / V^T DMA "
+                  "(create the model with a smaller max_rows)", qk_plane, vt_plane);
+        return PGMI_EINVAL;
+    }
     if (head_dim == 128) {
         // ESM2-15B class: H heads of 128 = 2 H slot groups of 64 in the operand planes; only the fused-QKV operand path
         // (no prep pass), no causal / ALiBi flavour; 2-stage ring (2 x 32 KB) so that two workgroups share a CU

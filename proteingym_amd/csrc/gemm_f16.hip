@@ -24,6 +24,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <algorithm>
+#include <mutex>
 #include <type_traits>
 #include <vector>
 
@@ -785,12 +786,31 @@ __global__ __launch_bounds__(XNT) void splitk_fix_kernel(const float* __restrict
         }
 }
 
+// Per-device launch state (a process may drive several devices through distinct model handles: nothing here is shared
+// between devices).  Indexed by the current HIP device of the calling thread; written under a mutex because two handles on two
+// devices may launch from two host threads.
+constexpr int kMaxDevices = 64;
+struct XDeviceState {
+    int num_cus = 0;
+    float* splitk_ws = nullptr;                                   // K-sliced tail workspace (PGMI_GEMM_SPLITK=1 only)
+    size_t splitk_ws_bytes = 0;
+};
+static XDeviceState g_xdev[kMaxDevices];
+static std::mutex g_xdev_mu;
+
+static int x_current_device() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
+    return dev;
+}
+
 static int x_num_cus() {
-    static int n = 0;
+    const int dev = x_current_device();
+    std::lock_guard<std::mutex> lk(g_xdev_mu);
+    int& n = g_xdev[dev].num_cus;
     if (!n) {
-        int dev = 0;
         hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+        if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
         if (n <= 0) n = 256;
         n -= n % 8;                                              // the XCD-aware item order wants a multiple of 8
         if (n <= 0) n = 8;
@@ -798,21 +818,17 @@ static int x_num_cus() {
     return n;
 }
 
-static float* g_splitk_ws = nullptr;                              // one per process and device in use (single-GPU ranks)
-static size_t g_splitk_ws_bytes = 0;
-static int g_splitk_ws_dev = -1;
-
 // stg: 0 register staging, 1 direct-to-LDS DMA, 3 the same with the DMA issued after the fragment reads (tuning).  splitk: allow K-sliced tail items (fp32-output GEMMs only).
-static int launch_gemm16x(const unsigned short* A, const unsigned short* W,
-                          const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
-                          int M, int N, int K, int epilogue, float out_scale, int stg, bool splitk, hipStream_t s,
-                          const QkvOut* qkv = nullptr) {
+static int launch_gemm16x_one(const unsigned short* A, const unsigned short* W,
+                              const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
+                              int M, int N, int K, int epilogue, float out_scale, int stg, bool splitk, hipStream_t s,
+                              const QkvOut* qkv) {
     TilePlan tp{};
     tp.tiles_m = (M + XBM - 1) / XBM;
     tp.tiles_n = (N + XBN - 1) / XBN;
     const int T = tp.tiles_m * tp.tiles_n, G = x_num_cus(), nk = K / 32;
     tp.n_main = T; tp.split = 1; tp.n_items = T;
-    if ((unsigned long long)std::max(M, N) * (unsigned long long)K * 4ull >= (1ull << 32)) {
+    if ((unsigned long long)std::max(M, N) * (unsigned long long)K * 4ull >= (1ull << 32)) {      // launch_gemm16x chunks M below this
         set_error("gemm16x: operand of %d x %d split elements exceeds the 32-bit offset range", std::max(M, N), K);
         return PGMI_EINVAL;
     }
@@ -826,16 +842,20 @@ static int launch_gemm16x(const unsigned short* A, const unsigned short* W,
         int split = std::min(std::min(G / rem, 8), nk / 4);       // every slice keeps >= 4 K tiles
         if (split >= 2) {
             const size_t need = (size_t)rem * split * XBM * XBN * sizeof(float);
-            int dev = 0;
-            hipGetDevice(&dev);
-            if (need > g_splitk_ws_bytes || dev != g_splitk_ws_dev) {
-                if (g_splitk_ws && dev == g_splitk_ws_dev) hipFree(g_splitk_ws);
-                g_splitk_ws = nullptr; g_splitk_ws_bytes = 0;
-                const size_t cap = std::max(need, (size_t)G * XBM * XBN * sizeof(float));
-                if (hipMalloc(reinterpret_cast<void**>(&g_splitk_ws), cap) == hipSuccess) { g_splitk_ws_bytes = cap; g_splitk_ws_dev = dev; }
+            float* ws = nullptr;
+            {
+                std::lock_guard<std::mutex> lk(g_xdev_mu);
+                XDeviceState& st = g_xdev[x_current_device()];
+                if (need > st.splitk_ws_bytes) {
+                    if (st.splitk_ws) hipFree(st.splitk_ws);
+                    st.splitk_ws = nullptr; st.splitk_ws_bytes = 0;
+                    const size_t cap = std::max(need, (size_t)G * XBM * XBN * sizeof(float));
+                    if (hipMalloc(reinterpret_cast<void**>(&st.splitk_ws), cap) == hipSuccess) st.splitk_ws_bytes = cap;
+                }
+                ws = st.splitk_ws;
             }
-            if (g_splitk_ws) {
-                tp.n_main = T - rem; tp.split = split; tp.n_items = tp.n_main + rem * split; tp.ws = g_splitk_ws;
+            if (ws) {
+                tp.n_main = T - rem; tp.split = split; tp.n_items = tp.n_main + rem * split; tp.ws = ws;
             }
         }
     }
@@ -930,6 +950,46 @@ static int launch_gemm16x(const unsigned short* A, const unsigned short* W,
         hipLaunchKernelGGL(splitk_fix_kernel, dim3(T - tp.n_main), dim3(XNT), 0, s, tp.ws, tp.split, tp.n_main, tp.tiles_m,
                            tp.tiles_n, bias, residual, Cf, M, N, out_scale);
     PGMI_HIP(hipGetLastError());
+    return PGMI_OK;
+}
+
+// The kernel addresses its operands with 32-bit byte offsets from a buffer descriptor (no 64-bit address arithmetic in the
+// memory phases): one launch covers at most 2^32 bytes of A, i.e. rows * K * 4 < 4 GiB.  Larger activations (ESM2-15B FC2:
+// K = 20480 allows 52 428 rows; an MSA Transformer alignment of 400 x 1024 tokens at K = 3072) are cut into row chunks --
+// rows are independent and every row is computed exactly as in one launch (bit-identical), the chunks run back to back on the
+// stream.  Fused QKV output: chunks are whole sequences (the V^T scatter is per (sequence, head)).
+static int launch_gemm16x(const unsigned short* A, const unsigned short* W,
+                          const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
+                          int M, int N, int K, int epilogue, float out_scale, int stg, bool splitk, hipStream_t s,
+                          const QkvOut* qkv = nullptr) {
+    const unsigned long long lim = (1ull << 32) - 1;
+    if ((unsigned long long)N * (unsigned long long)K * 4ull > lim) {
+        set_error("gemm16x: weight of %d x %d split elements exceeds the 32-bit offset range", N, K);
+        return PGMI_EINVAL;
+    }
+    const char* tr = getenv("PGMI_GEMM_MAX_ROWS");                      // tests: force chunking at small shapes (read per launch)
+    const long long test_rows = tr ? atoll(tr) : 0;
+    long long max_rows = (long long)(lim / ((unsigned long long)K * 4ull));
+    if (test_rows > 0) max_rows = std::min(max_rows, test_rows);
+    if (M <= max_rows) return launch_gemm16x_one(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, stg, splitk, s, qkv);
+    long long per = qkv ? (max_rows / qkv->T) * qkv->T : (max_rows / XBM) * XBM;
+    if (per <= 0) per = qkv ? 0 : max_rows;
+    if (per <= 0) { set_error("gemm16x: one sequence of %d tokens x K = %d exceeds the 32-bit offset range", qkv->T, K); return PGMI_EINVAL; }
+    for (long long m0 = 0; m0 < M; m0 += per) {
+        const int mc = (int)std::min<long long>(per, M - m0);
+        const unsigned short* Ac = A + (size_t)m0 * (size_t)K * 2;                     // K-interleaved rows: 2 K halfs each
+        int rc;
+        if (qkv) {
+            QkvOut q = *qkv;                                                           // rows m0.. are sequences m0 / T ..
+            q.vt16 = qkv->vt16 + (size_t)(m0 / qkv->T) * (size_t)qkv->H * kHeadDim * (size_t)qkv->Tp;
+            rc = launch_gemm16x_one(Ac, W, bias, nullptr, nullptr, Ch + (size_t)m0 * (size_t)(2 * (N / 3)), c_plane, mc, N, K, epilogue,
+                                    out_scale, stg, splitk, s, &q);
+        } else {
+            rc = launch_gemm16x_one(Ac, W, bias, residual ? residual + (size_t)m0 * N : nullptr, Cf ? Cf + (size_t)m0 * N : nullptr,
+                                    Ch ? Ch + (size_t)m0 * (size_t)(2 * N) : nullptr, c_plane, mc, N, K, epilogue, out_scale, stg, splitk, s, nullptr);
+        }
+        if (rc) return rc;
+    }
     return PGMI_OK;
 }
 

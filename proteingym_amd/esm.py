@@ -69,11 +69,45 @@ class Alphabet:
     def to_dict(self):
         return self.tok_to_idx.copy()
 
+    def tokenize(self, text: str) -> List[str]:
+        """Behaviour of the reference tokenizer (esm/data.py:178-251; every vocabulary entry is a no-split token): the text
+        is cut at every vocabulary token -- the single residue letters and literal special tokens such as "<mask>" --
+        whitespace between tokens is dropped, and whatever is left (a run of characters outside the vocabulary: lower
+        case, 'J', '*', ...) stays ONE token, which ``encode`` then fails on exactly like the reference."""
+        if not hasattr(self, "_single"):
+            self._single = frozenset(t for t in self.all_toks if len(t) == 1)
+            self._multi = sorted((t for t in self.all_toks if len(t) > 1), key=len, reverse=True)
+        if all(ch in self._single for ch in text):
+            return list(text)
+        out, run, i, n = [], [], 0, len(text)
+
+        def flush():
+            if run:
+                out.extend("".join(run).split())
+                run.clear()
+        while i < n:
+            ch = text[i]
+            if ch in self._single:
+                flush()
+                out.append(ch)
+                i += 1
+                continue
+            if ch == "<":
+                hit = next((t for t in self._multi if text.startswith(t, i)), None)
+                if hit:
+                    flush()
+                    out.append(hit)
+                    i += len(hit)
+                    continue
+            run.append(ch)
+            i += 1
+        flush()
+        return out
+
     def encode(self, text: str) -> List[int]:
-        """One token per residue letter; unknown letters -> <unk>.  (The reference's tokenizer
-        also recognises literal special-token strings such as "<mask>" inside the text,
-        data.py:176-251; protein sequences never contain them.)"""
-        return [self.get_idx(ch) for ch in text]
+        """esm/data.py:253-254: ``[self.tok_to_idx[tok] for tok in self.tokenize(text)]`` -- a character outside the
+        vocabulary is a KeyError (the reference does not map it to <unk>; only ``get_idx`` does, for mutant letters)."""
+        return [self.tok_to_idx[tok] for tok in self.tokenize(text)]
 
     def get_batch_converter(self, truncation_seq_length: int = None):
         return BatchConverter(self, truncation_seq_length)
@@ -372,15 +406,24 @@ class Assay:
 
 def pack_sequences(sequences: Sequence[str], alphabet: Optional[Alphabet] = None):
     """BatchConverter (esm/data.py:262-297) for a whole column without padding: every sequence as <cls> + one token
-    per residue letter (unknown letters -> <unk>) + <eos>, concatenated, one byte per token.
+    per residue letter + <eos>, concatenated, one byte per token (anything but residue letters takes the slow path through
+    Alphabet.encode: same tokens and same KeyError as the reference).
     Returns (tokens uint8 [sum(len)+2N], seq_off int64 [N+1])."""
     alphabet = alphabet or Alphabet()
     n = len(sequences)
-    lut = np.full(256, alphabet.unk_idx, dtype=np.uint8)              # Alphabet.get_idx per residue letter
+    lut = np.full(256, 255, dtype=np.uint8)                            # vocabulary index per residue letter, 255 = not a letter token
     for tok, i in alphabet.tok_to_idx.items():
         if len(tok) == 1:
             lut[ord(tok)] = i
-    lens = np.fromiter((len(s) for s in sequences), dtype=np.int64, count=n)
+    flat = lut[np.frombuffer("".join(sequences).encode("latin-1", "replace"), dtype=np.uint8)]
+    if flat.size and flat.max() == 255:
+        # some member holds something else than residue letters (whitespace, a literal "<mask>", or a character the
+        # reference tokenizer raises KeyError on): those go through Alphabet.encode, one by one
+        enc = [np.asarray(alphabet.encode(s), dtype=np.uint8) for s in sequences]
+        lens = np.fromiter((e.size for e in enc), dtype=np.int64, count=n)
+        flat = np.concatenate(enc) if n else np.zeros(0, np.uint8)
+    else:
+        lens = np.fromiter((len(s) for s in sequences), dtype=np.int64, count=n)
     seq_off = np.zeros(n + 1, dtype=np.int64)
     np.cumsum(lens + 2, out=seq_off[1:])
     toks = np.empty(int(seq_off[-1]), dtype=np.uint8)
@@ -389,7 +432,7 @@ def pack_sequences(sequences: Sequence[str], alphabet: Optional[Alphabet] = None
     body[seq_off[1:] - 1] = False
     toks[seq_off[:-1]] = alphabet.cls_idx
     toks[seq_off[1:] - 1] = alphabet.eos_idx
-    toks[body] = lut[np.frombuffer("".join(sequences).encode("latin-1", "replace"), dtype=np.uint8)]
+    toks[body] = flat
     return toks, seq_off
 
 

@@ -83,17 +83,23 @@ def resolve_inputs(args):
     return dms_id, wild_type, assay_file, msa
 
 
+def retrieval_arguments(args, wild_type, msa):
+    """The retrieval dict of ``tranception.from_pretrained`` / ``build_retrieval`` for one assay (None without
+    --inference_time_retrieval)."""
+    if msa is None:
+        return None
+    if args.indel_mode:
+        raise NotImplementedError("indel scoring with retrieval needs Clustal Omega re-alignment (not built)")
+    return dict(MSA_filename=msa[0], MSA_weight_file_name=msa[1], MSA_start=msa[2], MSA_end=msa[3],
+                full_protein_length=len(wild_type), retrieval_inference_weight=args.retrieval_inference_weight)
+
+
 def main(args=None):
     args = create_parser().parse_args() if args is None else args
     if args.model_framework != "pytorch":
         raise NotImplementedError("only --model_framework pytorch has an MI355X backend")
     dms_id, wild_type, assay_file, msa = resolve_inputs(args)
-    retrieval = None
-    if msa is not None:
-        if args.indel_mode:
-            raise NotImplementedError("indel scoring with retrieval needs Clustal Omega re-alignment (not built)")
-        retrieval = dict(MSA_filename=msa[0], MSA_weight_file_name=msa[1], MSA_start=msa[2], MSA_end=msa[3],
-                         full_protein_length=len(wild_type), retrieval_inference_weight=args.retrieval_inference_weight)
+    retrieval = retrieval_arguments(args, wild_type, msa)
     print("Model leverages both autoregressive and retrieval inference" if retrieval else "Model only uses autoregressive inference")
     model = ptr.from_pretrained(args.checkpoint, device=args.device, scoring_window=args.scoring_window, retrieval=retrieval)
     os.makedirs(args.output_scores_folder, exist_ok=True)

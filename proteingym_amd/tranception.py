@@ -462,11 +462,12 @@ class TranceptionModel:
         return out[['mutated_sequence', column]]
 
     def score_mutants(self, DMS_data, target_seq=None, scoring_mirror=True, batch_size_inference=10, num_workers=10,
-                      indel_mode=False):
+                      indel_mode=False, append_wildtype_row=True):
         """Same contract as the reference method (model_pytorch.py:878-928): returns mutated_sequence,
         avg_score_L_to_R, [avg_score_R_to_L,] avg_score; a zero row for the wild type when it is among the inputs
         (under column 'mutant' in indel mode, as the reference writes it).  batch_size_inference / num_workers are
-        accepted and ignored: batching happens on the device side."""
+        accepted and ignored: batching happens on the device side.  ``append_wildtype_row=False`` (additive; used by
+        run_sharded when an assay's rows are scored in chunks) leaves that row to the caller."""
         frame = DMS_data.copy()
         if 'mutated_sequence' not in frame and not indel_mode:
             frame['mutated_sequence'] = [get_mutated_sequence(target_seq, m) for m in frame['mutant']]
@@ -493,7 +494,7 @@ class TranceptionModel:
         else:
             result['avg_score'] = result['avg_score_L_to_R']
         key = "mutant" if indel_mode else "mutated_sequence"
-        if target_seq in DMS_data[key].values:                           # the scorer drops the wild type: add it back, score 0
+        if append_wildtype_row and target_seq in DMS_data[key].values:   # the scorer drops the wild type: add it back, score 0
             names = [key, 'avg_score_L_to_R'] + (['avg_score_R_to_L'] if scoring_mirror else []) + ['avg_score']
             result = pd.concat([result, pd.DataFrame([[target_seq] + [0] * (len(names) - 1)], columns=names)], ignore_index=True)
         return result
@@ -506,13 +507,20 @@ def from_pretrained(checkpoint_dir: str, device: int = 0, scoring_window: str = 
     MSA_end, full_protein_length, retrieval_inference_weight, MSA_weight_file_name=None,
     seq_name_to_weight=None) builds the log-prior exactly as model_pytorch.py:662-672 does."""
     cfg, blob = load_checkpoint(checkpoint_dir)
-    r = None
-    if retrieval:
-        prior = get_msa_prior(retrieval["MSA_filename"], retrieval.get("MSA_weight_file_name"), retrieval["MSA_start"],
-                              retrieval["MSA_end"], retrieval["full_protein_length"],
-                              seq_name_to_weight=retrieval.get("seq_name_to_weight"))
-        import torch
-        log_prior = torch.log(torch.tensor(prior).float()).numpy()          # same rounding as the reference (:662-672)
-        r = dict(log_prior=log_prior, MSA_start=int(retrieval["MSA_start"]), MSA_end=int(retrieval["MSA_end"]),
-                 weight=float(retrieval.get("retrieval_inference_weight", 0.6)))
-    return TranceptionModel(cfg, blob, device=device, scoring_window=scoring_window, retrieval=r, max_rows=max_rows)
+    return TranceptionModel(cfg, blob, device=device, scoring_window=scoring_window, retrieval=build_retrieval(retrieval),
+                            max_rows=max_rows)
+
+
+def build_retrieval(retrieval: Optional[dict]) -> Optional[dict]:
+    """The per-assay retrieval state of a model (``TranceptionModel.retrieval``): the log-prior exactly as
+    model_pytorch.py:662-672 builds it.  A resident model scores many assays by swapping this dict
+    (run_sharded): the network weights do not depend on the assay."""
+    if not retrieval:
+        return None
+    prior = get_msa_prior(retrieval["MSA_filename"], retrieval.get("MSA_weight_file_name"), retrieval["MSA_start"],
+                          retrieval["MSA_end"], retrieval["full_protein_length"],
+                          seq_name_to_weight=retrieval.get("seq_name_to_weight"))
+    import torch
+    log_prior = torch.log(torch.tensor(prior).float()).numpy()              # same rounding as the reference (:662-672)
+    return dict(log_prior=log_prior, MSA_start=int(retrieval["MSA_start"]), MSA_end=int(retrieval["MSA_end"]),
+                weight=float(retrieval.get("retrieval_inference_weight", 0.6)))

@@ -66,7 +66,7 @@ def _sharded_worker(rank, world, port, mapping_csv, q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
                       WORLD_SIZE=str(world))
     from proteingym_amd import run_sharded
-    mine = run_sharded.main(["tranception", "--dry-run", "--backend", "gloo", "--", "--checkpoint", "x",
+    mine = run_sharded.main(["tranception", "--shard", "assay", "--dry-run", "--backend", "gloo", "--", "--checkpoint", "x",
                              "--DMS_reference_file_path", mapping_csv, "--DMS_data_folder", "."])
     q.put((rank, mine))
 
@@ -97,6 +97,137 @@ def test_run_sharded_world2_covers_every_assay_once(tmp_path):
     assert max(cost) / sum(cost) < 0.6
     with pytest.raises(SystemExit):
         run_sharded.main(["tranception", "--", "--DMS_index", "3", "--DMS_reference_file_path", csv])
+
+
+# ---- Tranception: chunks of mutant rows (BASELINE config 4 on N GPUs) -------------------------------------------------
+def _fake_tranception(checkpoint, device, scoring_window):
+    """Stands in for the device: the log-likelihood of a sliced sequence is a deterministic function of (sequence,
+    reading direction, retrieval weight); everything above it (slices, wild-type deltas, mirror average, frames) is
+    the product's own TranceptionModel code."""
+    import zlib
+    from proteingym_amd import tranception as ptr
+
+    class Fake(ptr.TranceptionModel):
+        def __init__(self):
+            self.n_ctx, self.scoring_window, self.retrieval, self._h, self.cfg = 66, scoring_window, None, None, {}
+
+        def sequence_loglik(self, sliced, window_start=None, window_end=None, reverse=False):
+            salt = 7 if reverse else 3
+            return np.array([-(zlib.crc32((s + str(salt)).encode()) % 100003) / 977.0 for s in sliced], dtype=np.float32)
+
+        def close(self):
+            pass
+    return Fake()
+
+
+def _make_tranception_assays(workdir, indel):
+    import pandas as pd
+    from proteingym_amd import synthetic, tranception as ptr
+    rng = np.random.default_rng(5)
+    rows = []
+    os.makedirs(os.path.join(workdir, "dms"), exist_ok=True)
+    for a, (L, n) in enumerate([(40, 700), (150, 90), (64, 300), (33, 5)]):          # 150 > the fake context of 64 residues
+        seq, muts, _ = synthetic.random_assay(seed=a, L=L, n_single=n // 2, n_multi=n - n // 2)
+        if indel:
+            wt, lib_ = synthetic.random_indel_library(a, L, n)
+            df = pd.DataFrame({"mutant": [f"v{i}" for i in range(n)], "mutated_sequence": lib_})
+            df.loc[n // 3, "mutated_sequence"] = wt                                   # the wild type is listed
+            df.loc[n // 3, "mutant"] = wt
+            df.loc[n - 1, "mutated_sequence"] = df.loc[0, "mutated_sequence"]         # a duplicate sequence under another label
+            seq = wt
+        else:
+            muts[n // 4] = muts[0]                                                    # a duplicated row
+            df = pd.DataFrame({"mutant": muts, "mutated_sequence": [ptr.get_mutated_sequence(seq, m) for m in muts],
+                               "DMS_score": rng.standard_normal(n)})
+        df.to_csv(os.path.join(workdir, "dms", f"T{a}.csv"), index=False)
+        rows.append({"DMS_id": f"T{a}", "DMS_filename": f"T{a}.csv", "target_seq": seq, "DMS_total_number_mutants": n})
+    pd.DataFrame(rows).to_csv(os.path.join(workdir, "map.csv"), index=False)
+    return rows
+
+
+def _tranception_args(workdir, window, indel):
+    return ["tranception", "--backend", "gloo", "--max-chunk-rows", "64", "--", "--checkpoint", "fake",
+            "--DMS_reference_file_path", os.path.join(workdir, "map.csv"), "--DMS_data_folder", os.path.join(workdir, "dms"),
+            "--output_scores_folder", os.path.join(workdir, "out"), "--scoring_window", window] + (["--indel_mode"] if indel else [])
+
+
+def _mutant_chunk_worker(rank, world, port, workdir, window, indel, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    from proteingym_amd import run_sharded
+    mine = run_sharded.main(_tranception_args(workdir, window, indel), make_model=_fake_tranception)
+    q.put((rank, mine))
+
+
+@pytest.mark.parametrize("window,indel", [("optimal", False), ("sliding", False), ("optimal", True)])
+def test_tranception_mutant_chunks_world2_equal_the_unsharded_scorer(tmp_path, window, indel):
+    """run_sharded tranception (--shard mutants): two gloo ranks score chunks of <= 64 rows of four assays (one longer than
+    the context: several windows / sliding chunks; duplicated rows; in indel mode the wild type among the rows), one
+    all_gather, the owners write the CSVs -- which must equal, value for value and row for row, what the single-assay
+    scorer returns for the whole file."""
+    import pandas as pd
+    from proteingym_amd import run_sharded
+    workdir = str(tmp_path)
+    rows = _make_tranception_assays(workdir, indel)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mutant_chunk_worker, args=(r, 2, port, workdir, window, indel, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    items = sorted(res[0] + res[1])
+    assert len(res[0]) and len(res[1]) and len(set(items)) == len(items)
+    for k, r in enumerate(rows):                                                      # every row of every assay exactly once
+        spans = [(a, b) for kk, a, b in items if kk == k]
+        assert spans[0][0] == 0 and spans[-1][1] == r["DMS_total_number_mutants"] and all(x[1] == y[0] for x, y in zip(spans, spans[1:]))
+        assert max(b - a for a, b in spans) <= 64
+    model = _fake_tranception("fake", 0, window)
+    for r in rows:
+        df = pd.read_csv(os.path.join(workdir, "dms", r["DMS_filename"]))
+        want = model.score_mutants(DMS_data=df, target_seq=r["target_seq"], indel_mode=indel)
+        got = pd.read_csv(os.path.join(workdir, "out", r["DMS_id"] + ".csv"), float_precision="round_trip")
+        assert list(got.columns) == list(want.columns)
+        assert len(got) == len(want)
+        for c in want.columns:
+            if want[c].dtype == object:
+                assert list(got[c].fillna("")) == list(want[c].fillna("")), (r["DMS_id"], c)
+            else:
+                assert np.array_equal(got[c].to_numpy(dtype=np.float64), want[c].to_numpy(dtype=np.float64), equal_nan=True), (r["DMS_id"], c)
+    # one process, no chunk cap: one item per assay, the same CSVs
+    argv = _tranception_args(workdir, window, indel)
+    cli_part = argv[argv.index("--") + 1:]
+    cli_part[cli_part.index("--output_scores_folder") + 1] = os.path.join(workdir, "out1")
+    one = run_sharded.main(["tranception", "--", *cli_part], make_model=_fake_tranception)
+    assert one == [(k, 0, r["DMS_total_number_mutants"]) for k, r in enumerate(rows)]
+    for r in rows:
+        a = open(os.path.join(workdir, "out", r["DMS_id"] + ".csv")).read()
+        assert a == open(os.path.join(workdir, "out1", r["DMS_id"] + ".csv")).read()
+
+
+def test_tranception_chunk_plan_balances_the_real_table():
+    """Config 4 on 8 GPUs: whole assays give max/mean 2.08 on the real substitution table (one assay is 26 % of the
+    cost); mutant chunks must bring every rank within 2 % of the mean, and keep the number of assays a rank touches (one
+    retrieval prior each) near 217 / world."""
+    from proteingym_amd import run_sharded, synthetic
+    shapes = synthetic.dms_shapes()
+    L, n = [s["seq_len"] for s in shapes], [s["n_total"] for s in shapes]
+    for world in (2, 4, 8):
+        items, assignment, costs = run_sharded.plan_mutant_chunks(L, n, world)
+        loads = np.array([sum(costs[j] for j in part) for part in assignment])
+        assert loads.max() / loads.mean() < 1.02
+        assert sorted(j for part in assignment for j in part) == list(range(len(items)))
+        for k in range(217):                                                          # chunks tile every assay's rows
+            spans = [(a, b) for kk, a, b in items if kk == k]
+            assert spans[0][0] == 0 and spans[-1][1] == n[k] and all(x[1] == y[0] for x, y in zip(spans, spans[1:]))
+        assert max(len({items[j][0] for j in part}) for part in assignment) <= 217 // world + 16
+    whole = pdist.lpt_partition([run_sharded.chunk_cost(min(l + 2, 1024), m) for l, m in zip(L, n)], 8)
+    wl = np.array([sum(run_sharded.chunk_cost(min(L[k] + 2, 1024), n[k]) for k in part) for part in whole])
+    assert wl.max() / wl.mean() > 1.9                                                  # what the plan replaces
 
 
 class _FakeTables:

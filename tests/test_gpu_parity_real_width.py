@@ -1,0 +1,241 @@
+"""Parity at real model WIDTHS on the configurations the shorter tests never reach:
+
+  * ESM-1v 650M through the 1 024-token window (16 of the 217 substitution assays are longer than 1 022 residues:
+    every one of their forwards runs T = 1024 -- 32 key tiles per online softmax, learned positions up to 1 025);
+  * ESM2-650M pseudo-perplexity at BASELINE config 5's own shape (two ~735-residue members, 731 / 735-term sums) against
+    terms the UNMODIFIED reference model produced (tests/golden/make_golden_real_width.py);
+  * Tranception-L shape at its full context (n_ctx 1024: 32 causal key tiles, ALiBi bias up to key 1 023), both reading
+    directions, and a 1 100-residue protein through the optimal-window scorer;
+  * ESM2-15B layer shape (5120 wide, 40 heads of 128, FFN 20480) at 8 layers.
+
+Bars: flat 1e-4 abs against the CPU fp32 oracle / the reference goldens (the north-star's bar) unless a comment says why
+not; where the fp32 reference's own distance to exact arithmetic is the same size as the bar, the fp64 oracle is the
+yardstick and the fp32 noise is printed next to the result.
+References: /root/reference/proteingym/baselines/esm/compute_fitness.py:258-279,486-504; proteingym/utils/scoring_utils.py:43-52;
+proteingym/baselines/tranception/tranception/model_pytorch.py:155-183,878-928, utils/scoring_utils.py:152-203.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from proteingym_amd import esm as pesm, synthetic
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+_BLOBS = {}
+
+
+def _blob(name, seed, embed_std, layers=None):
+    key = (name, seed, embed_std, layers)
+    if key not in _BLOBS:
+        _BLOBS.clear()                                                   # one multi-GB blob at a time
+        cfg = dict(getattr(synthetic, name))
+        if layers:
+            cfg["layers"] = layers
+        _BLOBS[key] = (cfg, synthetic.random_weights(cfg, seed=seed, embed_std=embed_std))
+    return _BLOBS[key]
+
+
+def _threads():
+    import torch
+    torch.set_num_threads(max(1, __import__("bench").usable_cores()))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# (i) ESM-1v 650M, a 1 100-residue protein: every forward is a 1 024-token window
+# ---------------------------------------------------------------------------------------------------------------------
+_LONG = {}
+
+
+def _long_case():
+    """Sequence, mutants and the oracle rows (computed once, shared by the precision modes)."""
+    if "ref" in _LONG:
+        return _LONG["seq"], _LONG["muts"], _LONG["positions"], _LONG["ref"]
+    from oracle import esm_oracle as eo
+    rng = np.random.default_rng(1100)
+    L = 1100
+    seq = synthetic.random_sequence(rng, L)
+    aa = list(synthetic.AA)
+
+    def sub(p):                                                          # residue index p (0-based) -> "A17G"
+        return f"{seq[p]}{p + 1}{rng.choice([a for a in aa if a != seq[p]])}"
+    # token i = p + 1; n = 1102 tokens, W = 1024: windows [0,1024) for i < 512, [i-512, i+512) for 512 <= i < 590,
+    # [78, 1102) for i >= 590 (scoring_utils.py:43-52).  Both window edges, both ends of the protein, the middle.
+    residues = [0, 510, 511, 550, 588, 589, 1023, 1099]
+    muts = [sub(p) for p in residues]
+    muts.append(":".join(sub(p) for p in (0, 511, 550, 589, 1099)))      # depth 5 across all three window kinds
+    muts.append(":".join(sub(p) for p in (510, 588)))
+    positions = sorted(p + 1 for p in residues)
+    cfg, blob = _blob("ESM1V_650M", 1, 0.15)
+    _threads()
+    ocfg, W = eo.from_arrays(arrays=synthetic.blob_to_arrays(cfg, blob), **cfg)
+    ref = eo.masked_marginals_table(ocfg, W, seq, positions=positions, batch=4)
+    _LONG.update(seq=seq, muts=muts, positions=positions, ref=ref)
+    return seq, muts, positions, ref
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
+def test_esm1v_650m_t1024_windows_vs_oracle(lib, precision):
+    from oracle import esm_oracle as eo
+    seq, muts, positions, ref = _long_case()
+    cfg, blob = _blob("ESM1V_650M", 1, 0.15)
+    model = pesm.EsmModel(cfg, blob, device=0, precision=precision)
+    assay = pesm.Assay(model, seq, muts)
+    assert assay.T == 1024 and sorted(int(p) for p in assay.positions) == positions
+    scores, table = assay.run(want_table=True)
+    err_t = float(np.abs(table[positions] - ref[positions]).max())
+    ref_s = np.array([eo.label_row(m, seq, ref, 1) for m in muts])
+    err_s = np.abs(scores - ref_s)
+    llr = ref[positions][:, 4:24]
+    print(f"[{precision}] ESM-1v 650M, L=1100 (T=1024 windows): {len(positions)} rows max|err| {err_t:.2e}; scores max|err| "
+          f"{err_s.max():.2e} (depth-5 {err_s[-2]:.2e}); log-prob range {float(llr.max() - llr.min()):.1f}")
+    assert err_t < TOL
+    assert err_s.max() < TOL
+    assay.close()
+    model.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# (ii) ESM2-650M pseudo-ppl at config 5's shape vs reference-generated goldens
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
+def test_esm2_650m_pppl_735_residues_vs_reference(lib, golden_dir, precision):
+    path = os.path.join(golden_dir, "golden_pppl_650m.npz")
+    if not os.path.exists(path):
+        pytest.skip("golden_pppl_650m.npz not generated (tests/golden/make_golden_real_width.py)")
+    g = np.load(path)
+    seqs = [str(g[f"seq/{r}"]) for r in range(2) if f"terms/{r}" in g]
+    assert seqs == synthetic.random_indel_library(7, 735, 2)[1][: len(seqs)]        # the fixture's inputs are reproducible
+    cfg, blob = _blob("ESM2_650M", 5, 0.15)
+    model = pesm.EsmModel(cfg, blob, device=0, precision=precision)
+    lib_ = pesm.SequenceLibrary(model, seqs)
+    scores, terms = lib_.score(want_terms=True)
+    for r, s in enumerate(seqs):
+        ref = g[f"terms/{r}"]
+        assert len(terms[r]) == len(ref) == len(s) - 2
+        e_term = float(np.abs(terms[r].astype(np.float64) - ref).max())
+        e_sum = abs(scores[r] - float(g[f"sum/{r}"]))
+        msg = f"[{precision}] ESM2-650M pseudo-ppl, member {r} ({len(s)} residues, {len(ref)} terms): per-term max|err| {e_term:.2e}; sum |err| {e_sum:.2e} on {float(g[f'sum/{r}']):.2f}"
+        if f"terms64/{r}" in g:
+            t64 = g[f"terms64/{r}"]
+            msg += (f"; the reference's own fp32 arithmetic vs fp64: per-term {np.abs(ref - t64).max():.2e}, sum {abs(float(g[f'sum/{r}']) - t64.sum()):.2e}"
+                    f"; HIP vs fp64: per-term {np.abs(terms[r] - t64).max():.2e}, sum {abs(scores[r] - t64.sum()):.2e}")
+        print(msg)
+        assert scores[r] == sum(float(v) for v in terms[r])                          # python's left-to-right double sum of the f32 terms
+        assert e_term < TOL
+        assert e_sum < TOL                                                           # flat, on a ~733-term sum
+    # a member scored alone (another batch composition: what a rank of run_indels sees) has the SAME BITS
+    for r in range(len(seqs)):
+        alone, t_alone = lib_.score(first=r, count=1, want_terms=True)
+        assert np.array_equal(t_alone[0], terms[r])
+        assert alone[0] == scores[r]
+    lib_.close()
+    model.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# (iii) Tranception-L shape at the full 1 024-token context
+# ---------------------------------------------------------------------------------------------------------------------
+def test_tranception_l_full_context_vs_oracle(lib):
+    import torch
+    import pandas as pd
+    from oracle import tranception_oracle as to
+    from proteingym_amd import tranception as ptr
+    _threads()
+    cfg = dict(synthetic.TRANCEPTION_L)
+    blob = synthetic.random_tranception_weights(cfg, seed=3)
+    model = ptr.TranceptionModel(cfg, blob, device=0)
+    ocfg, W = to.from_arrays(arrays=synthetic.tranception_blob_to_arrays(cfg, blob), **cfg)
+    rng = np.random.default_rng(1024)
+    full = "".join(rng.choice(list(synthetic.AA), size=1022))              # [CLS] + 1022 + [SEP] = n_ctx tokens
+    seqs = [full, full[::-1]]                                              # the scorer's two reading directions
+    ids, mask = to.encode_batch(seqs)
+    assert ids.shape == (2, 1024)
+    with torch.no_grad():
+        ref = torch.log_softmax(to.forward_logits(ocfg, W, ids, mask), -1).numpy()
+        W64 = {k: v.double() for k, v in W.items()}
+        ref64 = torch.log_softmax(to.forward_logits(ocfg, W64, ids, mask), -1).numpy()
+        del W64
+    got = model.token_logprobs(ids)
+    noise = float(np.abs(ref - ref64).max())
+    err64 = float(np.abs(got - ref64).max())
+    err32 = float(np.abs(got - ref).max())
+    # the scored quantity: log p(token t+1 | <= t) summed over the sequence, per residue (scoring_utils.py:118-141)
+    tgt = ids[:, 1:]
+    pick = lambda lp: np.take_along_axis(lp[:, :-1], tgt[..., None], -1)[..., 0]
+    tok_err = float(np.abs(pick(got) - pick(ref64)).max())
+    ll = model.sequence_loglik(seqs)
+    ll_ref = pick(ref64).sum(1)
+    ll_err = float(np.abs(ll - ll_ref).max() / 1022)
+    print(f"Tranception-L at n_ctx 1024: token log-probs HIP vs fp64 {err64:.2e} (all 25 symbols) / {tok_err:.2e} (the scored symbol), "
+          f"HIP vs CPU fp32 {err32:.2e}, CPU fp32 vs fp64 {noise:.2e}; per-residue log-likelihood |err| {ll_err:.2e} "
+          f"(sum {float(ll_ref[0]):.1f})")
+    assert err64 < max(TOL, 3.0 * noise)
+    assert tok_err < max(TOL, 3.0 * noise)
+    assert ll_err < TOL
+    # a 1 100-residue protein through score_mutants (optimal windows of 1 022 residues, both directions, delta to the wild
+    # type of the same window) against the oracle's scorer
+    L = 1100
+    wt = "".join(rng.choice(list(synthetic.AA), size=L))
+    muts = []
+    for p in (3, 511, 700, 1096):
+        muts.append(f"{wt[p]}{p + 1}{'A' if wt[p] != 'A' else 'C'}")
+    df = pd.DataFrame({"mutant": muts})
+    with torch.no_grad():
+        want = to.score_mutants(ocfg, W, df, wt)
+    have = model.score_mutants(DMS_data=df, target_seq=wt)
+    assert list(have["mutated_sequence"]) == list(want["mutated_sequence"])
+    for col in ("avg_score_L_to_R", "avg_score_R_to_L", "avg_score"):
+        e = float(np.abs(have[col].to_numpy() - want[col].to_numpy()).max())
+        print(f"Tranception-L, L=1100 optimal windows: {col} max|err| {e:.2e}")
+        assert e < TOL
+    model.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# (iv) ESM2-15B layer shape at 8 layers
+# ---------------------------------------------------------------------------------------------------------------------
+def _avail_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                return int(line.split()[1]) / 1e6
+    except Exception:
+        pass
+    return 0.0
+
+
+def test_esm2_15b_width_8_layers_vs_oracle(lib):
+    """Operand rounding at K = 5120 / 20480 accumulates over depth: 8 of the 48 layers (2.5 G parameters, 10 GB of fp32
+    weights), T = 152, realistic-range weights (embed_std 0.075, see test_esm2_15b_width_vs_oracle)."""
+    import torch
+    from oracle import esm_oracle as eo
+    layers = int(os.environ.get("PGMI_TEST_15B_LAYERS", "8"))
+    need = 3.3 * layers + 8                                              # blob + fp32 oracle (shares memory) + fp64 copy
+    if _avail_gb() < need:
+        pytest.skip(f"needs ~{need:.0f} GB of host memory for the fp64 oracle")
+    _threads()
+    cfg, blob = _blob("ESM2_15B", 15, 0.075, layers=layers)
+    seq, muts, _ = synthetic.random_assay(seed=8, L=150, n_single=40, n_multi=10)
+    m = pesm.EsmModel(cfg, blob, device=0)
+    a = pesm.Assay(m, seq, muts)
+    scores, table = a.run(want_table=True)
+    a.close()
+    m.close()
+    positions = sorted(int(p) for p in a.positions)[:12]
+    tabs = {}
+    for dt in (torch.float64, torch.float32):
+        ocfg, W = eo.from_arrays(arrays=synthetic.blob_to_arrays(cfg, blob), dtype=dt, **cfg)
+        tabs[dt] = eo.masked_marginals_table(ocfg, W, seq, positions=positions, batch=6)
+        del W
+    t32, t64 = tabs[torch.float32], tabs[torch.float64]
+    noise = float(np.abs(t32[positions] - t64[positions]).max())
+    err64 = float(np.abs(table[positions] - t64[positions]).max())
+    err32 = float(np.abs(table[positions] - t32[positions]).max())
+    rng_lp = float(t64[positions][:, 4:24].max() - t64[positions][:, 4:24].min())
+    print(f"ESM2-15B width, {layers} layers: HIP vs fp64 {err64:.2e}, HIP vs CPU fp32 {err32:.2e}, CPU fp32 vs fp64 {noise:.2e}, "
+          f"log-prob range {rng_lp:.1f}")
+    assert err64 < TOL
+    assert err32 < TOL + noise

@@ -91,6 +91,30 @@ def test_oracle_vs_live_reference(tmp_path):
                 assert cf.get_optimal_window(i, n, 1024) == eo.get_optimal_window(i, n, 1024)
 
 
+@pytest.mark.skipif(not rh.reference_available(), reason="/root/reference not present (GPU box)")
+def test_tokenizer_vs_live_reference():
+    """esm/data.py:178-254 on odd inputs: whitespace dropped, literal special tokens recognised, a character outside the
+    vocabulary is a KeyError (the product's Alphabet.encode / pack_sequences and the oracle's tokenize follow it)."""
+    from proteingym_amd import esm as pesm
+    rh.load_reference()
+    from esm import data as ref_data
+    ref = ref_data.Alphabet.from_architecture("ESM-1b")
+    mine = pesm.Alphabet()
+    for text in ["ACD", "A C D", "AC<mask>D", "A<mask>", "<cls>AC<eos>", "XBZ-.UO", "", "AC\nD", " A", "acd", "AJC", "A*C",
+                 "ajJ K", "A<foo>C", "A<"]:
+        try:
+            want = ref.encode(text)
+        except KeyError as e:
+            with pytest.raises(KeyError) as got:
+                mine.encode(text)
+            assert got.value.args == e.args, text
+            continue
+        assert mine.encode(text) == want, text
+        assert mine.tokenize(text) == ref.tokenize(text), text
+        if all(len(t) == 1 for t in ref.tokenize(text)) and " " not in text and "\n" not in text:
+            assert eo.tokenize(text).tolist() == [0] + want + [2]
+
+
 # ---- Tranception -----------------------------------------------------------------------------------
 def test_tranception_oracle_reproduces_golden(golden_dir):
     from oracle import tranception_oracle as to

@@ -53,7 +53,7 @@ def test_oracle_pppl_reproduces_reference(gp, golden_dir, name):
 def test_pack_sequences_equals_batch_converter(gp):
     from proteingym_amd import esm as pesm
     _, df = gp
-    seqs = list(df["mutated_sequence"]) + ["", "XBZ-.", "acd"]        # empty, rare symbols, lower case -> <unk>
+    seqs = list(df["mutated_sequence"]) + ["", "XBZ-."]               # empty, rare symbols
     toks, off = pesm.pack_sequences(seqs)
     conv = pesm.Alphabet().get_batch_converter()
     for n, s in enumerate(seqs):
@@ -61,3 +61,13 @@ def test_pack_sequences_equals_batch_converter(gp):
         assert np.array_equal(toks[off[n]:off[n + 1]], t[0].astype(np.uint8))
         assert np.array_equal(t[0], eo.tokenize(s))
     assert off[-1] == toks.size and toks.dtype == np.uint8
+    # anything but residue letters takes the slow path = Alphabet.encode = the reference tokenizer's behaviour
+    # (esm/data.py:178-254; pinned against the live reference in tests/test_oracle_pinning.py): whitespace is dropped, a literal
+    # special token is ONE token, a character outside the vocabulary is a KeyError -- not <unk>
+    toks2, off2 = pesm.pack_sequences(["AC D", "AC<mask>D", "ACD"])
+    assert toks2.tolist() == [0, 5, 23, 13, 2, 0, 5, 23, 32, 13, 2, 0, 5, 23, 13, 2] and off2.tolist() == [0, 5, 11, 16]
+    for bad in ("acd", "AJC", "A*C"):
+        with pytest.raises(KeyError):
+            pesm.pack_sequences(["ACD", bad])
+        with pytest.raises(KeyError):
+            eo.tokenize(bad)
