@@ -10,10 +10,14 @@ masked windows -> 33-layer forward over every masked position -> LM head on the 
 -> log-softmax table -> per-mutant score (label_row).  Synthetic sequence, synthetic
 random-init weights (no network), deterministic seeds.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): assays shard over ranks with no
-data-path collective (each rank scores its own assay of the same shape: weak scaling), followed
-by the RCCL all_gather of the per-mutant score vectors that the north-star names.  value =
-all ranks' mutants / max-over-ranks time.
+N > 1 (launched by torch.distributed.run, one rank per GPU): STRONG scaling on the north-star's own
+workload -- one pass over the 217-assay-shaped substitution benchmark (2 465 767 mutants), assays
+sharded over the ranks by the product planner (run_benchmark.plan_assays), inputs resident, no
+data-path collective until the ONE RCCL all_gather of the per-mutant score vectors at the end
+(scripts/bench_scale.py).  value = all mutants / max-over-ranks time; the K "steps" are K consecutive
+slices of that one pass.  The one-GPU point of this curve is the N = 1 line's
+`secondary.benchmark_217_end_to_end.rank0_wall_clock.assay_run_s`.  The weak-scaling figure (one
+BLAT-shaped assay per rank) stays in the line as `weak_scaling`.
 
 Extra objects on the JSON line: `roofline` (dominant kernel = the FFN GEMMs, HIP-event timed
 inside the timed region, against the MFMA peak of the dtype) and `cpu_baseline` (the oracle's
@@ -32,21 +36,31 @@ sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "f16x3": 2500.0}   # MI355X_MICROARCH.md, dense
 L_BLAT, N_MUT_BLAT = 286, 4996
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r2", "pmc_traffic.json")
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r3", "pmc_traffic.json")
 
 
 def ffn_traffic(precision, M, D, F):
     """HBM-side bytes per FFN GEMM launch from the committed rocprofv3 --pmc passes of this same command
     (scripts/pmc_profile.sh: FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md).
-    Counters cannot be read from inside the run; the summary is per launch and shape-specific, so it is only used when
-    it was taken on this precision's kernels."""
-    if precision != "f16x3" or not os.path.exists(PMC_TRAFFIC):
-        return None, None
-    k = json.load(open(PMC_TRAFFIC))["kernels"]
+    Counters cannot be read from inside the run, so the summary is a committed file -- and it is only used when it was
+    taken on THIS build: pmc_profile.sh stamps it with build_native._digest() (sha256 over the kernel sources, headers
+    and compiler flags); any other digest, precision or shape gives traffic = null and says why."""
+    if precision != "f16x3":
+        return None, {"unavailable": "PMC passes were taken on the f16x3 kernels only"}
+    if not os.path.exists(PMC_TRAFFIC):
+        return None, {"unavailable": f"{os.path.relpath(PMC_TRAFFIC, ROOT)} not found"}
+    from proteingym_amd import build_native
+    doc = json.load(open(PMC_TRAFFIC))
+    if doc.get("lib_digest") != build_native._digest():
+        return None, {"unavailable": f"{os.path.relpath(PMC_TRAFFIC, ROOT)} was collected on another build of the kernels "
+                                     f"(digest {str(doc.get('lib_digest'))[:12]} != {build_native._digest()[:12]}): re-run scripts/pmc_profile.sh"}
+    if doc.get("rows_per_launch") not in (None, M):
+        return None, {"unavailable": f"PMC passes cover launches of {doc.get('rows_per_launch')} rows, this run has {M}"}
+    k = doc["kernels"]
     fc1 = next((v for n, v in k.items() if "gemm16x_kernel<1, 1," in n), None)          # FC1 + GELU, split output
     fc2 = next((v for n, v in k.items() if "gemm16x_kernel<0, 0," in n), None)          # FC2 and out-projection share a kernel
     if not fc1 or not fc2:
-        return None, None
+        return None, {"unavailable": "kernel names not found in the PMC summary"}
     algo = {"fc1": {"read": 4.0 * (M * D + F * D), "write": 4.0 * M * F}, "fc2_and_out_mean": {"read": 4.0 * (M * (F + D) / 2 + (D * F + D * D) / 2) + 4.0 * M * D, "write": 4.0 * M * D}}
     detail = {"fc1": {"fetch_bytes": fc1["fetch_bytes"], "write_bytes": fc1["write_bytes"], "algorithmic_read": algo["fc1"]["read"],
                       "algorithmic_write": algo["fc1"]["write"], "fetch_over_algorithmic": fc1["fetch_bytes"] / algo["fc1"]["read"],
@@ -55,8 +69,9 @@ def ffn_traffic(precision, M, D, F):
                                               "algorithmic_read": algo["fc2_and_out_mean"]["read"], "algorithmic_write": algo["fc2_and_out_mean"]["write"],
                                               "fetch_over_algorithmic": fc2["fetch_bytes"] / algo["fc2_and_out_mean"]["read"],
                                               "l2_hit_rate": fc2["l2_hit_rate"]},
-              "source": "profiles/r2/pmc_traffic.json (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes of `bench.py --layers 4`; "
-                        "bytes at the L2<->fabric boundary: requests served by the 256 MB Infinity Cache are counted)"}
+              "lib_digest": doc["lib_digest"][:16], "git_head": doc.get("git_head"),
+              "source": f"{os.path.relpath(PMC_TRAFFIC, ROOT)} (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes of `bench.py --layers 4` on "
+                        "this build; bytes at the L2<->fabric boundary: requests served by the 256 MB Infinity Cache are counted)"}
     return fc1["fetch_bytes"] + fc1["write_bytes"], detail
 
 
@@ -141,85 +156,175 @@ def secondary(precision, budget_note="bounded: every leg is a few seconds of GPU
         return (time.perf_counter() - t0) / reps
 
     seq, muts, _ = synthetic.random_assay(seed=23, L=L_BLAT, n_single=N_MUT_BLAT, n_multi=0)
-    # (1) ESM-1v ensemble rate: five checkpoints per assay, plain mean (compute_fitness.py:532-537)
     cfg = dict(synthetic.ESM1V_650M)
-    blob = synthetic.random_weights(cfg, seed=2)
-    models = [pesm.EsmModel(cfg, blob, device=0, precision=precision) for _ in range(5)]
-    assays = [pesm.Assay(m, seq, muts) for m in models]
-    dt = timed(lambda: [a.run_device_only() for a in assays])
-    out["esm1v_5_checkpoint_ensemble"] = {"mutants_per_s": len(muts) / dt, "ms_per_assay": dt * 1e3,
-                                          "what": "BLAT-shaped assay scored with 5 resident ESM-1v-650M-shaped checkpoints"}
-    for a in assays:
-        a.close()
-    for m in models[1:]:
-        m.close()
-    # (2) end to end through the product runner incl. checkpoint read, assay upload and CSV writes: the first 8 assays of the
-    #     217-assay-shaped benchmark (DMS_substitutions.csv rows 0-7)
-    sys.path.insert(0, os.path.join(ROOT, "scripts"))
-    import bench_217
-    from proteingym_amd import run_benchmark
-    with tempfile.TemporaryDirectory() as d:
-        os.makedirs(os.path.join(d, "dms"))
-        shapes = synthetic.dms_shapes()[:8]
-        rows = []
-        for sh in shapes:
-            rng = np.random.default_rng(sh["DMS_index"])
-            sq, df = bench_217.make_assay(rng, sh["seq_len"], sh["n_single"], sh["n_total"] - sh["n_single"])
-            df.to_csv(os.path.join(d, "dms", sh["DMS_id"] + ".csv"), index=False)
-            rows.append({"DMS_id": sh["DMS_id"], "DMS_filename": sh["DMS_id"] + ".csv", "target_seq": sq, "DMS_total_number_mutants": len(df)})
-        pd.DataFrame(rows).to_csv(os.path.join(d, "map.csv"), index=False)
-        ck = synthetic.save_fair_esm_checkpoint(os.path.join(d, "esm1v_synth_1.pt"), cfg, blob)
-        a8 = run_benchmark.create_parser().parse_args(["--model-location", ck, "--model_type", "ESM1v", "--dms_mapping", os.path.join(d, "map.csv"),
-                                                       "--dms-input", os.path.join(d, "dms"), "--dms-output", os.path.join(d, "out"), "--precision", precision])
+
+    # every leg is independent (own models, closed at its end) and individually guarded: one failing leg costs that leg only
+    def leg_ensemble():
+        # (1) ESM-1v ensemble rate: five checkpoints per assay, plain mean (compute_fitness.py:532-537)
+        cfg = dict(synthetic.ESM1V_650M)
+        blob = synthetic.random_weights(cfg, seed=2)
+        models = [pesm.EsmModel(cfg, blob, device=0, precision=precision) for _ in range(5)]
+        assays = [pesm.Assay(m, seq, muts) for m in models]
+        dt = timed(lambda: [a.run_device_only() for a in assays])
+        out["esm1v_5_checkpoint_ensemble"] = {"mutants_per_s": len(muts) / dt, "ms_per_assay": dt * 1e3,
+                                              "what": "BLAT-shaped assay scored with 5 resident ESM-1v-650M-shaped checkpoints"}
+        for a in assays:
+            a.close()
+        for m in models:
+            m.close()
+
+    def leg_benchmark_217():
+        # (2) the WHOLE 217-assay-shaped substitution benchmark end to end through the product runner: checkpoint read + upload, DMS
+        #     files read, mutants parsed + uploaded, masked-marginals with optimal 1024 windows, CSVs written (1 checkpoint)
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import bench_217
+        from proteingym_amd import run_benchmark
+        blob = synthetic.random_weights(cfg, seed=2)
+        n_assays = int(os.environ.get("PGMI_BENCH_217_ASSAYS", "217"))
+        with tempfile.TemporaryDirectory() as d:
+            os.makedirs(os.path.join(d, "dms"))
+            shapes = synthetic.dms_shapes()[:n_assays]
+            rows = []
+            t0 = time.perf_counter()
+            for sh in shapes:
+                rng = np.random.default_rng(sh["DMS_index"])
+                sq, df = bench_217.make_assay(rng, sh["seq_len"], sh["n_single"], sh["n_total"] - sh["n_single"])
+                df.to_csv(os.path.join(d, "dms", sh["DMS_id"] + ".csv"), index=False)
+                rows.append({"DMS_id": sh["DMS_id"], "DMS_filename": sh["DMS_id"] + ".csv", "target_seq": sq, "DMS_total_number_mutants": len(df)})
+            pd.DataFrame(rows).to_csv(os.path.join(d, "map.csv"), index=False)
+            ck = synthetic.save_fair_esm_checkpoint(os.path.join(d, "esm1v_synth_1.pt"), cfg, blob)
+            gen_s = time.perf_counter() - t0
+            a8 = run_benchmark.create_parser().parse_args(["--model-location", ck, "--model_type", "ESM1v", "--dms_mapping", os.path.join(d, "map.csv"),
+                                                           "--dms-input", os.path.join(d, "dms"), "--dms-output", os.path.join(d, "out"), "--precision", precision])
+            t0 = time.perf_counter()
+            st = run_benchmark.main(a8)
+            dt = time.perf_counter() - t0
+        log = st["rank0_assays"]
+        fl = [e["positions_run"] * pdist.forward_flops(e["T"]) for e in log]
+        bins = [(0, 60), (60, 100), (100, 200), (200, 400), (400, 1023), (1023, 10 ** 9)]
+        hist = []
+        for lo, hi in bins:
+            sel = [k for k, e in enumerate(log) if lo <= e["seq_len"] < hi]
+            if sel:
+                t = sum(log[k]["run_s"] for k in sel)
+                hist.append({"residues": f"{lo}-{hi - 1}" if hi < 10 ** 9 else f">={lo}", "assays": len(sel), "seconds_in_Assay_run": round(t, 2),
+                             "executed_tflops": round(sum(fl[k] for k in sel) / max(t, 1e-9) / 1e12, 1),
+                             "min_assay_tflops": round(min(fl[k] / max(log[k]["run_s"], 1e-9) for k in sel) / 1e12, 1),
+                             "max_assay_tflops": round(max(fl[k] / max(log[k]["run_s"], 1e-9) for k in sel) / 1e12, 1)})
+        clock = {k: round(v, 2) for k, v in st["rank0_wall_clock"].items()}
+        out["benchmark_217_end_to_end"] = {
+            "mutants_per_s": st["mutants"] / dt, "seconds": dt, "mutants": st["mutants"], "assays": st["assays"],
+            "positions_run": int(sum(e["positions_run"] for e in log)), "positions_the_reference_runs": int(sum(e["seq_len"] + 2 for e in log)),
+            "executed_algorithmic_pflop": sum(fl) / 1e15, "executed_tflops_over_wall": sum(fl) / dt / 1e12,
+            "executed_tflops_inside_Assay_run": sum(fl) / max(clock.get("assay_run_s", 0.0), 1e-9) / 1e12,
+            "rank0_wall_clock": clock,
+            "wall_split": "checkpoint_load_s = read + split + upload of the 2.6 GB checkpoint; assay_create_s = mutant parse + upload; "
+                          "assay_run_s = GPU + 8 bytes per mutant back (the one-GPU point of the N > 1 strong-scaling curve); wait_read_s / "
+                          "wait_write_s = time the scoring loop waited for the background DMS reader / CSV writer",
+            "per_assay_rate_by_protein_length": hist, "setup_seconds_not_timed": round(gen_s, 1),
+            "what": f"the {'whole ' if n_assays >= 217 else 'first ' + str(n_assays) + ' assays of the '}217-assay-shaped benchmark through run_benchmark (1 checkpoint, CSVs written)"}
+
+    def leg_esm2_3b():
+        # (3) BASELINE config 3's model: ESM2-3B (36 x 2560 x 40), one BLAT-shaped assay
+        cfg3 = dict(synthetic.ESM2_3B)
+        n3 = sum(int(np.prod(sh)) for _, sh in synthetic.key_shapes(cfg3))
+        block = (np.random.default_rng(3).random(1 << 24, dtype=np.float32) - 0.5) * 0.04      # timing only: a tiled random block
+        blob3 = np.tile(block, n3 // block.size + 1)[:n3]
+        m3 = pesm.EsmModel(cfg3, blob3, device=0, precision=precision)
+        del blob3
+        a3 = pesm.Assay(m3, seq, muts)
+        dt = timed(a3.run_device_only, reps=1)
+        fl = len(a3.positions) * pdist.forward_flops(a3.T, layers=36, D=2560, F=10240)
+        out["esm2_3b_one_assay"] = {"mutants_per_s": len(muts) / dt, "ms_per_assay": dt * 1e3, "algorithmic_tflops": fl / dt / 1e12,
+                                    "what": "config 3 model shape, BLAT-shaped assay (286 positions x 288 tokens), 1 GPU"}
+        a3.close()
+        m3.close()
+
+    def leg_pseudo_ppl():
+        # (4) BASELINE config 5: pseudo-ppl on a CAPSD_AAV2S-shaped slice (variable-length members, ESM2-650M shape): six members =
+        #     4 400 masked forwards of ~737 tokens, several workspace batches -> the steady-state rate of the packed path
+        cfg5 = dict(synthetic.ESM2_650M)
+        m5 = pesm.EsmModel(cfg5, synthetic.random_weights(cfg5, seed=5), device=0, precision=precision)
+        n5 = 6
+        lib5 = pesm.SequenceLibrary(m5, synthetic.random_indel_library(7, 735, n5)[1])
+        lib5.score(first=0, count=1)                                        # warm-up
         t0 = time.perf_counter()
-        run_benchmark.main(a8)
+        lib5.score()
         dt = time.perf_counter() - t0
-        n = sum(sh["n_total"] for sh in shapes)
-        out["run_benchmark_8_assays_end_to_end"] = {"mutants_per_s": n / dt, "seconds": dt, "mutants": n, "assays": len(shapes),
-                                                    "what": "checkpoint read + upload, 8 assay uploads, masked-marginals, CSVs written (1 checkpoint)"}
-    models[0].close()
-    # (3) BASELINE config 3's model: ESM2-3B (36 x 2560 x 40), one BLAT-shaped assay
-    cfg3 = dict(synthetic.ESM2_3B)
-    n3 = sum(int(np.prod(sh)) for _, sh in synthetic.key_shapes(cfg3))
-    block = (np.random.default_rng(3).random(1 << 24, dtype=np.float32) - 0.5) * 0.04      # timing only: a tiled random block
-    blob3 = np.tile(block, n3 // block.size + 1)[:n3]
-    m3 = pesm.EsmModel(cfg3, blob3, device=0, precision=precision)
-    del blob3
-    a3 = pesm.Assay(m3, seq, muts)
-    dt = timed(a3.run_device_only, reps=1)
-    fl = len(a3.positions) * pdist.forward_flops(a3.T, layers=36, D=2560, F=10240)
-    out["esm2_3b_one_assay"] = {"mutants_per_s": len(muts) / dt, "ms_per_assay": dt * 1e3, "algorithmic_tflops": fl / dt / 1e12,
-                                "what": "config 3 model shape, BLAT-shaped assay (286 positions x 288 tokens), 1 GPU"}
-    a3.close()
-    m3.close()
-    # (4) BASELINE config 5: pseudo-ppl on a CAPSD_AAV2S-shaped slice (variable-length members, ESM2-650M shape)
-    cfg5 = dict(synthetic.ESM2_650M)
-    m5 = pesm.EsmModel(cfg5, synthetic.random_weights(cfg5, seed=5), device=0, precision=precision)
-    lib5 = pesm.SequenceLibrary(m5, synthetic.random_indel_library(7, 735, 2)[1])
-    t0 = time.perf_counter()
-    lib5.score()
-    dt = time.perf_counter() - t0
-    st = lib5.stats()
-    out["esm2_650m_pseudo_ppl_capsd_shaped"] = {"mutants_per_s": 2 / dt, "masked_forwards_per_s": st["rows"] / dt, "tokens_per_s": st["tokens"] / dt,
-                                                "packing_efficiency": st["packing_efficiency"],
-                                                "what": "config 5: 2 members of a 735-residue indel library = 1 470 masked forwards of ~737 tokens"}
-    lib5.close()
-    m5.close()
-    # (5) BASELINE config 4's model: Tranception-L shape, both directions, no retrieval
-    from proteingym_amd import tranception as ptr
-    cfgt = dict(synthetic.TRANCEPTION_L)
-    mt = ptr.TranceptionModel(cfgt, synthetic.random_tranception_weights(cfgt, seed=3), device=0)
-    sq, mu, _ = synthetic.random_assay(seed=23, L=L_BLAT, n_single=512, n_multi=0)
-    df = pd.DataFrame({"mutant": mu})
-    df["mutated_sequence"] = df["mutant"].apply(lambda m: ptr.get_mutated_sequence(sq, m))
-    df = df.drop_duplicates("mutated_sequence")
-    mt.score_mutants(DMS_data=df.iloc[:32], target_seq=sq)
-    t0 = time.perf_counter()
-    mt.score_mutants(DMS_data=df, target_seq=sq, scoring_mirror=True)
-    dt = time.perf_counter() - t0
-    out["tranception_l_one_batch"] = {"mutants_per_s": len(df) / dt, "seconds": dt, "mutants": len(df),
-                                      "what": "config 4 model shape (36 x 1280 x 20), 286-residue protein, both directions, no retrieval"}
-    mt.close()
+        st = lib5.stats()
+        fl5 = st["rows"] * pdist.forward_flops(737)
+        out["esm2_650m_pseudo_ppl_capsd_shaped"] = {"mutants_per_s": n5 / dt, "masked_forwards_per_s": st["rows"] / dt, "tokens_per_s": st["tokens"] / dt,
+                                                    "packing_efficiency": st["packing_efficiency"], "batches": st["batches"], "seconds": dt,
+                                                    "algorithmic_tflops": fl5 / dt / 1e12,
+                                                    "what": f"config 5: {n5} members of a 735-residue indel library = {st['rows']} masked forwards of ~737 tokens"}
+        lib5.close()
+        m5.close()
+
+    def leg_tranception():
+        # (5) BASELINE config 4's model: Tranception-L shape, both directions; one 485-mutant batch without retrieval, then a WHOLE
+        #     BLAT-shaped assay (4 996 rows) with inference-time retrieval: alignment parsed, EVE sequence weights counted by the HIP
+        #     kernel, prior built and fused on the device
+        from proteingym_amd import tranception as ptr
+        cfgt = dict(synthetic.TRANCEPTION_L)
+        mt = ptr.TranceptionModel(cfgt, synthetic.random_tranception_weights(cfgt, seed=3), device=0)
+        sq, mu, _ = synthetic.random_assay(seed=23, L=L_BLAT, n_single=512, n_multi=0)
+        df = pd.DataFrame({"mutant": mu})
+        df["mutated_sequence"] = df["mutant"].apply(lambda m: ptr.get_mutated_sequence(sq, m))
+        df = df.drop_duplicates("mutated_sequence")
+        mt.score_mutants(DMS_data=df.iloc[:32], target_seq=sq)
+        t0 = time.perf_counter()
+        mt.score_mutants(DMS_data=df, target_seq=sq, scoring_mirror=True)
+        dt = time.perf_counter() - t0
+        out["tranception_l_one_batch"] = {"mutants_per_s": len(df) / dt, "seconds": dt, "mutants": len(df),
+                                          "what": "config 4 model shape (36 x 1280 x 20), 286-residue protein, both directions, no retrieval"}
+        with tempfile.TemporaryDirectory() as d:
+            rng = np.random.default_rng(11)
+            n_seq, aa = 4000, np.array(list(synthetic.AA))
+            wt_idx = np.array([synthetic.AA.index(c) for c in sq])
+            msa = np.tile(wt_idx, (n_seq, 1))
+            flip = rng.random(msa.shape) < rng.uniform(0.05, 0.6, size=(n_seq, 1))       # members 5 .. 60 % away from the query
+            msa[flip] = rng.integers(0, 20, size=int(flip.sum()))
+            msa[0] = wt_idx
+            gaps = rng.random(msa.shape) < 0.03
+            gaps[0] = False
+            with open(os.path.join(d, "synth.a2m"), "w") as f:
+                for k in range(n_seq):
+                    row = aa[msa[k]]
+                    row[gaps[k]] = "-"
+                    f.write(f">seq{k}/1-{L_BLAT}\n{''.join(row)}\n")
+            sq2, mu2, _ = synthetic.random_assay(seed=23, L=L_BLAT, n_single=N_MUT_BLAT, n_multi=0)
+            assert sq2 == sq
+            full = pd.DataFrame({"mutant": mu2})
+            full["mutated_sequence"] = [ptr.get_mutated_sequence(sq, m) for m in mu2]
+            t0 = time.perf_counter()
+            wfile = os.path.join(d, "weights.npy")
+            ptr.MSA_processing(MSA_location=os.path.join(d, "synth.a2m"), weights_location=wfile, device=0)       # counts on the GPU, saved
+            t_w = time.perf_counter() - t0
+            mt.retrieval = ptr.build_retrieval(dict(MSA_filename=os.path.join(d, "synth.a2m"), MSA_weight_file_name=wfile, MSA_start=0,
+                                                    MSA_end=L_BLAT, full_protein_length=L_BLAT, retrieval_inference_weight=0.6))
+            t_p = time.perf_counter() - t0 - t_w
+            res = mt.score_mutants(DMS_data=full, target_seq=sq, scoring_mirror=True)
+            dt = time.perf_counter() - t0
+        out["tranception_l_whole_assay_with_retrieval"] = {
+            "mutants_per_s": len(full) / dt, "seconds": dt, "mutants": len(full), "scored_sequences": int(len(res)),
+            "sequence_weights_s": t_w, "prior_s": t_p, "scoring_s": dt - t_w - t_p,
+            "tokens_per_s": 2 * len(res) * (L_BLAT + 2) / max(dt - t_w - t_p, 1e-9),
+            "what": f"config 4 model shape, BLAT-shaped assay ({len(full)} rows), both directions, inference-time retrieval on a synthetic {n_seq}-sequence "
+                    "alignment (weights by the HIP pair-count kernel, prior fused on the device)"}
+        mt.close()
+
+    only = [x for x in os.environ.get("PGMI_BENCH_LEGS", "").split(",") if x]
+    for fn in (leg_ensemble, leg_benchmark_217, leg_esm2_3b, leg_pseudo_ppl, leg_tranception):
+        if only and fn.__name__[4:] not in only:
+            continue
+        t0 = time.perf_counter()
+        try:
+            fn()
+        except Exception as e:
+            import traceback
+            traceback.print_exc(file=sys.stderr)
+            out[fn.__name__[4:] + "_error"] = repr(e)
+        out.setdefault("leg_seconds", {})[fn.__name__[4:]] = round(time.perf_counter() - t0, 1)
     return out
 
 
@@ -286,13 +391,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # N > 1: the BLAT-per-rank loop is the secondary weak-scaling figure (3 steps); the headline is the strong-scaling pass below
+    blat_steps = args.steps if world == 1 else min(args.steps, 3)
+    for _ in range(args.warmup if world == 1 else 1):
         step()
     model.profile_reset()
     model.profile_enable(True)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(blat_steps):
         step()
     fence()
     dt = time.perf_counter() - t0
@@ -301,6 +408,57 @@ def main():
         tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+
+    if world > 1:
+        weak = {"value": world * n_mut * blat_steps / dt, "unit": "mutants/s", "ms_per_step": dt / blat_steps * 1e3, "steps": blat_steps,
+                "what": "one BLAT-shaped assay (L=286, 4 996 mutants) per rank per step + all_gather of the score vectors: per-GPU work fixed"}
+        assay.close()
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import bench_scale
+        st = bench_scale.run(model, rank, world, args.steps, args.warmup, torch, dist,
+                             max_assays=int(os.environ.get("PGMI_BENCH_217_ASSAYS", "0")))
+        prof = model.profile()
+        if rank == 0:
+            ffn_ms = prof["gemm_fc1"]["ms"] + prof["gemm_fc2"]["ms"]
+            ffn_fl = prof["gemm_fc1"]["flops"] + prof["gemm_fc2"]["flops"]
+            ffn_n = prof["gemm_fc1"]["launches"] + prof["gemm_fc2"]["launches"]
+            achieved = ffn_fl / (ffn_ms * 1e-3) / 1e12 if ffn_ms > 0 else 0.0
+            peak = PEAK_TFLOPS[args.precision]
+            passes = 3 if args.precision == "f16x3" else 1
+            out = {
+                "metric": "mutants scored/sec (ESM-1v 650M masked-marginal)",
+                "value": st["mutants"] / st["seconds"], "unit": "mutants/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": st["seconds"] / args.steps * 1e3,
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "dtype": {"fp32": "f32", "bf16": "bf16",
+                          "f16x3": "f16x3 (fp32 operands split into 2 fp16 planes, 3 fp16 MFMAs per product, fp32 accumulate)"}[args.precision],
+                "data": "synthetic",
+                "config": {"workload": f"ESM-1v 650M masked-marginals, ONE pass over the {st['assays']}-assay-shaped DMS substitution benchmark "
+                                       f"({st['mutants']} mutants; real seq_len / mutant counts of reference_files/DMS_substitutions.csv, optimal 1024 windows), "
+                                       f"1 checkpoint, assays sharded over {world} ranks by run_benchmark.plan_assays, inputs resident in HBM, one RCCL "
+                                       "all_gather of the per-mutant score vectors; total work fixed",
+                           "steps_are": f"{args.steps} consecutive slices of each rank's work list (the timed region is exactly one pass); "
+                                        f"warm-up = the first {min(args.warmup, args.steps)} slices, untimed, then repeated inside the pass",
+                           "one_gpu_point_of_this_curve": "the N = 1 line's secondary.benchmark_217_end_to_end: mutants / rank0_wall_clock.assay_run_s",
+                           "precision": args.precision, "layers": args.layers},
+                "strong_scaling": st,
+                "weak_scaling": weak,
+                "roofline": {"bound": "mfma", "kernel": "gemm (fc1+GELU, fc2+residual), rank 0, all shapes of its share of the benchmark",
+                             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                             "avg_launch_ms": ffn_ms / max(ffn_n, 1), "traffic": None,
+                             "traffic_detail": {"unavailable": "PMC passes cover the N = 1 workload's launch shape only"},
+                             "mfma_passes": passes, "mfma_util": passes * achieved / peak,
+                             "note": "achieved = algorithmic FLOPs (2*M*N*K per GEMM) / HIP-event time of rank 0's FFN GEMM launches in the timed pass"},
+                "kernels": {k: {"ms": round(v["ms"], 2), "launches": v["launches"],
+                                "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 and v["flops"] > 0 else None}
+                            for k, v in prof.items()},
+            }
+            print(json.dumps(out), flush=True)
+        model.close()
+        dist.barrier()
+        dist.destroy_process_group()
+        return
 
     prof = model.profile()
     if rank == 0:
@@ -327,10 +485,10 @@ def main():
                       "f16x3": "f16x3 (fp32 operands split into 2 fp16 planes, 3 fp16 MFMAs per product, fp32 accumulate)"}[args.precision],
             "data": "synthetic",
             "config": {"workload": "ESM-1v 650M (33x1280, 20 heads, FFN 5120) masked-marginals, one "
-                                   "BLAT_ECOLX_Stiffler_2015-shaped assay per GPU per step (L=286, T=288, "
+                                   "BLAT_ECOLX_Stiffler_2015-shaped assay per step (BASELINE.json configs[1]: L=286, T=288, "
                                    f"{len(assay.positions)} masked positions run, {n_mut} single mutants), "
                                    f"{args.checkpoints} checkpoint{'s averaged (ensemble rate)' if args.checkpoints > 1 else ''}; "
-                                   "assays shard over ranks + RCCL all_gather of score vectors",
+                                   "N > 1 runs the 217-assay-shaped benchmark sharded over the ranks (strong scaling)",
                        "precision": args.precision, "layers": args.layers,
                        "last_layer": ("after its attention the last layer runs on the masked row of every sequence only -- the one row "
                                       "masked-marginals reads (class kept_rows); scores bit-identical to the full evaluation"

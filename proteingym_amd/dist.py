@@ -80,7 +80,7 @@ def gather_tables(local: Dict[int, np.ndarray], n_toks: Sequence[int], vocab: in
     import torch.distributed as dist
     world = dist.get_world_size() if dist.is_initialized() else 1
     order = sorted(range(len(n_toks)))
-    if world == 1:
+    if not dist.is_initialized():          # (an initialised one-rank group still goes through the collective: tests/test_gpu_dist.py)
         return {a: np.asarray(local[a], dtype=np.float32) for a in order}
     flat = np.concatenate([np.asarray(local[a], dtype=np.float32).ravel() for a in order])
     buf = torch.from_numpy(flat).to(device) if device else torch.from_numpy(flat)
@@ -104,7 +104,7 @@ def gather_score_vectors(local: Dict[int, np.ndarray], sizes: Sequence[int], ass
     import torch.distributed as dist
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
-    if world == 1:
+    if not dist.is_initialized():
         return {i: np.asarray(v, dtype=np.float64) for i, v in local.items()}
     per_rank = [sum(int(sizes[i]) for i in items) for items in assignment]
     stride = max(max(per_rank), 1)

@@ -78,6 +78,7 @@ class _DeviceScorer:
         self.model, self.alphabet = pesm.load_model_and_alphabet(location, device=device, precision=precision)
         self.all_positions = all_positions
         self.create_s = self.run_s = 0.0            # wall clock in Assay() (parse + upload) / Assay.run() (GPU + 8 bytes per mutant back)
+        self.log = []                               # per assay: residues, rows, masked positions run, T, seconds in Assay() / Assay.run()
 
     def score(self, seq, mutants, offset):
         t0 = time.time()
@@ -85,9 +86,12 @@ class _DeviceScorer:
                            all_positions=self.all_positions)
         t1 = time.time()
         out = assay.run()
+        t2 = time.time()
+        self.log.append(dict(seq_len=len(seq), rows=len(mutants), positions_run=int(len(assay.positions)), T=int(assay.T),
+                             create_s=t1 - t0, run_s=t2 - t1))
         assay.close()
         self.create_s += t1 - t0
-        self.run_s += time.time() - t1
+        self.run_s += t2 - t1
         return out
 
     def close(self):
@@ -172,8 +176,11 @@ def main(args, make_model=None):
     # formatting (2.47 M rows over the benchmark) overlaps the scoring of the following assays (the C calls drop the GIL);
     writer = ThreadPoolExecutor(max_workers=2) if owner_writes else None
     pending = []
+    assay_log = []
     for ci, loc in enumerate(args.model_location):
+        t = time.time()
         model = make_model(loc) if make_model is not None else _DeviceScorer(loc, local_rank, args.precision, args.all_positions)
+        clock["checkpoint_load_s"] = clock.get("checkpoint_load_s", 0.0) + time.time() - t
         last = ci == len(args.model_location) - 1
         for i in order:
             df, mutant_col, seq, offset = frame(i)
@@ -186,6 +193,7 @@ def main(args, make_model=None):
         for k in ("create_s", "run_s"):
             if hasattr(model, k):
                 clock["assay_" + k] = clock.get("assay_" + k, 0.0) + getattr(model, k)
+        assay_log += [dict(e, checkpoint=ci, DMS_id=str(mapping.iloc[i]["DMS_id"])) for e, i in zip(getattr(model, "log", []), order)]
         model.close()
     t = time.time()
     for f in pending:
@@ -239,10 +247,15 @@ def main(args, make_model=None):
               f"in {dt:.1f}s = {n_mut / max(dt, 1e-9):.1f} mutants/s (ensemble rate)")
         print("rank 0 wall clock: " + ", ".join(f"{k} {v:.1f}" for k, v in clock.items())
               + " (score_s = mutant parse + upload + GPU; checkpoint load and the rest are the difference)")
+        stats = dict(seconds=dt, mutants=n_mut, assays=len(todo), checkpoints=len(cols), world=world, rank0_wall_clock=dict(clock),
+                     rank0_assays=assay_log)
+    else:
+        stats = None
     if world > 1:
         import torch.distributed as tdist
         tdist.barrier()
         tdist.destroy_process_group()
+    return stats
 
 
 def main_position_shards(args, mapping, todo, cols, ens_cols, rank, local_rank, world, make_model=None):

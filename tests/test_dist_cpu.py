@@ -552,3 +552,59 @@ def test_msa_transformer_seed_position_pairs_shard_over_two_ranks(tmp_path):
         assert np.array_equal(d1[c].to_numpy(), d2[c].to_numpy())
     for seed_k in range(2):                       # per seed: the two ranks' positions are disjoint and together the single rank's
         assert sorted(c2[0][seed_k] + c2[1][seed_k]) == sorted(c1[0][seed_k]) and not set(c2[0][seed_k]) & set(c2[1][seed_k])
+
+
+# ---- bench.py --gpus N: the strong-scaling pass over the 217-assay-shaped table (scripts/bench_scale.py) -----------------
+class _FakeBenchAssay:
+    def __init__(self, model, seq, muts):
+        self.positions = np.arange(min(len(seq), len(muts)))
+        self.T = min(len(seq) + 2, 1024)
+        self.n = len(muts)
+        model.append(self.n)
+
+    def run_device_only(self, ptr=0):
+        pass
+
+    def close(self):
+        pass
+
+
+def _bench_scale_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(1)
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import bench_scale
+    pdist.init_from_env("gloo")
+    seen = []
+    st = bench_scale.run(seen, rank, world, steps=5, warmup=2, torch=torch, tdist=dist, max_assays=24, make_assay=_FakeBenchAssay)
+    q.put((rank, sum(seen), st))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_strong_scaling_pass_covers_the_table_once_on_two_ranks():
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import bench_scale
+    from proteingym_amd import synthetic
+    for n, k in ((0, 4), (3, 20), (20, 20), (41, 5)):                       # K slices tile a work list of any length
+        sl = bench_scale.step_slices(n, k)
+        assert len(sl) == k and sl[0][0] == 0 and sl[-1][1] == n and all(a[1] == b[0] for a, b in zip(sl, sl[1:]))
+    shapes, assignment = bench_scale.plan(8)
+    assert len(shapes) == 217 and sorted(i for part in assignment for i in part) == list(range(217))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_scale_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = sum(s["n_total"] for s in synthetic.dms_shapes()[:24])
+    assert sum(r[1] for r in res) == want                                   # every assay generated and uploaded by exactly one rank
+    for _, _, st in res:
+        assert st["mutants"] == want and st["assays"] == 24 and st["seconds"] >= st["fastest_rank_seconds"] > 0
+        assert st["positions_run"] > 0 and st["executed_algorithmic_flops"] > 0

@@ -148,3 +148,28 @@ def test_cli_writes_reference_csv(lib, gold, golden_dir, tmp_path):
     df = pd.read_csv(os.path.join(golden_dir, "TOY_TRANCEPTION_DMS.csv"))
     r = _merge(df, out)
     assert np.abs(r["avg_score"].to_numpy() - gold["scores_retrieval/avg_score"]).max() < TOL
+
+
+def test_run_sharded_mutant_chunks_equal_the_cli(lib, gold, golden_dir, tmp_path):
+    """run_sharded tranception (config 4's multi-GPU runner) on one GPU with the work cut into chunks of <= 7 rows: one
+    checkpoint load, the retrieval prior swapped in per assay (assay 0 with retrieval arguments from the reference table,
+    assay 1 = the same file under another id), per-row scores gathered and re-assembled -- the CSVs must be byte-identical
+    to the single-assay CLI's (a sequence's bits do not depend on what shares its batch)."""
+    from proteingym_amd import run_sharded, score_tranception_proteingym as cli
+    src = pd.read_csv(os.path.join(golden_dir, "TOY_TRANCEPTION_DMS.csv"))
+    dms = tmp_path / "dms"
+    dms.mkdir()
+    src.to_csv(dms / "A.csv", index=False)
+    src.iloc[::-1].to_csv(dms / "B.csv", index=False)
+    s0, s1 = int(gold["msa_start_end"][0]) + 1, int(gold["msa_start_end"][1])
+    ref = pd.DataFrame({"DMS_id": ["A", "B"], "DMS_filename": ["A.csv", "B.csv"], "target_seq": [str(gold["seq"])] * 2,
+                        "DMS_total_number_mutants": [len(src)] * 2, "MSA_filename": ["TOY_MSA.a2m"] * 2,
+                        "MSA_start": [s0] * 2, "MSA_end": [s1] * 2, "weight_file_name": ["none.npy"] * 2})
+    ref.to_csv(tmp_path / "ref.csv", index=False)
+    common = ["--checkpoint", os.path.join(golden_dir, "Tranception_toy"), "--DMS_reference_file_path", str(tmp_path / "ref.csv"),
+              "--DMS_data_folder", str(dms), "--inference_time_retrieval", "--MSA_folder", golden_dir]
+    items = run_sharded.main(["tranception", "--max-chunk-rows", "7", "--", *common, "--output_scores_folder", str(tmp_path / "sharded")])
+    assert len(items) == 2 * -(-len(src) // 7)
+    for i, name in enumerate(("A", "B")):
+        cli.main(cli.create_parser().parse_args(common + ["--output_scores_folder", str(tmp_path / "single"), "--DMS_index", str(i)]))
+        assert open(tmp_path / "sharded" / f"{name}.csv").read() == open(tmp_path / "single" / f"{name}.csv").read()
