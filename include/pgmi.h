@@ -65,7 +65,7 @@ typedef struct pgmi_config {
     int32_t arch;                 /* PGMI_ARCH_* */
     int32_t layers;               /* encoder_layers */
     int32_t embed_dim;            /* D  (encoder_embed_dim) */
-    int32_t heads;                /* H  (encoder_attention_heads); head_dim D/H: 64, an even value below 64 (ESM2 8M/35M/150M: 16/24/32), or 128 (ESM2-15B; precision f16x3) */
+    int32_t heads;                /* H  (encoder_attention_heads); head_dim D/H: 64, an even value below 64 (ESM2 8M/35M/150M: 16/24/32), or 128 (ESM2-15B) */
     int32_t ffn_dim;              /* F  (encoder_ffn_embed_dim; 4*D for ESM2, esm2.py:52) */
     int32_t vocab;                /* = 33 */
     int32_t max_positions;        /* ESM-1b learned positions (table has max_positions+2 rows, modules.py:246-251); 0 for ESM2 */

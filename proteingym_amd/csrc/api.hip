@@ -202,7 +202,6 @@ int check_cfg(const pgmi_config* c) {
         const bool ok = c->embed_dim % c->heads == 0 &&
                         (dh == kHeadDim || (dh < kHeadDim && dh % 2 == 0 && esm) || (dh == 2 * kHeadDim && esm));
         if (!ok) { set_error("unsupported head_dim %d (embed_dim %d / heads %d): this build supports head_dim 64, even head dims below 64 and head_dim 128 (ESM)", dh, c->embed_dim, c->heads); return PGMI_EINVAL; }
-        if (dh == 2 * kHeadDim && c->precision != PGMI_PREC_F16X3) { set_error("head_dim 128 (ESM2-15B class) is available in precision f16x3 only"); return PGMI_EINVAL; }
     }
     if (c->embed_dim % 32 || c->ffn_dim % 32) { set_error("embed_dim and ffn_dim must be multiples of 32"); return PGMI_EINVAL; }
     if (c->arch == PGMI_ARCH_TRANCEPTION) {
@@ -351,7 +350,7 @@ int run_encoder(pgmi_model* m, int B, int T, const int32_t* keep = nullptr, int 
           if (prec == PGMI_PREC_FP32) launch_layernorm(m->x, L.ln1_w, L.ln1_b, M, D, 1e-5f, m->h, s);
           else launch_layernorm16(m->x, L.ln1_w, L.ln1_b, M, D, 1e-5f, m->h16, m->h16_plane, mode16, s); }
         const bool fused_qkv = prec == PGMI_PREC_F16X3 && m->att16 == 3;
-        if (m->rot_halves > 1 && !fused_qkv) { set_error("head_dim 128 needs the fused QKV + DMA-ring attention path (PGMI_ATT16=3)"); return PGMI_EINVAL; }
+        if (m->rot_halves > 1 && !fused_qkv && prec == PGMI_PREC_F16X3) { set_error("head_dim 128 in precision f16x3 needs the fused QKV + DMA-ring attention path (PGMI_ATT16=3)"); return PGMI_EINVAL; }
         { ProfScope p(m, PGMI_K_GEMM_QKV, 2.0 * M * 3 * D * D, 0);
           if (fused_qkv)
               rc = launch_gemm16_qkv(m->h16, m->h16_plane, L.wqkv16.p, L.wqkv16.plane, L.bqkv, M, Da, D, L.wqkv16.out_scale,
@@ -362,7 +361,7 @@ int run_encoder(pgmi_model* m, int B, int T, const int32_t* keep = nullptr, int 
           if (rc) return rc; }
         { ProfScope p(m, PGMI_K_ATTENTION, 4.0 * M * T * D, 0);
           const bool v2 = prec == PGMI_PREC_F16X3 && m->att16 >= 2;
-          if (c.arch == PGMI_ARCH_ESM2 && !v2) launch_rotary(m->qkv, m->rot_cos, m->rot_sin, M, T, H, s);
+          if (c.arch == PGMI_ARCH_ESM2 && !v2) launch_rotary(m->qkv, m->rot_cos, m->rot_sin, M, T, m->Hs, s, m->rot_halves);
           if (v2)
               rc = launch_attention_f16x3_v2(fused_qkv ? nullptr : m->qkv, m->kv_len, m->rot_cos, m->rot_sin, c.arch == PGMI_ARCH_ESM2, B, T, H,
                                              m->qk16, m->qk16_plane, m->vt16, m->vt16_plane, nullptr, m->h16,
@@ -371,7 +370,7 @@ int run_encoder(pgmi_model* m, int B, int T, const int32_t* keep = nullptr, int 
               rc = launch_attention_f16x3(m->qkv, m->kv_len, B, T, H, m->h, m->h16, m->h16_plane, 1, s);
           else
               rc = launch_attention_f32(m->qkv, m->kv_len, B, T, H, m->h, m->h16, m->h16_plane,
-                                        prec == PGMI_PREC_FP32 ? 0 : mode16, s);
+                                        prec == PGMI_PREC_FP32 ? 0 : mode16, s, m->rot_halves * kHeadDim);
           if (rc) return rc; }
         if (keep && m->keep_rows && l == c.layers - 1) {
             const int R = n_keep;

@@ -26,6 +26,8 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int AKT = 32;                       // keys per tile
+constexpr int kAttTuneDefault = 0;            // attention_f16x3_v2_kernel `tune` bits used when PGMI_ATT_TUNE is not set
+constexpr float kAttDeferDefault = 0.0f;      // ... and its `defer_thr` (PGMI_ATT_DEFER)
 constexpr int K_CH = AKT * 8;                 // chunks per K plane
 constexpr int V_CH = 64 * 4;                  // chunks per V^T plane
 constexpr int A_STAGE = 2 * K_CH + 2 * V_CH;  // chunks per buffer (hi+lo planes of K and V^T) = 16 KB
@@ -477,7 +479,9 @@ template <int WPB, int OUT, int NSTG, int DH = 64>
 __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
     const unsigned short* __restrict__ qk16, size_t qk_plane, const unsigned short* __restrict__ vt16,
     size_t vt_plane, const int32_t* __restrict__ kv_len, const float* __restrict__ slopes, int T, int H,
-    int Tp, float* __restrict__ ctx, unsigned short* __restrict__ ctx16, size_t plane) {
+    int Tp, float* __restrict__ ctx, unsigned short* __restrict__ ctx16, size_t plane, int tune, float defer_thr) {
+    // tune (A/B switches, see launch_attention_f16x3_v2): 1 = static priority for the waves in odd hardware wave slots, 2 = the
+    // lane <-> lane + 32 max exchange through LDS (ds_bpermute) instead of v_permlane32_swap.  defer_thr: see the rescale below.
     // slopes != nullptr selects the Tranception flavour (tranception/model_pytorch.py:155-183): causal
     // mask (key <= query) and the grouped-ALiBi bias slope[h] * key added to the scaled scores.
     constexpr int NT = WPB * 64;
@@ -500,6 +504,10 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
     const int Tk = kv_len ? kv_len[b] : T;
     const int q0 = (blockIdx.x * WPB + wave) * 32;
     const bool active = q0 < T;
+    // Two workgroups share a CU, one wave of each per SIMD, both running this same loop: with equal priorities the pair tends to
+    // sit in the same kind of phase (both in the softmax's VALU chain, then both in the MFMAs).  A static priority for the wave in
+    // the odd hardware slot lets it run unimpeded while its partner fills the unit it leaves idle.
+    if ((tune & 1) && (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1)) __builtin_amdgcn_s_setprio(2);
 
     // Q fragments straight from the planes: lane (r,kh) holds Q[q0+r][16s + 8kh .. +7]
     u32x4 qh[NS], ql[NS];
@@ -626,9 +634,21 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
             float mloc = st[0];
 #pragma unroll
             for (int v = 1; v < 16; ++v) mloc = fmaxf(mloc, st[v]);
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+            if (tune & 2) {
+                mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
+            } else {                                      // v_permlane32_swap: both halves of the query's row without an LDS round trip
+                const unsigned int mu = __builtin_bit_cast(unsigned int, mloc);
+                const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
+                const unsigned int s0 = sw[0], s1 = sw[1];
+                mloc = fmaxf(__builtin_bit_cast(float, s0), __builtin_bit_cast(float, s1));
+            }
             const float m_new = fmaxf(m_run, mloc);
-            if (!__all(m_new == m_run)) {                 // exact: no rescale when no lane's max moved
+            // Deferred rescale: the running reference m_run may lag the true row maximum by up to defer_thr (base-2 units).  P is
+            // then up to 2^(10 + defer_thr) instead of 2^10 -- still exact to 22 bits in its hi | lo split and, for defer_thr <= 5,
+            // inside fp16's range -- and O and l carry the same factor, which cancels in O / l.  The O-wide rescale (36 packed
+            // multiplies on 64 accumulator registers + their wait for the previous P V MFMAs) then runs on the first key tiles
+            // only instead of on nearly every tile.  defer_thr = 0: rescale whenever any lane's maximum moved (exact running max).
+            if (!__all(m_new <= m_run + defer_thr)) {
                 const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
                 l_run *= alpha;
 #pragma unroll
@@ -639,16 +659,15 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
             }
             const float mb = m_run - 10.0f;
             typedef float f32x2 __attribute__((ext_vector_type(2)));
-            float psum = 0.f;
 #pragma unroll
             for (int v = 0; v < 16; v += 2) {                    // packed fp32 subtract (v_pk_add_f32): same values, half the issue slots
                 const f32x2 dlt = f32x2{st[v], st[v + 1]} - f32x2{mb, mb};
-                st[v] = __builtin_amdgcn_exp2f(dlt[0]);          // P * 2^10 in [0, 1024]
+                st[v] = __builtin_amdgcn_exp2f(dlt[0]);          // P * 2^10 in [0, 1024 * 2^defer_thr]
                 st[v + 1] = __builtin_amdgcn_exp2f(dlt[1]);
-                psum += st[v];
-                psum += st[v + 1];
             }
-            l_run += psum;
+            // row sum as a tree (four independent chains of depth 2 + 2): a 16-long serial add chain is 16 dependent-issue latencies
+            l_run += ((st[0] + st[1]) + (st[2] + st[3])) + ((st[4] + st[5]) + (st[6] + st[7])) +
+                     (((st[8] + st[9]) + (st[10] + st[11])) + ((st[12] + st[13]) + (st[14] + st[15])));
 #pragma unroll
             for (int m = 0; m < 2; ++m) {
                 u32x4 ph, pl;
@@ -713,13 +732,22 @@ template <int WPB, int OUT, int NSTG, int DH>
 static int launch_att16v2_one(dim3 grid, const unsigned short* qk16, size_t qk_plane, const unsigned short* vt16, size_t vt_plane,
                               const int32_t* kv_len, const float* slopes, int T, int H, int Tp, float* ctx, unsigned short* ctx16,
                               size_t plane, hipStream_t s) {
+    // tuning switches, read per launch (the A/B scripts toggle them inside one process): PGMI_ATT_TUNE bit 0 = asymmetric static
+    // priority, bit 1 = ds_bpermute max exchange (the old form); PGMI_ATT_DEFER = lag allowed before O is rescaled (0 .. 5)
+    const char* et = getenv("PGMI_ATT_TUNE");
+    const char* ed = getenv("PGMI_ATT_DEFER");
+    const int tune = et ? atoi(et) : kAttTuneDefault;
+    float defer_thr = ed ? (float)atof(ed) : kAttDeferDefault;
+    if (!(defer_thr >= 0.0f)) defer_thr = 0.0f;
+    if (defer_thr > 5.0f) defer_thr = 5.0f;                             // P 2^(10 + thr) must stay below fp16's 65504
     constexpr size_t lds_bytes = (size_t)NSTG * (DH * 16) * 16;          // stage = DH * 16 chunks of 16 B
     auto kfn = attention_f16x3_v2_kernel<WPB, OUT, NSTG, DH>;
     if (lds_bytes > 65536) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PGMI_EHIP; }
     }
-    hipLaunchKernelGGL(kfn, grid, dim3(WPB * 64), lds_bytes, s, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane);
+    hipLaunchKernelGGL(kfn, grid, dim3(WPB * 64), lds_bytes, s, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane,
+                       tune, defer_thr);
     return PGMI_OK;
 }
 
@@ -778,7 +806,7 @@ int launch_attention_f16x3_v2(const float* qkv, const int32_t* kv_len, const flo
     const int nblk = (n32 + 3) / 4;
     int wpb = (n32 + nblk - 1) / nblk;
     if (wpb == 3) wpb = 4;                        // measured: a 4th (idle) wave that only helps loading beats 3-wave blocks
-    static const int wpb_env = getenv("PGMI_ATT_WPB") ? atoi(getenv("PGMI_ATT_WPB")) : 0;   // tuning only
+    const int wpb_env = getenv("PGMI_ATT_WPB") ? atoi(getenv("PGMI_ATT_WPB")) : 0;   // tuning only (read per launch: scripts/att_bench.py)
     dim3 grid(nblk, H, B);
     if (wpb_env >= 1 && wpb_env <= 4) { wpb = wpb_env; grid.x = (n32 + wpb - 1) / wpb; }
     if (out_mode == 0) rc = launch_att16v2_mode<0, 3>(wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane, s);

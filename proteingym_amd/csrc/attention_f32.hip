@@ -24,36 +24,41 @@
 namespace pgmi {
 
 constexpr int KT = 32;          // keys per tile
-constexpr int KS_STRIDE = 68;   // K tile row stride (floats): conflict-free ds_read_b128
-constexpr int VS_STRIDE = 64;
 
-template <int WPB, int OUT>
+// DH = 64 (heads of <= 64 dims, zero-padded slots) or 128 (ESM2-15B: a head is two adjacent 64-lane slot groups of the
+// projection; pretrained.py:387-394): the S^T contraction runs over DH / 8 fragments, O^T has DH / 32 column tiles.
+template <int WPB, int OUT, int DH = 64>
 __global__ __launch_bounds__(WPB * 64) void attention_f32_kernel(
     const float* __restrict__ qkv, const int32_t* __restrict__ kv_len, int T, int H,
     float* __restrict__ ctx, unsigned short* __restrict__ ctx16, size_t plane) {
     constexpr int NT = WPB * 64;
-    constexpr int NL = (512 + NT - 1) / NT;   // float4 loads per thread per tensor per tile
-    __shared__ __attribute__((aligned(16))) float lds[2 * KT * KS_STRIDE + 2 * KT * VS_STRIDE];
-    float* Ks = lds;                          // [2][KT][KS_STRIDE]
-    float* Vs = lds + 2 * KT * KS_STRIDE;     // [2][KT][VS_STRIDE]
+    constexpr int KS_STRIDE = DH + 4;         // K tile row stride (floats): conflict-free ds_read_b128
+    constexpr int VS_STRIDE = DH;
+    constexpr int NF4 = KT * DH / 4;          // float4 units per tensor per tile
+    constexpr int NL = (NF4 + NT - 1) / NT;   // float4 loads per thread per tensor per tile
+    constexpr int C4 = DH / 4;                // float4 units per key row
+    constexpr int NG = DH / 8, ND = DH / 32;
+    extern __shared__ __attribute__((aligned(16))) float lds[];   // [2][KT][KS_STRIDE] K, then [2][KT][VS_STRIDE] V
+    float* Ks = lds;
+    float* Vs = lds + 2 * KT * KS_STRIDE;
 
     const int b = blockIdx.z, h = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, kh = lane >> 5;
-    const int D = H * kHeadDim;
+    const int D = H * DH;
     const size_t RS = (size_t)3 * D;
-    const float* base = qkv + (size_t)b * T * RS + (size_t)h * kHeadDim;
+    const float* base = qkv + (size_t)b * T * RS + (size_t)h * DH;
     const int Tk = kv_len ? kv_len[b] : T;
     const int q0 = (blockIdx.x * WPB + wave) * 32;
     const bool active = q0 < T;
 
     // Q fragment: lane (r,kh) holds Q[q0+r][8g+4kh+e]
-    f32x4 qf[8];
+    f32x4 qf[NG];
     {
         const int qrow = min(q0 + r, T - 1);
         const float* qp = base + (size_t)qrow * RS + kh * 4;
 #pragma unroll
-        for (int g = 0; g < 8; ++g) qf[g] = *reinterpret_cast<const f32x4*>(qp + g * 8);
+        for (int g = 0; g < NG; ++g) qf[g] = *reinterpret_cast<const f32x4*>(qp + g * 8);
     }
 
     // staging of K/V tiles through registers
@@ -62,8 +67,8 @@ __global__ __launch_bounds__(WPB * 64) void attention_f32_kernel(
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             const int f = tid + NT * i;
-            if (f < 512) {
-                const int key = kt * KT + (f >> 4), c4 = f & 15;
+            if (f < NF4) {
+                const int key = kt * KT + f / C4, c4 = f % C4;
                 if (key < T) {
                     const float* p = base + (size_t)key * RS + D + c4 * 4;
                     k_st[i] = *reinterpret_cast<const f32x4*>(p);
@@ -79,8 +84,8 @@ __global__ __launch_bounds__(WPB * 64) void attention_f32_kernel(
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
             const int f = tid + NT * i;
-            if (f < 512) {
-                const int key = f >> 4, c4 = f & 15;
+            if (f < NF4) {
+                const int key = f / C4, c4 = f % C4;
                 *reinterpret_cast<f32x4*>(Ks + buf * KT * KS_STRIDE + key * KS_STRIDE + c4 * 4) = k_st[i];
                 *reinterpret_cast<f32x4*>(Vs + buf * KT * VS_STRIDE + key * VS_STRIDE + c4 * 4) = v_st[i];
             }
@@ -92,9 +97,9 @@ __global__ __launch_bounds__(WPB * 64) void attention_f32_kernel(
     stage_store(0);
     __syncthreads();
 
-    f32x16 o[2];
+    f32x16 o[ND];
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
         for (int v = 0; v < 16; ++v) o[dt][v] = 0.f;
     float m_run = -INFINITY, l_run = 0.f;
@@ -110,7 +115,7 @@ __global__ __launch_bounds__(WPB * 64) void attention_f32_kernel(
 #pragma unroll
             for (int v = 0; v < 16; ++v) st[v] = 0.f;
 #pragma unroll
-            for (int g = 0; g < 8; ++g) {
+            for (int g = 0; g < NG; ++g) {
                 const f32x4 kf = *reinterpret_cast<const f32x4*>(Kb + g * 8);
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
@@ -138,7 +143,7 @@ __global__ __launch_bounds__(WPB * 64) void attention_f32_kernel(
             l_run = l_run * alpha + psum;
             m_run = m_new;
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
+            for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) o[dt][v] *= alpha;
             // O^T += V^T P^T : k pair for register v is (key_v, key_v + 4), key_v = (v&3)+8(v>>2)
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(WPB * 64) void attention_f32_kernel(
                 const int key = (v & 3) + 8 * (v >> 2);
                 const float* vp = Vb + (key + 4 * kh) * VS_STRIDE;
 #pragma unroll
-                for (int dt = 0; dt < 2; ++dt)
+                for (int dt = 0; dt < ND; ++dt)
                     o[dt] = __builtin_amdgcn_mfma_f32_32x32x2f32(vp[dt * 32], st[v], o[dt], 0, 0, 0);
             }
         }
@@ -160,9 +165,9 @@ __global__ __launch_bounds__(WPB * 64) void attention_f32_kernel(
         const float l_tot = l_run + __shfl_xor(l_run, 32);
         if (q0 + r < T) {
             const float inv = 1.0f / l_tot;
-            const size_t off = ((size_t)b * T + q0 + r) * D + (size_t)h * kHeadDim + 4 * kh;
+            const size_t off = ((size_t)b * T + q0 + r) * D + (size_t)h * DH + 4 * kh;
 #pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
+            for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     f32x4 val;
@@ -181,8 +186,8 @@ __global__ __launch_bounds__(WPB * 64) void attention_f32_kernel(
                             hi[e] = a;
                             lo[e] = b2;
                         }
-                        // K-interleaved GEMM operand (common.h ki_off): column h*64 + dt*32 + 8g + 4kh of a row of D
-                        unsigned short* dst = ctx16 + ((size_t)b * T + q0 + r) * (size_t)(2 * D) + (size_t)(2 * h + dt) * 64 + 8 * g + 4 * kh;
+                        // K-interleaved GEMM operand (common.h ki_off): column h*DH + dt*32 + 8g + 4kh of a row of D
+                        unsigned short* dst = ctx16 + ((size_t)b * T + q0 + r) * (size_t)(2 * D) + (size_t)(ND * h + dt) * 64 + 8 * g + 4 * kh;
                         *reinterpret_cast<h4*>(dst) = hi;
                         *reinterpret_cast<h4*>(dst + 32) = lo;
                     } else {                              // bf16
@@ -205,30 +210,51 @@ __global__ __launch_bounds__(WPB * 64) void attention_f32_kernel(
     }
 }
 
-template <int OUT>
-static void launch_att_mode(int wpb, dim3 grid, const float* qkv, const int32_t* kv_len, int T, int H,
-                            float* ctx, unsigned short* ctx16, size_t plane, hipStream_t s) {
+template <int WPB, int OUT, int DH>
+static int launch_att_one(dim3 grid, const float* qkv, const int32_t* kv_len, int T, int H, float* ctx, unsigned short* ctx16,
+                          size_t plane, hipStream_t s) {
+    constexpr size_t lds_bytes = (size_t)(2 * KT * (DH + 4) + 2 * KT * DH) * sizeof(float);      // 33 KB at DH 64, 66.6 KB at DH 128
+    auto kfn = attention_f32_kernel<WPB, OUT, DH>;
+    if (lds_bytes > 65536) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PGMI_EHIP; }
+    }
+    hipLaunchKernelGGL(kfn, grid, dim3(WPB * 64), lds_bytes, s, qkv, kv_len, T, H, ctx, ctx16, plane);
+    return PGMI_OK;
+}
+
+template <int OUT, int DH>
+static int launch_att_mode(int wpb, dim3 grid, const float* qkv, const int32_t* kv_len, int T, int H,
+                           float* ctx, unsigned short* ctx16, size_t plane, hipStream_t s) {
     switch (wpb) {
-        case 1: hipLaunchKernelGGL((attention_f32_kernel<1, OUT>), grid, dim3(64), 0, s, qkv, kv_len, T, H, ctx, ctx16, plane); break;
-        case 2: hipLaunchKernelGGL((attention_f32_kernel<2, OUT>), grid, dim3(128), 0, s, qkv, kv_len, T, H, ctx, ctx16, plane); break;
-        case 3: hipLaunchKernelGGL((attention_f32_kernel<3, OUT>), grid, dim3(192), 0, s, qkv, kv_len, T, H, ctx, ctx16, plane); break;
-        default: hipLaunchKernelGGL((attention_f32_kernel<4, OUT>), grid, dim3(256), 0, s, qkv, kv_len, T, H, ctx, ctx16, plane); break;
+        case 1: return launch_att_one<1, OUT, DH>(grid, qkv, kv_len, T, H, ctx, ctx16, plane, s);
+        case 2: return launch_att_one<2, OUT, DH>(grid, qkv, kv_len, T, H, ctx, ctx16, plane, s);
+        case 3: return launch_att_one<3, OUT, DH>(grid, qkv, kv_len, T, H, ctx, ctx16, plane, s);
+        default: return launch_att_one<4, OUT, DH>(grid, qkv, kv_len, T, H, ctx, ctx16, plane, s);
     }
 }
 
 int launch_attention_f32(const float* qkv, const int32_t* kv_len, int B, int T, int H, float* ctx,
-                         unsigned short* ctx16, size_t plane, int out_mode, hipStream_t s) {
-    if (B <= 0 || T <= 0 || H <= 0) {
-        set_error("attention_f32: bad shape B=%d T=%d H=%d", B, T, H);
+                         unsigned short* ctx16, size_t plane, int out_mode, hipStream_t s, int head_dim) {
+    if (B <= 0 || T <= 0 || H <= 0 || (head_dim != 64 && head_dim != 128) || out_mode < 0 || out_mode > 2) {
+        set_error("attention_f32: bad arguments B=%d T=%d H=%d head_dim=%d out=%d", B, T, H, head_dim, out_mode);
         return PGMI_EINVAL;
     }
     const int n32 = (T + 31) / 32;
     const int nblk = (n32 + 3) / 4;
     const int wpb = (n32 + nblk - 1) / nblk;
     const dim3 grid(nblk, H, B);
-    if (out_mode == 0) launch_att_mode<0>(wpb, grid, qkv, kv_len, T, H, ctx, ctx16, plane, s);
-    else if (out_mode == 1) launch_att_mode<1>(wpb, grid, qkv, kv_len, T, H, ctx, ctx16, plane, s);
-    else launch_att_mode<2>(wpb, grid, qkv, kv_len, T, H, ctx, ctx16, plane, s);
+    int rc;
+    if (head_dim == 128) {
+        if (out_mode == 0) rc = launch_att_mode<0, 128>(wpb, grid, qkv, kv_len, T, H, ctx, ctx16, plane, s);
+        else if (out_mode == 1) rc = launch_att_mode<1, 128>(wpb, grid, qkv, kv_len, T, H, ctx, ctx16, plane, s);
+        else rc = launch_att_mode<2, 128>(wpb, grid, qkv, kv_len, T, H, ctx, ctx16, plane, s);
+    } else {
+        if (out_mode == 0) rc = launch_att_mode<0, 64>(wpb, grid, qkv, kv_len, T, H, ctx, ctx16, plane, s);
+        else if (out_mode == 1) rc = launch_att_mode<1, 64>(wpb, grid, qkv, kv_len, T, H, ctx, ctx16, plane, s);
+        else rc = launch_att_mode<2, 64>(wpb, grid, qkv, kv_len, T, H, ctx, ctx16, plane, s);
+    }
+    if (rc) return rc;
     PGMI_HIP(hipGetLastError());
     return PGMI_OK;
 }

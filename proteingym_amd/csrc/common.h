@@ -88,8 +88,9 @@ void launch_seq_loglik(const float* lp, const int32_t* tokens, const int32_t* le
 void launch_score_mutants(const float* table, int V, const int32_t* sub_pos, const int32_t* sub_wt,
                           const int32_t* sub_mt, const int64_t* mut_off, int64_t n_mut,
                           double* scores, hipStream_t s);
+// H = 64-lane slot groups per token; rot_halves = table rows per token (2 for head_dim 128: the slot group's parity picks the row)
 void launch_rotary(float* qkv, const float* cos_t, const float* sin_t, int rows, int T, int H,
-                   hipStream_t s);
+                   hipStream_t s, int rot_halves = 1);
 // pseudo-perplexity (compute_fitness.py:258-279): rows enumerated on the device from a resident sequence library
 void launch_make_pppl_rows(const uint8_t* tok8, const int64_t* seq_off, const int32_t* sid, const int64_t* rp, int J,
                            int64_t g0, int bc, int T, int32_t* tokens, int32_t* row_idx, int32_t* target, hipStream_t s);
@@ -140,7 +141,7 @@ void launch_split16(const float* x, int64_t n, float scale, int mode, int K, uns
 // qkv [B*T, 3*H*64] (q pre-scaled by 1/8); kv_len[b] (nullable) = valid keys.  Output: ctx fp32
 // [B*T, H*64] (out_mode 0), or fp16 hi/lo planes (1) / one bf16 plane (2) in ctx16.
 int launch_attention_f32(const float* qkv, const int32_t* kv_len, int B, int T, int H, float* ctx,
-                         unsigned short* ctx16, size_t plane, int out_mode, hipStream_t s);
+                         unsigned short* ctx16, size_t plane, int out_mode, hipStream_t s, int head_dim = 64);   // 128: heads of two adjacent slot groups
 
 // ---- attention_f16.hip -------------------------------------------------------------------
 // Same interface as launch_attention_f32, split-fp16 (f16x3) arithmetic on the 16-bit MFMA pipe.

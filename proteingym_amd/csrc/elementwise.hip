@@ -251,26 +251,27 @@ void launch_layernorm16(const float* x, const float* w, const float* b, int rows
 // qkv [rows, 3*H*64]; tables cos/sin [T, 64] (emb = cat(freqs,freqs)) built on the host in f32
 // exactly as the reference does.  One thread handles the pair (d, d+32) of one head.
 __global__ void rotary_kernel(float* __restrict__ qkv, const float* __restrict__ cos_t,
-                              const float* __restrict__ sin_t, int64_t n, int T, int H) {
+                              const float* __restrict__ sin_t, int64_t n, int T, int H, int rh) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;                      // n = rows * 2 * H * 32
     const int d = (int)(i & 31);
     const int64_t j = i >> 5;
-    const int h = (int)(j % H);
+    const int h = (int)(j % H);              // 64-lane slot group: a head, or half a head of 128 dims
     const int64_t k2 = j / H;
     const int which = (int)(k2 & 1);         // 0 = q, 1 = k
     const int64_t row = k2 >> 1;
     const int t = (int)(row % T);
     float* p = qkv + row * (size_t)(3 * H * 64) + (size_t)which * H * 64 + h * 64 + d;
     const float x1 = p[0], x2 = p[32];
-    const float c1 = cos_t[t * 64 + d], s1 = sin_t[t * 64 + d];
-    const float c2 = cos_t[t * 64 + d + 32], s2 = sin_t[t * 64 + d + 32];
+    const int tr = (t * rh + (h % rh)) * 64;  // table row: one per token, or per (token, slot-group parity) for head_dim 128 (api.hip ensure_rotary)
+    const float c1 = cos_t[tr + d], s1 = sin_t[tr + d];
+    const float c2 = cos_t[tr + d + 32], s2 = sin_t[tr + d + 32];
     p[0] = x1 * c1 + (-x2) * s1;             // x*cos + rotate_half(x)*sin, first half: -x2
     p[32] = x2 * c2 + x1 * s2;               // second half: +x1
 }
-void launch_rotary(float* qkv, const float* cos_t, const float* sin_t, int rows, int T, int H, hipStream_t s) {
+void launch_rotary(float* qkv, const float* cos_t, const float* sin_t, int rows, int T, int H, hipStream_t s, int rot_halves) {
     const int64_t n = (int64_t)rows * 2 * H * 32;
-    hipLaunchKernelGGL(rotary_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, qkv, cos_t, sin_t, n, T, H);
+    hipLaunchKernelGGL(rotary_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, qkv, cos_t, sin_t, n, T, H, rot_halves);
 }
 
 // ---- row gather / scatter -------------------------------------------------------------------

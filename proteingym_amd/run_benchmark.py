@@ -35,6 +35,13 @@ def create_parser():
     p.add_argument("--dms_indices", type=int, nargs="*", default=None, help="default: every row of the mapping")
     p.add_argument("--mutation-col", type=str, default="mutant")
     p.add_argument("--precision", type=str, default="f16x3", choices=sorted(pesm._lib.PRECISIONS))
+    p.add_argument("--scoring-strategy", type=str, default="masked-marginals", choices=["masked-marginals", "wt-marginals"],
+                   help="wt-marginals: one unmasked forward per assay (blended 1024-token windows with --scoring-window overlapping), the "
+                        "ESM-1b launchers' strategy (scripts/scoring_DMS_zero_shot/scoring_ESM1b_substitutions.sh, "
+                        "scripts/scoring_clinical_zero_shot/scoring_ESM1b_substitutions.sh: 2 525 genes) with the checkpoint resident "
+                        "instead of re-read per gene")
+    p.add_argument("--scoring-window", type=str, default="optimal", choices=["optimal", "overlapping"])
+    p.add_argument("--offset-idx", type=int, default=1, help="first residue number when the mapping has no start_idx column")
     p.add_argument("--all-positions", action="store_true")
     p.add_argument("--overwrite-prior-scores", action="store_true")
     p.add_argument("--backend", type=str, default=None, help="torch.distributed backend (default nccl)")
@@ -59,15 +66,37 @@ GPU_FLOPS_PER_S = 3.0e14          # planning constants only (ratios matter): sus
 HOST_S_PER_ROW = 4.0e-6           # ... and parse + CSV seconds per mutant row on the rank that owns the assay
 
 
-def assay_seconds(seq_len: int, n_rows: int, n_checkpoints: int) -> float:
-    """Planned wall time of one assay on one rank: masked-marginals FLOPs for every checkpoint + the host work that
+WT_MARGINALS_FIXED_S = 3.0e-3     # launch-bound floor of one unmasked forward + table download
+
+
+def wt_marginals_windows(n_tok: int, scoring_window: str) -> int:
+    """Forwards wt-marginals runs for a protein of n_tok tokens (compute_fitness.py:433-475): one, or with 'overlapping'
+    above 1024 tokens the left/right window pairs stepped by 511 (+ a central one when the last pair barely overlaps)."""
+    if n_tok <= 1024 or scoring_window != "overlapping":
+        return 1
+    n, el, sr = 2, 1023, n_tok - 1024
+    while el <= sr:
+        el += 511
+        sr -= 511
+        n += 2
+    return n + (1 if el - sr + 1 < 511 else 0)
+
+
+def assay_seconds(seq_len: int, n_rows: int, n_checkpoints: int, strategy: str = "masked-marginals",
+                  scoring_window: str = "optimal") -> float:
+    """Planned wall time of one assay on one rank: the strategy's FLOPs for every checkpoint + the host work that
     scales with the number of mutants (parsing, CSV): the 537k-row assay costs 2 s of host time against 0.3 s of GPU."""
+    if strategy == "wt-marginals":
+        n_tok = seq_len + 2
+        gpu = wt_marginals_windows(n_tok, scoring_window) * pdist.forward_flops(min(n_tok, 1024)) / GPU_FLOPS_PER_S + WT_MARGINALS_FIXED_S
+        return gpu * n_checkpoints + n_rows * HOST_S_PER_ROW
     return pdist.assay_cost(seq_len) * n_checkpoints / GPU_FLOPS_PER_S + n_rows * HOST_S_PER_ROW
 
 
-def plan_assays(mapping, todo, world, n_checkpoints):
-    rows = mapping["DMS_total_number_mutants"] if "DMS_total_number_mutants" in mapping.columns else None
-    costs = [assay_seconds(len(str(mapping.iloc[i]["target_seq"])), int(rows.iloc[i]) if rows is not None else 0, n_checkpoints) for i in todo]
+def plan_assays(mapping, todo, world, n_checkpoints, strategy: str = "masked-marginals", scoring_window: str = "optimal"):
+    rows = mapping["DMS_total_number_mutants"] if "DMS_total_number_mutants" in mapping.columns else None   # (the clinical table has none)
+    costs = [assay_seconds(len(str(mapping.iloc[i]["target_seq"])), int(rows.iloc[i]) if rows is not None and rows.iloc[i] == rows.iloc[i] else 0,
+                           n_checkpoints, strategy, scoring_window) for i in todo]
     return pdist.lpt_partition(costs, world)
 
 
@@ -92,6 +121,36 @@ class _DeviceScorer:
         assay.close()
         self.create_s += t1 - t0
         self.run_s += t2 - t1
+        return out
+
+    def close(self):
+        self.model.close()
+
+
+class _DeviceWtMarginals:
+    """wt-marginals with a resident checkpoint: score(seq, mutants, offset) = one unmasked forward (or the blended
+    overlapping windows) + label_row for every mutant (compute_fitness.py:433-485).  The table comes from the same
+    function the single-assay CLI calls; the look-ups are ``esm.score_from_table`` (f32 difference, double
+    accumulation in mutation order: the arithmetic of the reference's python loop)."""
+
+    def __init__(self, location, device, precision, scoring_window):
+        self.model, self.alphabet = pesm.load_model_and_alphabet(location, device=device, precision=precision)
+        self.scoring_window = scoring_window
+        self.create_s = self.run_s = 0.0
+        self.log = []
+
+    def score(self, seq, mutants, offset):
+        from .compute_fitness import wt_marginals_table
+        t0 = time.time()
+        table = wt_marginals_table(self.model, self.alphabet, seq, self.scoring_window)
+        t1 = time.time()
+        out = pesm.score_from_table(table[0], mutants, seq, int(offset))
+        t2 = time.time()
+        n_tok = len(seq) + 2
+        self.log.append(dict(seq_len=len(seq), rows=len(mutants), positions_run=wt_marginals_windows(n_tok, self.scoring_window),
+                             T=min(n_tok, 1024), create_s=t2 - t1, run_s=t1 - t0))
+        self.run_s += t1 - t0
+        self.create_s += t2 - t1
         return out
 
     def close(self):
@@ -140,9 +199,14 @@ def main(args, make_model=None):
         box = [todo]
         tdist.broadcast_object_list(box, src=0)
         todo = box[0]
+    wt_marginals = args.scoring_strategy == "wt-marginals"
     if args.shard == "positions":
+        if wt_marginals:
+            raise SystemExit("run_benchmark: --shard positions cuts MASKED positions; wt-marginals has one forward per assay")
         return main_position_shards(args, mapping, todo, cols, ens_cols, rank, local_rank, world, make_model=make_model)
-    assignment = plan_assays(mapping, todo, world, len(args.model_location))
+    if not wt_marginals and args.scoring_window == "overlapping":
+        raise SystemExit("Overlapping not yet implemented for masked-marginals")        # compute_fitness.py:487-488
+    assignment = plan_assays(mapping, todo, world, len(args.model_location), args.scoring_strategy, args.scoring_window)
     mine = [todo[k] for k in assignment[rank]]
 
     t0 = time.time()
@@ -154,7 +218,7 @@ def main(args, make_model=None):
         row = mapping.iloc[i].replace(np.nan, "")
         mutant_col = row["DMS_mutant_column"] if "DMS_mutant_column" in mapping.columns else args.mutation_col
         return (pd.read_csv(os.path.join(args.dms_input, row["DMS_filename"])), mutant_col, str(row["target_seq"]).upper(),
-                row["start_idx"] if "start_idx" in mapping.columns and row["start_idx"] != "" else 1)
+                row["start_idx"] if "start_idx" in mapping.columns and row["start_idx"] != "" else args.offset_idx)
 
     # the DMS files are read by a background thread in scoring order, ahead of the GPU (the C parser and the scoring calls
     # both drop the GIL); every frame is kept: the checkpoint columns are added to it at the end
@@ -179,7 +243,9 @@ def main(args, make_model=None):
     assay_log = []
     for ci, loc in enumerate(args.model_location):
         t = time.time()
-        model = make_model(loc) if make_model is not None else _DeviceScorer(loc, local_rank, args.precision, args.all_positions)
+        model = make_model(loc) if make_model is not None else \
+            (_DeviceWtMarginals(loc, local_rank, args.precision, args.scoring_window) if wt_marginals
+             else _DeviceScorer(loc, local_rank, args.precision, args.all_positions))
         clock["checkpoint_load_s"] = clock.get("checkpoint_load_s", 0.0) + time.time() - t
         last = ci == len(args.model_location) - 1
         for i in order:

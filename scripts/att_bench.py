@@ -1,0 +1,61 @@
+"""Attention-kernel A/B inside one process (PGMI_ATT_TUNE / PGMI_ATT_DEFER are read per launch): ms per launch and algorithmic
+TFLOP/s of the attention class at several (sequences, tokens) shapes of the ESM-1v 650M layer, rounds interleaved.
+
+    python scripts/att_bench.py [--rounds 5] [--configs 0:0:0,0:4:0,1:0:0,1:4:0,2:0:0,0:4:3]        (config = TUNE:DEFER:WPB, WPB 0 = default)
+"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from proteingym_amd import esm as pesm, synthetic  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--layers", type=int, default=4)
+    ap.add_argument("--configs", default="0:0:0,2:0:0,0:4:0,1:0:0,1:4:0,0:4:3,1:4:3")
+    ap.add_argument("--shapes", default="286x286,90x1100,600x120,1200x60")      # positions x residues
+    a = ap.parse_args()
+    cfg = dict(synthetic.ESM1V_650M, layers=a.layers)
+    model = pesm.EsmModel(cfg, synthetic.random_weights(cfg, seed=1), device=0)
+    confs = [tuple(c.split(":")) for c in a.configs.split(",")]
+    out = {}
+    for shp in a.shapes.split(","):
+        P, L = (int(v) for v in shp.split("x"))
+        rng = np.random.default_rng(L)
+        seq = synthetic.random_sequence(rng, L)
+        pos = np.sort(rng.choice(L, size=min(P, L), replace=False))
+        muts = [f"{seq[p]}{p + 1}{'A' if seq[p] != 'A' else 'C'}" for p in pos]
+        if P > L:                                   # more sequences than residues: several assays' worth is emulated by --all-positions-like repeats
+            muts = muts * (P // L + 1)
+        assay = pesm.Assay(model, seq, muts)
+        assay.run_device_only()
+        res = {c: [] for c in confs}
+        for _ in range(a.rounds):
+            for c in confs:
+                os.environ["PGMI_ATT_TUNE"], os.environ["PGMI_ATT_DEFER"], os.environ["PGMI_ATT_WPB"] = c
+                model.profile_reset()
+                model.profile_enable(True)
+                assay.run_device_only()
+                model.profile_enable(False)
+                pr = model.profile()["attention"]
+                res[c].append((pr["ms"] / pr["launches"], pr["flops"] / (pr["ms"] * 1e-3) / 1e12))
+        ref = None
+        for c in confs:
+            ms = float(np.median([r[0] for r in res[c]]))
+            tf = float(np.median([r[1] for r in res[c]]))
+            ref = ref or ms
+            out[f"{shp} tune={c[0]} defer={c[1]} wpb={c[2]}"] = {"ms_per_launch": round(ms, 4), "tflops": round(tf, 1), "vs_first": round(ref / ms, 3)}
+            print(f"{shp:>10s} T={assay.T:4d} seqs={len(assay.positions):4d}  tune={c[0]} defer={c[1]} wpb={c[2]}: {ms:.4f} ms/launch  {tf:6.1f} TFLOP/s  x{ref / ms:.3f}", flush=True)
+        assay.close()
+    print(json.dumps(out))
+    model.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -112,3 +112,34 @@ def test_runner_position_shards_equal_assay_shards(lib, golden, golden_dir, tmp_
         for c in ("esm1v_toy_1", "esm1v_toy_2", "Ensemble_ESM1v"):
             assert np.array_equal(a[c].to_numpy(), p[c].to_numpy())
     assert np.abs(p["esm1v_toy_1"].to_numpy() - golden["cli_long/esm1v_toy_1"]).max() < TOL
+
+
+def test_runner_wt_marginals_on_a_clinical_shaped_mapping_equals_the_cli(lib, golden, golden_dir, tmp_path):
+    """The fifth caller of the ESM scorer (scripts/scoring_clinical_zero_shot/scoring_ESM1b_substitutions.sh:29-37): wt-marginals
+    with overlapping windows over a mapping with the CLINICAL column set (file_length, no DMS_total_number_mutants, no
+    start_idx / DMS_mutant_column).  run_benchmark keeps the checkpoint resident across genes; its CSVs must hold the same
+    numbers, bit for bit, and the same columns as one single-assay CLI run per --dms_index (a gene > 1022 residues included)."""
+    from proteingym_amd import run_benchmark as rb
+    genes = [("NP_TOY_A.1", "TOY_DMS.csv", str(golden["seq"])), ("NP_TOY_LONG.2", "TOY_LONG_DMS.csv", str(golden["seq_long"])),
+             ("NP_TOY_B.1", "TOY_DMS.csv", str(golden["seq"]))]
+    mapping = pd.DataFrame({"DMS_id": [g[0] for g in genes], "target_seq": [g[2] for g in genes], "file_length": [len(g[2]) for g in genes],
+                            "DMS_filename": [g[1] for g in genes], "EVE_model_path": ["x"] * 3, "MSA_filename": ["x.a2m"] * 3,
+                            "alignment_source": ["Invitae"] * 3, "weight_file_name": ["x.npy"] * 3, "MSA_start": [1] * 3,
+                            "MSA_end": [len(g[2]) for g in genes], "MSA_len": [len(g[2]) for g in genes]})
+    mapping.to_csv(tmp_path / "clinical.csv", index=False)
+    ck = os.path.join(golden_dir, "esm1v_toy_1.pt")
+    rb.main(rb.create_parser().parse_args(["--model-location", ck, "--model_type", "ESM1b", "--dms_mapping", str(tmp_path / "clinical.csv"),
+                                           "--dms-input", golden_dir, "--dms-output", str(tmp_path / "runner"),
+                                           "--scoring-strategy", "wt-marginals", "--scoring-window", "overlapping"]))
+    for i, (gene, _, _) in enumerate(genes):
+        _run_cli(["--model-location", ck, "--model_type", "ESM1b", "--dms-input", golden_dir, "--dms-output", str(tmp_path / "cli"),
+                  "--scoring-strategy", "wt-marginals", "--scoring-window", "overlapping", "--dms_mapping", str(tmp_path / "clinical.csv"),
+                  "--dms_index", str(i)])
+        a = pd.read_csv(tmp_path / "cli" / f"{gene}.csv", float_precision="round_trip")
+        b = pd.read_csv(tmp_path / "runner" / f"{gene}.csv", float_precision="round_trip")
+        assert list(a.columns) == list(b.columns) and "Ensemble_ESM1v" not in b.columns
+        assert np.array_equal(a["esm1v_toy_1"].to_numpy(), b["esm1v_toy_1"].to_numpy())
+    assert np.abs(b["esm1v_toy_1"].to_numpy() - golden["cli/esm1v_toy_1"]).max() > 1e-3        # a different strategy, not a relabelled masked-marginals column
+    long = pd.read_csv(tmp_path / "runner" / "NP_TOY_LONG.2.csv")
+    assert np.abs(long["esm1v_toy_1"].to_numpy() - golden["cli_wt_long/esm1v_toy_1"]).max() < TOL   # = the reference CLI's overlapping-window column
+    assert [rb.wt_marginals_windows(n, "overlapping") for n in (500, 1024, 1025, 1535, 2047, 3425)] == [1, 1, 2, 2, 4, 6]

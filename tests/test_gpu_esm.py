@@ -109,13 +109,29 @@ def test_determinism_and_chunking(lib, golden, golden_dir):
     assert np.array_equal(s1, s2)
 
 
+@pytest.mark.parametrize("name", ["esm1v_toy_1", "esm2_toy", "esm2_toy_h128"])
+def test_gemm_row_chunks_inside_a_model_bit_identical(lib, golden, golden_dir, name, monkeypatch):
+    """Every GEMM of the forward cut into row chunks (the path activations beyond 4 GiB take: gemm_f16.hip launch_gemm16x;
+    the fused QKV projection chunks at sequence boundaries and offsets its V^T scatter): same table, same scores."""
+    import pandas as pd
+    seq = str(golden["seq"])
+    muts = list(pd.read_csv(os.path.join(golden_dir, "TOY_DMS.csv"))["mutant"])
+    path = os.path.join(golden_dir, name + ".pt")
+    m = pesm.load_model_and_alphabet(path)[0]
+    a = pesm.Assay(m, seq, muts)
+    s0, t0 = a.run(want_table=True)
+    monkeypatch.setenv("PGMI_GEMM_MAX_ROWS", "300")            # a few sequences per chunk (T = len(seq) + 2 tokens each)
+    s1, t1 = a.run(want_table=True)
+    assert np.array_equal(s0, s1) and np.array_equal(t0, t1, equal_nan=True)
+    a.close()
+    m.close()
+
+
 @pytest.mark.parametrize("precision", ["f16x3", "fp32", "bf16"])
 @pytest.mark.parametrize("name", ["esm1v_toy_1", "esm1b_toy_lnb", "esm2_toy", "esm2_toy_h128"])
 def test_last_layer_kept_rows_bit_identical(lib, golden, golden_dir, name, precision, monkeypatch):
     """Masked-marginals and pseudo-ppl read ONE output row per forward (compute_fitness.py:503, :274-276); the last layer's
     row-local stages run on those rows only.  Same bits as the full evaluation (PGMI_KEEP_ROWS=0)."""
-    if name == "esm2_toy_h128" and precision != "f16x3":
-        pytest.skip("head_dim 128 is f16x3-only")
     seq = str(golden["seq"])
     _, _, toks = pesm.Alphabet().get_batch_converter()([("p", seq)])
     n = toks.shape[1]
@@ -213,14 +229,16 @@ def test_small_head_dims_vs_reference(lib, golden_dir, name, precision):
 
 
 # ---- ESM2 with head_dim 128 (ESM2-15B: 48 x 5120, 40 heads), run as two 64-lane slot groups per head ----
-def test_head_dim_128_vs_reference(lib, golden_dir):
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
+def test_head_dim_128_vs_reference(lib, golden_dir, precision):
     """Reference-generated goldens (tests/golden/make_golden_h128.py: unmodified reference model and CLI on a 2-layer
-    D=256, 2-head checkpoint): unmasked table, masked-marginals table, a padded batch and the CLI's score column."""
+    D=256, 2-head checkpoint): unmasked table, masked-marginals table, a padded batch and the CLI's score column -- in
+    both parity-gated modes (fp32: the second mode an ESM2-15B user is sent to by PGMI_EOVERFLOW; attention_f32.hip DH = 128)."""
     import pandas as pd
     g = np.load(os.path.join(golden_dir, "golden_esm_h128.npz"))
     seq = str(np.load(os.path.join(golden_dir, "golden_esm.npz"))["seq"])
-    m, _ = pesm.load_model_and_alphabet(os.path.join(golden_dir, "esm2_toy_h128.pt"))
-    assert m.cfg["embed_dim"] // m.cfg["heads"] == 128 and m.precision == "f16x3"
+    m, _ = pesm.load_model_and_alphabet(os.path.join(golden_dir, "esm2_toy_h128.pt"), precision=precision)
+    assert m.cfg["embed_dim"] // m.cfg["heads"] == 128 and m.precision == precision
     _, _, toks = pesm.Alphabet().get_batch_converter()([("p", seq)])
     assert np.abs(m(toks)["logits"][0] - g["wt_logprobs"]).max() < TOL
     n = toks.shape[1]
@@ -234,8 +252,6 @@ def test_head_dim_128_vs_reference(lib, golden_dir):
     assert np.abs(a.run() - g["cli"]).max() < TOL
     a.close()
     m.close()
-    with pytest.raises(pesm.PgmiError, match="f16x3 only"):
-        pesm.load_model_and_alphabet(os.path.join(golden_dir, "esm2_toy_h128.pt"), precision="fp32")
 
 
 def test_esm2_15b_width_vs_oracle(lib):

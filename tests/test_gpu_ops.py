@@ -169,3 +169,44 @@ def test_gemm_bf16(lib, M, N, K, epi, res):
     if res:
         ref = ref + torch.from_numpy(R).double()
     assert np.abs(Cc - ref.numpy()).max() < 1e-4       # exact bf16 inputs, fp32 accumulate
+
+
+def test_gemm16x_row_chunks_are_bit_identical(lib, monkeypatch):
+    """The f16x3 GEMM addresses an operand with 32-bit byte offsets: launches above rows * K * 4 = 4 GiB are cut into row
+    chunks (gemm_f16.hip launch_gemm16x).  Forced here at a small shape (PGMI_GEMM_MAX_ROWS): same bits as one launch,
+    fp32 output with residual and the split-plane path behind GELU alike."""
+    rng = np.random.default_rng(3)
+    M, N, K = 2100, 640, 256
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    R = rng.standard_normal((M, N)).astype(np.float32)
+
+    def run(epi, res):
+        Cc = np.empty((M, N), np.float32)
+        _lib.check(lib.pgmi_op_gemm(0, _lib.PREC_F16X3, _p(A), _p(W), _p(bias), _p(R) if res else None, M, N, K, epi, _p(Cc)))
+        return Cc
+    whole = [run(0, True), run(1, False)]
+    monkeypatch.setenv("PGMI_GEMM_MAX_ROWS", "700")                      # -> chunks of 512 rows (whole 256-row tiles) + a tail
+    parts = [run(0, True), run(1, False)]
+    for a, b in zip(whole, parts):
+        assert np.array_equal(a, b)
+
+
+def test_gemm16x_operand_beyond_4_gib(lib):
+    """ESM2-15B's FC2 shape class: K = 20480 allows 52 428 rows per launch; 52 480 rows = a 4.3 GB split operand.  Rows on
+    both sides of the chunk boundary against float64 (advisor finding r2: this used to be refused with EINVAL)."""
+    M, N, K = 52480, 64, 20480
+    rng = np.random.default_rng(5)
+    block = rng.standard_normal((256, K)).astype(np.float32)
+    A = np.empty((M, K), np.float32)
+    for r0 in range(0, M, 256):                                          # distinct rows without 1e9 random draws
+        A[r0:r0 + 256] = block * np.float32(1.0 + (r0 // 256) * 1e-3)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    Cc = np.empty((M, N), np.float32)
+    _lib.check(lib.pgmi_op_gemm(0, _lib.PREC_F16X3, _p(A), _p(W), _p(bias), None, M, N, K, 0, _p(Cc)))
+    rows = [0, 255, 30000, 52223, 52224, 52428, 52429, M - 1]
+    ref = A[rows].astype(np.float64) @ W.astype(np.float64).T + bias.astype(np.float64)
+    err = np.abs(Cc[rows] - ref).max()
+    assert err < 2e-5, err

@@ -182,7 +182,7 @@ def test_tranception_l_full_context_vs_oracle(lib):
     muts = []
     for p in (3, 511, 700, 1096):
         muts.append(f"{wt[p]}{p + 1}{'A' if wt[p] != 'A' else 'C'}")
-    df = pd.DataFrame({"mutant": muts})
+    df = pd.DataFrame({"mutant": muts, "mutated_sequence": [ptr.get_mutated_sequence(wt, m) for m in muts]})   # as the real DMS files
     with torch.no_grad():
         want = to.score_mutants(ocfg, W, df, wt)
     have = model.score_mutants(DMS_data=df, target_seq=wt)
