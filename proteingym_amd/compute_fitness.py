@@ -10,8 +10,8 @@ here, and ``proteingym/merge.py`` + ``performance_DMS_benchmarks.py`` consume th
 Reference: /root/reference/proteingym/baselines/esm/compute_fitness.py
   create_parser :100-238   main :282-543   label_row :240-250   compute_pppl :258-279
 Additive flags (not in the reference): --device, --precision, --all-positions, --shard-positions.
-The MSA-Transformer branch (:358-425) is score_msa_transformer below (masked-marginals; its pseudo-ppl variant is
-not built and raises NotImplementedError -- listed in INTEGRATION.md).
+The MSA-Transformer branch (:358-425) is score_msa_transformer below (masked-marginals, and the pseudo-ppl variant exactly as
+the reference behaves -- compute_pppl_msa).
 """
 from __future__ import annotations
 
@@ -105,6 +105,25 @@ def compute_pppl_batch(sequences, model, alphabet):
         return library.score()
     finally:
         library.close()
+
+
+def compute_pppl_msa(sequence, model, alphabet, msa_rows):
+    """compute_fitness.py:258-279 with mode == "MSA_Transformer", AS THE REFERENCE BEHAVES: the mutated sequence is put in front
+    of the sampled alignment ([1, R+1, L+1] tokens), and for i in range(1, len(sequence) - 1) the statement
+    ``batch_tokens_masked[0, i] = mask`` of :272 indexes the ROW axis of that 3-D tensor -- it masks alignment row i entirely
+    (not token i of the first row) -- before log p(sequence[i]) is read at row 0, column i (:278).  Alignments with fewer than
+    len(sequence) - 1 rows end in the reference's IndexError.  Reproduced as is (no launcher uses this branch; one full
+    alignment-wide forward per residue and mutant, as in the reference)."""
+    tokens = alphabet.get_batch_converter()([[("protein1", sequence)] + list(msa_rows)])[2][0]        # [R+1, L+1]
+    n_rows = tokens.shape[0]
+    total = []
+    for i in range(1, len(sequence) - 1):
+        if i >= n_rows:
+            raise IndexError(f"index {i} is out of bounds for dimension 1 with size {n_rows}")
+        masked = tokens.copy()
+        masked[i, :] = alphabet.mask_idx
+        total.append(float(model.token_logprobs(masked)[0, i, alphabet.get_idx(sequence[i])]))
+    return sum(total)
 
 
 def wt_marginals_table(model, alphabet, sequence, scoring_window):
@@ -262,8 +281,9 @@ def score_msa_transformer(args, df, mutant_col, msa_start_index, MSA_weight_file
     from . import msa_transformer as pmsa
     seeds = list(args.seeds) if isinstance(args.seeds, (list, tuple)) else [args.seeds]
     assert args.scoring_strategy in ["masked-marginals", "pseudo-ppl"], "Zero-shot scoring strategy not supported with MSA Transformer"
-    if args.scoring_strategy == "pseudo-ppl":
-        raise NotImplementedError("pseudo-ppl with the MSA Transformer is not built (the reference launcher uses masked-marginals)")
+    pppl = args.scoring_strategy == "pseudo-ppl"
+    if pppl and getattr(args, "shard_positions", False):
+        raise NotImplementedError("--shard-positions cuts the masked-marginals table; pseudo-ppl with the MSA Transformer runs unsharded")
     out_csv = args.dms_output
     shard_rank, shard_world = 0, 1
     if getattr(args, "shard_positions", False):
@@ -275,7 +295,7 @@ def score_msa_transformer(args, df, mutant_col, msa_start_index, MSA_weight_file
     cells = sorted({1 + int(one[1:-1]) - args.offset_idx for m in mutants for one in m.split(":")})   # +1: <cls>
     pad32 = lambda n: (n + 31) // 32 * 32
     for location in args.model_location:
-        max_rows = pad32(min(args.msa_samples, 1024)) * pad32(min(len(args.sequence) + 1, 1024))
+        max_rows = pad32(min(args.msa_samples + (1 if pppl else 0), 1024)) * pad32(min(len(args.sequence) + 1, 1024))
         model, alphabet = pmsa.load_model_and_alphabet(location, device=args.device, max_rows=max_rows)
         stem = checkpoint_stem(location)
         print("Transferred model to GPU")
@@ -294,6 +314,15 @@ def score_msa_transformer(args, df, mutant_col, msa_start_index, MSA_weight_file
                                    device=args.device)
             tokens = to_tokens([rows])[2][0]                      # [R, L+1]
             print(f"Batch sizes: {(1,) + tokens.shape}")
+            if pppl:                                              # compute_fitness.py:403-417
+                if "mutated_sequence" not in df:
+                    df["mutated_sequence"] = [get_mutated_sequence(m, args.sequence, args.offset_idx) for m in mutants]
+                df[column] = [compute_pppl_msa(sq, model, alphabet, rows) for sq in df["mutated_sequence"]]
+                if on_disk is not None and not args.overwrite_prior_scores:
+                    assert column not in on_disk.columns, f"Column {column} already exists in {out_csv}"
+                    df = on_disk.merge(df[[column, "mutant"]], on="mutant")
+                df.to_csv(out_csv, index=False)
+                continue
             T = tokens.shape[1]
             # the reference forwards every column; only cells some mutant reads are needed (--all-positions restores it)
             positions = list(range(T)) if args.all_positions else cells

@@ -27,7 +27,7 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int AKT = 32;                       // keys per tile
 constexpr int kAttTuneDefault = 0;            // attention_f16x3_v2_kernel `tune` bits used when PGMI_ATT_TUNE is not set
-constexpr float kAttDeferDefault = 0.0f;      // ... and its `defer_thr` (PGMI_ATT_DEFER)
+constexpr float kAttDeferDefault = 4.0f;      // ... and its `defer_thr` (PGMI_ATT_DEFER): measured +3.5 % (T = 288) / +4.5 % (T = 1024) over 0
 constexpr int K_CH = AKT * 8;                 // chunks per K plane
 constexpr int V_CH = 64 * 4;                  // chunks per V^T plane
 constexpr int A_STAGE = 2 * K_CH + 2 * V_CH;  // chunks per buffer (hi+lo planes of K and V^T) = 16 KB
@@ -481,7 +481,8 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
     size_t vt_plane, const int32_t* __restrict__ kv_len, const float* __restrict__ slopes, int T, int H,
     int Tp, float* __restrict__ ctx, unsigned short* __restrict__ ctx16, size_t plane, int tune, float defer_thr) {
     // tune (A/B switches, see launch_attention_f16x3_v2): 1 = static priority for the waves in odd hardware wave slots, 2 = the
-    // lane <-> lane + 32 max exchange through LDS (ds_bpermute) instead of v_permlane32_swap.  defer_thr: see the rescale below.
+    // lane <-> lane + 32 max exchange through LDS (ds_bpermute) instead of v_permlane32_swap, 4 = 8-byte epilogue stores (the old
+    // form) instead of 16-byte ones, 8 = Q fragments straight from global memory (the old form).  defer_thr: see the rescale below.
     // slopes != nullptr selects the Tranception flavour (tranception/model_pytorch.py:155-183): causal
     // mask (key <= query) and the grouped-ALiBi bias slope[h] * key added to the scaled scores.
     constexpr int NT = WPB * 64;
@@ -509,9 +510,15 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
     // the odd hardware slot lets it run unimpeded while its partner fills the unit it leaves idle.
     if ((tune & 1) && (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1)) __builtin_amdgcn_s_setprio(2);
 
-    // Q fragments straight from the planes: lane (r,kh) holds Q[q0+r][16s + 8kh .. +7]
+    // Q fragments: lane (r,kh) holds Q[q0+r][16s + 8kh .. +7] of both planes.  Loaded straight from the planes each of the 2 NS
+    // 16-byte loads of a wave touches 32 different rows (one per lane pair): 8 x 32 row segments for an 8 KB tile.  With
+    // kQviaLds the wave's Q tile is instead moved like a K tile -- 8 lanes per 128-byte row, DMA into LDS in the K tile's swizzled
+    // image (ring stages 1 and 2 are still free) -- and the fragments are read from there: a quarter of the row segments on the
+    // texture-address path, which this kernel keeps busy (9 % of wave-cycles with its FIFO full).
+    constexpr bool kQviaLds = NSTG >= 3;
+    const bool q_lds = kQviaLds && !(tune & 8);
     u32x4 qh[NS], ql[NS];
-    {
+    if (!q_lds) {
         const int qrow = min(q0 + r, T - 1);
         const unsigned short* qp = qk16 + ((size_t)b * T + qrow) * (2 * D) + h * DH + kh * 8;
 #pragma unroll
@@ -575,9 +582,40 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
     // flight across the barrier; a __syncthreads() would drain them)
     constexpr float kLog2e = 1.4426950408889634f;
     const float slope2 = causal ? slopes[h] * kLog2e : 0.0f;      // the q planes carry log2(e) (kQLog2e), the ALiBi term must too
+    if (q_lds) {
+        issue_tile(0, 0);
+        u32x4* qbase = lds + STG_CH + wave * (2 * KCH);             // this wave's half of stages 1 .. 2: [2 planes][32 rows][KCPR chunks]
+        if (active) {
+            constexpr int NQ = 2 * KCH / 64;                        // wave-instructions of 1 KiB
 #pragma unroll
-    for (int t = 0; t < NSTG - 1; ++t)
-        if (t < nkt) issue_tile(t, t);
+            for (int i = 0; i < NQ; ++i) {
+                const int f = i * 64 + lane, pq = f / KCH, row = (f % KCH) / KCPR;
+                const int c = (f % KCPR) ^ (DH == 64 ? ((row >> 1) & 7) : (row & 15));
+                const int vo = (int)((((unsigned int)b * T + (unsigned int)min(q0 + row, T - 1)) * (unsigned int)(2 * D) + (unsigned int)(h * DH)) * 2u + (unsigned int)c * 16u);
+                const int so = (int)((unsigned int)pq * (unsigned int)qk_plane * 2u);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQK, (__attribute__((address_space(3))) void*)(qbase + i * 64), 16, vo, so, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's share of tile 0 and its own Q tile have landed
+        if (active) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int ci = r * KCPR + ((2 * s + kh) ^ (DH == 64 ? ((r >> 1) & 7) : (r & 15)));
+                qh[s] = qbase[ci];
+                ql[s] = qbase[KCH + ci];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                               // every wave holds its Q in registers: stages 1 and 2 are free again
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int t = 1; t < NSTG - 1; ++t)
+            if (t < nkt) issue_tile(t, t);
+    } else {
+#pragma unroll
+        for (int t = 0; t < NSTG - 1; ++t)
+            if (t < nkt) issue_tile(t, t);
+    }
 
     f32x16 om[ND], oc[ND];
 #pragma unroll
@@ -614,11 +652,19 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
             }
             float st[16];
             if (causal) {
+                // ALiBi: slope * key index (model_pytorch.py:167-168), key = 32 kt + 4 kh + c_v with c_v a compile-time constant per
+                // accumulator register; the causal mask (:161-165) only on tiles that reach beyond the wave's first query -- every
+                // tile below the diagonal band is fully visible and skips the 16 compares and selects
+                const float kb = (float)(kt * AKT + 4 * kh);                // key index as a float: small integers, every sum below is exact
 #pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const int key = kt * AKT + (v & 3) + 8 * (v >> 2) + 4 * kh;
-                    const float sv = fmaf(sc[v], kInvLo, sm[v]) + slope2 * (float)key;
-                    st[v] = (key > q0 + r) ? -INFINITY : sv;
+                for (int v = 0; v < 16; ++v)
+                    st[v] = fmaf(slope2, kb + (float)((v & 3) + 8 * (v >> 2)), fmaf(sc[v], kInvLo, sm[v]));
+                if (kt * AKT + AKT - 1 > q0) {
+#pragma unroll
+                    for (int v = 0; v < 16; ++v) {
+                        const int key = kt * AKT + (v & 3) + 8 * (v >> 2) + 4 * kh;
+                        if (key > q0 + r) st[v] = -INFINITY;
+                    }
                 }
             } else {
 #pragma unroll
@@ -701,7 +747,43 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
 
     if (active) {
         const float l_tot = l_run + __shfl_xor(l_run, 32);
-        if (q0 + r < T) {
+        if (OUT == 1 && !(tune & 4)) {
+            // Split-plane output, 16-byte stores: lane (r, kh) holds columns 8g + 4kh .. + 3 of its query row for g = 0 .. 3; one
+            // v_permlane32_swap per dword hands lane (r, 0) its partner's half of an even g and lane (r, 1) its partner's half of
+            // the following odd g, so every lane owns 8 consecutive columns = one dwordx4 per plane: 8 store instructions per
+            // lane instead of 16 of half the width (a row-per-lane store touches 32-64 lines per instruction: the epilogue is bound
+            // by store issue, not by bytes).  All 64 lanes take part in the swaps; rows beyond T only skip the stores.
+            const float inv = 1.0f / l_tot;
+            const bool row_ok = q0 + r < T;
+            unsigned short* rowp = ctx16 + ((size_t)b * T + min(q0 + r, T - 1)) * (size_t)(2 * D) + (size_t)(ND * h) * 64;
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    unsigned int w[2][4];                        // [g parity][hi0 hi1 lo0 lo1]
+#pragma unroll
+                    for (int gi = 0; gi < 2; ++gi) {
+                        const int g = 2 * gp + gi;
+                        _Float16 hh[4], ll[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) split_act(fmaf(oc[dt][4 * g + e], kInvLo, om[dt][4 * g + e]) * inv, hh[e], ll[e]);
+                        w[gi][0] = pack_h2(hh[0], hh[1]); w[gi][1] = pack_h2(hh[2], hh[3]);
+                        w[gi][2] = pack_h2(ll[0], ll[1]); w[gi][3] = pack_h2(ll[2], ll[3]);
+                    }
+                    unsigned int first[4], second[4];            // columns c .. c + 3 and c + 4 .. c + 7 of this lane's 8-column run
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(w[0][k], w[1][k], false, false);
+                        first[k] = sw[0];                        // kh 0: own g even          kh 1: partner's (kh 0) g odd
+                        second[k] = sw[1];                       // kh 0: partner's g even    kh 1: own g odd
+                    }
+                    if (row_ok) {
+                        unsigned short* dst = rowp + dt * 64 + 8 * (2 * gp + kh);
+                        *reinterpret_cast<u32x4*>(dst) = u32x4{first[0], first[1], second[0], second[1]};
+                        *reinterpret_cast<u32x4*>(dst + 32) = u32x4{first[2], first[3], second[2], second[3]};
+                    }
+                }
+        } else if (q0 + r < T) {
             const float inv = 1.0f / l_tot;
             const size_t off = ((size_t)b * T + q0 + r) * D + (size_t)h * DH + 4 * kh;
 #pragma unroll

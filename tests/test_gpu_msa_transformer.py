@@ -85,6 +85,38 @@ def test_cli_matches_reference_columns(lib, gold, golden_dir, tmp_path):
         assert np.abs(df[c].to_numpy() - gold[f"cli/{c}"]).max() < TOL
 
 
+def test_cli_pseudo_ppl_branch_matches_the_reference(lib, golden_dir, tmp_path):
+    """--scoring-strategy pseudo-ppl with the MSA Transformer (compute_fitness.py:258-279, mode == "MSA_Transformer"; driver
+    :403-417) against the reference CLI's own output (tests/golden/make_golden_msa_pppl.py): the mutated sequence in front of
+    64 sampled rows, one alignment-wide forward per residue with alignment row i masked (the reference's indexing), sums of 58
+    terms held to the flat 1e-4 bar; too few rows end in the reference's IndexError."""
+    from proteingym_amd import compute_fitness as cf
+    g = np.load(os.path.join(golden_dir, "golden_msa_pppl.npz"))
+    src = pd.read_csv(os.path.join(golden_dir, "TOY_MSA_DMS.csv"))
+    rows = src[src["mutant"].isin(list(g["mutants"]))].iloc[: len(g["mutants"])]
+    assert list(rows["mutant"]) == list(g["mutants"])
+    rows.to_csv(tmp_path / "TOY_MSA_PPPL.csv", index=False)
+    mp = pd.read_csv(os.path.join(golden_dir, "TOY_MSA_MAPPING.csv"))
+    mp["DMS_id"], mp["DMS_filename"] = "TOY_MSA_PPPL", "TOY_MSA_PPPL.csv"
+    mp.to_csv(tmp_path / "map.csv", index=False)
+
+    def run(samples, out):
+        cf.main(cf.create_parser().parse_args([
+            "--model-location", os.path.join(golden_dir, "msa_toy.pt"), "--model_type", "MSA_transformer", "--dms_index", "0",
+            "--dms_mapping", str(tmp_path / "map.csv"), "--dms-input", str(tmp_path), "--dms-output", str(tmp_path / out),
+            "--scoring-strategy", "pseudo-ppl", "--msa-path", golden_dir, "--msa-weights-folder", golden_dir,
+            "--msa-samples", str(samples), "--seeds", "1", "2"]))
+    run(64, "o")
+    df = pd.read_csv(tmp_path / "o" / "TOY_MSA_PPPL.csv")
+    assert list(df.columns) == list(g["cli/columns"])
+    for c in ("msa_toy_seed1", "msa_toy_seed2", "msa_toy_ensemble"):
+        err = np.abs(df[c].to_numpy() - g[f"cli/{c}"]).max()
+        print(f"MSA Transformer pseudo-ppl {c}: max|err| {err:.2e} on sums of ~{g[f'cli/{c}'].mean():.0f}")
+        assert err < TOL
+    with pytest.raises(IndexError, match="out of bounds for dimension 1 with size 13"):
+        run(12, "o2")
+
+
 def test_long_alignment_optimal_window(lib, gold, golden_dir, tmp_path):
     from proteingym_amd import compute_fitness as cf
     seq_long = str(np.load(os.path.join(golden_dir, "golden_esm.npz"))["seq_long"])
