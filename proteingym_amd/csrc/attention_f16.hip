@@ -15,6 +15,7 @@
 //                                ds_read_b128 of V^T agree on the k order of the 16-deep MFMA.
 // Roofline: after the switch the kernel is VALU-bound (exp, splits, rescale), not MFMA-bound.
 #include <stdlib.h>
+#include <algorithm>
 
 #include "common.h"
 
@@ -535,8 +536,14 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
     // Every wave-instruction (64 slots) lies inside ONE plane of one tensor, so the tensor, the plane and the (sequence, head,
     // tile) part of the address are wave-uniform: they go into the buffer descriptor and the SGPR offset, the lane keeps one
     // 32-bit byte offset per instruction -- no per-tile address arithmetic.
-    const __amdgpu_buffer_rsrc_t rsQK = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(qk16), 0, (int)(unsigned int)(qk_plane * 4), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsVT = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(vt16), 0, (int)(unsigned int)(vt_plane * 4), 0x00020000);
+    // The descriptors are based at THIS block's sequence / (sequence, head) in the hi plane, so the 32-bit offsets only span one plane
+    // stride plus one sequence (the launcher checks plane * 2 + extent < 4 GiB): operand arrays themselves may be larger than 4 GiB
+    // (an MSA Transformer workspace of 1024 x 1024 tokens).  b and h are block-uniform: the bases stay in SGPRs.
+    const size_t seq_halfs = (size_t)T * (2 * D), vt_halfs = (size_t)DH * Tp;
+    const unsigned long long qk_bytes = std::min<unsigned long long>(0xFFFFFFFFull, (unsigned long long)qk_plane * 2ull + seq_halfs * 2ull);
+    const unsigned long long vt_bytes = std::min<unsigned long long>(0xFFFFFFFFull, (unsigned long long)vt_plane * 2ull + vt_halfs * 2ull);
+    const __amdgpu_buffer_rsrc_t rsQK = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(qk16) + (size_t)b * seq_halfs, 0, (int)(unsigned int)qk_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsVT = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(vt16) + ((size_t)b * H + h) * vt_halfs, 0, (int)(unsigned int)vt_bytes, 0x00020000);
     // causal: keys beyond the block's last query tile are never needed (uniform bound for the block)
     const bool causal = slopes != nullptr;
     const int last_q = min(T, (int)(blockIdx.x * WPB + WPB) * 32);
@@ -556,14 +563,18 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
             const int c = (lane % KCPR) ^ (DH == 64 ? ((key >> 1) & 7) : (key & 15));
             voff[i] = key * (2 * D) * 2 + c * 16;
             voff_last[i] = min(key, T - 1 - (nkt - 1) * AKT) * (2 * D) * 2 + c * 16;
-            sbase[i] = (int)((unsigned int)p * (unsigned int)qk_plane * 2u + ((unsigned int)b * T * (2 * D) + D + h * DH) * 2u);
+            sbase[i] = (int)((unsigned int)p * (unsigned int)qk_plane * 2u + (unsigned int)(D + h * DH) * 2u);
             sstep[i] = AKT * (2 * D) * 2;
         } else {
             const int wv = wi - 2 * KCH / 64, p = wv / (VCH / 64), g = (wv % (VCH / 64)) * 64 + lane;
             const int d = g >> 2, c = (g & 3) ^ ((d >> 2) & 3);
             voff[i] = voff_last[i] = d * Tp * 2 + c * 16;
-            sbase[i] = (int)((unsigned int)p * (unsigned int)vt_plane * 2u + (((unsigned int)b * H + h) * DH) * (unsigned int)Tp * 2u);
+            sbase[i] = (int)((unsigned int)p * (unsigned int)vt_plane * 2u);
             sstep[i] = (AKT / 8) * 16;
+            if (tune & 16) {        // TIMING PROBE ONLY (wrong numbers): a V^T tile read as one contiguous 4 KB block of the same (sequence, head) region
+                voff[i] = voff_last[i] = g * 16;
+                sstep[i] = DH * 64;
+            }
         }
     }
     auto issue_tile = [&](int kt, int buf) {
@@ -591,7 +602,7 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
             for (int i = 0; i < NQ; ++i) {
                 const int f = i * 64 + lane, pq = f / KCH, row = (f % KCH) / KCPR;
                 const int c = (f % KCPR) ^ (DH == 64 ? ((row >> 1) & 7) : (row & 15));
-                const int vo = (int)((((unsigned int)b * T + (unsigned int)min(q0 + row, T - 1)) * (unsigned int)(2 * D) + (unsigned int)(h * DH)) * 2u + (unsigned int)c * 16u);
+                const int vo = (int)(((unsigned int)min(q0 + row, T - 1) * (unsigned int)(2 * D) + (unsigned int)(h * DH)) * 2u + (unsigned int)c * 16u);
                 const int so = (int)((unsigned int)pq * (unsigned int)qk_plane * 2u);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQK, (__attribute__((address_space(3))) void*)(qbase + i * 64), 16, vo, so, 0, 0);
             }
@@ -859,13 +870,18 @@ int launch_attention_f16x3_v2(const float* qkv, const int32_t* kv_len, const flo
     }
     const int n32 = (T + 31) / 32, Tp = n32 * 32;
     int rc = PGMI_OK;
-    // The K / V^T DMA addresses a plane pair through one buffer descriptor with 32-bit byte offsets (num_records = 2 planes =
-    // plane * 4 bytes): both operand arrays must stay below 4 GiB.  Every supported model fits at the default workspace
-    // (ESM2-15B is closest: 4.03e9 bytes of q|k planes at 98 304 rows); a larger max_rows is refused here instead of wrapping.
-    if ((unsigned long long)qk_plane * 4ull >= (1ull << 32) || (unsigned long long)vt_plane * 4ull >= (1ull << 32)) {
-        set_error("attention_f16x3_v2: operand planes of %zu / %zu halfs exceed the 32-bit offset range of the K / V^T DMA "
-                  "(create the model with a smaller max_rows)", qk_plane, vt_plane);
-        return PGMI_EINVAL;
+    // The K / V^T DMA addresses both planes of ONE sequence / (sequence, head) through a buffer descriptor based there, with 32-bit
+    // byte offsets: the lo plane sits one plane stride further, so plane stride + one sequence must stay below 4 GiB (the arrays
+    // themselves may be larger).  Every supported model fits with room (ESM2-15B at 98 304 rows: 2.0e9 bytes per q|k plane; an MSA
+    // Transformer workspace of 1024 x 1024 tokens: 3.2e9); anything beyond is refused here instead of wrapping.
+    {
+        const unsigned long long seq_bytes = (unsigned long long)T * 2ull * (unsigned long long)H * (unsigned long long)head_dim * 2ull;
+        const unsigned long long vt_bytes = (unsigned long long)head_dim * (unsigned long long)Tp * 2ull;
+        if ((unsigned long long)qk_plane * 2ull + seq_bytes >= (1ull << 32) || (unsigned long long)vt_plane * 2ull + vt_bytes >= (1ull << 32)) {
+            set_error("attention_f16x3_v2: operand planes of %zu / %zu halfs exceed the 32-bit offset range of the K / V^T DMA "
+                      "(plane stride + one sequence must stay below 4 GiB: create the model with a smaller max_rows)", qk_plane, vt_plane);
+            return PGMI_EINVAL;
+        }
     }
     if (head_dim == 128) {
         // ESM2-15B class: H heads of 128 = 2 H slot groups of 64 in the operand planes; only the fused-QKV operand path

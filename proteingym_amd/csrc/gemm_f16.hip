@@ -29,61 +29,9 @@
 #include <vector>
 
 #include "common.h"
+#include "gemm16x_kernel.h"            // typedefs, gelu_erf16, QkvOut, TilePlan, gemm16x_kernel (the persistent ping-pong kernel)
 
 namespace pgmi {
-
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-typedef __bf16 b8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-
-// erf-GELU (modules.py:17-24, nn.GELU) without calling erff: 17 VALU ops instead of ~38 per value, which matters
-// because the FC1 epilogue runs while the matrix pipe idles (18 % of FC1 at K = 1280, 30 % at K = 768).
-//   gelu(x) = max(x,0) - 0.5|x| erfc(|x|/sqrt2),   erfc(z) ~= t Q(t) exp(-z^2),  t = 1/(1 + p z)
-// (Abramowitz-Stegun 7.1.26 form, Q of degree 5 re-fitted by minimax to the product 0.5|x| erfc: fit error 3.7e-9).
-// The erfc form has no 1 + erf cancellation for x < 0: against fp64 the fp32 evaluation is within 2.4e-7 abs
-// (torch's fp32 gelu: 1.2e-6), mean 1.9e-8 (torch: 4.6e-8) -- scripts/fit_gelu.py.
-__device__ __forceinline__ float gelu_erf16(float x) {
-    const float ax = fabsf(x);
-    const float z = fminf(ax * 0.70710678118654752440f, 13.0f);
-    const float t = __builtin_amdgcn_rcpf(fmaf(3.973660903e-01f, z, 1.0f));
-    float q = -2.134610164e-01f;
-    q = fmaf(q, t, 7.781763039e-01f);
-    q = fmaf(q, t, -4.744764895e-01f);
-    q = fmaf(q, t, 5.422912625e-01f);
-    q = fmaf(q, t, 1.330677808e-01f);
-    q = fmaf(q, t, 2.344017484e-01f);
-    const float e = __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);
-    return fmaf(-0.5f * ax, t * q * e, fmaxf(x, 0.0f));
-}
-
-// Attention operands straight from the fused QKV projection (OUT 2): q|k as split planes qk16 [2][M][2D] (ESM2 rotary
-// applied here, rotary_embedding.py:11-20), v as the transposed, key-permuted planes vt16 [2][B*H*64][Tp] that
-// attention_f16.hip consumes.
-struct QkvOut {
-    unsigned short* vt16;
-    size_t vt_plane;
-    const float* cos_t;
-    const float* sin_t;
-    int T, H, Tp, rotary;
-    int rot_halves;       // rotary table rows per token: 1, or 2 for head_dim 128 (row = slot-group parity)
-};
-
-template <bool BF>
-__device__ __forceinline__ f32x16 mfma16(u32x4 a, u32x4 b, f32x16 c) {
-    if constexpr (BF) {
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(b8, a), __builtin_bit_cast(b8, b), c, 0, 0, 0);
-    } else {
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
-    }
-}
-
-__device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
-    unsigned int u = __builtin_bit_cast(unsigned int, f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
-}
 
 // ---- bf16 (throughput mode, NOT parity-gated): plain bf16 operands, one MFMA per product block ----------------------
 // Tiling (wave64): workgroup (WM*TM*32) x (WN*TN*32) x 32, WM*WN waves, each wave TM x TN MFMA tiles of 32x32
@@ -260,489 +208,6 @@ static int launch_bf16_cfg(const unsigned short* A, const unsigned short* W, con
     return PGMI_OK;
 }
 
-// =================================================================================================
-// Persistent ping-pong kernel (f16x3, 256 x 256 x 32 tile, 8 waves = 2(M) x 4(N), wave tile 128 x 64).
-// One workgroup per CU walks a list of work items; per item the K loop is the ping-pong schedule of
-// gemm16_kernel<PP> (the two waves of a SIMD run one phase apart: one issues its 24 MFMAs while the other reads
-// fragments / stages the next K tile).  What the persistent form adds:
-//   * no workgroup launch/retire gap between tiles, the output stores of tile i drain under the prologue and
-//     main loop of tile i+1, and (STG 0) the first K tile of item i+1 is loaded into the staging registers
-//     BEFORE the epilogue of item i runs;
-//   * the tail of the launch is balanced: with T tiles on G workgroups the last partial round (T mod G tiles,
-//     1610 tiles on 256 CUs = 6.29 rounds for the N = 1280 GEMMs) is cut into `split` K slices per tile, so every
-//     CU gets a slice instead of 29 % of the chip working a full round.  Sliced items leave their raw fp32
-//     accumulators in a workspace (fully coalesced 16-byte stores in accumulator order); splitk_fix_kernel adds
-//     the slices in a fixed order (deterministic) and applies scale, bias and the residual.  Only the fp32-output
-//     GEMMs (out-projection, FC2) use slices; their N = D gives the few tiles that make the tail matter.
-// LDS image of a K tile (per operand): [256 rows][8 chunks of 16 B] = the row's 128-byte line (4 hi chunks, 4 lo chunks)
-// with the chunk index XORed by (row >> 1) & 7: conflict-free ds_read_b128 fragment reads at a 128-byte row pitch, and
-// both staging forms write whole rows.  STG 0: global -> VGPR -> LDS staging.  STG 1: global -> LDS DMA (the swizzle
-// moves to the SOURCE chunk, which stays inside the row's line); the wave's share of tile kt+1 is issued in the first
-// memory phase of tile kt and waited for at the LAST barrier of tile kt (two to three phases of latency cover).
-// =================================================================================================
-struct TilePlan {
-    int tiles_m, tiles_n;
-    int n_main;       // tiles [0, n_main) in launch order: one full-K item each
-    int split;        // every later tile is cut into `split` K slices (<= 1: none)
-    int n_items;      // n_main + (tiles - n_main) * split (or * 2 with half)
-    int half;         // 1: every later tile is cut into its upper and lower 128 rows instead (two items, full K each)
-    float* ws;        // raw accumulators of the sliced items
-    unsigned long long* diag;   // DIAG instantiation only: [2 waves][kDiagSamples][2] shader-clock stamps (barrier arrival, release)
-    int diag_flags;             // DIAG instantiation only (ablations, wrong numbers): 1 no global loads in the loop, 2 no
-                                // ds_write staging, 4 loads issued in memory phase 1, 8 no fragment reads after the first K tile, 32 no s_setprio, 64 static
-                                // priority 1 for the late waves only
-};
-constexpr int kDiagSamples = 1024;
-
-constexpr int XBM = 256, XBN = 256, XNT = 512, XCPR = 8;   // 8 chunks = one 128-byte line per row and K tile (hi | lo)
-constexpr int X_OP_CH = XBM * XCPR;                        // 16-byte chunks of one operand tile
-constexpr int X_STAGE = 2 * X_OP_CH;                       // chunks per stage = 64 KB
-
-__device__ __forceinline__ void x_tile_coords(int wgid, int tiles_m, int tiles_n, int& tm, int& tn) {
-    constexpr int GROUP_M = 8;
-    const int width = GROUP_M * tiles_n;
-    const int group = wgid / width, first_m = group * GROUP_M;
-    const int gsz = min(tiles_m - first_m, GROUP_M);
-    tm = first_m + (wgid % width) % gsz;
-    tn = (wgid % width) / gsz;
-}
-
-template <int EPI, int OUT, int STG, int DFLAGS = -1>     // DFLAGS >= 0: tuning-only phase-timing instantiation with these ablation flags
-__global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
-    const unsigned short* __restrict__ A, const unsigned short* __restrict__ W, const float* __restrict__ bias,
-    const float* residual, float* Cf, unsigned short* Ch, size_t c_plane, int M, int N, int K, float out_scale,
-    TilePlan tp, QkvOut qo) {
-    constexpr int WN = 4, TMX = 4, TN = 2, LD = 4;               // TMX: 32-row MFMA tiles per wave of a full item (a half item: 2)
-    constexpr bool DIAG = DFLAGS >= 0;
-    constexpr bool DMA = STG == 1 || STG == 3;                    // 3 (tuning): DMA issued after the fragment reads of memory phase 1
-    constexpr int kFlags = DIAG ? DFLAGS % 1000 : 0;              // DFLAGS >= 1000: the DMA form (launched with STG 1)
-    extern __shared__ __attribute__((aligned(16))) u32x4 lds[];  // [2][X_STAGE]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // provably wave-uniform: scalar branches, SGPR LDS bases
-    const int wm = wave / WN, wn = wave % WN;
-    const int r = lane & 31, kh = lane >> 5;
-    const bool late = wave >= 4;                                  // the second wave of every SIMD
-
-    // staging geometry (the same for both operands): slot f = tid + 512 i is (row (tid >> 3) + 64 i, chunk tid & 7) -- 8
-    // consecutive lanes move one row's 128-byte line -- at LDS index row * 8 + (chunk ^ ((row >> 1) & 7)); the swizzle does
-    // not depend on i, so one LDS index + 512 i serves all four, plus one 32-bit byte offset per row and operand.
-    const int row_lo = tid >> 3, c8 = tid & 7, sw8 = (row_lo >> 1) & 7;
-    const int dst0 = DMA ? tid : row_lo * XCPR + (c8 ^ sw8);
-    const int csrc = DMA ? (c8 ^ sw8) : c8;               // DMA: lane-linear slot, swizzled SOURCE chunk
-    // buffer descriptors built from kernel arguments only (provably wave-uniform): loads take a 32-bit per-lane byte offset
-    // and the K-tile offset as an SGPR -- no 64-bit address arithmetic in the memory phases
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(A), 0, (int)((unsigned int)M * (unsigned int)K * 4u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(W), 0, (int)((unsigned int)N * (unsigned int)K * 4u), 0x00020000);
-    unsigned int a_off[LD], w_off[LD];
-    u32x4 a_st[LD], w_st[LD];
-    int m0 = 0, n0 = 0, kt0 = 0, kt1 = 0, slice_item = -1, a_ld = LD;
-    bool half_item = false;                                       // the upper or lower 128 rows of a tile (tail of the item list)
-    auto decode = [&](int item) {                                 // sets m0, n0, [kt0, kt1), slice_item and the source offsets
-        const int nk = K / 32;
-        int wgid;
-        if (item < tp.n_main) {
-            // XCD-aware order: item i runs on XCD i % 8 (grid size is a multiple of 8); every XCD walks a contiguous
-            // run of the grouped tile order so that its L2 keeps the live A panels and W tiles
-            const int nwg = tp.n_main, xcd = item & 7, q = nwg >> 3, r8 = nwg & 7;
-            wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (item >> 3);
-            kt0 = 0; kt1 = nk; slice_item = -1;
-        } else if (tp.half) {
-            wgid = tp.n_main + ((item - tp.n_main) >> 1);
-            kt0 = 0; kt1 = nk; slice_item = -1;
-        } else {
-            const int rel = item - tp.n_main, ks = rel % tp.split;
-            wgid = tp.n_main + rel / tp.split;
-            kt0 = (int)((long long)nk * ks / tp.split);
-            kt1 = (int)((long long)nk * (ks + 1) / tp.split);
-            slice_item = rel;
-        }
-        int tm, tn;
-        x_tile_coords(wgid, tp.tiles_m, tp.tiles_n, tm, tn);
-        half_item = tp.half && item >= tp.n_main;
-        a_ld = half_item ? LD / 2 : LD;                           // A rows staged per K tile: 64 per instruction
-        m0 = __builtin_amdgcn_readfirstlane(tm * XBM + (half_item ? ((item - tp.n_main) & 1) * (XBM / 2) : 0));
-        n0 = __builtin_amdgcn_readfirstlane(tn * XBN);
-        kt0 = __builtin_amdgcn_readfirstlane(kt0); kt1 = __builtin_amdgcn_readfirstlane(kt1);
-        slice_item = __builtin_amdgcn_readfirstlane(slice_item);
-#pragma unroll
-        for (int i = 0; i < LD; ++i) {                            // row pitch 4 K bytes; the launcher guarantees rows * 4 K < 4 GiB
-            a_off[i] = (unsigned int)min(m0 + row_lo + 64 * i, M - 1) * (unsigned int)K * 4u + (unsigned int)csrc * 16u;
-            w_off[i] = (unsigned int)min(n0 + row_lo + 64 * i, N - 1) * (unsigned int)K * 4u + (unsigned int)csrc * 16u;
-        }
-    };
-    auto stage_load = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < LD; ++i) a_st[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)a_off[i], kt * 128, 0));
-#pragma unroll
-        for (int i = 0; i < LD; ++i) w_st[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)w_off[i], kt * 128, 0));
-    };
-    auto stage_store = [&](int buf) {
-        u32x4* base = lds + buf * X_STAGE + dst0;
-#pragma unroll
-        for (int i = 0; i < LD; ++i) base[XNT * i] = a_st[i];
-#pragma unroll
-        for (int i = 0; i < LD; ++i) base[X_OP_CH + XNT * i] = w_st[i];
-    };
-    auto issue_tile = [&](int kt, int buf) {                      // STG 1: 1 KiB per wave-instruction, wave-uniform LDS base
-        u32x4* base = lds + buf * X_STAGE + wave * 64;
-#pragma unroll
-        for (int i = 0; i < LD; ++i)
-            if (i < a_ld)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(base + XNT * i), 16, (int)a_off[i], kt * 128, 0, 0);
-#pragma unroll
-        for (int i = 0; i < LD; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(base + X_OP_CH + XNT * i), 16, (int)w_off[i], kt * 128, 0, 0);
-    };
-    // phase boundary: everything issued before stays before, this wave's LDS traffic has landed; VMEM stays in flight
-    // DIAG (tuning-only instantiation): waves 0 and 4 of workgroup 0 stamp the shader clock when they ARRIVE at every phase
-    // barrier, with a tag saying what the phase was (0 mem1, 1 cmp1, 3 mem2, 4 cmp2, 2 other).  The stamp is an SMEM read
-    // issued before the barrier and consumed at the next one: a wave that waits at the barrier pays nothing for it; the wave
-    // that arrives last (a computing wave) pays its latency at the start of its next -- memory -- phase.  (A second stamp
-    // after the barrier made every instrumented compute phase wait for the SMEM round trip: +200-350 clocks.)  The host
-    // takes release(k) = max over the two waves of arrival(k).
-    const bool diag_on = DIAG && blockIdx.x == 0 && (wave == 0 || wave == 4);
-    unsigned long long d_arr = 0;
-    int d_n = 0, d_tag = 0;
-    auto phase_impl = [&](bool vm, int tag) {
-        __builtin_amdgcn_sched_barrier(0);
-        if (DIAG && diag_on) {
-            if (d_n > 0 && d_n <= kDiagSamples && lane == 0) {
-                unsigned long long* q = tp.diag + ((size_t)(wave >> 2) * kDiagSamples + (d_n - 1)) * 2;
-                q[0] = d_arr; q[1] = (unsigned long long)d_tag + 1;
-            }
-        }
-        if (vm && !(DIAG && (kFlags & 128))) __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
-        else __builtin_amdgcn_s_waitcnt(0xC07F);                                    // lgkmcnt(0)
-        if (DIAG && diag_on) { d_arr = __builtin_readcyclecounter(); d_tag = tag; ++d_n; }
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    auto phase = [&](int tag = 2) { phase_impl(false, tag); };
-    auto phase_vm = [&](int tag = 2) { phase_impl(true, tag); };   // the same, plus this wave's DMA has landed (DMA form)
-
-    f32x16 acc[TN][TMX];
-    u32x4 af[2][TMX], wf[2][TN], whs[TN];
-    const int fsw = (r >> 1) & 7;                                 // fragment rows are (multiple of 32) + r: the row swizzle is per lane
-    auto read_frags = [&](auto tmc, const u32x4* Ab, const u32x4* Wb, int ks) {
-        constexpr int TM = decltype(tmc)::value;
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-            const int c = (p * 4 + ks * 2 + kh) ^ fsw;            // chunk p*4 + (2 ks + kh) of the row's line, swizzled
-#pragma unroll
-            for (int i = 0; i < TM; ++i) af[p][i] = Ab[((wm * TM + i) * 32 + r) * XCPR + c];
-#pragma unroll
-            for (int j = 0; j < TN; ++j) wf[p][j] = Wb[((wn * TN + j) * 32 + r) * XCPR + c];
-        }
-    };
-    // w_hi 2^-11 (exact: weights are pre-scaled to ~2^13), the third operand of the split product.  Computed at the head of
-    // the wave's own COMPUTE phase, interleaved with the first MFMAs (which do not need it): in the memory phase the partner
-    // wave holds priority and these eight VALU ops sat on the critical path to the phase barrier (measured: a memory phase
-    // with nothing but them still took 600-700 clocks).
-    auto scale_whi = [&]() {
-        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-        const h2 sc = {(_Float16)(1.0f / kLoScale), (_Float16)(1.0f / kLoScale)};
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const unsigned int u = wf[0][j][e];
-                const h2 t = __builtin_bit_cast(h2, u) * sc;
-                whs[j][e] = __builtin_bit_cast(unsigned int, t);
-            }
-    };
-    auto mfmas = [&](auto tmc) {
-        constexpr int TM = decltype(tmc)::value;
-        scale_whi();
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int i = 0; i < TM; ++i) acc[j][i] = mfma16<false>(wf[1][j], af[0][i], acc[j][i]);    // w_lo a_hi
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int i = 0; i < TM; ++i) acc[j][i] = mfma16<false>(whs[j], af[1][i], acc[j][i]);      // (w_hi 2^-11)(a_lo 2^11)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int i = 0; i < TM; ++i) acc[j][i] = mfma16<false>(wf[0][j], af[0][i], acc[j][i]);    // w_hi a_hi
-        // one MFMA, one VALU: the eight scalings ride in the shadow of the first eight MFMAs
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
-        }
-        __builtin_amdgcn_sched_group_barrier(0x008, 3 * TN * TM - 8, 0);
-    };
-
-    int item = blockIdx.x;
-    if (item >= tp.n_items) return;
-    bool dma_ahead = false;                                       // the item's first K tile was issued before the previous epilogue
-    decode(item);
-    if constexpr (STG == 0) stage_load(kt0);
-    // the fp32-output epilogue has the registers to spare for the next item's first K tile; the split-plane and
-    // attention-operand epilogues do not (the prefetch spilled 12-23 registers): they fetch after the epilogue
-    constexpr bool kPrefetchAcrossEpilogue = STG == 0 && OUT == 0;
-    // one item, start to finish; TM (compile time) = 32-row MFMA tiles per wave: 4, or 2 for a half item.  Returns "more items".
-    auto run_item = [&](auto tmc) -> bool {
-        constexpr int TM = decltype(tmc)::value;
-        // ---- prologue: first K tile of the item into buffer 0 (the LDS patches of the previous epilogue are done:
-        //      every wave passed the barrier below only after finishing its own patch reads) ----
-        __syncthreads();
-        if constexpr (STG == 0) {
-            stage_store(0);
-            if (kt0 + 1 < kt1) stage_load(kt0 + 1);
-            __syncthreads();
-        } else {
-            if (!dma_ahead) issue_tile(kt0, 0);
-            phase_vm();
-        }
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) acc[j][i][v] = 0.0f;
-        int cur = 0;
-        if (DIAG && (kFlags & 64) && late) __builtin_amdgcn_s_setprio(1);
-        if (late) phase();
-        for (int kt = kt0; kt < kt1; ++kt) {
-            const u32x4* Ab = lds + cur * X_STAGE;
-            const u32x4* Wb = Ab + X_OP_CH;
-            // -- memory phase 1: fragments of the first k16 step (STG 1: DMA of tile kt+1 into the other buffer, last read
-            //    two phases ago by the other wave group) --
-            if (!(DIAG && (kFlags & 96))) __builtin_amdgcn_s_setprio(0);
-            // the DMA goes first: with the fragment reads ahead of it the memory phase outlasts the partner's 24 MFMAs
-            // (tools/mfma_phase.hip: 829 -> 797 clocks per phase on the bare loop); STG 3 keeps the old order for A/B
-            if (STG == 1 && kt + 1 < kt1 && !(DIAG && (kFlags & 16) && kt > kt0)) issue_tile(kt + 1, cur ^ 1);
-            if (!(DIAG && (kFlags & 8) && kt > kt0)) read_frags(tmc, Ab, Wb, 0);
-            if (STG == 3 && kt + 1 < kt1) issue_tile(kt + 1, cur ^ 1);
-            if (DIAG && (kFlags & 4) && kt > kt0 && kt + 1 < kt1) stage_load(kt + 1);
-            phase(0);
-            // -- compute phase 1 --
-            if (!(DIAG && (kFlags & 96))) __builtin_amdgcn_s_setprio(1);
-            mfmas(tmc);
-            phase(1);
-            // -- memory phase 2: fragments of the second k16 step; STG 0: tile kt+1 registers -> LDS, loads of kt+2 --
-            if (!(DIAG && (kFlags & 96))) __builtin_amdgcn_s_setprio(0);
-            if (!(DIAG && (kFlags & 8) && kt > kt0)) read_frags(tmc, Ab, Wb, 1);
-            if (STG == 0 && kt + 1 < kt1) {
-                __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0); lgkmcnt / expcnt untouched
-                if (!(DIAG && (kFlags & 2))) stage_store(cur ^ 1);
-                if (kt + 2 < kt1 && !(DIAG && (kFlags & 5))) stage_load(kt + 2);
-            }
-            if (DMA && late) phase_vm(3); else phase(3);        // late waves close tile kt here: their DMA share must have landed
-            // -- compute phase 2 --
-            if (!(DIAG && (kFlags & 96))) __builtin_amdgcn_s_setprio(1);
-            mfmas(tmc);
-            if (DMA && !late) phase_vm(4); else phase(4);       // early waves close tile kt here
-            cur ^= 1;
-        }
-        __builtin_amdgcn_s_setprio(0);
-        if (!late) phase();
-
-        // ---- the item just finished; fetch the next one's first K tile before the epilogue (STG 0) ----
-        const int em0 = m0, en0 = n0, eslice = slice_item;
-        item += gridDim.x;
-        const bool more = item < tp.n_items;
-        if (more) {
-            decode(item);
-            if constexpr (kPrefetchAcrossEpilogue) stage_load(kt0);
-            // DMA form: the fp32-output epilogue does not touch LDS and both K-tile buffers are free after the last phase barrier,
-            // so the next item's first K tile is already in flight while this item's epilogue runs
-            if constexpr (DMA && OUT == 0) { issue_tile(kt0, 0); dma_ahead = true; }
-        }
-
-        if (eslice >= 0) {
-            // raw accumulators, accumulator order: [item][wave][j][i][q][lane] f32x4 -> 1 KiB per store instruction
-            f32x4* dst = reinterpret_cast<f32x4*>(tp.ws) + ((size_t)eslice * 8 + wave) * (TN * TM * 4 * 64) + lane;
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4)
-                        dst[((j * TM + i) * 4 + q4) * 64] = f32x4{acc[j][i][4 * q4], acc[j][i][4 * q4 + 1], acc[j][i][4 * q4 + 2], acc[j][i][4 * q4 + 3]};
-        } else if constexpr (OUT == 2) {
-            const int Dm = N / 3;
-            const int nb = en0 + wn * 64;                      // first column of this wave's head
-            if (nb < N) {
-            const int which = nb / Dm, hcol = nb - which * Dm, hh = hcol >> 6;
-            constexpr int SPQ = 144;
-            unsigned char* patch_q = reinterpret_cast<unsigned char*>(lds) + wave * (2 * 32 * SPQ);
-            const bool staged_q = which < 2;
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int m = em0 + (wm * TM + i) * 32 + r;
-                const bool row_ok = m < M;
-                if (!staged_q && !row_ok) continue;
-                const int bb = m / qo.T, t = m - bb * qo.T;
-                if (row_ok)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int d0 = 8 * g + 4 * kh;             // dims d0..d0+3 (x0) and d0+32.. (x1) of the head
-                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + nb + d0);
-                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + nb + 32 + d0);
-                    float x0[4], x1[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        x0[e] = acc[0][i][4 * g + e] * out_scale + b0[e];
-                        x1[e] = acc[1][i][4 * g + e] * out_scale + b1[e];
-                    }
-                    if (which == 0) {                          // attention's softmax is base 2: q carries log2(e) (common.h)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { x0[e] *= kQLog2e; x1[e] *= kQLog2e; }
-                    }
-                    if (which < 2) {
-                        if (qo.rotary) {                       // rotary_embedding.py:11-20
-                            const int tr = (t * qo.rot_halves + (hh % qo.rot_halves)) * 64;
-                            const f32x4 c1 = *reinterpret_cast<const f32x4*>(qo.cos_t + tr + d0);
-                            const f32x4 s1 = *reinterpret_cast<const f32x4*>(qo.sin_t + tr + d0);
-                            const f32x4 c2 = *reinterpret_cast<const f32x4*>(qo.cos_t + tr + 32 + d0);
-                            const f32x4 s2 = *reinterpret_cast<const f32x4*>(qo.sin_t + tr + 32 + d0);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                const float y0 = x0[e] * c1[e] + (-x1[e]) * s1[e];
-                                const float y1 = x1[e] * c2[e] + x0[e] * s2[e];
-                                x0[e] = y0;
-                                x1[e] = y1;
-                            }
-                        }
-                        h4 hi0, lo0, hi1, lo1;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            _Float16 a, b2;
-                            split_act(x0[e], a, b2); hi0[e] = a; lo0[e] = b2;
-                            split_act(x1[e], a, b2); hi1[e] = a; lo1[e] = b2;
-                        }
-                        unsigned char* cell = patch_q + r * SPQ + d0 * 2;
-                        *reinterpret_cast<h4*>(cell) = hi0;
-                        *reinterpret_cast<h4*>(cell + 32 * SPQ) = lo0;
-                        *reinterpret_cast<h4*>(cell + 64) = hi1;
-                        *reinterpret_cast<h4*>(cell + 32 * SPQ + 64) = lo1;
-                    } else {
-                        const int tk = t & 31;
-                        const int pos = (t & ~31) + ((tk & 0x13) | ((tk & 4) << 1) | ((tk & 8) >> 1));   // swap key bits 2,3
-                        unsigned short* col = qo.vt16 + (((size_t)bb * qo.H + hh) * kHeadDim + d0) * qo.Tp + pos;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            _Float16 a0, l0, a1, l1;
-                            split_act(x0[e], a0, l0);
-                            split_act(x1[e], a1, l1);
-                            unsigned short* c0 = col + (size_t)e * qo.Tp;
-                            unsigned short* c1p = c0 + (size_t)32 * qo.Tp;
-                            c0[0] = __builtin_bit_cast(unsigned short, a0);
-                            c0[qo.vt_plane] = __builtin_bit_cast(unsigned short, l0);
-                            c1p[0] = __builtin_bit_cast(unsigned short, a1);
-                            c1p[qo.vt_plane] = __builtin_bit_cast(unsigned short, l1);
-                        }
-                    }
-                }
-                if (staged_q) {
-                    __builtin_amdgcn_wave_barrier();
-                    const int m_base = em0 + (wm * TM + i) * 32;
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int q = lane + 64 * k, row = q >> 3, cc = q & 7;
-                        const u32x4 vh = *reinterpret_cast<const u32x4*>(patch_q + row * SPQ + cc * 16);
-                        const u32x4 vl = *reinterpret_cast<const u32x4*>(patch_q + (32 + row) * SPQ + cc * 16);
-                        if (m_base + row < M) {
-                            unsigned short* dst = Ch + (size_t)(m_base + row) * (2 * Dm) + (size_t)which * Dm + hcol + cc * 8;
-                            *reinterpret_cast<u32x4*>(dst) = vh;
-                            *reinterpret_cast<u32x4*>(dst + c_plane) = vl;
-                        }
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-            }
-        } else {
-            // lane holds column m = m_base + r of C^T, rows n = (v&3) + 8(v>>2) + 4kh; split-plane output leaves through a
-            // per-wave LDS transpose as full 128-byte row segments (see gemm16_kernel)
-            // per-wave LDS patch: 32 rows x (256 B in OUTPUT order: group 0 hi | group 0 lo | group 1 hi | group 1 lo) + 16 B pad
-            constexpr int SP = 272;
-            const bool staged = (OUT == 1) && (N % 8 == 0) && (en0 + (wn * TN + TN) * 32 <= N);
-            unsigned char* patch = reinterpret_cast<unsigned char*>(lds) + wave * (32 * SP);
-#pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int m = em0 + (wm * TM + i) * 32 + r;
-                const bool row_ok = m < M;
-                if (!staged && !row_ok) continue;
-                if (row_ok)
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        const int n = en0 + (wn * TN + j) * 32 + 8 * g + 4 * kh;
-                        if (n >= N) continue;                    // N % 4 == 0 is required by the launcher
-                        const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-                        f32x4 val;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float t = acc[j][i][4 * g + e] * out_scale + bv[e];
-                            if (EPI == EPI_GELU) t = gelu_erf16(t);
-                            if (EPI == EPI_SQRELU) { t = fmaxf(t, 0.0f); t = t * t; }     // tranception/activations.py:79-84
-                            val[e] = t;
-                        }
-                        const size_t o = (size_t)m * N + n;
-                        if constexpr (OUT == 0) {
-                            if (residual) {
-                                const f32x4 rv = *reinterpret_cast<const f32x4*>(residual + o);
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) val[e] = rv[e] + val[e];
-                            }
-                            *reinterpret_cast<f32x4*>(Cf + o) = val;
-                        } else {
-                            h4 hi, lo;
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                _Float16 a, b;
-                                split_act(val[e], a, b);
-                                hi[e] = a;
-                                lo[e] = b;
-                            }
-                            if (staged) {
-                                unsigned char* cell = patch + r * SP + j * 128 + (8 * g + 4 * kh) * 2;
-                                *reinterpret_cast<h4*>(cell) = hi;
-                                *reinterpret_cast<h4*>(cell + 64) = lo;
-                            } else {
-                                unsigned short* dst = Ch + ki_off((size_t)m, n, N);
-                                *reinterpret_cast<h4*>(dst) = hi;
-                                *reinterpret_cast<h4*>(dst + 32) = lo;
-                            }
-                        }
-                    }
-                }
-                if (OUT == 1 && staged) {
-                    // K-interleaved output: the wave's 64 columns are two 32-column groups = 2 x (64 B hi | 64 B lo) = 256
-                    // contiguous bytes per row: 16 lanes write one row
-                    __builtin_amdgcn_wave_barrier();
-                    const int m_base = em0 + (wm * TM + i) * 32;
-                    const size_t ncol0 = (size_t)en0 + (size_t)wn * TN * 32;
-#pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const int q = lane + 64 * k;                 // 16-byte chunk: row q/16, chunk q%16 of the 256-byte run
-                        const int row = q >> 4, cc = q & 15;
-                        const u32x4 v = *reinterpret_cast<const u32x4*>(patch + row * SP + cc * 16);
-                        if (m_base + row < M)
-                            *reinterpret_cast<u32x4*>(Ch + (size_t)(m_base + row) * (2 * (size_t)N) + ncol0 * 2 + cc * 8) = v;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-        }
-        return more;
-    };
-    using Full = std::integral_constant<int, TMX>;
-    using Half = std::integral_constant<int, TMX / 2>;
-    while (true) {
-        bool more;
-        if constexpr (OUT != 2 && DMA && !DIAG) more = half_item ? run_item(Half{}) : run_item(Full{});
-        else more = run_item(Full{});
-        if (!more) break;
-        if constexpr (STG == 0 && !kPrefetchAcrossEpilogue) stage_load(kt0);
-    }
-}
-
 // Sum of the K slices of the sliced tiles (fixed order: deterministic) + the fp32 epilogue of gemm16x_kernel<EPI_NONE, 0>:
 // C = residual + (sum acc) * out_scale + bias.  One workgroup per sliced tile, same thread <-> element map as the GEMM.
 __global__ __launch_bounds__(XNT) void splitk_fix_kernel(const float* __restrict__ ws, int split, int n_main, int tiles_m, int tiles_n,
@@ -871,61 +336,6 @@ static int launch_gemm16x_one(const unsigned short* A, const unsigned short* W,
     if (qkv) qo = *qkv;
     const size_t lds_bytes = (size_t)2 * X_STAGE * 16;
     const dim3 grid(std::min(G, tp.n_items)), block(XNT);
-    if (stg == 2) {                                               // tuning only: phase-timing instantiation (fp32-out GEMM)
-        if (!Cf || qkv || epilogue != EPI_NONE) { set_error("gemm16x diag: fp32-output GEMM without activation only"); return PGMI_EINVAL; }
-        static unsigned long long* dbuf = nullptr;
-        const size_t n = (size_t)2 * kDiagSamples * 2;
-        if (!dbuf && hipMalloc(reinterpret_cast<void**>(&dbuf), n * 8) != hipSuccess) { set_error("diag alloc failed"); return PGMI_ENOMEM; }
-        PGMI_HIP(hipMemsetAsync(dbuf, 0, n * 8, s));
-        tp.diag = dbuf;
-        tp.diag_flags = getenv("PGMI_GEMM_DIAG_FLAGS") ? atoi(getenv("PGMI_GEMM_DIAG_FLAGS")) : 0;
-#define PGMI_DIAG_CASE(F_)                                                                                          \
-        case F_: {                                                                                                  \
-            auto kfn = gemm16x_kernel<EPI_NONE, 0, (F_ >= 1000 ? 1 : 0), F_>;                                       \
-            PGMI_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes)); \
-            hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, A, W, bias, residual, Cf, Ch, c_plane, M, N, K, out_scale, tp, qo); \
-        } break;
-        switch (tp.diag_flags) {
-            // register staging: 0 as shipped, 11 no loads / LDS writes / fragment reads.  DMA form (+1000): 1000 as shipped, 1016 no DMA
-            // after the first K tile, 1008 no fragment reads, 1024 neither, 1128 no wait for the DMA (wrong numbers, timing only)
-            PGMI_DIAG_CASE(0) PGMI_DIAG_CASE(11) PGMI_DIAG_CASE(1000) PGMI_DIAG_CASE(1016) PGMI_DIAG_CASE(1008) PGMI_DIAG_CASE(1024) PGMI_DIAG_CASE(1128)
-            default: set_error("gemm16x diag: flags %d not instantiated", tp.diag_flags); return PGMI_EINVAL;
-        }
-#undef PGMI_DIAG_CASE
-        if (tp.split > 1)
-            hipLaunchKernelGGL(splitk_fix_kernel, dim3(T - tp.n_main), dim3(XNT), 0, s, tp.ws, tp.split, tp.n_main, tp.tiles_m,
-                               tp.tiles_n, bias, residual, Cf, M, N, out_scale);
-        std::vector<unsigned long long> h(n);
-        PGMI_HIP(hipMemcpyAsync(h.data(), dbuf, n * 8, hipMemcpyDeviceToHost, s));
-        PGMI_HIP(hipStreamSynchronize(s));
-        // per wave: work = release(k-1) -> arrival(k), wait = arrival(k) -> release(k), release(k) = the later arrival of the two
-        static int printed = 0;
-        if (!printed++) {
-            fprintf(stderr, "[gemm16x diag] flags %d\n", tp.diag_flags);
-            const unsigned long long* q0 = h.data();
-            const unsigned long long* q1 = h.data() + (size_t)kDiagSamples * 2;
-            for (int g = 0; g < 2; ++g) {
-                const unsigned long long* q = g ? q1 : q0;
-                double work[5] = {0, 0, 0, 0, 0}, wait[5] = {0, 0, 0, 0, 0};
-                int cnt[5] = {0, 0, 0, 0, 0};
-                for (int k = 16; k < kDiagSamples && q0[2 * k + 1] && q1[2 * k + 1]; ++k) {     // skip the pipeline fill
-                    const int tag = (int)q[2 * k + 1] - 1;
-                    const unsigned long long rel_prev = std::max(q0[2 * (k - 1)], q1[2 * (k - 1)]);
-                    const unsigned long long rel = std::max(q0[2 * k], q1[2 * k]);
-                    if (tag < 0 || tag > 4 || q[2 * k] < rel_prev) continue;
-                    work[tag] += (double)(q[2 * k] - rel_prev);
-                    wait[tag] += (double)(rel - q[2 * k]);
-                    cnt[tag]++;
-                }
-                fprintf(stderr, "[gemm16x diag] %s waves: ", g ? "late " : "early");
-                static const char* nm[5] = {"mem1", "cmp1", "other", "mem2", "cmp2"};
-                for (int p : {0, 1, 3, 4})
-                    fprintf(stderr, "%s work %.0f wait %.0f | ", nm[p], cnt[p] ? work[p] / cnt[p] : 0.0, cnt[p] ? wait[p] / cnt[p] : 0.0);
-                fprintf(stderr, "(shader clocks, mean over %d K tiles)\n", cnt[0]);
-            }
-        }
-        return PGMI_OK;
-    }
 #define PGMI_LAUNCH16X(EPI_, OUT_, STG_)                                                                  \
     do {                                                                                                 \
         auto kfn = gemm16x_kernel<EPI_, OUT_, STG_>;                                                      \
@@ -994,7 +404,8 @@ static int launch_gemm16x(const unsigned short* A, const unsigned short* W,
 }
 
 // f16x3 variants (tuning; 0 is the product's): 0 persistent ping-pong kernel with global->LDS DMA staging; 2 the same with
-// the DMA issued after the fragment reads; 1 / 3 register staging; 13 phase-timing diagnostics (PGMI_GEMM_DIAG_FLAGS).  K-sliced tails only with PGMI_GEMM_SPLITK=1 (not with 3).
+// the DMA issued after the fragment reads; 1 / 3 register staging.  K-sliced tails only with PGMI_GEMM_SPLITK=1 (not with 3).
+// The phase-timing instantiations of the kernel live in tools/gemm_diag.hip (their own binary).
 int launch_gemm16(const unsigned short* A, size_t a_plane, const unsigned short* W, size_t w_plane,
                   const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
                   int M, int N, int K, int epilogue, float out_scale, int planes, bool bf, int variant,
@@ -1010,7 +421,6 @@ int launch_gemm16(const unsigned short* A, size_t a_plane, const unsigned short*
             case 1: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 0, true, s);
             case 2: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 3, true, s);
             case 3: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 0, false, s);
-            case 13: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 2, false, s);
             // measured (profiles/r2/README.md): with buffer loads the DMA form wins for every output kind (FFN 368 -> 379 TFLOP/s
             // against register staging for the fp32-output GEMMs)
             default: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 1, true, s);
