@@ -87,6 +87,7 @@ struct TilePlan {
     int split;        // every later tile is cut into `split` K slices (<= 1: none)
     int n_items;      // n_main + (tiles - n_main) * split (or * 2 with half)
     int half;         // 1: every later tile is cut into its upper and lower 128 rows instead (two items, full K each)
+    int group_m;      // row panels per group of the grouped tile order (gemm_f16.hip kGroupM; tuning variants 100 + g of launch_gemm16 set g)
     float* ws;        // raw accumulators of the sliced items
     unsigned long long* diag;   // DIAG instantiation only: [2 waves][kDiagSamples][2] shader-clock stamps (barrier arrival, release)
     int diag_flags;             // DIAG instantiation only (ablations, wrong numbers): 1 no global loads in the loop, 2 no
@@ -99,8 +100,7 @@ constexpr int XBM = 256, XBN = 256, XNT = 512, XCPR = 8;   // 8 chunks = one 128
 constexpr int X_OP_CH = XBM * XCPR;                        // 16-byte chunks of one operand tile
 constexpr int X_STAGE = 2 * X_OP_CH;                       // chunks per stage = 64 KB
 
-__device__ __forceinline__ void x_tile_coords(int wgid, int tiles_m, int tiles_n, int& tm, int& tn) {
-    constexpr int GROUP_M = 8;
+__device__ __forceinline__ void x_tile_coords(int wgid, int tiles_m, int tiles_n, int& tm, int& tn, int GROUP_M) {
     const int width = GROUP_M * tiles_n;
     const int group = wgid / width, first_m = group * GROUP_M;
     const int gsz = min(tiles_m - first_m, GROUP_M);
@@ -158,7 +158,7 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
             slice_item = rel;
         }
         int tm, tn;
-        x_tile_coords(wgid, tp.tiles_m, tp.tiles_n, tm, tn);
+        x_tile_coords(wgid, tp.tiles_m, tp.tiles_n, tm, tn, tp.group_m);
         half_item = tp.half && item >= tp.n_main;
         a_ld = half_item ? LD / 2 : LD;                           // A rows staged per K tile: 64 per instruction
         m0 = __builtin_amdgcn_readfirstlane(tm * XBM + (half_item ? ((item - tp.n_main) & 1) * (XBM / 2) : 0));

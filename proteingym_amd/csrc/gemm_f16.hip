@@ -212,12 +212,12 @@ static int launch_bf16_cfg(const unsigned short* A, const unsigned short* W, con
 // C = residual + (sum acc) * out_scale + bias.  One workgroup per sliced tile, same thread <-> element map as the GEMM.
 __global__ __launch_bounds__(XNT) void splitk_fix_kernel(const float* __restrict__ ws, int split, int n_main, int tiles_m, int tiles_n,
                                                          const float* __restrict__ bias, const float* residual, float* Cf,
-                                                         int M, int N, float out_scale) {
+                                                         int M, int N, float out_scale, int group_m) {
     constexpr int WN = 4, TM = 4, TN = 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN, r = lane & 31, kh = lane >> 5;
     int tm, tn;
-    x_tile_coords(n_main + blockIdx.x, tiles_m, tiles_n, tm, tn);
+    x_tile_coords(n_main + blockIdx.x, tiles_m, tiles_n, tm, tn, group_m);
     const int m0 = tm * XBM, n0 = tn * XBN;
     const f32x4* src = reinterpret_cast<const f32x4*>(ws) + ((size_t)blockIdx.x * split * 8 + wave) * (TN * TM * 4 * 64) + lane;
     const size_t slice_stride = (size_t)8 * (TN * TM * 4 * 64);
@@ -284,11 +284,20 @@ static int x_num_cus() {
 }
 
 // stg: 0 register staging, 1 direct-to-LDS DMA, 3 the same with the DMA issued after the fragment reads (tuning).  splitk: allow K-sliced tail items (fp32-output GEMMs only).
+// Row panels per group of the grouped tile order.  An XCD's 32 concurrent tiles then cover ~g row panels x 32/g column panels: per K
+// step g A slices + 32/g W slices miss its L2.  W (the layer's weights, 6.5 - 26 MB) is shared by every tile of the launch and
+// stays in the Infinity Cache; A (the activations, 0.4 - 1.7 GB) streams from HBM: fewer A slices per step win although the slice
+// count is the same -- measured (scripts/gemm_ab.py, BLAT shape) g = 8 -> 4: QKV 400 -> 414, out 374 -> 383, FC2 419 -> 429 TFLOP/s,
+// FC1 unchanged; g = 2 within noise of 4, 16 / 32 / 64 worse.  Tile order does not touch a row's arithmetic: same bits.
+constexpr int kGroupM = 4;
+static thread_local int g_group_m = kGroupM;                      // variants 100 + g of launch_gemm16 override it (tuning only)
+
 static int launch_gemm16x_one(const unsigned short* A, const unsigned short* W,
                               const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
                               int M, int N, int K, int epilogue, float out_scale, int stg, bool splitk, hipStream_t s,
                               const QkvOut* qkv) {
     TilePlan tp{};
+    tp.group_m = g_group_m;
     tp.tiles_m = (M + XBM - 1) / XBM;
     tp.tiles_n = (N + XBN - 1) / XBN;
     const int T = tp.tiles_m * tp.tiles_n, G = x_num_cus(), nk = K / 32;
@@ -358,7 +367,7 @@ static int launch_gemm16x_one(const unsigned short* A, const unsigned short* W,
 #undef PGMI_LAUNCH16X
     if (tp.split > 1)
         hipLaunchKernelGGL(splitk_fix_kernel, dim3(T - tp.n_main), dim3(XNT), 0, s, tp.ws, tp.split, tp.n_main, tp.tiles_m,
-                           tp.tiles_n, bias, residual, Cf, M, N, out_scale);
+                           tp.tiles_n, bias, residual, Cf, M, N, out_scale, tp.group_m);
     PGMI_HIP(hipGetLastError());
     return PGMI_OK;
 }
@@ -423,7 +432,12 @@ int launch_gemm16(const unsigned short* A, size_t a_plane, const unsigned short*
             case 3: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 0, false, s);
             // measured (profiles/r2/README.md): with buffer loads the DMA form wins for every output kind (FFN 368 -> 379 TFLOP/s
             // against register staging for the fp32-output GEMMs)
-            default: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 1, true, s);
+            default: {
+                g_group_m = (variant >= 101 && variant <= 164) ? variant - 100 : kGroupM;      // 100 + g: the product kernel with g row panels per group
+                const int rc = launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 1, true, s);
+                g_group_m = kGroupM;
+                return rc;
+            }
         }
     }
     if (planes == 1 && bf) {

@@ -67,6 +67,7 @@ int main(int argc, char** argv) {
     tp.tiles_n = (N + XBN - 1) / XBN;
     tp.n_main = tp.n_items = tp.tiles_m * tp.tiles_n;
     tp.split = 1;
+    tp.group_m = 4;
     tp.diag = dbuf;
     tp.diag_flags = flags;
     const size_t lds_bytes = (size_t)2 * X_STAGE * 16;
