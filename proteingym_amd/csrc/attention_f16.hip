@@ -391,6 +391,7 @@ __global__ __launch_bounds__(256) void qkv_prep_conv_kernel(
     const float* __restrict__ qkv, const float* __restrict__ conv, int T, int H, int Tp,
     unsigned short* __restrict__ qk16, size_t qk_plane, unsigned short* __restrict__ vt16, size_t vt_plane) {
     constexpr int RSTR = 196;                                 // 192 floats (q|k|v of one head) + pad
+    constexpr int NLD = (38 * 48 + 255) / 256;                // float4 loads per thread: all issued before the first LDS store
     __shared__ __attribute__((aligned(16))) float raw[38 * RSTR];
     __shared__ __attribute__((aligned(16))) float cwl[3 * 8 * 64];   // [which][tap (7 = bias)][d]
     const int b = blockIdx.z, h = blockIdx.y, t0 = blockIdx.x * 32;
@@ -398,79 +399,85 @@ __global__ __launch_bounds__(256) void qkv_prep_conv_kernel(
     const int D = H * kHeadDim;
     const size_t RS = (size_t)3 * D;
     const int group = h / (H / 4);
-    for (int i = tid; i < 38 * 48; i += 256) {
+    f32x4 ld[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {                           // 8 independent 16-byte loads in flight per thread (round 2: a rolled
+        const int i = tid + 256 * k;                          // loop, one load waited for at a time -- 2.45 TB/s)
         const int row = i / 48, seg = (i % 48) >> 4, c4 = i & 15;
         const int t = t0 - 6 + row;
-        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-        if (t >= 0 && t < T)
-            v = *reinterpret_cast<const f32x4*>(qkv + ((size_t)b * T + t) * RS + (size_t)seg * D + h * kHeadDim + c4 * 4);
-        *reinterpret_cast<f32x4*>(&raw[row * RSTR + seg * 64 + c4 * 4]) = v;
+        ld[k] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (i < 38 * 48 && t >= 0 && t < T)
+            ld[k] = *reinterpret_cast<const f32x4*>(qkv + ((size_t)b * T + t) * RS + (size_t)seg * D + h * kHeadDim + c4 * 4);
     }
     for (int i = tid; i < 3 * 64 * 8; i += 256) {
         const int which = i >> 9, d = (i >> 3) & 63, j = i & 7;
         cwl[(which * 8 + j) * 64 + d] = conv[((size_t)(which * 4 + group) * kHeadDim + d) * 8 + j];
     }
+#pragma unroll
+    for (int k = 0; k < NLD; ++k) {
+        const int i = tid + 256 * k;
+        const int row = i / 48, seg = (i % 48) >> 4, c4 = i & 15;
+        if (i < 38 * 48) *reinterpret_cast<f32x4*>(&raw[row * RSTR + seg * 64 + c4 * 4]) = ld[k];
+    }
     __syncthreads();
-    // ---- q and k: unit (token, which, dims 4c..4c+3 and 32+4c..32+4c+3) ----------------------------
+    // ---- q and k: unit (token, which, dims 8c .. 8c+7): one 16-byte store per plane, 8 lanes per 128-byte row segment ----------
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int u = tid + 256 * it;
         const int which = u >> 8, tok = (u >> 3) & 31, c = u & 7;
         const int t = t0 + tok;
         if (t < T) {
-            f32x4 x1 = *reinterpret_cast<const f32x4*>(&cwl[(which * 8 + 7) * 64 + 4 * c]);
-            f32x4 x2 = *reinterpret_cast<const f32x4*>(&cwl[(which * 8 + 7) * 64 + 32 + 4 * c]);
+            f32x4 x1 = *reinterpret_cast<const f32x4*>(&cwl[(which * 8 + 7) * 64 + 8 * c]);
+            f32x4 x2 = *reinterpret_cast<const f32x4*>(&cwl[(which * 8 + 7) * 64 + 8 * c + 4]);
 #pragma unroll
             for (int j = 0; j < 7; ++j) {
-                const f32x4 w1 = *reinterpret_cast<const f32x4*>(&cwl[(which * 8 + j) * 64 + 4 * c]);
-                const f32x4 w2 = *reinterpret_cast<const f32x4*>(&cwl[(which * 8 + j) * 64 + 32 + 4 * c]);
-                const f32x4 a1 = *reinterpret_cast<const f32x4*>(&raw[(tok + j) * RSTR + which * 64 + 4 * c]);
-                const f32x4 a2 = *reinterpret_cast<const f32x4*>(&raw[(tok + j) * RSTR + which * 64 + 32 + 4 * c]);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(&cwl[(which * 8 + j) * 64 + 8 * c]);
+                const f32x4 w2 = *reinterpret_cast<const f32x4*>(&cwl[(which * 8 + j) * 64 + 8 * c + 4]);
+                const f32x4 a1 = *reinterpret_cast<const f32x4*>(&raw[(tok + j) * RSTR + which * 64 + 8 * c]);
+                const f32x4 a2 = *reinterpret_cast<const f32x4*>(&raw[(tok + j) * RSTR + which * 64 + 8 * c + 4]);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     x1[e] = fmaf(w1[e], a1[e], x1[e]);
                     x2[e] = fmaf(w2[e], a2[e], x2[e]);
                 }
             }
-            unsigned short* dst = qk16 + ((size_t)b * T + t) * (2 * D) + (size_t)which * D + h * kHeadDim + 4 * c;
             if (which == 0) {                        // base-2 softmax downstream: q carries log2(e) (common.h kQLog2e)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) { x1[e] *= kQLog2e; x2[e] *= kQLog2e; }
             }
+            _Float16 hh[8], ll[8];
 #pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const f32x4 x = half ? x2 : x1;
-                _Float16 hh[4], ll[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float xe = x[e];
-                    split_act(xe, hh[e], ll[e]);
-                }
-                *reinterpret_cast<u32x2*>(dst + 32 * half) = u32x2{pack_h2(hh[0], hh[1]), pack_h2(hh[2], hh[3])};
-                *reinterpret_cast<u32x2*>(dst + qk_plane + 32 * half) = u32x2{pack_h2(ll[0], ll[1]), pack_h2(ll[2], ll[3])};
+            for (int e = 0; e < 4; ++e) {
+                const float v1 = x1[e], v2 = x2[e];
+                split_act(v1, hh[e], ll[e]);
+                split_act(v2, hh[4 + e], ll[4 + e]);
             }
+            unsigned short* dst = qk16 + ((size_t)b * T + t) * (2 * D) + (size_t)which * D + h * kHeadDim + 8 * c;
+            *reinterpret_cast<u32x4*>(dst) = u32x4{pack_h2(hh[0], hh[1]), pack_h2(hh[2], hh[3]), pack_h2(hh[4], hh[5]), pack_h2(hh[6], hh[7])};
+            *reinterpret_cast<u32x4*>(dst + qk_plane) = u32x4{pack_h2(ll[0], ll[1]), pack_h2(ll[2], ll[3]), pack_h2(ll[4], ll[5]), pack_h2(ll[6], ll[7])};
         }
     }
-    // ---- v: thread (d, kq) transposes keys 8kq .. 8kq+7 of dimension d ------------------------------
+    // ---- v: thread (d, p) produces the 8 CONSECUTIVE POSITIONS 8p .. 8p+7 of row d of the transposed tile = keys 16a + 4b + 0..3 and
+    //      16a + 8 + 4b + 0..3 (a = p >> 1, b = p & 1: positions are keys with bits 2 and 3 swapped) -> one 16-byte store per plane ----
     {
-        const int d = tid & 63, kq = tid >> 6;
+        const int d = tid & 63, p = tid >> 6;
+        const int k1 = 16 * (p >> 1) + 4 * (p & 1);
         _Float16 hh[8], ll[8];
         float w[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) w[j] = cwl[(2 * 8 + j) * 64 + d];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
+            const int key = k1 + (e & 3) + 8 * (e >> 2);
             float y = w[7];
 #pragma unroll
-            for (int j = 0; j < 7; ++j) y = fmaf(w[j], raw[(8 * kq + e + j) * RSTR + 128 + d], y);
-            if (t0 + 8 * kq + e >= T) y = 0.0f;
+            for (int j = 0; j < 7; ++j) y = fmaf(w[j], raw[(key + j) * RSTR + 128 + d], y);
+            if (t0 + key >= T) y = 0.0f;
             split_act(y, hh[e], ll[e]);
         }
-        unsigned short* row = vt16 + (((size_t)b * H + h) * kHeadDim + d) * Tp + t0 + 16 * (kq >> 1) + 4 * (kq & 1);
-        *reinterpret_cast<u32x2*>(row) = u32x2{pack_h2(hh[0], hh[1]), pack_h2(hh[2], hh[3])};
-        *reinterpret_cast<u32x2*>(row + 8) = u32x2{pack_h2(hh[4], hh[5]), pack_h2(hh[6], hh[7])};
-        *reinterpret_cast<u32x2*>(row + vt_plane) = u32x2{pack_h2(ll[0], ll[1]), pack_h2(ll[2], ll[3])};
-        *reinterpret_cast<u32x2*>(row + vt_plane + 8) = u32x2{pack_h2(ll[4], ll[5]), pack_h2(ll[6], ll[7])};
+        unsigned short* row = vt16 + (((size_t)b * H + h) * kHeadDim + d) * Tp + t0 + 8 * p;
+        *reinterpret_cast<u32x4*>(row) = u32x4{pack_h2(hh[0], hh[1]), pack_h2(hh[2], hh[3]), pack_h2(hh[4], hh[5]), pack_h2(hh[6], hh[7])};
+        *reinterpret_cast<u32x4*>(row + vt_plane) = u32x4{pack_h2(ll[0], ll[1]), pack_h2(ll[2], ll[3]), pack_h2(ll[4], ll[5]), pack_h2(ll[6], ll[7])};
     }
 }
 

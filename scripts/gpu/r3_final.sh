@@ -15,6 +15,13 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_tr
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*agent_info.csv" -delete
 bash scripts/pmc_profile.sh r3 > $OUT/pmc.log 2>&1
 bash scripts/pmc_stalls.sh r3 > $OUT/pmc_stalls.log 2>&1
+# the causal / ALiBi flavour of the attention kernel and the depth-wise-conv prep pass (Tranception): issue-side counters, own pass
+mkdir -p $OUT/pmc_tr
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU --output-format csv -d $OUT/pmc_tr/sq -o p -- python scripts/bench_tranception.py --layers 4 --mutants 256 > $OUT/pmc_tr/sq.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_tr/fetch -o p -- python scripts/bench_tranception.py --layers 4 --mutants 256 > $OUT/pmc_tr/fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_tr/write -o p -- python scripts/bench_tranception.py --layers 4 --mutants 256 > $OUT/pmc_tr/write.log 2>&1
+python scripts/pmc_summarize.py $OUT/pmc_tr > $OUT/pmc_tranception_summary.txt 2>&1
+find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*agent_info.csv" -delete
 timeout 300 python scripts/att_bench.py --rounds 5 --configs 0:4:0:0,14:0:0:0 > $OUT/att_bench.log 2>&1
 cat $OUT/box.txt; tail -3 $OUT/gpu_suite.log; python - <<PY
 import json

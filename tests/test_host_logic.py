@@ -47,11 +47,14 @@ def test_alphabet_matches_oracle_and_reference_vocab():
     a = pesm.Alphabet()
     assert a.all_toks == eo.ALL_TOKS and len(a) == 33
     assert (a.cls_idx, a.padding_idx, a.eos_idx, a.unk_idx, a.mask_idx) == (0, 1, 2, 3, 32)
-    seq = "MKTAYIAKQXBZJ"
+    seq = "MKTAYIAKQXBZUO"
     _, _, t = a.get_batch_converter()([("p", seq), ("q", seq[:5])])
     assert np.array_equal(t[0], eo.tokenize(seq))
     assert t[1, 6] == a.eos_idx and (t[1, 7:] == a.padding_idx).all()
-    assert a.get_idx("J") == a.unk_idx
+    assert a.get_idx("J") == a.unk_idx                        # get_idx (mutant letters, data.py:125-126) maps unknown -> <unk> ...
+    with pytest.raises(KeyError):                             # ... the tokenizer (data.py:253-254) does not: 'J' is not in the vocabulary
+        a.get_batch_converter()([("p", "MKJ")])
+    assert a.encode("M K<mask>T") == [a.get_idx("M"), a.get_idx("K"), a.mask_idx, a.get_idx("T")]
 
 
 def test_parse_mutants_matches_label_row_parsing(lib):
