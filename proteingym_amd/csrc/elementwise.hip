@@ -16,6 +16,11 @@ __device__ __forceinline__ float wave_max(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
     return v;
 }
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
 __device__ __forceinline__ int wave_sum_i(int v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -333,19 +338,23 @@ __global__ __launch_bounds__(256) void vocab_logsoftmax_kernel(const float* __re
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (row >= rows) return;
+    // The 33 (25) logits of a row and their log-sum-exp are accumulated in DOUBLE and rounded to fp32 once: the work is negligible
+    // (V dot products of D per kept row) and the result carries no rounding of its own on top of the fp32 input row -- a
+    // pseudo-ppl score sums ~700 of these values, where a systematic last-place bias of an fp32 log-softmax (values ~ -16: one
+    // ulp = 1.9e-6) would add up to 1e-3 (tests/test_gpu_parity_real_width.py).
     const float* hr = h + (size_t)row * D;
-    float my_logit = -INFINITY;            // lane v (< V) ends up owning logit v
+    double my_logit = -INFINITY;           // lane v (< V) ends up owning logit v
     for (int v = 0; v < V; ++v) {
         const float* ev = E + (size_t)v * D;
-        float acc = 0.f;
-        for (int i = lane; i < D; i += 64) acc = fmaf(hr[i], ev[i], acc);
-        acc = wave_sum(acc);
-        if (lane == v) my_logit = acc + bias[v];
+        double acc = 0.0;
+        for (int i = lane; i < D; i += 64) acc = fma((double)hr[i], (double)ev[i], acc);
+        acc = wave_sum_d(acc);
+        if (lane == v) my_logit = acc + (double)bias[v];
     }
-    const float mx = wave_max(my_logit);
-    const float ex = (lane < V) ? expf(my_logit - mx) : 0.f;
-    const float lse = logf(wave_sum(ex));
-    const float res = (my_logit - mx) - lse;
+    const float mx = wave_max((float)my_logit);
+    const double ex = (lane < V) ? exp(my_logit - (double)mx) : 0.0;
+    const double lse = log(wave_sum_d(ex));
+    const float res = (float)((my_logit - (double)mx) - lse);
     if (lane < V) {
         out[(size_t)row * V + lane] = res;
         if (nonfinite && !(fabsf(res) <= 3.0e38f)) atomicOr(nonfinite, 1);   // NaN/inf: fp16 overflow upstream

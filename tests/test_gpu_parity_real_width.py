@@ -2,8 +2,9 @@
 
   * ESM-1v 650M through the 1 024-token window (16 of the 217 substitution assays are longer than 1 022 residues:
     every one of their forwards runs T = 1024 -- 32 key tiles per online softmax, learned positions up to 1 025);
-  * ESM2-650M pseudo-perplexity at BASELINE config 5's own shape (two ~735-residue members, 731 / 735-term sums) against
-    terms the UNMODIFIED reference model produced (tests/golden/make_golden_real_width.py);
+  * ESM2-650M pseudo-perplexity at BASELINE config 5's own shape (two ~735-residue members, 736 / 735-term sums) against
+    terms the UNMODIFIED reference model produced (tests/golden/make_golden_real_width.py), with the reference arithmetic's own
+    distance to fp64 frozen next to them;
   * Tranception-L shape at its full context (n_ctx 1024: 32 causal key tiles, ALiBi bias up to key 1 023), both reading
     directions, and a 1 100-residue protein through the optimal-window scorer;
   * ESM2-15B layer shape (5120 wide, 40 heads of 128, FFN 20480) at 8 layers.
@@ -112,20 +113,28 @@ def test_esm2_650m_pppl_735_residues_vs_reference(lib, golden_dir, precision):
     model = pesm.EsmModel(cfg, blob, device=0, precision=precision)
     lib_ = pesm.SequenceLibrary(model, seqs)
     scores, terms = lib_.score(want_terms=True)
+    # The sum bar.  A flat 1e-4 on a 736-term sum is not a meaningful bar at this size: the UNMODIFIED reference's own fp32 sum is
+    # 2.6e-3 away from the same sum in exact (fp64) arithmetic (terms64/0 of the fixture: per-term 2.4e-5, i.e. the per-term
+    # differences do not average out over the sum).  Held instead: every TERM within the flat 1e-4; the sum within 2x the
+    # reference's own distance to fp64, against the reference AND against fp64 (no worse than twice the reference's error).
+    ref_noise = abs(float(g["sum/0"]) - g["terms64/0"].sum()) if "terms64/0" in g else 2.6e-3
     for r, s in enumerate(seqs):
         ref = g[f"terms/{r}"]
         assert len(terms[r]) == len(ref) == len(s) - 2
         e_term = float(np.abs(terms[r].astype(np.float64) - ref).max())
         e_sum = abs(scores[r] - float(g[f"sum/{r}"]))
-        msg = f"[{precision}] ESM2-650M pseudo-ppl, member {r} ({len(s)} residues, {len(ref)} terms): per-term max|err| {e_term:.2e}; sum |err| {e_sum:.2e} on {float(g[f'sum/{r}']):.2f}"
+        msg = (f"[{precision}] ESM2-650M pseudo-ppl, member {r} ({len(s)} residues, {len(ref)} terms): per-term max|err| {e_term:.2e}; "
+               f"sum |err| {e_sum:.2e} on {float(g[f'sum/{r}']):.2f} (relative {e_sum / abs(float(g[f'sum/{r}'])):.1e})")
         if f"terms64/{r}" in g:
             t64 = g[f"terms64/{r}"]
+            e64 = abs(scores[r] - t64.sum())
             msg += (f"; the reference's own fp32 arithmetic vs fp64: per-term {np.abs(ref - t64).max():.2e}, sum {abs(float(g[f'sum/{r}']) - t64.sum()):.2e}"
-                    f"; HIP vs fp64: per-term {np.abs(terms[r] - t64).max():.2e}, sum {abs(scores[r] - t64.sum()):.2e}")
+                    f"; HIP vs fp64: per-term {np.abs(terms[r] - t64).max():.2e}, sum {e64:.2e}")
+            assert e64 < 2.0 * ref_noise
         print(msg)
         assert scores[r] == sum(float(v) for v in terms[r])                          # python's left-to-right double sum of the f32 terms
-        assert e_term < TOL
-        assert e_sum < TOL                                                           # flat, on a ~733-term sum
+        assert e_term < TOL                                                          # flat 1e-4 on every term
+        assert e_sum < max(TOL, 2.0 * ref_noise)
     # a member scored alone (another batch composition: what a rank of run_indels sees) has the SAME BITS
     for r in range(len(seqs)):
         alone, t_alone = lib_.score(first=r, count=1, want_terms=True)
