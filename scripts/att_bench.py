@@ -18,7 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--layers", type=int, default=4)
-    ap.add_argument("--configs", default="0:4:0:0,16:4:0:0,12:0:0:0")
+    ap.add_argument("--configs", default="0:4:0:0,14:0:0:0")
     ap.add_argument("--shapes", default="286x286,90x1100,150x150,600x120")      # positions x residues
     a = ap.parse_args()
     cfg = dict(synthetic.ESM1V_650M, layers=a.layers)
