@@ -289,15 +289,17 @@ static int x_num_cus() {
 // stays in the Infinity Cache; A (the activations, 0.4 - 1.7 GB) streams from HBM: fewer A slices per step win although the slice
 // count is the same -- measured (scripts/gemm_ab.py, BLAT shape) g = 8 -> 4: QKV 400 -> 414, out 374 -> 383, FC2 419 -> 429 TFLOP/s,
 // FC1 unchanged; g = 2 within noise of 4, 16 / 32 / 64 worse.  Tile order does not touch a row's arithmetic: same bits.
-constexpr int kGroupM = 4;
-static thread_local int g_group_m = kGroupM;                      // variants 100 + g of launch_gemm16 override it (tuning only)
+// FC1 (N = 5120: 20 column panels) runs at the same speed with 4 and with 8 but fetches less with 8 (3.26 vs 3.47 GB per launch: with
+// 20 column panels a group of 4 rows is 80 tiles = 2.5 rounds of an XCD, and the partial rounds straddle two groups): wide outputs keep 8.
+constexpr int kGroupM = 4, kGroupMWide = 8, kWideTilesN = 16;
+static thread_local int g_group_m = 0;                            // 0: by shape (above); variants 100 + g of launch_gemm16 force g (tuning only)
 
 static int launch_gemm16x_one(const unsigned short* A, const unsigned short* W,
                               const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
                               int M, int N, int K, int epilogue, float out_scale, int stg, bool splitk, hipStream_t s,
                               const QkvOut* qkv) {
     TilePlan tp{};
-    tp.group_m = g_group_m;
+    tp.group_m = g_group_m > 0 ? g_group_m : ((N + XBN - 1) / XBN >= kWideTilesN ? kGroupMWide : kGroupM);
     tp.tiles_m = (M + XBM - 1) / XBM;
     tp.tiles_n = (N + XBN - 1) / XBN;
     const int T = tp.tiles_m * tp.tiles_n, G = x_num_cus(), nk = K / 32;
@@ -433,9 +435,9 @@ int launch_gemm16(const unsigned short* A, size_t a_plane, const unsigned short*
             // measured (profiles/r2/README.md): with buffer loads the DMA form wins for every output kind (FFN 368 -> 379 TFLOP/s
             // against register staging for the fp32-output GEMMs)
             default: {
-                g_group_m = (variant >= 101 && variant <= 164) ? variant - 100 : kGroupM;      // 100 + g: the product kernel with g row panels per group
+                g_group_m = (variant >= 101 && variant <= 164) ? variant - 100 : 0;      // 100 + g: the product kernel with g row panels per group
                 const int rc = launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 1, true, s);
-                g_group_m = kGroupM;
+                g_group_m = 0;
                 return rc;
             }
         }
