@@ -356,13 +356,23 @@ def main():
     import torch
     from proteingym_amd import build_native, esm as pesm, synthetic
     build_native.build(verbose=False)
+    # PGMI_BENCH_SHARE_GPU=1 (rehearsal only, never a measurement): the ranks share the GPUs that exist (local_rank modulo the device
+    # count) and talk over gloo through host memory -- RCCL refuses two ranks on one device -- so that the N > 1 code path can run
+    # end to end on a one-GPU box
+    share = os.environ.get("PGMI_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+    cdev = "cpu" if share else "cuda"                                 # where collective buffers live
 
     cfg = dict(synthetic.ESM1V_650M, layers=args.layers)
     blob = synthetic.random_weights(cfg, seed=1)                      # same "checkpoint" on every rank
@@ -371,7 +381,7 @@ def main():
     assay = pesm.Assay(model, seq, muts, offset_idx=1)                # uploads: inputs resident in HBM
     n_mut = len(muts)
     scores_dev = torch.zeros(n_mut, dtype=torch.float64, device="cuda")
-    gathered = torch.zeros(world * n_mut, dtype=torch.float64, device="cuda") if world > 1 else None
+    gathered = torch.zeros(world * n_mut, dtype=torch.float64, device=cdev) if world > 1 else None
     extra = []                                                        # checkpoints 2..N of an ensemble step
     for c in range(1, args.checkpoints):
         m2 = pesm.EsmModel(cfg, synthetic.random_weights(cfg, seed=1 + c), device=local_rank, precision=args.precision)
@@ -384,7 +394,7 @@ def main():
                 a2.run_device_only(buf.data_ptr())
             scores_dev.add_(sum(buf for _, _, buf in extra)).div_(args.checkpoints)
         if world > 1:
-            dist.all_gather_into_tensor(gathered, scores_dev)         # RCCL over xGMI
+            dist.all_gather_into_tensor(gathered, scores_dev if not share else scores_dev.cpu())   # RCCL over xGMI
 
     def fence():
         if world > 1:
@@ -405,7 +415,7 @@ def main():
     dt = time.perf_counter() - t0
     model.profile_enable(False)
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -444,6 +454,7 @@ def main():
                            "precision": args.precision, "layers": args.layers},
                 "strong_scaling": st,
                 "weak_scaling": weak,
+                **({"REHEARSAL": "PGMI_BENCH_SHARE_GPU=1: ranks share a GPU and use gloo -- not a measurement"} if share else {}),
                 "roofline": {"bound": "mfma", "kernel": "gemm (fc1+GELU, fc2+residual), rank 0, all shapes of its share of the benchmark",
                              "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                              "avg_launch_ms": ffn_ms / max(ffn_n, 1), "traffic": None,

@@ -58,8 +58,11 @@ def run(model, rank: int, world: int, steps: int, warmup: int, torch, tdist, max
     per_rank = [sum(shapes[i]["n_total"] for i in part) for part in assignment]
     stride = max(max(per_rank), 1)
     dev = "cuda" if torch.cuda.is_available() else "cpu"
+    # collectives run on the device buffers over RCCL; with the gloo backend (CPU tests, and the two-ranks-on-one-GPU rehearsal
+    # PGMI_BENCH_SHARE_GPU=1) they are staged through host memory
+    cdev = dev if (world == 1 or tdist.get_backend() == "nccl") else "cpu"
     buf = torch.zeros(stride, dtype=torch.float64, device=dev)
-    gathered = torch.empty(world * stride, dtype=torch.float64, device=dev) if world > 1 else None
+    gathered = torch.empty(world * stride, dtype=torch.float64, device=cdev) if world > 1 else None
     offs = np.concatenate([[0], np.cumsum(n_rows)]).astype(np.int64)
 
     def run_items(a, b):
@@ -84,22 +87,22 @@ def run(model, rank: int, world: int, steps: int, warmup: int, torch, tdist, max
     for a, b in slices:
         run_items(a, b)
     if world > 1:
-        tdist.all_gather_into_tensor(gathered, buf)             # per-mutant score vectors of every rank, one collective
+        tdist.all_gather_into_tensor(gathered, buf if cdev == dev else buf.to(cdev))   # per-mutant score vectors of every rank, one collective
     fence()
     dt = time.perf_counter() - t0
     busy = dt
     if hasattr(model, "profile_enable"):
         model.profile_enable(False)
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=cdev)
         tdist.all_reduce(t, op=tdist.ReduceOp.MAX)
         dt = float(t.item())
-        tmin = torch.tensor([busy], dtype=torch.float64, device=dev)
+        tmin = torch.tensor([busy], dtype=torch.float64, device=cdev)
         tdist.all_reduce(tmin, op=tdist.ReduceOp.MIN)
         busy = float(tmin.item())
     positions = sum(int(len(a.positions)) for a in assays)
     flops = sum(len(a.positions) * pdist.forward_flops(a.T) for a in assays)
-    tot = torch.tensor([float(positions), float(flops)], dtype=torch.float64, device=dev)
+    tot = torch.tensor([float(positions), float(flops)], dtype=torch.float64, device=cdev)
     if world > 1:
         tdist.all_reduce(tot)
     for a in assays:
