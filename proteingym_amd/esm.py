@@ -533,10 +533,14 @@ def score_from_table(table: np.ndarray, mutants: Sequence[str], sequence: str, o
     substitution an f32 difference table[pos, mt] - table[pos, wt], accumulated in double in the order of the
     mutation string -- the arithmetic of the reference's ``.item()`` sum and of ``score_mutants_kernel``, so the
     result is bit-identical to ``Assay.run()``.  Used when the table was assembled from position shards."""
-    sub_pos, sub_wt, sub_mt, mut_off = parse_mutants(mutants, sequence, offset_idx)
+    return score_parsed(table, *parse_mutants(mutants, sequence, offset_idx))
+
+
+def score_parsed(table: np.ndarray, sub_pos, sub_wt, sub_mt, mut_off) -> np.ndarray:
+    """score_from_table on the arrays parse_mutants returns (callers that need the parse for something else as well)."""
     t = np.asarray(table, dtype=np.float32)
     diff = (t[sub_pos, sub_mt] - t[sub_pos, sub_wt]).astype(np.float64)
-    out = np.zeros(len(mutants), dtype=np.float64)
+    out = np.zeros(len(mut_off) - 1, dtype=np.float64)
     start = np.asarray(mut_off[:-1], dtype=np.int64)
     depth = np.asarray(mut_off[1:], dtype=np.int64) - start
     for j in range(int(depth.max()) if len(depth) else 0):  # j-th substitution of every mutant that has one:

@@ -50,6 +50,13 @@ def create_parser():
                         "chunks of masked positions inside assays (few, unequal assays: the log-prob tables are "
                         "gathered instead of the score vectors)")
     p.add_argument("--chunk-forwards", type=int, default=64, help="positions per work item with --shard positions")
+    p.add_argument("--batch-short-tokens", type=int, default=200,
+                   help="masked-marginals, --shard assay: assays of at most this many tokens (residues + 2) and at most --batch-short-rows "
+                        "mutants are scored several at a time -- their masked copies share one launch sequence, each padded to the group's "
+                        "longest member behind a key mask (a 40-residue protein alone is 42 x 42 rows: a sixth of one round of GEMM tiles); "
+                        "same bits as one assay at a time; 0 = off")
+    p.add_argument("--batch-short-rows", type=int, default=20000)
+    p.add_argument("--batch-group-rows", type=int, default=98304, help="cap on masked copies x padded tokens of one group")
     p.add_argument("--write", type=str, default="owner", choices=["owner", "rank0"],
                    help="--shard assay with N > 1: 'owner' = every rank writes the CSVs of the assays it scored (parallel "
                         "I/O; rank 0 still receives every score vector through the all_gather and writes "
@@ -100,6 +107,22 @@ def plan_assays(mapping, todo, world, n_checkpoints, strategy: str = "masked-mar
     return pdist.lpt_partition(costs, world)
 
 
+def plan_short_groups(candidates, n_tok, group_rows: int):
+    """Groups of short assays that share a launch sequence.  ``candidates``: assay ids; ``n_tok[i]``: tokens of assay i.  Sorted by
+    length so that the padding to the longest member stays small; a group is closed when (masked copies) x (padded tokens) --
+    bounded from above by every position of every member -- would pass ``group_rows``.  Groups of one are not groups."""
+    groups, cur, copies = [], [], 0
+    for i in sorted(candidates, key=lambda i: (n_tok[i], i)):
+        if cur and (copies + n_tok[i]) * n_tok[i] > group_rows:
+            groups.append(cur)
+            cur, copies = [], 0
+        cur.append(i)
+        copies += n_tok[i]
+    if cur:
+        groups.append(cur)
+    return [g for g in groups if len(g) > 1]
+
+
 class _DeviceScorer:
     """One checkpoint on this rank's GPU: score(seq, mutants, offset) = Assay.run()."""
 
@@ -122,6 +145,49 @@ class _DeviceScorer:
         self.create_s += t1 - t0
         self.run_s += t2 - t1
         return out
+
+    def score_group(self, assays):
+        """[(seq, mutants, offset), ...] of SHORT assays -> their score vectors, from ONE launch sequence: every masked copy of every
+        member is a row of one [copies, T] token matrix (T = the longest member; shorter ones end in <pad>, which the attention
+        masks as keys and the position / token-dropout arithmetic does not count: pgmi_masked_logprobs), the table rows come
+        back together and each member's mutants are looked up on the host (esm.score_parsed: the arithmetic of
+        score_mutants_kernel).  Bits equal score() member by member (tests/test_gpu_cli.py)."""
+        t0 = time.time()
+        conv = self.alphabet.get_batch_converter()
+        members = []
+        for seq, mutants, offset in assays:
+            _, _, toks = conv([("protein1", seq)])
+            wt = np.asarray(toks[0], dtype=np.int32)
+            parsed = pesm.parse_mutants(mutants, seq, int(offset))
+            pos = np.arange(wt.size, dtype=np.int32) if self.all_positions else np.unique(parsed[0]).astype(np.int32)
+            members.append((wt, parsed, pos))
+        T = max(wt.size for wt, _, _ in members)
+        copies = sum(pos.size for _, _, pos in members)
+        tokens = np.full((copies, T), self.alphabet.padding_idx, dtype=np.int32)
+        mask_pos = np.empty(copies, dtype=np.int32)
+        b = 0
+        for wt, _, pos in members:
+            tokens[b:b + pos.size, :wt.size] = wt
+            mask_pos[b:b + pos.size] = pos
+            b += pos.size
+        t1 = time.time()
+        rows = self.model.masked_logprobs(tokens, mask_pos) if copies else np.zeros((0, 33), dtype=np.float32)
+        t2 = time.time()
+        outs, b = [], 0
+        for wt, parsed, pos in members:
+            table = np.full((wt.size, rows.shape[1]), np.nan, dtype=np.float32)
+            table[pos] = rows[b:b + pos.size]
+            b += pos.size
+            outs.append(pesm.score_parsed(table, *parsed))
+        t3 = time.time()
+        work = [pos.size * pdist.forward_flops(wt.size) for wt, _, pos in members]
+        for (seq, mutants, _), (wt, _, pos), w in zip(assays, members, work):
+            share = w / max(sum(work), 1e-30)                  # the group's seconds, split by the members' algorithmic FLOPs
+            self.log.append(dict(seq_len=len(seq), rows=len(mutants), positions_run=int(pos.size), T=int(wt.size),
+                                 create_s=(t1 - t0 + t3 - t2) * share, run_s=(t2 - t1) * share, group_of=len(assays), padded_T=int(T)))
+        self.create_s += t1 - t0 + t3 - t2
+        self.run_s += t2 - t1
+        return outs
 
     def close(self):
         self.model.close()
@@ -224,8 +290,15 @@ def main(args, make_model=None):
     # both drop the GIL); every frame is kept: the checkpoint columns are added to it at the end
     rows_of = {i: int(mapping.iloc[i]["DMS_total_number_mutants"]) if "DMS_total_number_mutants" in mapping.columns else 0 for i in mine}
     order = sorted(mine, key=lambda i: -rows_of[i])      # most rows first: the CSV written last, un-overlapped, is a small one
+    # short assays with few rows go several at a time (score_group), after the others: they are the tail of `order` anyway
+    groups = []
+    if not wt_marginals and args.batch_short_tokens > 0:
+        n_tok = {i: len(str(mapping.iloc[i]["target_seq"])) + 2 for i in mine}
+        groups = plan_short_groups([i for i in mine if n_tok[i] <= args.batch_short_tokens and rows_of[i] <= args.batch_short_rows],
+                                   n_tok, args.batch_group_rows)
+    in_group = {i for g in groups for i in g}
     reader = ThreadPoolExecutor(max_workers=1)
-    for i in order:
+    for i in [i for i in order if i not in in_group] + [i for g in groups for i in g]:
         reads[i] = reader.submit(read_frame, i)
 
     def frame(i):
@@ -248,18 +321,27 @@ def main(args, make_model=None):
              else _DeviceScorer(loc, local_rank, args.precision, args.all_positions))
         clock["checkpoint_load_s"] = clock.get("checkpoint_load_s", 0.0) + time.time() - t
         last = ci == len(args.model_location) - 1
-        for i in order:
-            df, mutant_col, seq, offset = frame(i)
+        grouped = hasattr(model, "score_group") and bool(groups)
+        logged = []
+        for unit in ([[i] for i in order if i not in in_group] + groups) if grouped else [[i] for i in order]:
+            fr = [frame(i) for i in unit]
             t = time.time()
-            local.setdefault(i, []).append(np.asarray(model.score(seq, [str(m) for m in df[mutant_col]], offset), dtype=np.float64))
+            if len(unit) == 1:
+                df, mutant_col, seq, offset = fr[0]
+                got = [model.score(seq, [str(m) for m in df[mutant_col]], offset)]
+            else:
+                got = model.score_group([(seq, [str(m) for m in df[mutant_col]], offset) for df, mutant_col, seq, offset in fr])
             clock["score_s"] += time.time() - t
-            if last and writer is not None:
-                pending.append(writer.submit(_write_csv, _finish_frame(df, cols, ens_cols, local[i]),
-                                             os.path.join(args.dms_output, str(mapping.iloc[i]["DMS_id"]) + ".csv")))
+            logged += unit
+            for i, v, (df, _, _, _) in zip(unit, got, fr):
+                local.setdefault(i, []).append(np.asarray(v, dtype=np.float64))
+                if last and writer is not None:
+                    pending.append(writer.submit(_write_csv, _finish_frame(df, cols, ens_cols, local[i]),
+                                                 os.path.join(args.dms_output, str(mapping.iloc[i]["DMS_id"]) + ".csv")))
         for k in ("create_s", "run_s"):
             if hasattr(model, k):
                 clock["assay_" + k] = clock.get("assay_" + k, 0.0) + getattr(model, k)
-        assay_log += [dict(e, checkpoint=ci, DMS_id=str(mapping.iloc[i]["DMS_id"])) for e, i in zip(getattr(model, "log", []), order)]
+        assay_log += [dict(e, checkpoint=ci, DMS_id=str(mapping.iloc[i]["DMS_id"])) for e, i in zip(getattr(model, "log", []), logged)]
         model.close()
     t = time.time()
     for f in pending:

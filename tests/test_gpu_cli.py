@@ -143,3 +143,30 @@ def test_runner_wt_marginals_on_a_clinical_shaped_mapping_equals_the_cli(lib, go
     long = pd.read_csv(tmp_path / "runner" / "NP_TOY_LONG.2.csv")
     assert np.abs(long["esm1v_toy_1"].to_numpy() - golden["cli_wt_long/esm1v_toy_1"]).max() < TOL   # = the reference CLI's overlapping-window column
     assert [rb.wt_marginals_windows(n, "overlapping") for n in (500, 1024, 1025, 1535, 2047, 3425)] == [1, 1, 2, 2, 4, 6]
+
+
+@pytest.mark.parametrize("ckpts,model_type,extra", [(("esm1v_toy_1.pt", "esm1v_toy_2.pt"), "ESM1v", []), (("esm2_toy.pt",), "ESM2", []),
+                                                    (("esm1b_toy_lnb.pt",), "ESM1b", ["--all-positions"])])
+def test_runner_short_assay_groups_write_the_one_at_a_time_files(lib, golden_dir, tmp_path, ckpts, model_type, extra):
+    """run_benchmark scores short assays several at a time (every masked copy of every member in one launch sequence, padded to
+    the longest member behind a key mask, scored on the host from the table rows).  The CSVs must be byte-identical to the ones
+    written one assay at a time (--batch-short-tokens 0 = Assay.run per assay): lengths on both sides of the 32-key tile edges,
+    learned positions + token dropout (ESM-1v), LN-before (ESM-1b), rotary (ESM2), multi-mutants."""
+    from proteingym_amd import run_benchmark as rb, synthetic
+    rows = []
+    for k, L in enumerate((31, 40, 47, 62, 63, 90, 97, 130, 30)):
+        seq, muts, score = synthetic.random_assay(seed=40 + k, L=L, n_single=3 * L // 2, n_multi=12)
+        pd.DataFrame({"mutant": muts, "DMS_score": score}).to_csv(tmp_path / f"G{k}.csv", index=False)
+        rows.append({"DMS_id": f"G{k}", "DMS_filename": f"G{k}.csv", "target_seq": seq, "DMS_total_number_mutants": len(muts)})
+    pd.DataFrame(rows).to_csv(tmp_path / "map.csv", index=False)
+    common = ["--model-location", *[os.path.join(golden_dir, c) for c in ckpts], "--model_type", model_type,
+              "--dms_mapping", str(tmp_path / "map.csv"), "--dms-input", str(tmp_path), *extra]
+    st = rb.main(rb.create_parser().parse_args(common + ["--dms-output", str(tmp_path / "grouped"), "--batch-group-rows", "20000"]))
+    sizes = sorted({e.get("group_of", 1) for e in st["rank0_assays"]})
+    assert sizes[-1] > 1 and len([e for e in st["rank0_assays"] if e.get("group_of", 1) > 1]) >= 6 * len(ckpts)     # several groups, padded members
+    assert any(e.get("padded_T", e["T"]) > e["T"] for e in st["rank0_assays"])
+    rb.main(rb.create_parser().parse_args(common + ["--dms-output", str(tmp_path / "single"), "--batch-short-tokens", "0"]))
+    for r in rows:
+        a = open(tmp_path / "grouped" / f"{r['DMS_id']}.csv").read()
+        assert a == open(tmp_path / "single" / f"{r['DMS_id']}.csv").read(), r["DMS_id"]
+        assert "nan" not in a.lower()

@@ -250,3 +250,25 @@ def test_esm2_15b_width_8_layers_vs_oracle(lib):
           f"log-prob range {rng_lp:.1f}")
     assert err64 < TOL
     assert err32 < TOL + noise
+
+
+def test_esm1v_650m_short_assays_grouped_equal_one_at_a_time(lib):
+    """run_benchmark's short-assay groups at the REAL width (33 x 1280 x 20): three proteins of 40 / 57 / 95 residues, their masked
+    copies in one padded launch sequence, against one Assay.run() per protein -- every score bit for bit."""
+    from proteingym_amd import run_benchmark as rb
+    cfg = dict(synthetic.ESM1V_650M)
+    model = pesm.EsmModel(cfg, synthetic.random_weights(cfg, seed=1, embed_std=0.15), device=0, precision="f16x3")
+    sc = rb._DeviceScorer.__new__(rb._DeviceScorer)
+    sc.model, sc.alphabet, sc.all_positions, sc.log, sc.create_s, sc.run_s = model, pesm.Alphabet(), False, [], 0.0, 0.0
+    assays = []
+    for k, L in enumerate((40, 57, 95)):
+        seq, muts, _ = synthetic.random_assay(seed=70 + k, L=L, n_single=2 * L, n_multi=20)
+        assays.append((seq, muts, 1))
+    grouped = sc.score_group(assays)
+    for (seq, muts, off), g in zip(assays, grouped):
+        one = sc.score(seq, muts, off)
+        assert np.array_equal(np.asarray(g), np.asarray(one)), f"L={len(seq)}: max |diff| {np.abs(np.asarray(g) - np.asarray(one)).max():.3e}"
+        assert np.isfinite(one).all()
+    print(f"ESM-1v 650M short-assay group (40/57/95 residues, padded to 97 tokens): scores bit-identical to one assay at a time; "
+          f"group {sc.log[0]['run_s'] + sc.log[1]['run_s'] + sc.log[2]['run_s']:.3f} s vs one at a time {sum(e['run_s'] for e in sc.log[3:]):.3f} s")
+    model.close()

@@ -264,3 +264,75 @@ def test_checkpoint_loading_is_restricted_and_accepts_fused_in_proj(tmp_path, go
     torch.save({"args": raw["args"], "model": {"x": Evil()}}, bad)
     with pytest.raises(RuntimeError, match="PGMI_UNSAFE_TORCH_LOAD"):
         pesm.load_checkpoint_file(bad)
+
+
+# ---- run_benchmark: short assays scored several at a time (score_group) -------------------------------------------------
+def test_short_assay_groups_plan():
+    from proteingym_amd import run_benchmark as rb
+    n_tok = {0: 42, 1: 60, 2: 44, 3: 199, 4: 90, 5: 43, 6: 150}
+    groups = rb.plan_short_groups(list(n_tok), n_tok, group_rows=98304)
+    flat = [i for g in groups for i in g]
+    assert sorted(flat) == sorted(set(flat)) and set(flat) <= set(n_tok)
+    for g in groups:
+        assert len(g) > 1                                                     # a group of one is an ordinary assay
+        assert [n_tok[i] for i in g] == sorted(n_tok[i] for i in g)           # sorted by length: padding to the last member
+        assert sum(n_tok[i] for i in g) * max(n_tok[i] for i in g) <= 98304
+    assert groups[0][:3] == [0, 5, 2]
+    # a tight cap: every group still fits, nothing is lost except singletons
+    tight = rb.plan_short_groups(list(n_tok), n_tok, group_rows=6000)
+    assert all(sum(n_tok[i] for i in g) * max(n_tok[i] for i in g) <= 6000 for g in tight)
+    assert rb.plan_short_groups([3], n_tok, 98304) == [] and rb.plan_short_groups([], n_tok, 98304) == []
+
+
+class _GroupingFake:
+    """A scorer whose score_group must give what score gives, member by member; records how it was called."""
+    calls = []
+
+    def __init__(self, location):
+        self.salt = sum(map(ord, location))
+        self.log = []
+
+    def score(self, seq, mutants, offset):
+        _GroupingFake.calls.append(("one", len(seq)))
+        self.log.append(dict(seq_len=len(seq), rows=len(mutants), positions_run=1, T=len(seq) + 2, create_s=0.0, run_s=0.0))
+        return np.array([((self.salt * 31 + len(seq) * 7 + sum(map(ord, m))) % 1000) / 37.0 for m in mutants])
+
+    def score_group(self, assays):
+        _GroupingFake.calls.append(("group", tuple(len(s) for s, _, _ in assays)))
+        out = []
+        for seq, mutants, offset in assays:
+            out.append(np.array([((self.salt * 31 + len(seq) * 7 + sum(map(ord, m))) % 1000) / 37.0 for m in mutants]))
+            self.log.append(dict(seq_len=len(seq), rows=len(mutants), positions_run=1, T=len(seq) + 2, create_s=0.0, run_s=0.0))
+        return out
+
+    def close(self):
+        pass
+
+
+def test_runner_groups_short_assays_and_keeps_every_csv(tmp_path):
+    """Five assays, three of them short with few rows: the runner scores the long / many-row ones one at a time in its usual
+    order, then the short ones as ONE group; every CSV holds its own rows' scores; the per-assay log names the right assay."""
+    import pandas as pd
+    from proteingym_amd import run_benchmark as rb
+    rows, assays = [], {}
+    for k, (L, n) in enumerate(((40, 30), (300, 50), (60, 25), (45, 400), (52, 20))):
+        seq, muts, score = synthetic.random_assay(seed=20 + k, L=L, n_single=n, n_multi=4)
+        pd.DataFrame({"mutant": muts, "DMS_score": score}).to_csv(tmp_path / f"S{k}.csv", index=False)
+        rows.append({"DMS_id": f"S{k}", "DMS_filename": f"S{k}.csv", "target_seq": seq, "DMS_total_number_mutants": len(muts)})
+        assays[f"S{k}"] = (seq, muts)
+    pd.DataFrame(rows).to_csv(tmp_path / "map.csv", index=False)
+    common = ["--model-location", "ckA.pt", "ckB.pt", "--model_type", "ESM1v", "--dms_mapping", str(tmp_path / "map.csv"), "--dms-input", str(tmp_path)]
+    _GroupingFake.calls = []
+    st = rb.main(rb.create_parser().parse_args(common + ["--dms-output", str(tmp_path / "g"), "--batch-short-rows", "100"]), make_model=_GroupingFake)
+    per_ck = _GroupingFake.calls[: len(_GroupingFake.calls) // 2]
+    assert per_ck == [("one", 45), ("one", 300), ("group", (40, 52, 60))]          # 404-row S3 is short but has too many rows for a group
+    assert _GroupingFake.calls[len(per_ck):] == per_ck                          # same for the second checkpoint
+    _GroupingFake.calls = []
+    rb.main(rb.create_parser().parse_args(common + ["--dms-output", str(tmp_path / "n"), "--batch-short-tokens", "0"]), make_model=_GroupingFake)
+    assert all(kind == "one" for kind, _ in _GroupingFake.calls)
+    for name, (seq, muts) in assays.items():
+        assert open(tmp_path / "g" / f"{name}.csv").read() == open(tmp_path / "n" / f"{name}.csv").read()
+        got = pd.read_csv(tmp_path / "g" / f"{name}.csv", float_precision="round_trip")
+        assert np.array_equal(got["ckA"].to_numpy(), _GroupingFake("ckA.pt").score(seq, muts, 1)) and list(got["mutant"]) == muts
+    by_id = {(e["DMS_id"], e["checkpoint"]): e for e in st["rank0_assays"]}
+    assert len(by_id) == 10 and all(by_id[(f"S{k}", c)]["seq_len"] == len(assays[f"S{k}"][0]) for k in range(5) for c in range(2))
