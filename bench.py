@@ -122,7 +122,9 @@ def cpu_baseline(cfg, blob, seq, n_mut, budget_s, gpu_table=None):
     k = int(max(2, min(L, budget_s / reps / max(per_layer, 1e-6))))
     if k < L:
         fwd(3, k)                               # first touch of the k layers' weights: not timed
-    ts = [fwd(4 + r, k) for r in range(reps)]
+    else:                                       # full-depth forwards fit: as many of them as the budget holds (<= 32)
+        reps = int(max(3, min(32, budget_s / max(per_layer * L, 1e-6))))
+    ts = [fwd(1 + (3 + r) % (n_tok - 2), k) for r in range(reps)]
     per_fwd = float(np.mean(ts)) * L / k
     assay_s = per_fwd * n_tok                   # the reference runs all L+2 positions, batch 1
     out = {"value": n_mut / assay_s, "unit": "mutants/s", "cores": cores, "kind": "port",
