@@ -5,7 +5,7 @@ import os
 import numpy as np
 import pytest
 
-from proteingym_amd import esm as pesm
+from proteingym_amd import esm as pesm, synthetic
 
 pytestmark = pytest.mark.gpu
 
@@ -319,3 +319,37 @@ def test_spearman_vs_dms_score_identical_to_reference(models, golden, golden_dir
         ref = spearmanr(golden[f"cli/{name}"], df["DMS_score"]).correlation
         a.close()
         assert round(mine, 4) == round(ref, 4)
+
+
+@pytest.mark.parametrize("arch", ["esm1v", "esm2"])
+def test_window_edges_around_1022_residues_vs_oracle(lib, arch):
+    """The 1 024-token window is exactly full at 1 022 residues (compute_fitness.py:492-495, utils/scoring_utils.py:43-52): proteins
+    of 1 021 ... 1 025 residues sit on both sides of that edge (no window; window == sequence; first protein that is cropped, by
+    one and by three tokens).  Rows of the first / middle / last positions -- the three branches of get_optimal_window -- and a
+    multi-mutant across them, against the oracle at a narrow width (the window logic, the learned-position offsets inside a
+    cropped window and the rotary tables do not depend on the width)."""
+    from oracle import esm_oracle as eo
+    base = synthetic.ESM1V_650M if arch == "esm1v" else synthetic.ESM2_650M
+    cfg = dict(base, layers=2, embed_dim=128, heads=4, ffn_dim=256)
+    blob = synthetic.random_weights(cfg, seed=11, embed_std=0.3)
+    ocfg, W = eo.from_arrays(arrays=synthetic.blob_to_arrays(cfg, blob), **cfg)
+    model = pesm.EsmModel(cfg, blob, device=0, precision="f16x3")
+    rng = np.random.default_rng(5)
+    for L in (1021, 1022, 1023, 1025):
+        seq = synthetic.random_sequence(rng, L)
+        res = [1, 2, 511, 512, 513, L // 2, L - 512, L - 511, L - 1, L]          # 1-based residues = token positions
+        aa = [a for a in synthetic.AA]
+        subs = [f"{seq[p - 1]}{p}{next(a for a in aa if a != seq[p - 1])}" for p in res]
+        muts = subs + [":".join(subs[::3])]
+        assay = pesm.Assay(model, seq, muts)
+        scores, table = assay.run(want_table=True)
+        positions = [int(p) for p in assay.positions]
+        assert positions == sorted(set(res))
+        ref = eo.masked_marginals_table(ocfg, W, seq, positions=positions, batch=len(positions))
+        err_t = float(np.abs(table[positions] - ref[positions]).max())
+        ref_s = np.array([eo.label_row(m, seq, ref, 1) for m in muts])
+        err_s = float(np.abs(scores - ref_s).max())
+        print(f"[{arch}] L={L} (tokens {L + 2}): rows max|err| {err_t:.2e}, scores max|err| {err_s:.2e}")
+        assert err_t < 1e-4 and err_s < 1e-4
+        assay.close()
+    model.close()
