@@ -170,3 +170,32 @@ def test_runner_short_assay_groups_write_the_one_at_a_time_files(lib, golden_dir
         a = open(tmp_path / "grouped" / f"{r['DMS_id']}.csv").read()
         assert a == open(tmp_path / "single" / f"{r['DMS_id']}.csv").read(), r["DMS_id"]
         assert "nan" not in a.lower()
+
+
+def test_cli_wt_marginals_overlapping_beyond_two_windows(lib, golden_dir, tmp_path):
+    """wt-marginals, overlapping windows, on proteins of 1 023 ... 3 425 residues: two windows, the extra central window, the
+    stepping loop (four / five / six windows) -- every branch of compute_fitness.py:433-475 -- against the reference CLI's
+    scores (tests/golden/make_golden_wt_overlapping.py), through the single-assay CLI and the resident-model runner."""
+    from proteingym_amd import run_benchmark as rb
+    g = np.load(os.path.join(golden_dir, "golden_wt_overlapping.npz"))
+    ck = os.path.join(golden_dir, "esm1v_toy_1.pt")
+    rows = []
+    for n_tok in g["n_tok"]:
+        seq, muts = str(g[f"{n_tok}/seq"]), [str(m) for m in g[f"{n_tok}/mutants"]]
+        pd.DataFrame({"mutant": muts, "DMS_score": np.zeros(len(muts))}).to_csv(tmp_path / f"W{n_tok}.csv", index=False)
+        rows.append({"DMS_id": f"W{n_tok}", "DMS_filename": f"W{n_tok}.csv", "target_seq": seq, "file_length": len(seq)})
+    pd.DataFrame(rows).to_csv(tmp_path / "map.csv", index=False)
+    rb.main(rb.create_parser().parse_args(["--model-location", ck, "--model_type", "ESM1b", "--dms_mapping", str(tmp_path / "map.csv"),
+                                           "--dms-input", str(tmp_path), "--dms-output", str(tmp_path / "runner"),
+                                           "--scoring-strategy", "wt-marginals", "--scoring-window", "overlapping"]))
+    for k, n_tok in enumerate(g["n_tok"]):
+        want = g[f"{n_tok}/scores"]
+        got = pd.read_csv(tmp_path / "runner" / f"W{n_tok}.csv", float_precision="round_trip")["esm1v_toy_1"].to_numpy()
+        print(f"wt-marginals overlapping, {n_tok} tokens ({rb.wt_marginals_windows(int(n_tok), 'overlapping')} windows): max|err| {np.abs(got - want).max():.2e}")
+        assert np.abs(got - want).max() < TOL
+        if n_tok in (1538, 3000):                                    # the central-window branch also through the single-assay CLI
+            _run_cli(["--model-location", ck, "--model_type", "ESM1b", "--dms-input", str(tmp_path), "--dms-output", str(tmp_path / "cli"),
+                      "--scoring-strategy", "wt-marginals", "--scoring-window", "overlapping", "--dms_mapping", str(tmp_path / "map.csv"),
+                      "--dms_index", str(k)])
+            one = pd.read_csv(tmp_path / "cli" / f"W{n_tok}.csv", float_precision="round_trip")["esm1v_toy_1"].to_numpy()
+            assert np.array_equal(one, got)

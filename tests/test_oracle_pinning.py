@@ -526,3 +526,29 @@ def test_oracle_head_dim_128_reproduces_reference(golden_dir, golden):
     df = pd.read_csv(os.path.join(golden_dir, "TOY_DMS.csv"))
     got = np.array([eo.label_row(m, seq, table, 1) for m in df["mutant"]])
     assert np.abs(got - g["cli"]).max() < 5e-5
+
+
+@pytest.mark.parametrize("n_tok", [1025, 1537, 1538, 2048, 3000, 3427])
+def test_wt_marginals_overlapping_windows_beyond_two(golden_dir, n_tok):
+    """wt-marginals with overlapping windows on proteins that take the stepping loop and the central window
+    (compute_fitness.py:433-475; tests/golden/make_golden_wt_overlapping.py ran the unmodified reference CLI): the oracle's
+    restatement, the product's host blend over oracle-backed forwards, and the runner's window count, branch by branch."""
+    from proteingym_amd import compute_fitness as cf, esm as pesm, run_benchmark as rb
+    g = np.load(os.path.join(golden_dir, "golden_wt_overlapping.npz"))
+    seq, muts, want = str(g[f"{n_tok}/seq"]), [str(m) for m in g[f"{n_tok}/mutants"]], g[f"{n_tok}/scores"]
+    assert len(seq) + 2 == n_tok
+    ck = os.path.join(golden_dir, "esm1v_toy_1.pt")
+    got = eo.score_dms([ck], seq, muts, strategy="wt-marginals", model_type=["ESM1b"], scoring_window="overlapping")["esm1v_toy_1"]
+    assert np.abs(got - want).max() < 2e-5
+
+    class Counting(_OracleBackedEsm):
+        windows = 0
+
+        def token_logprobs(self, tokens):
+            Counting.windows += len(tokens)
+            return super().token_logprobs(tokens)
+
+    table = cf.wt_marginals_table(Counting(ck), pesm.Alphabet(), seq, "overlapping")
+    mine = np.array([cf.label_row(m, seq, table, pesm.Alphabet(), 1) for m in muts])
+    assert np.abs(mine - want).max() < 2e-5
+    assert Counting.windows == rb.wt_marginals_windows(n_tok, "overlapping") == {1025: 2, 1537: 2, 1538: 3, 2048: 4, 3000: 5, 3427: 6}[n_tok]
