@@ -353,3 +353,50 @@ def test_window_edges_around_1022_residues_vs_oracle(lib, arch):
         assert err_t < 1e-4 and err_s < 1e-4
         assay.close()
     model.close()
+
+
+def test_esm2_beyond_1024_tokens_vs_oracle(lib):
+    """ESM2 has no positional table, so the reference runs it at ANY length where it does not window: wt-marginals without
+    --scoring-window overlapping (compute_fitness.py:476: the whole protein in one forward) and pseudo-ppl (:258-279: no window at
+    all).  A 1 500-residue forward and the pseudo-ppl of a 1 030-residue sequence -- rotary angles and attention tiles beyond
+    1 024 tokens -- against the oracle; the ESM-1b arch refuses the same input like the reference's positional embedding does."""
+    import torch
+    from oracle import esm_oracle as eo
+    torch.set_num_threads(max(1, __import__("bench").usable_cores()))
+    cfg = dict(synthetic.ESM2_650M, layers=2, embed_dim=128, heads=4, ffn_dim=256)
+    blob = synthetic.random_weights(cfg, seed=13, embed_std=0.3)
+    ocfg, W = eo.from_arrays(arrays=synthetic.blob_to_arrays(cfg, blob), **cfg)
+    model = pesm.EsmModel(cfg, blob, device=0, precision="f16x3")
+    rng = np.random.default_rng(8)
+    seq = synthetic.random_sequence(rng, 1500)
+    toks = eo.tokenize(seq)
+    got = model.token_logprobs(toks[None])[0]
+    with torch.no_grad():
+        ref = torch.log_softmax(eo.forward_logits(ocfg, W, toks[None]), dim=-1)[0].numpy()
+    err = float(np.abs(got - ref).max())
+    print(f"ESM2 one forward of {len(toks)} tokens: max|err| {err:.2e}")
+    assert err < TOL
+    seq2 = synthetic.random_sequence(rng, 1030)
+    lib2 = pesm.SequenceLibrary(model, [seq2])
+    s, terms = lib2.score(want_terms=True)
+    assert len(terms[0]) == len(seq2) - 2 and abs(float(s[0]) - float(np.sum(terms[0], dtype=np.float64))) < 1e-9
+    # the terms at 20 positions (both ends, around token 1 024, beyond it), each from its own oracle forward with compute_pppl's
+    # indexing (oracle/esm_oracle.py:293-305: token i masked, the letter sequence[i] looked up); the sum of all 1 028 terms carries
+    # ~1e-3 of fp32 accumulation noise on either side (tests/test_gpu_parity_real_width.py), so the terms are what is compared
+    t2 = eo.tokenize(seq2)
+    worst = 0.0
+    for i in [1, 2, 3, 511, 512, 1020, 1021, 1022, 1023, 1024, 1025, 1026, 1027, 1028] + [int(x) for x in rng.integers(4, 1028, 6)]:
+        t = t2.copy()
+        t[i] = eo.MASK
+        with torch.no_grad():
+            want = float(torch.log_softmax(eo.forward_logits(ocfg, W, t[None]), dim=-1)[0, i, eo.get_idx(seq2[i])])
+        worst = max(worst, abs(float(terms[0][i - 1]) - want))
+    print(f"ESM2 pseudo-ppl of a 1 030-residue sequence ({len(terms[0])} terms, 1 032 tokens): per-term max|err| {worst:.2e} at 20 positions")
+    assert worst < TOL
+    lib2.close()
+    model.close()
+    cfg1 = dict(synthetic.ESM1V_650M, layers=2, embed_dim=128, heads=4, ffn_dim=256)
+    m1 = pesm.EsmModel(cfg1, synthetic.random_weights(cfg1, seed=13, embed_std=0.3), device=0, precision="f16x3")
+    with pytest.raises(pesm.PgmiError, match="above maximum sequence length"):
+        m1.token_logprobs(toks[None])
+    m1.close()
