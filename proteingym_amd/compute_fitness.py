@@ -126,41 +126,49 @@ def compute_pppl_msa(sequence, model, alphabet, msa_rows):
     return sum(total)
 
 
+def window_blend_weights():
+    """Weight of a token by its place in a 1 024-token window when overlapping windows are averaged (compute_fitness.py:439-443):
+    1 in the middle, a logistic ramp centred 128 tokens inside either edge (scale 16) over tokens 1..256 and 766..1022; the
+    first and the last token of a window keep weight 1.  Evaluated in double, stored in float32, as the reference does."""
+    w = np.ones(1024, dtype=np.float32)
+    w[1:257] = [1 / (1 + math.exp(-(i - 128) / 16)) for i in range(1, 257)]
+    w[766:1023] = [1 / (1 + math.exp((i - 894) / 16)) for i in range(766, 1023)]
+    return w
+
+
+def overlapping_windows(n_tok: int):
+    """[(first, last)] token spans of the 1 024-token windows that cover a protein of n_tok > 1 024 tokens, in the order the
+    reference accumulates them (compute_fitness.py:444-470): a left window from token 0 and a right window ending at the last
+    token, both stepped inwards by 511 until they overlap; one more window around the middle when that last overlap is
+    narrower than 511 tokens.  ``run_benchmark`` prices an assay by the length of this list."""
+    left, right = 0, n_tok - 1024
+    spans = [(left, left + 1023), (right, right + 1023)]
+    while left + 1023 <= right:
+        left, right = left + 511, right - 511
+        spans += [(left, left + 1023), (right, right + 1023)]
+    if left + 1023 - right + 1 < 511:
+        centre = int(n_tok / 2) - 512
+        spans.append((centre, centre + 1023))
+    return spans
+
+
 def wt_marginals_table(model, alphabet, sequence, scoring_window):
-    """compute_fitness.py:433-475."""
+    """compute_fitness.py:433-475: the log-prob table of the unmasked wild type -- one forward, or with ``overlapping`` above
+    1 024 tokens the weighted mean of the windows' tables (all windows go through the model as one batch; the sums run in
+    float32 in the reference's order, so the blend has the reference's bits given the same window tables)."""
     _, _, batch_tokens = alphabet.get_batch_converter()([("protein1", sequence)])
-    seq_len = batch_tokens.shape[1]
-    if seq_len > 1024 and scoring_window == "overlapping":
-        token_probs = np.zeros((1, seq_len, len(alphabet)), dtype=np.float32)
-        token_weights = np.zeros((1, seq_len), dtype=np.float32)
-        weights = np.ones(1024, dtype=np.float32)          # 1 for 256<=i<1022-256
-        for i in range(1, 257):
-            weights[i] = 1 / (1 + math.exp(-(i - 128) / 16))
-        for i in range(1022 - 256, 1023):
-            weights[i] = 1 / (1 + math.exp((i - 1022 + 128) / 16))
-        start_left_window, end_left_window = 0, 1023
-        start_right_window = (seq_len - 1) - 1024 + 1
-        end_right_window = seq_len - 1
-        windows = []
-        while True:
-            windows.append((start_left_window, end_left_window))
-            windows.append((start_right_window, end_right_window))
-            if end_left_window > start_right_window:
-                break
-            start_left_window += 511; end_left_window += 511
-            start_right_window -= 511; end_right_window -= 511
-        final_overlap = end_left_window - start_right_window + 1
-        if final_overlap < 511:
-            start_central_window = int(seq_len / 2) - 512
-            windows.append((start_central_window, start_central_window + 1023))
-        lps = model.token_logprobs(np.stack([batch_tokens[0, s:e + 1] for s, e in windows]))
-        for (s, e), lp in zip(windows, lps):               # same accumulation order as the reference
-            token_probs[:, s:e + 1] += lp * weights.reshape(-1, 1)
-            token_weights[:, s:e + 1] += weights
-        token_probs = token_probs / token_weights.reshape(1, -1, 1)
-    else:
-        token_probs = model.token_logprobs(batch_tokens)
-    return token_probs
+    n_tok = batch_tokens.shape[1]
+    if n_tok <= 1024 or scoring_window != "overlapping":
+        return model.token_logprobs(batch_tokens)
+    spans = overlapping_windows(n_tok)
+    weights = window_blend_weights()
+    tables = model.token_logprobs(np.stack([batch_tokens[0, a:b + 1] for a, b in spans]))
+    total = np.zeros((1, n_tok, len(alphabet)), dtype=np.float32)
+    norm = np.zeros((1, n_tok), dtype=np.float32)
+    for (a, b), t in zip(spans, tables):
+        total[:, a:b + 1] += t * weights.reshape(-1, 1)
+        norm[:, a:b + 1] += weights
+    return total / norm.reshape(1, -1, 1)
 
 
 def _cell(row, name, default):

@@ -78,15 +78,11 @@ WT_MARGINALS_FIXED_S = 3.0e-3     # launch-bound floor of one unmasked forward +
 
 def wt_marginals_windows(n_tok: int, scoring_window: str) -> int:
     """Forwards wt-marginals runs for a protein of n_tok tokens (compute_fitness.py:433-475): one, or with 'overlapping'
-    above 1024 tokens the left/right window pairs stepped by 511 (+ a central one when the last pair barely overlaps)."""
+    above 1024 tokens the windows ``compute_fitness.overlapping_windows`` lists."""
     if n_tok <= 1024 or scoring_window != "overlapping":
         return 1
-    n, el, sr = 2, 1023, n_tok - 1024
-    while el <= sr:
-        el += 511
-        sr -= 511
-        n += 2
-    return n + (1 if el - sr + 1 < 511 else 0)
+    from .compute_fitness import overlapping_windows
+    return len(overlapping_windows(n_tok))
 
 
 def assay_seconds(seq_len: int, n_rows: int, n_checkpoints: int, strategy: str = "masked-marginals",
