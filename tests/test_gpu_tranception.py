@@ -173,3 +173,31 @@ def test_run_sharded_mutant_chunks_equal_the_cli(lib, gold, golden_dir, tmp_path
     for i, name in enumerate(("A", "B")):
         cli.main(cli.create_parser().parse_args(common + ["--output_scores_folder", str(tmp_path / "single"), "--DMS_index", str(i)]))
         assert open(tmp_path / "sharded" / f"{name}.csv").read() == open(tmp_path / "single" / f"{name}.csv").read()
+
+
+def test_context_edges_around_1022_residues_vs_oracle(lib):
+    """The Tranception context holds 1 022 residues + [CLS] / [SEP] (scoring_utils.py:152-203: a protein that fits is scored
+    whole, a longer one through the optimal window of every mutant, Delta to the wild type OF THE SAME WINDOW): proteins of
+    1 021 ... 1 025 residues on both sides of that edge, mutants at the ends, at the window's centre and just off it, both
+    reading directions, against the oracle's scorer at a narrow width (2 layers x 256, 4 heads of 64)."""
+    import torch
+    from oracle import tranception_oracle as to
+    from proteingym_amd import synthetic, tranception as ptr
+    cfg = dict(synthetic.TRANCEPTION_L, layers=2, embed_dim=256, heads=4, ffn_dim=1024)
+    blob = synthetic.random_tranception_weights(cfg, seed=5)
+    model = ptr.TranceptionModel(cfg, blob, device=0)
+    ocfg, W = to.from_arrays(arrays=synthetic.tranception_blob_to_arrays(cfg, blob), **cfg)
+    rng = np.random.default_rng(77)
+    for L in (1021, 1022, 1023, 1025):
+        wt = "".join(rng.choice(list(synthetic.AA), size=L))
+        muts = [f"{wt[p - 1]}{p}{'A' if wt[p - 1] != 'A' else 'C'}" for p in (1, 2, 510, 511, 512, 513, L // 2, L - 511, L - 1, L)]
+        muts.append(":".join(muts[::4]))
+        df = pd.DataFrame({"mutant": muts, "mutated_sequence": [ptr.get_mutated_sequence(wt, m) for m in muts]})
+        with torch.no_grad():
+            want = to.score_mutants(ocfg, W, df, wt)
+        have = model.score_mutants(DMS_data=df, target_seq=wt)
+        assert list(have["mutated_sequence"]) == list(want["mutated_sequence"])
+        worst = max(float(np.abs(have[c].to_numpy() - want[c].to_numpy()).max()) for c in ("avg_score_L_to_R", "avg_score_R_to_L", "avg_score"))
+        print(f"Tranception, {L} residues: avg scores max|err| {worst:.2e}")
+        assert worst < TOL
+    model.close()
