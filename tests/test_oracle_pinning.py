@@ -552,3 +552,100 @@ def test_wt_marginals_overlapping_windows_beyond_two(golden_dir, n_tok):
     mine = np.array([cf.label_row(m, seq, table, pesm.Alphabet(), 1) for m in muts])
     assert np.abs(mine - want).max() < 2e-5
     assert Counting.windows == rb.wt_marginals_windows(n_tok, "overlapping") == {1025: 2, 1537: 2, 1538: 3, 2048: 4, 3000: 5, 3427: 6}[n_tok]
+
+
+class _FakeEsmScorer:
+    """Device stand-in for the runner's test seam: a deterministic score per (checkpoint, mutant)."""
+
+    def __init__(self, location):
+        self.salt = sum(map(ord, os.path.basename(location)))
+
+    def score(self, seq, mutants, offset):
+        return np.array([((self.salt * 31 + len(seq) * 7 + sum(map(ord, m))) % 1000) / 37.0 - 13.0 for m in mutants])
+
+    def close(self):
+        pass
+
+
+@pytest.mark.skipif(not rh.reference_available(), reason="/root/reference not present (GPU box)")
+def test_reference_merge_script_consumes_the_runners_csvs(tmp_path, monkeypatch):
+    """The CONSUMER side of the drop-in boundary: the reference's own proteingym/merge.py, with the registry entries of
+    its own config.json (key column, score column, folder, directionality), reads the CSVs that run_benchmark (ESM-1v x 5 +
+    ensemble; ESM2-3B) and run_sharded tranception write -- device calls replaced by stand-ins, everything that shapes the files is
+    the product's -- and merges every model column onto the assay, one row per mutant."""
+    import importlib.util
+    import json
+    import sys
+    from proteingym_amd import run_benchmark as rb, run_sharded, synthetic, tranception as ptr
+    from test_dist_cpu import _fake_tranception
+    # one assay in ProteinGym's own file layout
+    seq, muts, score = synthetic.random_assay(seed=3, L=50, n_single=40, n_multi=12)
+    dms = tmp_path / "dms"
+    dms.mkdir()
+    assay = pd.DataFrame({"mutant": muts, "mutated_sequence": [ptr.get_mutated_sequence(seq, m) for m in muts], "DMS_score": score,
+                          "DMS_score_bin": (score > 0).astype(int)})
+    assay.to_csv(dms / "TOY_A.csv", index=False)
+    pd.DataFrame([{"DMS_id": "TOY_A", "DMS_filename": "TOY_A.csv", "target_seq": seq, "DMS_total_number_mutants": len(muts),
+                   "MSA_filename": "x.a2m", "MSA_start": 1, "MSA_end": len(seq), "weight_file_name": "x.npy"}]).to_csv(tmp_path / "ref.csv", index=False)
+    registry = json.load(open("/root/reference/config.json"))["model_list_zero_shot_substitutions_DMS"]
+    models = {k: registry[k] for k in ("ESM1v_single", "ESM1v_ensemble", "ESM2_3B", "Tranception_L_no_retrieval")}
+    scores = tmp_path / "scores"
+    # ESM-1v: five checkpoints named like the released files -> <scores>/ESM1v ; ESM2-3B -> <scores>/ESM2/3B
+    stems = [f"esm1v_t33_650M_UR90S_{k}" for k in range(1, 6)]
+    common = ["--dms_mapping", str(tmp_path / "ref.csv"), "--dms-input", str(dms)]
+    rb.main(rb.create_parser().parse_args(["--model-location", *[f"/ckpt/{s}.pt" for s in stems], "--model_type", "ESM1v", *common,
+                                           "--dms-output", str(scores / models["ESM1v_ensemble"]["location"])]), make_model=_FakeEsmScorer)
+    rb.main(rb.create_parser().parse_args(["--model-location", "/ckpt/esm2_t36_3B_UR50D.pt", "--model_type", "ESM2", *common,
+                                           "--dms-output", str(scores / models["ESM2_3B"]["location"])]), make_model=_FakeEsmScorer)
+    run_sharded.main(["tranception", "--", "--checkpoint", "fake", "--DMS_reference_file_path", str(tmp_path / "ref.csv"),
+                      "--DMS_data_folder", str(dms), "--output_scores_folder", str(scores / models["Tranception_L_no_retrieval"]["location"])],
+                     make_model=_fake_tranception)
+    cfg = {"model_list_zero_shot_substitutions_DMS": models}
+    json.dump(cfg, open(tmp_path / "config.json", "w"))
+    spec = importlib.util.spec_from_file_location("pg_reference_merge", "/root/reference/proteingym/merge.py")
+    merge = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(merge)
+    monkeypatch.setattr(sys, "argv", ["merge.py", "--DMS_assays_location", str(dms), "--model_scores_location", str(scores),
+                                      "--DMS_reference_file", str(tmp_path / "ref.csv"), "--config_file", str(tmp_path / "config.json")])
+    merge.main()
+    merged = pd.read_csv(scores / "merged_scores" / "TOY_A.csv")
+    assert len(merged) == len(assay) and list(merged["mutant"]) == muts
+    ours = pd.read_csv(scores / "ESM1v" / "TOY_A.csv")
+    assert list(ours.columns) == list(assay.columns) + stems + ["Ensemble_ESM1v"]
+    assert np.allclose(merged["ESM1v_ensemble"], ours["Ensemble_ESM1v"]) and np.allclose(merged["ESM1v_single"], ours[stems[0]])
+    assert np.allclose(merged["ESM2_3B"], pd.read_csv(scores / "ESM2" / "3B" / "TOY_A.csv")["esm2_t36_3B_UR50D"])
+    tr = pd.read_csv(scores / "Tranception_no_retrieval" / "Tranception_L" / "TOY_A.csv").drop_duplicates("mutated_sequence").set_index("mutated_sequence")
+    assert np.allclose(merged["Tranception_L_no_retrieval"], tr.loc[merged["mutated_sequence"], "avg_score"].to_numpy())
+    assert not merged[list(models)].isna().any().any()
+
+
+@pytest.mark.skipif(not rh.reference_available(), reason="/root/reference not present (GPU box)")
+def test_reference_merge_script_consumes_the_indel_csvs(tmp_path, monkeypatch):
+    """Same for the indel benchmark (merge.py --mutation_type indels; key mutated_sequence): run_sharded tranception --indel_mode."""
+    import importlib.util
+    import json
+    import sys
+    from proteingym_amd import run_sharded, synthetic
+    from test_dist_cpu import _fake_tranception
+    wt, lib_ = synthetic.random_indel_library(4, 48, 30)
+    dms = tmp_path / "dms"
+    dms.mkdir()
+    assay = pd.DataFrame({"mutant": lib_, "mutated_sequence": lib_, "DMS_score": np.linspace(-1, 1, len(lib_)), "DMS_score_bin": [0, 1] * (len(lib_) // 2)})
+    assay.to_csv(dms / "TOY_I.csv", index=False)
+    pd.DataFrame([{"DMS_id": "TOY_I", "DMS_filename": "TOY_I.csv", "target_seq": wt, "DMS_total_number_mutants": len(lib_)}]).to_csv(tmp_path / "ref.csv", index=False)
+    registry = json.load(open("/root/reference/config.json"))["model_list_zero_shot_indels_DMS"]
+    models = {"Tranception_L_no_retrieval": registry["Tranception_L_no_retrieval"]}
+    scores = tmp_path / "scores"
+    run_sharded.main(["tranception", "--", "--checkpoint", "fake", "--DMS_reference_file_path", str(tmp_path / "ref.csv"), "--DMS_data_folder", str(dms),
+                      "--output_scores_folder", str(scores / models["Tranception_L_no_retrieval"]["location"]), "--indel_mode"], make_model=_fake_tranception)
+    json.dump({"model_list_zero_shot_indels_DMS": models}, open(tmp_path / "config.json", "w"))
+    spec = importlib.util.spec_from_file_location("pg_reference_merge_indels", "/root/reference/proteingym/merge.py")
+    merge = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(merge)
+    monkeypatch.setattr(sys, "argv", ["merge.py", "--DMS_assays_location", str(dms), "--model_scores_location", str(scores), "--mutation_type", "indels",
+                                      "--DMS_reference_file", str(tmp_path / "ref.csv"), "--config_file", str(tmp_path / "config.json")])
+    merge.main()
+    merged = pd.read_csv(scores / "merged_scores" / "TOY_I.csv")
+    tr = pd.read_csv(scores / "Tranception_no_retrieval" / "Tranception_L" / "TOY_I.csv").drop_duplicates("mutated_sequence").set_index("mutated_sequence")
+    assert len(merged) == len(assay) and not merged["Tranception_L_no_retrieval"].isna().any()
+    assert np.allclose(merged["Tranception_L_no_retrieval"], tr.loc[merged["mutated_sequence"], "avg_score"].to_numpy())
