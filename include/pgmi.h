@@ -238,7 +238,9 @@ int pgmi_tr_sequence_loglik(pgmi_model* m, const int32_t* tokens, const int32_t*
                             const int32_t* prior_n, const int32_t* prior_flip, float alpha, float* out);
 
 /* Tuning utility: times `iters` launches of the production GEMM (device-resident random operands,
- * HIP events) for one shape; variant selects the tile configuration (negative = library default).
+ * HIP events) for one shape; variant selects the launch parameters (negative or below 1000 = library default;
+ * 1000 + t: see gemm_f16.hip set_tune).  split_out: 0 fp32 output, 1 split fp16 planes (the next GEMM's operand),
+ * 2 fp32 output with the in-place residual of the out-projection / FC2, 3 the fused QKV epilogue (N = 3 D).
  * Writes the mean milliseconds per launch. */
 int pgmi_bench_gemm(int device, int precision, int M, int N, int K, int epilogue, int split_out,
                     int variant, int iters, double* ms_per_launch);

@@ -958,7 +958,7 @@ int pgmi_model_create(const pgmi_config* cfg, const float* w, int64_t n_weights,
         PGMI_HIP(hipMemset(m->vt16, 0, m->vt16_plane * 2 * sizeof(unsigned short)));
     }
     m->keep_rows = env_int("PGMI_KEEP_ROWS", 1);
-    m->gemm_variant = env_int("PGMI_GEMM_VARIANT", 0);   // tuning only; 0 = persistent ping-pong kernel, register staging, K-sliced tail
+    m->gemm_variant = env_int("PGMI_GEMM_VARIANT", 0);   // tuning only (gemm_f16.hip set_tune); below 1000 = the product configuration
     if (cfg->arch == PGMI_ARCH_MSA) {
         TRY(dev_alloc(m->allocs, &m->xt, R * D));
         TRY(dev_alloc(m->allocs, &m->msa_kv_len, (size_t)2048));
@@ -1578,14 +1578,31 @@ int pgmi_bench_gemm_ab(int device, int precision, int M, int N, int K, int epilo
         if ((rc = make_w16(pool, hW.data(), hW.size(), (size_t)K, precision, nullptr, &w16)) ||
             (rc = dev_alloc(pool, &a16, (size_t)M * K * planes))) { cleanup(); return rc; }
         launch_split16(dA, (int64_t)M * K, 1.0f, bf ? 1 : 2, K, a16, nullptr);
-        if (split_out) rc = dev_alloc(pool, &c16, (size_t)M * N * planes);
-        else rc = dev_alloc(pool, &dC, (size_t)M * N);
+        if (split_out == 1) rc = dev_alloc(pool, &c16, (size_t)M * N * planes);
+        else if (split_out != 3) rc = dev_alloc(pool, &dC, (size_t)M * N);
         if (rc) { cleanup(); return rc; }
     }
+    // split_out 2: fp32 output with the in-place residual of the out-projection / FC2 (x += ...); 3: the fused QKV epilogue
+    // (attention operands; N = 3 D, sequences of 288 tokens when M allows)
+    const bool fused_qkv = split_out == 3 && !f32 && !bf;
+    const int Tq = (M % 288 == 0) ? 288 : M;
+    unsigned short *qk16 = nullptr, *vt16 = nullptr;
+    size_t qk_plane = 0, vt_plane = 0;
+    if (fused_qkv) {
+        if (N % 3 || (N / 3) % 64) { set_error("fused QKV bench needs N = 3 D, D %% 64 == 0"); cleanup(); return PGMI_EINVAL; }
+        const size_t Tp = (size_t)(Tq + 31) / 32 * 32;
+        qk_plane = (size_t)M * 2 * (N / 3);
+        vt_plane = (size_t)(M / Tq) * (N / 3) * Tp;
+        if ((rc = dev_alloc(pool, &qk16, qk_plane * 2)) || (rc = dev_alloc(pool, &vt16, vt_plane * 2))) { cleanup(); return rc; }
+    }
     auto run = [&](int var) -> int {
-        if (f32) return launch_gemm_f32(dA, dW, dB, nullptr, dC, M, N, K, epilogue, nullptr);
-        return launch_gemm16(a16, (size_t)M * K, w16.p, w16.plane, dB, nullptr, split_out ? nullptr : dC,
-                             split_out ? c16 : nullptr, (size_t)M * N, M, N, K, epilogue, w16.out_scale, planes, bf, var, nullptr);
+        if (f32) return launch_gemm_f32(dA, dW, dB, split_out == 2 ? dC : nullptr, dC, M, N, K, epilogue, nullptr);
+        if (fused_qkv)
+            return launch_gemm16_qkv(a16, (size_t)M * K, w16.p, w16.plane, dB, M, N / 3, K, w16.out_scale, qk16, qk_plane, vt16, vt_plane,
+                                     nullptr, nullptr, 0, Tq, N / 3 / kHeadDim, var, nullptr);
+        const bool planes_out = split_out == 1;
+        return launch_gemm16(a16, (size_t)M * K, w16.p, w16.plane, dB, split_out == 2 ? dC : nullptr, planes_out ? nullptr : dC,
+                             planes_out ? c16 : nullptr, (size_t)M * N, M, N, K, epilogue, w16.out_scale, planes, bf, var, nullptr);
     };
     std::vector<std::vector<double>> samples(n_variants);
     for (int v = 0; v < n_variants && !rc; ++v) rc = run(variants[v] >= 0 ? variants[v] : env_int("PGMI_GEMM_VARIANT", 0));   // warm-up

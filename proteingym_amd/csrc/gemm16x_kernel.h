@@ -1,6 +1,4 @@
-// gemm16x_kernel: the persistent ping-pong f16x3 GEMM kernel of libpgmi (launched by gemm_f16.hip) as a header, so that the
-// tuning-only phase-timing instantiations (DFLAGS >= 0) are built by tools/gemm_diag.hip into their own binary and the product
-// library holds the production instantiations only.
+// gemm16x_kernel: the persistent ping-pong f16x3 GEMM kernel of libpgmi (launched by gemm_f16.hip).
 #pragma once
 #include <type_traits>
 
@@ -63,42 +61,37 @@ __device__ __forceinline__ unsigned short f32_to_bf16_rne(float f) {
 
 // =================================================================================================
 // Persistent ping-pong kernel (f16x3, 256 x 256 x 32 tile, 8 waves = 2(M) x 4(N), wave tile 128 x 64).
-// One workgroup per CU walks a list of work items; per item the K loop is the ping-pong schedule of
-// gemm16_kernel<PP> (the two waves of a SIMD run one phase apart: one issues its 24 MFMAs while the other reads
-// fragments / stages the next K tile).  What the persistent form adds:
-//   * no workgroup launch/retire gap between tiles, the output stores of tile i drain under the prologue and
-//     main loop of tile i+1, and (STG 0) the first K tile of item i+1 is loaded into the staging registers
-//     BEFORE the epilogue of item i runs;
-//   * the tail of the launch is balanced: with T tiles on G workgroups the last partial round (T mod G tiles,
-//     1610 tiles on 256 CUs = 6.29 rounds for the N = 1280 GEMMs) is cut into `split` K slices per tile, so every
-//     CU gets a slice instead of 29 % of the chip working a full round.  Sliced items leave their raw fp32
-//     accumulators in a workspace (fully coalesced 16-byte stores in accumulator order); splitk_fix_kernel adds
-//     the slices in a fixed order (deterministic) and applies scale, bias and the residual.  Only the fp32-output
-//     GEMMs (out-projection, FC2) use slices; their N = D gives the few tiles that make the tail matter.
+// One workgroup per CU walks a list of work items; per item the K loop is a ping-pong schedule: the two waves of a SIMD
+// run one phase apart, one issues its 24 MFMAs while the other reads fragments / issues the DMA of the next K tile.
+// What the persistent form adds:
+//   * no workgroup launch/retire gap between tiles; the first K tile of item i+1 is in flight (DMA into buffer 0) while
+//     the epilogue of item i runs -- the epilogues' LDS patches start at buffer 1, which is free until the next K loop;
+//   * the tail of the launch is balanced: with T tiles on G workgroups the tiles of the last, partial round (1610 tiles on
+//     256 CUs = 6.29 rounds for the N = 1280 GEMMs) are cut into their upper and lower 128 rows -- two items, each over the
+//     full K range in the same order, so every output element is computed exactly as in a full tile (bit-identical);
+// Measured and NOT kept (round 4, scripts/gemm_ab.py, profiles/r4/README.md): starting the XCDs 2 - 12 us apart, or the CU slots
+// of an XCD 0.1 - 0.7 us apart, so that the epilogues' 67 MB of stores (+ 67 MB of residual reads) per round of items do not hit
+// the fabric in the same microseconds -- no gain at any setting; with the epilogue's stores dropped (timing probe) the
+// out-projection runs 8.8 % faster, with its residual loads dropped 6.7 %, with both 13 %: the waves wait for their own stores to
+// drain at the first vmcnt(0) of the next item (gfx9 counts loads and stores on ONE in-order counter).
 // LDS image of a K tile (per operand): [256 rows][8 chunks of 16 B] = the row's 128-byte line (4 hi chunks, 4 lo chunks)
-// with the chunk index XORed by (row >> 1) & 7: conflict-free ds_read_b128 fragment reads at a 128-byte row pitch, and
-// both staging forms write whole rows.  STG 0: global -> VGPR -> LDS staging.  STG 1: global -> LDS DMA (the swizzle
-// moves to the SOURCE chunk, which stays inside the row's line); the wave's share of tile kt+1 is issued in the first
-// memory phase of tile kt and waited for at the LAST barrier of tile kt (two to three phases of latency cover).
+// with the chunk index XORed by (row >> 1) & 7: conflict-free ds_read_b128 fragment reads at a 128-byte row pitch.  Staging
+// is global -> LDS DMA (buffer_load ... lds; the swizzle is applied to the SOURCE chunk, which stays inside the row's line);
+// the wave's share of tile kt+1 is issued in the first memory phase of tile kt and waited for at the LAST barrier of tile kt.
 // =================================================================================================
 struct TilePlan {
     int tiles_m, tiles_n;
-    int n_main;       // tiles [0, n_main) in launch order: one full-K item each
-    int split;        // every later tile is cut into `split` K slices (<= 1: none)
-    int n_items;      // n_main + (tiles - n_main) * split (or * 2 with half)
-    int half;         // 1: every later tile is cut into its upper and lower 128 rows instead (two items, full K each)
-    int group_m;      // row panels per group of the grouped tile order (gemm_f16.hip kGroupM; tuning variants 100 + g of launch_gemm16 set g)
-    float* ws;        // raw accumulators of the sliced items
-    unsigned long long* diag;   // DIAG instantiation only: [2 waves][kDiagSamples][2] shader-clock stamps (barrier arrival, release)
-    int diag_flags;             // DIAG instantiation only (ablations, wrong numbers): 1 no global loads in the loop, 2 no
-                                // ds_write staging, 4 loads issued in memory phase 1, 8 no fragment reads after the first K tile, 32 no s_setprio, 64 static
-                                // priority 1 for the late waves only
+    int n_main;       // items [0, n_main): one full tile each (XCD-aware grouped order); workgroup b runs b, b + G, ...
+    int n_tail;       // tail items n_main + h, h < n_tail, one per workgroup at most (half = 1: halves of the last round's tiles)
+    int half;         // 1: tail item h is the upper (h even) or lower (h odd) 128 rows of tile n_main + h / 2
+    int group_m;      // row panels per group of the grouped tile order (gemm_f16.hip kGroupM)
 };
-constexpr int kDiagSamples = 1024;
 
 constexpr int XBM = 256, XBN = 256, XNT = 512, XCPR = 8;   // 8 chunks = one 128-byte line per row and K tile (hi | lo)
 constexpr int X_OP_CH = XBM * XCPR;                        // 16-byte chunks of one operand tile
 constexpr int X_STAGE = 2 * X_OP_CH;                       // chunks per stage = 64 KB
+constexpr int X_PATCH_BYTES = 72 * 1024;                   // epilogue patches: buffer 1 and 8 KB beyond it (8 waves x <= 9 KB)
+constexpr size_t X_LDS_BYTES = (size_t)(X_STAGE * 16 + X_PATCH_BYTES);   // 136 KB
 
 __device__ __forceinline__ void x_tile_coords(int wgid, int tiles_m, int tiles_n, int& tm, int& tn, int GROUP_M) {
     const int width = GROUP_M * tiles_n;
@@ -108,54 +101,47 @@ __device__ __forceinline__ void x_tile_coords(int wgid, int tiles_m, int tiles_n
     tn = (wgid % width) / gsz;
 }
 
-template <int EPI, int OUT, int STG, int DFLAGS = -1>     // DFLAGS >= 0: tuning-only phase-timing instantiation with these ablation flags
+// OUT 0: fp32 [M,N] (+ residual); 1: split fp16 planes, K-interleaved (the next GEMM's operand); 2: attention operands (QkvOut).
+// CEPI (OUT 0 only): the fp32 epilogue goes through a per-wave LDS transpose so that 16 lanes cover 256 contiguous bytes of a
+// row (4 rows = 8 full lines per load / store instruction; the accumulator layout gives 32 rows x 32 bytes per instruction).
+template <int EPI, int OUT, bool CEPI>
 __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
     const unsigned short* __restrict__ A, const unsigned short* __restrict__ W, const float* __restrict__ bias,
     const float* residual, float* Cf, unsigned short* Ch, size_t c_plane, int M, int N, int K, float out_scale,
     TilePlan tp, QkvOut qo) {
     constexpr int WN = 4, TMX = 4, TN = 2, LD = 4;               // TMX: 32-row MFMA tiles per wave of a full item (a half item: 2)
-    constexpr bool DIAG = DFLAGS >= 0;
-    constexpr bool DMA = STG == 1 || STG == 3;                    // 3 (tuning): DMA issued after the fragment reads of memory phase 1
-    constexpr int kFlags = DIAG ? DFLAGS % 1000 : 0;              // DFLAGS >= 1000: the DMA form (launched with STG 1)
-    extern __shared__ __attribute__((aligned(16))) u32x4 lds[];  // [2][X_STAGE]
+    extern __shared__ __attribute__((aligned(16))) u32x4 lds[];  // [2][X_STAGE] + patches
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);    // provably wave-uniform: scalar branches, SGPR LDS bases
     const int wm = wave / WN, wn = wave % WN;
     const int r = lane & 31, kh = lane >> 5;
     const bool late = wave >= 4;                                  // the second wave of every SIMD
+    // epilogue patches: from buffer 1 on (free between the last phase barrier of an item and the first memory phase of the
+    // next one, which every wave enters through a barrier after its own epilogue) -- buffer 0 takes the next item's first K tile
+    unsigned char* const patches = reinterpret_cast<unsigned char*>(lds + X_STAGE);
 
     // staging geometry (the same for both operands): slot f = tid + 512 i is (row (tid >> 3) + 64 i, chunk tid & 7) -- 8
-    // consecutive lanes move one row's 128-byte line -- at LDS index row * 8 + (chunk ^ ((row >> 1) & 7)); the swizzle does
-    // not depend on i, so one LDS index + 512 i serves all four, plus one 32-bit byte offset per row and operand.
+    // consecutive lanes move one row's 128-byte line -- into the lane-linear LDS slot; the chunk swizzle is applied to the
+    // SOURCE: one 32-bit byte offset per row and operand.
     const int row_lo = tid >> 3, c8 = tid & 7, sw8 = (row_lo >> 1) & 7;
-    const int dst0 = DMA ? tid : row_lo * XCPR + (c8 ^ sw8);
-    const int csrc = DMA ? (c8 ^ sw8) : c8;               // DMA: lane-linear slot, swizzled SOURCE chunk
+    const int csrc = c8 ^ sw8;
     // buffer descriptors built from kernel arguments only (provably wave-uniform): loads take a 32-bit per-lane byte offset
     // and the K-tile offset as an SGPR -- no 64-bit address arithmetic in the memory phases
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(A), 0, (int)((unsigned int)M * (unsigned int)K * 4u), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(W), 0, (int)((unsigned int)N * (unsigned int)K * 4u), 0x00020000);
     unsigned int a_off[LD], w_off[LD];
-    u32x4 a_st[LD], w_st[LD];
-    int m0 = 0, n0 = 0, kt0 = 0, kt1 = 0, slice_item = -1, a_ld = LD;
+    int m0 = 0, n0 = 0, a_ld = LD;
     bool half_item = false;                                       // the upper or lower 128 rows of a tile (tail of the item list)
-    auto decode = [&](int item) {                                 // sets m0, n0, [kt0, kt1), slice_item and the source offsets
-        const int nk = K / 32;
+    const int nk = K / 32;
+    auto decode = [&](int item) {                                 // sets m0, n0, half_item and the source offsets
         int wgid;
         if (item < tp.n_main) {
             // XCD-aware order: item i runs on XCD i % 8 (grid size is a multiple of 8); every XCD walks a contiguous
             // run of the grouped tile order so that its L2 keeps the live A panels and W tiles
             const int nwg = tp.n_main, xcd = item & 7, q = nwg >> 3, r8 = nwg & 7;
             wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (item >> 3);
-            kt0 = 0; kt1 = nk; slice_item = -1;
-        } else if (tp.half) {
-            wgid = tp.n_main + ((item - tp.n_main) >> 1);
-            kt0 = 0; kt1 = nk; slice_item = -1;
         } else {
-            const int rel = item - tp.n_main, ks = rel % tp.split;
-            wgid = tp.n_main + rel / tp.split;
-            kt0 = (int)((long long)nk * ks / tp.split);
-            kt1 = (int)((long long)nk * (ks + 1) / tp.split);
-            slice_item = rel;
+            wgid = tp.n_main + ((item - tp.n_main) >> 1);
         }
         int tm, tn;
         x_tile_coords(wgid, tp.tiles_m, tp.tiles_n, tm, tn, tp.group_m);
@@ -163,28 +149,13 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
         a_ld = half_item ? LD / 2 : LD;                           // A rows staged per K tile: 64 per instruction
         m0 = __builtin_amdgcn_readfirstlane(tm * XBM + (half_item ? ((item - tp.n_main) & 1) * (XBM / 2) : 0));
         n0 = __builtin_amdgcn_readfirstlane(tn * XBN);
-        kt0 = __builtin_amdgcn_readfirstlane(kt0); kt1 = __builtin_amdgcn_readfirstlane(kt1);
-        slice_item = __builtin_amdgcn_readfirstlane(slice_item);
 #pragma unroll
         for (int i = 0; i < LD; ++i) {                            // row pitch 4 K bytes; the launcher guarantees rows * 4 K < 4 GiB
             a_off[i] = (unsigned int)min(m0 + row_lo + 64 * i, M - 1) * (unsigned int)K * 4u + (unsigned int)csrc * 16u;
             w_off[i] = (unsigned int)min(n0 + row_lo + 64 * i, N - 1) * (unsigned int)K * 4u + (unsigned int)csrc * 16u;
         }
     };
-    auto stage_load = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < LD; ++i) a_st[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (int)a_off[i], kt * 128, 0));
-#pragma unroll
-        for (int i = 0; i < LD; ++i) w_st[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsW, (int)w_off[i], kt * 128, 0));
-    };
-    auto stage_store = [&](int buf) {
-        u32x4* base = lds + buf * X_STAGE + dst0;
-#pragma unroll
-        for (int i = 0; i < LD; ++i) base[XNT * i] = a_st[i];
-#pragma unroll
-        for (int i = 0; i < LD; ++i) base[X_OP_CH + XNT * i] = w_st[i];
-    };
-    auto issue_tile = [&](int kt, int buf) {                      // STG 1: 1 KiB per wave-instruction, wave-uniform LDS base
+    auto issue_tile = [&](int kt, int buf) {                      // 1 KiB per wave-instruction, wave-uniform LDS base
         u32x4* base = lds + buf * X_STAGE + wave * 64;
 #pragma unroll
         for (int i = 0; i < LD; ++i)
@@ -195,31 +166,18 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(base + X_OP_CH + XNT * i), 16, (int)w_off[i], kt * 128, 0, 0);
     };
     // phase boundary: everything issued before stays before, this wave's LDS traffic has landed; VMEM stays in flight
-    // DIAG (tuning-only instantiation): waves 0 and 4 of workgroup 0 stamp the shader clock when they ARRIVE at every phase
-    // barrier, with a tag saying what the phase was (0 mem1, 1 cmp1, 3 mem2, 4 cmp2, 2 other).  The stamp is an SMEM read
-    // issued before the barrier and consumed at the next one: a wave that waits at the barrier pays nothing for it; the wave
-    // that arrives last (a computing wave) pays its latency at the start of its next -- memory -- phase.  (A second stamp
-    // after the barrier made every instrumented compute phase wait for the SMEM round trip: +200-350 clocks.)  The host
-    // takes release(k) = max over the two waves of arrival(k).
-    const bool diag_on = DIAG && blockIdx.x == 0 && (wave == 0 || wave == 4);
-    unsigned long long d_arr = 0;
-    int d_n = 0, d_tag = 0;
-    auto phase_impl = [&](bool vm, int tag) {
+    auto phase = [&]() {
         __builtin_amdgcn_sched_barrier(0);
-        if (DIAG && diag_on) {
-            if (d_n > 0 && d_n <= kDiagSamples && lane == 0) {
-                unsigned long long* q = tp.diag + ((size_t)(wave >> 2) * kDiagSamples + (d_n - 1)) * 2;
-                q[0] = d_arr; q[1] = (unsigned long long)d_tag + 1;
-            }
-        }
-        if (vm && !(DIAG && (kFlags & 128))) __builtin_amdgcn_s_waitcnt(0x0070);   // vmcnt(0) lgkmcnt(0)
-        else __builtin_amdgcn_s_waitcnt(0xC07F);                                    // lgkmcnt(0)
-        if (DIAG && diag_on) { d_arr = __builtin_readcyclecounter(); d_tag = tag; ++d_n; }
+        __builtin_amdgcn_s_waitcnt(0xC07F);                                    // lgkmcnt(0)
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
     };
-    auto phase = [&](int tag = 2) { phase_impl(false, tag); };
-    auto phase_vm = [&](int tag = 2) { phase_impl(true, tag); };   // the same, plus this wave's DMA has landed (DMA form)
+    auto phase_vm = [&]() {                                                    // the same, plus this wave's DMA has landed
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0070);                                    // vmcnt(0) lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
 
     f32x16 acc[TN][TMX];
     u32x4 af[2][TMX], wf[2][TN], whs[TN];
@@ -275,28 +233,17 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
         __builtin_amdgcn_sched_group_barrier(0x008, 3 * TN * TM - 8, 0);
     };
 
+    // ---- this workgroup's item list: b, b + G, ... below n_main, then at most one tail item ----
+    const int n_items = tp.n_main + tp.n_tail;
     int item = blockIdx.x;
-    if (item >= tp.n_items) return;
-    bool dma_ahead = false;                                       // the item's first K tile was issued before the previous epilogue
+    if (item >= n_items) return;
     decode(item);
-    if constexpr (STG == 0) stage_load(kt0);
-    // the fp32-output epilogue has the registers to spare for the next item's first K tile; the split-plane and
-    // attention-operand epilogues do not (the prefetch spilled 12-23 registers): they fetch after the epilogue
-    constexpr bool kPrefetchAcrossEpilogue = STG == 0 && OUT == 0;
+    issue_tile(0, 0);
     // one item, start to finish; TM (compile time) = 32-row MFMA tiles per wave: 4, or 2 for a half item.  Returns "more items".
     auto run_item = [&](auto tmc) -> bool {
         constexpr int TM = decltype(tmc)::value;
-        // ---- prologue: first K tile of the item into buffer 0 (the LDS patches of the previous epilogue are done:
-        //      every wave passed the barrier below only after finishing its own patch reads) ----
-        __syncthreads();
-        if constexpr (STG == 0) {
-            stage_store(0);
-            if (kt0 + 1 < kt1) stage_load(kt0 + 1);
-            __syncthreads();
-        } else {
-            if (!dma_ahead) issue_tile(kt0, 0);
-            phase_vm();
-        }
+        // ---- prologue: the item's first K tile has been in flight into buffer 0 since before the previous epilogue ----
+        phase_vm();
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
@@ -304,73 +251,62 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[j][i][v] = 0.0f;
         int cur = 0;
-        if (DIAG && (kFlags & 64) && late) __builtin_amdgcn_s_setprio(1);
         if (late) phase();
-        for (int kt = kt0; kt < kt1; ++kt) {
+        for (int kt = 0; kt < nk; ++kt) {
             const u32x4* Ab = lds + cur * X_STAGE;
             const u32x4* Wb = Ab + X_OP_CH;
-            // -- memory phase 1: fragments of the first k16 step (STG 1: DMA of tile kt+1 into the other buffer, last read
-            //    two phases ago by the other wave group) --
-            if (!(DIAG && (kFlags & 96))) __builtin_amdgcn_s_setprio(0);
-            // the DMA goes first: with the fragment reads ahead of it the memory phase outlasts the partner's 24 MFMAs
-            // (tools/mfma_phase.hip: 829 -> 797 clocks per phase on the bare loop); STG 3 keeps the old order for A/B
-            if (STG == 1 && kt + 1 < kt1 && !(DIAG && (kFlags & 16) && kt > kt0)) issue_tile(kt + 1, cur ^ 1);
-            if (!(DIAG && (kFlags & 8) && kt > kt0)) read_frags(tmc, Ab, Wb, 0);
-            if (STG == 3 && kt + 1 < kt1) issue_tile(kt + 1, cur ^ 1);
-            if (DIAG && (kFlags & 4) && kt > kt0 && kt + 1 < kt1) stage_load(kt + 1);
-            phase(0);
+            // -- memory phase 1: DMA of tile kt+1 into the other buffer (last read two phases ago by the other wave group), then
+            //    the fragments of the first k16 step.  The DMA goes first: with the fragment reads ahead of it the memory phase
+            //    outlasts the partner's 24 MFMAs (tools/mfma_phase.hip: 829 -> 797 clocks per phase on the bare loop) --
+            __builtin_amdgcn_s_setprio(0);
+            if (kt + 1 < nk) issue_tile(kt + 1, cur ^ 1);
+            read_frags(tmc, Ab, Wb, 0);
+            phase();
             // -- compute phase 1 --
-            if (!(DIAG && (kFlags & 96))) __builtin_amdgcn_s_setprio(1);
+            __builtin_amdgcn_s_setprio(1);
             mfmas(tmc);
-            phase(1);
-            // -- memory phase 2: fragments of the second k16 step; STG 0: tile kt+1 registers -> LDS, loads of kt+2 --
-            if (!(DIAG && (kFlags & 96))) __builtin_amdgcn_s_setprio(0);
-            if (!(DIAG && (kFlags & 8) && kt > kt0)) read_frags(tmc, Ab, Wb, 1);
-            if (STG == 0 && kt + 1 < kt1) {
-                __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0); lgkmcnt / expcnt untouched
-                if (!(DIAG && (kFlags & 2))) stage_store(cur ^ 1);
-                if (kt + 2 < kt1 && !(DIAG && (kFlags & 5))) stage_load(kt + 2);
-            }
-            if (DMA && late) phase_vm(3); else phase(3);        // late waves close tile kt here: their DMA share must have landed
+            phase();
+            // -- memory phase 2: fragments of the second k16 step --
+            __builtin_amdgcn_s_setprio(0);
+            read_frags(tmc, Ab, Wb, 1);
+            if (late) phase_vm(); else phase();                 // late waves close tile kt here: their DMA share must have landed
             // -- compute phase 2 --
-            if (!(DIAG && (kFlags & 96))) __builtin_amdgcn_s_setprio(1);
+            __builtin_amdgcn_s_setprio(1);
             mfmas(tmc);
-            if (DMA && !late) phase_vm(4); else phase(4);       // early waves close tile kt here
+            if (!late) phase_vm(); else phase();                // early waves close tile kt here
             cur ^= 1;
         }
         __builtin_amdgcn_s_setprio(0);
         if (!late) phase();
 
-        // ---- the item just finished; fetch the next one's first K tile before the epilogue (STG 0) ----
-        const int em0 = m0, en0 = n0, eslice = slice_item;
+        // ---- the item just finished: both K-tile buffers are free after the last phase barrier; the next item's first K
+        //      tile is in flight while this item's epilogue runs ----
+        const int em0 = m0, en0 = n0;
         item += gridDim.x;
-        const bool more = item < tp.n_items;
+        const bool more = item < n_items;
         if (more) {
             decode(item);
-            if constexpr (kPrefetchAcrossEpilogue) stage_load(kt0);
-            // DMA form: the fp32-output epilogue does not touch LDS and both K-tile buffers are free after the last phase barrier,
-            // so the next item's first K tile is already in flight while this item's epilogue runs
-            if constexpr (DMA && OUT == 0) { issue_tile(kt0, 0); dma_ahead = true; }
+            issue_tile(0, 0);
         }
 
-        if (eslice >= 0) {
-            // raw accumulators, accumulator order: [item][wave][j][i][q][lane] f32x4 -> 1 KiB per store instruction
-            f32x4* dst = reinterpret_cast<f32x4*>(tp.ws) + ((size_t)eslice * 8 + wave) * (TN * TM * 4 * 64) + lane;
-#pragma unroll
-            for (int j = 0; j < TN; ++j)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4)
-                        dst[((j * TM + i) * 4 + q4) * 64] = f32x4{acc[j][i][4 * q4], acc[j][i][4 * q4 + 1], acc[j][i][4 * q4 + 2], acc[j][i][4 * q4 + 3]};
-        } else if constexpr (OUT == 2) {
+        if constexpr (OUT == 2) {
             const int Dm = N / 3;
             const int nb = en0 + wn * 64;                      // first column of this wave's head
             if (nb < N) {
             const int which = nb / Dm, hcol = nb - which * Dm, hh = hcol >> 6;
             constexpr int SPQ = 144;
-            unsigned char* patch_q = reinterpret_cast<unsigned char*>(lds) + wave * (2 * 32 * SPQ);
+            unsigned char* patch_q = patches + wave * (2 * 32 * SPQ);
             const bool staged_q = which < 2;
+            // the wave's bias values, once per item: a load inside the block loop is followed by a wait for EVERYTHING in
+            // flight (vmcnt counts the stores of the previous block as well) -- one memory round trip per 4 values
+            f32x4 bq0[4], bq1[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                bq0[g] = *reinterpret_cast<const f32x4*>(bias + nb + 8 * g + 4 * kh);
+                bq1[g] = *reinterpret_cast<const f32x4*>(bias + nb + 32 + 8 * g + 4 * kh);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) asm volatile("" :: "v"(bq0[g]), "v"(bq1[g]));      // waited for HERE, not inside the block loop
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int m = em0 + (wm * TM + i) * 32 + r;
@@ -381,8 +317,7 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const int d0 = 8 * g + 4 * kh;             // dims d0..d0+3 (x0) and d0+32.. (x1) of the head
-                    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bias + nb + d0);
-                    const f32x4 b1 = *reinterpret_cast<const f32x4*>(bias + nb + 32 + d0);
+                    const f32x4 b0 = bq0[g], b1 = bq1[g];
                     float x0[4], x1[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -456,13 +391,97 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
                 }
             }
             }
+        } else if constexpr (OUT == 0 && CEPI) {
+            // fp32 (+ residual) output through a per-wave LDS transpose, one 32 x 32 accumulator tile at a time.  Patch: 32 rows
+            // x 128 B, the 16-byte chunk index XORed with row & 7: the accumulator-order writes (ds_write_b128: 8 rows of one
+            // chunk column per group) and the row-order reads (ds_read_b128: four rows of 4 chunks per group) are conflict-free.
+            // In row order lane q holds chunk q & 7 of rows (q >> 3) + 8 k: 8 lanes cover one full 128-byte line, a load / store
+            // instruction 8 full lines (the accumulator layout gives 32 rows x 32 bytes per instruction: 4 x the line accesses).
+            // Loads and stores are BUFFER operations whose offset is pushed out of range for rows >= M / columns >= N: no branch
+            // around any of them.  A memory operation under a branch makes the compiler wait for everything in flight at the next
+            // use (vmcnt(0), which counts the stores already issued as well): one store round trip per 4 values.
+            unsigned char* patch = patches + wave * (32 * 128);
+            const int cc = lane & 7, rq = lane >> 3;
+            const unsigned int kOob = 0x80000000u;                // the launcher keeps M N 4 below 2^31
+            const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(Cf, 0, (int)((unsigned int)M * (unsigned int)N * 4u), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual ? residual : Cf), 0, (int)((unsigned int)M * (unsigned int)N * 4u), 0x00020000);
+            unsigned int coff[TN];                                // byte offset of the lane's four columns inside a row, or out of range
+            f32x4 bv[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = en0 + (wn * TN + j) * 32 + cc * 4;  // N % 4 == 0 is required by the launcher
+                coff[j] = n < N ? (unsigned int)n * 4u : kOob;
+                bv[j] = (bias && n < N) ? *reinterpret_cast<const f32x4*>(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(bv[j]));                     // waited for HERE, not inside the block loop
+            auto c_off = [&](int m, int j) -> int {
+                return (int)((m < M && coff[j] != kOob) ? (unsigned int)m * (unsigned int)N * 4u + coff[j] : kOob);
+            };
+            // residual rows of block i + 1 are loaded before block i is processed: one memory latency per item, not per block
+            u32x4 rv[2][TN][4];
+            auto load_residual = [&](int i, u32x4 (&dst)[TN][4]) {
+                const int m_base = em0 + (wm * TM + i) * 32;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        dst[j][k] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsR, c_off(m_base + rq + 8 * k, j), 0, 0));
+            };
+            if (residual) load_residual(0, rv[0]);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int m_base = em0 + (wm * TM + i) * 32;
+                if (residual && i + 1 < TM) load_residual(i + 1, rv[(i + 1) & 1]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        *reinterpret_cast<f32x4*>(patch + r * 128 + (((2 * g + kh) ^ (r & 7)) << 4)) =
+                            f32x4{acc[j][i][4 * g], acc[j][i][4 * g + 1], acc[j][i][4 * g + 2], acc[j][i][4 * g + 3]};
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int row = rq + 8 * k;
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(patch + row * 128 + ((cc ^ (row & 7)) << 4));
+                        f32x4 val;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float t = a[e] * out_scale + bv[j][e];
+                            if (EPI == EPI_GELU) t = gelu_erf16(t);
+                            if (EPI == EPI_SQRELU) { t = fmaxf(t, 0.0f); t = t * t; }     // tranception/activations.py:79-84
+                            val[e] = t;
+                        }
+                        if (residual) {
+                            const f32x4 rr = __builtin_bit_cast(f32x4, rv[i & 1][j][k]);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) val[e] = rr[e] + val[e];
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, val), rsC, c_off(m_base + row, j), 0, 0);
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
         } else {
             // lane holds column m = m_base + r of C^T, rows n = (v&3) + 8(v>>2) + 4kh; split-plane output leaves through a
-            // per-wave LDS transpose as full 128-byte row segments (see gemm16_kernel)
+            // per-wave LDS transpose as full 128-byte row segments
             // per-wave LDS patch: 32 rows x (256 B in OUTPUT order: group 0 hi | group 0 lo | group 1 hi | group 1 lo) + 16 B pad
             constexpr int SP = 272;
             const bool staged = (OUT == 1) && (N % 8 == 0) && (en0 + (wn * TN + TN) * 32 <= N);
-            unsigned char* patch = reinterpret_cast<unsigned char*>(lds) + wave * (32 * SP);
+            unsigned char* patch = patches + wave * (32 * SP);
+            // the wave's bias values, once per item (see OUT 2 above)
+            f32x4 bvs[TN][4];
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int n = en0 + (wn * TN + j) * 32 + 8 * g + 4 * kh;
+                    bvs[j][g] = (bias && n < N) ? *reinterpret_cast<const f32x4*>(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) asm volatile("" :: "v"(bvs[j][g]));              // waited for HERE, not inside the block loop
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
                 const int m = em0 + (wm * TM + i) * 32 + r;
@@ -475,7 +494,7 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
                     for (int g = 0; g < 4; ++g) {
                         const int n = en0 + (wn * TN + j) * 32 + 8 * g + 4 * kh;
                         if (n >= N) continue;                    // N % 4 == 0 is required by the launcher
-                        const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        const f32x4 bv = bvs[j][g];
                         f32x4 val;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -537,10 +556,9 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
     using Half = std::integral_constant<int, TMX / 2>;
     while (true) {
         bool more;
-        if constexpr (OUT != 2 && DMA && !DIAG) more = half_item ? run_item(Half{}) : run_item(Full{});
+        if constexpr (OUT != 2) more = half_item ? run_item(Half{}) : run_item(Full{});
         else more = run_item(Full{});
         if (!more) break;
-        if constexpr (STG == 0 && !kPrefetchAcrossEpilogue) stage_load(kt0);
     }
 }
 

@@ -208,71 +208,18 @@ static int launch_bf16_cfg(const unsigned short* A, const unsigned short* W, con
     return PGMI_OK;
 }
 
-// Sum of the K slices of the sliced tiles (fixed order: deterministic) + the fp32 epilogue of gemm16x_kernel<EPI_NONE, 0>:
-// C = residual + (sum acc) * out_scale + bias.  One workgroup per sliced tile, same thread <-> element map as the GEMM.
-__global__ __launch_bounds__(XNT) void splitk_fix_kernel(const float* __restrict__ ws, int split, int n_main, int tiles_m, int tiles_n,
-                                                         const float* __restrict__ bias, const float* residual, float* Cf,
-                                                         int M, int N, float out_scale, int group_m) {
-    constexpr int WN = 4, TM = 4, TN = 2;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave / WN, wn = wave % WN, r = lane & 31, kh = lane >> 5;
-    int tm, tn;
-    x_tile_coords(n_main + blockIdx.x, tiles_m, tiles_n, tm, tn, group_m);
-    const int m0 = tm * XBM, n0 = tn * XBN;
-    const f32x4* src = reinterpret_cast<const f32x4*>(ws) + ((size_t)blockIdx.x * split * 8 + wave) * (TN * TM * 4 * 64) + lane;
-    const size_t slice_stride = (size_t)8 * (TN * TM * 4 * 64);
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int m = m0 + (wm * TM + i) * 32 + r;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int n = n0 + (wn * TN + j) * 32 + 8 * g + 4 * kh;
-                f32x4 a = src[((j * TM + i) * 4 + g) * 64];
-                for (int s = 1; s < split; ++s) {
-                    const f32x4 b = src[s * slice_stride + ((j * TM + i) * 4 + g) * 64];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) a[e] += b[e];
-                }
-                if (m >= M || n >= N) continue;
-                const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
-                const size_t o = (size_t)m * N + n;
-                f32x4 val;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) val[e] = a[e] * out_scale + bv[e];
-                if (residual) {
-                    const f32x4 rv = *reinterpret_cast<const f32x4*>(residual + o);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) val[e] = rv[e] + val[e];
-                }
-                *reinterpret_cast<f32x4*>(Cf + o) = val;
-            }
-        }
-}
-
 // Per-device launch state (a process may drive several devices through distinct model handles: nothing here is shared
 // between devices).  Indexed by the current HIP device of the calling thread; written under a mutex because two handles on two
 // devices may launch from two host threads.
 constexpr int kMaxDevices = 64;
-struct XDeviceState {
-    int num_cus = 0;
-    float* splitk_ws = nullptr;                                   // K-sliced tail workspace (PGMI_GEMM_SPLITK=1 only)
-    size_t splitk_ws_bytes = 0;
-};
-static XDeviceState g_xdev[kMaxDevices];
+static int g_num_cus[kMaxDevices];
 static std::mutex g_xdev_mu;
 
-static int x_current_device() {
+static int x_num_cus() {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) dev = 0;
-    return dev;
-}
-
-static int x_num_cus() {
-    const int dev = x_current_device();
     std::lock_guard<std::mutex> lk(g_xdev_mu);
-    int& n = g_xdev[dev].num_cus;
+    int& n = g_num_cus[dev];
     if (!n) {
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
@@ -283,7 +230,6 @@ static int x_num_cus() {
     return n;
 }
 
-// stg: 0 register staging, 1 direct-to-LDS DMA, 3 the same with the DMA issued after the fragment reads (tuning).  splitk: allow K-sliced tail items (fp32-output GEMMs only).
 // Row panels per group of the grouped tile order.  An XCD's 32 concurrent tiles then cover ~g row panels x 32/g column panels: per K
 // step g A slices + 32/g W slices miss its L2.  W (the layer's weights, 6.5 - 26 MB) is shared by every tile of the launch and
 // stays in the Infinity Cache; A (the activations, 0.4 - 1.7 GB) streams from HBM: fewer A slices per step win although the slice
@@ -292,84 +238,59 @@ static int x_num_cus() {
 // FC1 (N = 5120: 20 column panels) runs at the same speed with 4 and with 8 but fetches less with 8 (3.26 vs 3.47 GB per launch: with
 // 20 column panels a group of 4 rows is 80 tiles = 2.5 rounds of an XCD, and the partial rounds straddle two groups): wide outputs keep 8.
 constexpr int kGroupM = 4, kGroupMWide = 8, kWideTilesN = 16;
-static thread_local int g_group_m = 0;                            // 0: by shape (above); variants 100 + g of launch_gemm16 force g (tuning only)
+// Launch parameters, product defaults; variants >= 1000 of launch_gemm16 override them for the interleaved A/B of
+// scripts/gemm_ab.py.  None of them touches a row's arithmetic: same bits.
+constexpr int kCoalescedEpilogue = 1;                             // fp32 epilogue through the per-wave LDS transpose
+struct GemmTune { int group_m = 0, cepi = kCoalescedEpilogue; };
+static thread_local GemmTune g_tune;
 
 static int launch_gemm16x_one(const unsigned short* A, const unsigned short* W,
                               const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
-                              int M, int N, int K, int epilogue, float out_scale, int stg, bool splitk, hipStream_t s,
-                              const QkvOut* qkv) {
+                              int M, int N, int K, int epilogue, float out_scale, hipStream_t s, const QkvOut* qkv) {
+    const GemmTune tune = g_tune;
     TilePlan tp{};
-    tp.group_m = g_group_m > 0 ? g_group_m : ((N + XBN - 1) / XBN >= kWideTilesN ? kGroupMWide : kGroupM);
+    tp.group_m = tune.group_m > 0 ? tune.group_m : ((N + XBN - 1) / XBN >= kWideTilesN ? kGroupMWide : kGroupM);
     tp.tiles_m = (M + XBM - 1) / XBM;
     tp.tiles_n = (N + XBN - 1) / XBN;
-    const int T = tp.tiles_m * tp.tiles_n, G = x_num_cus(), nk = K / 32;
-    tp.n_main = T; tp.split = 1; tp.n_items = T;
-    if ((unsigned long long)std::max(M, N) * (unsigned long long)K * 4ull >= (1ull << 32)) {      // launch_gemm16x chunks M below this
-        set_error("gemm16x: operand of %d x %d split elements exceeds the 32-bit offset range", std::max(M, N), K);
+    const int T = tp.tiles_m * tp.tiles_n, G = x_num_cus();
+    tp.n_main = T;
+    if ((unsigned long long)std::max(M, N) * (unsigned long long)K * 4ull >= (1ull << 32) ||
+        (Cf && (unsigned long long)M * (unsigned long long)N * 4ull >= (1ull << 31))) {      // launch_gemm16x chunks M below this
+        set_error("gemm16x: operand of %d x %d split elements (or %d x %d outputs) exceeds the 32-bit offset range", std::max(M, N), K, M, N);
         return PGMI_EINVAL;
     }
     const int rem = T % G;
-    // K-sliced tails are OPT-IN (PGMI_GEMM_SPLITK=1): a sliced tile adds its K range in a different association than a full
-    // tile, so a row's bits would depend on how many rows travel with it -- and the scorer guarantees that every way of
-    // batching an assay (whole, position chunks, any number of GPUs) gives bit-identical scores (tests/test_gpu_cli.py).
-    // Measured gain when enabled: FC2 386 -> 402 TFLOP/s at the BLAT shape (6.29 -> 6.33 rounds of tiles), +1.2 % per step.
-    const int want_split = getenv("PGMI_GEMM_SPLITK") ? atoi(getenv("PGMI_GEMM_SPLITK")) : 0;
-    if (splitk && want_split && Cf && !qkv && epilogue == EPI_NONE && rem > 0 && 4 * rem <= 3 * G) {
-        int split = std::min(std::min(G / rem, 8), nk / 4);       // every slice keeps >= 4 K tiles
-        if (split >= 2) {
-            const size_t need = (size_t)rem * split * XBM * XBN * sizeof(float);
-            float* ws = nullptr;
-            {
-                std::lock_guard<std::mutex> lk(g_xdev_mu);
-                XDeviceState& st = g_xdev[x_current_device()];
-                if (need > st.splitk_ws_bytes) {
-                    if (st.splitk_ws) hipFree(st.splitk_ws);
-                    st.splitk_ws = nullptr; st.splitk_ws_bytes = 0;
-                    const size_t cap = std::max(need, (size_t)G * XBM * XBN * sizeof(float));
-                    if (hipMalloc(reinterpret_cast<void**>(&st.splitk_ws), cap) == hipSuccess) st.splitk_ws_bytes = cap;
-                }
-                ws = st.splitk_ws;
-            }
-            if (ws) {
-                tp.n_main = T - rem; tp.split = split; tp.n_items = tp.n_main + rem * split; tp.ws = ws;
-            }
-        }
-    }
-    // Half-height tail (every output kind but the fused QKV, DMA form): the last, partial round of tiles leaves G - rem CUs idle for a whole tile
-    // time (N = 1280 at the BLAT shape: 6.29 rounds cost 7).  Its tiles are cut into their upper and lower 128 rows -- two
+    // Half-height tail (every output kind but the fused QKV): the last, partial round of tiles leaves G - rem CUs idle for a whole
+    // tile time (N = 1280 at the BLAT shape: 6.29 rounds cost 7).  Its tiles are cut into their upper and lower 128 rows -- two
     // items on two CUs, each over the full K range in the same order, so every output element is computed exactly as in a
-    // full tile (bit-identical; unlike the K slices above) -- when all the halves still fit one round.
+    // full tile (bit-identical: a row's bits must not depend on how many rows travel with it, tests/test_gpu_cli.py) -- when
+    // all the halves still fit one round.
     const int want_half = getenv("PGMI_GEMM_HALF_TAIL") ? atoi(getenv("PGMI_GEMM_HALF_TAIL")) : 1;   // read per launch: the tests toggle it
-    if (want_half && tp.split <= 1 && !qkv && (stg == 1 || stg == 3) && rem > 0 && 2 * rem <= G) {
-        tp.n_main = T - rem; tp.half = 1; tp.n_items = tp.n_main + 2 * rem;
+    if (want_half && !qkv && rem > 0 && 2 * rem <= G) {
+        tp.n_main = T - rem; tp.half = 1; tp.n_tail = 2 * rem;
     }
+    const int n_items = tp.n_main + tp.n_tail;
+    const dim3 grid(std::min(G, n_items)), block(XNT);
     QkvOut qo{};
     if (qkv) qo = *qkv;
-    const size_t lds_bytes = (size_t)2 * X_STAGE * 16;
-    const dim3 grid(std::min(G, tp.n_items)), block(XNT);
-#define PGMI_LAUNCH16X(EPI_, OUT_, STG_)                                                                  \
+#define PGMI_LAUNCH16X(EPI_, OUT_, CEPI_)                                                                 \
     do {                                                                                                 \
-        auto kfn = gemm16x_kernel<EPI_, OUT_, STG_>;                                                      \
+        auto kfn = gemm16x_kernel<EPI_, OUT_, CEPI_>;                                                     \
+        const size_t lds_bytes = X_LDS_BYTES;                                                            \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                           \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);  \
         if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PGMI_EHIP; } \
         hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, A, W, bias, residual, Cf, Ch, c_plane, M, N, K,  \
                            out_scale, tp, qo);                                                           \
     } while (0)
-#define PGMI_LAUNCH16X_S(EPI_, OUT_) do { if constexpr (OUT_ == 0) { if (stg == 3) { PGMI_LAUNCH16X(EPI_, OUT_, 3); break; } } \
-        if (stg) PGMI_LAUNCH16X(EPI_, OUT_, 1); else PGMI_LAUNCH16X(EPI_, OUT_, 0); } while (0)
-    if (qkv) PGMI_LAUNCH16X_S(EPI_NONE, 2);
-    else {
-        const int out = Ch ? 1 : 0;
-        if (epilogue == EPI_GELU) { if (out) PGMI_LAUNCH16X_S(EPI_GELU, 1); else PGMI_LAUNCH16X_S(EPI_GELU, 0); }
-        else if (epilogue == EPI_SQRELU) { if (out) PGMI_LAUNCH16X_S(EPI_SQRELU, 1); else PGMI_LAUNCH16X_S(EPI_SQRELU, 0); }
-        else { if (out) PGMI_LAUNCH16X_S(EPI_NONE, 1); else PGMI_LAUNCH16X_S(EPI_NONE, 0); }
-    }
-#undef PGMI_LAUNCH16X_S
+#define PGMI_LAUNCH16X_O(EPI_) do { if (Ch) PGMI_LAUNCH16X(EPI_, 1, false); else if (tune.cepi) PGMI_LAUNCH16X(EPI_, 0, true); \
+        else PGMI_LAUNCH16X(EPI_, 0, false); } while (0)
+    if (qkv) PGMI_LAUNCH16X(EPI_NONE, 2, false);
+    else if (epilogue == EPI_GELU) PGMI_LAUNCH16X_O(EPI_GELU);
+    else if (epilogue == EPI_SQRELU) PGMI_LAUNCH16X_O(EPI_SQRELU);
+    else PGMI_LAUNCH16X_O(EPI_NONE);
+#undef PGMI_LAUNCH16X_O
 #undef PGMI_LAUNCH16X
-    if (tp.split > 1)
-        hipLaunchKernelGGL(splitk_fix_kernel, dim3(T - tp.n_main), dim3(XNT), 0, s, tp.ws, tp.split, tp.n_main, tp.tiles_m,
-                           tp.tiles_n, bias, residual, Cf, M, N, out_scale, tp.group_m);
     PGMI_HIP(hipGetLastError());
     return PGMI_OK;
 }
@@ -381,8 +302,7 @@ static int launch_gemm16x_one(const unsigned short* A, const unsigned short* W,
 // stream.  Fused QKV output: chunks are whole sequences (the V^T scatter is per (sequence, head)).
 static int launch_gemm16x(const unsigned short* A, const unsigned short* W,
                           const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
-                          int M, int N, int K, int epilogue, float out_scale, int stg, bool splitk, hipStream_t s,
-                          const QkvOut* qkv = nullptr) {
+                          int M, int N, int K, int epilogue, float out_scale, hipStream_t s, const QkvOut* qkv = nullptr) {
     const unsigned long long lim = (1ull << 32) - 1;
     if ((unsigned long long)N * (unsigned long long)K * 4ull > lim) {
         set_error("gemm16x: weight of %d x %d split elements exceeds the 32-bit offset range", N, K);
@@ -391,8 +311,9 @@ static int launch_gemm16x(const unsigned short* A, const unsigned short* W,
     const char* tr = getenv("PGMI_GEMM_MAX_ROWS");                      // tests: force chunking at small shapes (read per launch)
     const long long test_rows = tr ? atoll(tr) : 0;
     long long max_rows = (long long)(lim / ((unsigned long long)K * 4ull));
+    if (Cf) max_rows = std::min(max_rows, (long long)(((1ull << 31) - 1) / ((unsigned long long)N * 4ull)));   // the fp32 epilogue's buffer offsets
     if (test_rows > 0) max_rows = std::min(max_rows, test_rows);
-    if (M <= max_rows) return launch_gemm16x_one(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, stg, splitk, s, qkv);
+    if (M <= max_rows) return launch_gemm16x_one(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s, qkv);
     long long per = qkv ? (max_rows / qkv->T) * qkv->T : (max_rows / XBM) * XBM;
     if (per <= 0) per = qkv ? 0 : max_rows;
     if (per <= 0) { set_error("gemm16x: one sequence of %d tokens x K = %d exceeds the 32-bit offset range", qkv->T, K); return PGMI_EINVAL; }
@@ -404,19 +325,28 @@ static int launch_gemm16x(const unsigned short* A, const unsigned short* W,
             QkvOut q = *qkv;                                                           // rows m0.. are sequences m0 / T ..
             q.vt16 = qkv->vt16 + (size_t)(m0 / qkv->T) * (size_t)qkv->H * kHeadDim * (size_t)qkv->Tp;
             rc = launch_gemm16x_one(Ac, W, bias, nullptr, nullptr, Ch + (size_t)m0 * (size_t)(2 * (N / 3)), c_plane, mc, N, K, epilogue,
-                                    out_scale, stg, splitk, s, &q);
+                                    out_scale, s, &q);
         } else {
             rc = launch_gemm16x_one(Ac, W, bias, residual ? residual + (size_t)m0 * N : nullptr, Cf ? Cf + (size_t)m0 * N : nullptr,
-                                    Ch ? Ch + (size_t)m0 * (size_t)(2 * N) : nullptr, c_plane, mc, N, K, epilogue, out_scale, stg, splitk, s, nullptr);
+                                    Ch ? Ch + (size_t)m0 * (size_t)(2 * N) : nullptr, c_plane, mc, N, K, epilogue, out_scale, s, nullptr);
         }
         if (rc) return rc;
     }
     return PGMI_OK;
 }
 
-// f16x3 variants (tuning; 0 is the product's): 0 persistent ping-pong kernel with global->LDS DMA staging; 2 the same with
-// the DMA issued after the fragment reads; 1 / 3 register staging.  K-sliced tails only with PGMI_GEMM_SPLITK=1 (not with 3).
-// The phase-timing instantiations of the kernel live in tools/gemm_diag.hip (their own binary).
+// variant (tuning; everything below 1000 is the product's configuration): 1000 + t sets the round-4 launch parameters for the
+// interleaved A/B of scripts/gemm_ab.py -- t bits 0-3: row panels per group (0: by shape), bit 9: fp32 epilogue through the
+// LDS transpose (the product's) or in accumulator order.
+static void set_tune(int variant) {
+    g_tune = GemmTune{};
+    if (variant >= 1000) {
+        const int t = variant - 1000;
+        g_tune.group_m = t & 15;
+        g_tune.cepi = (t >> 9) & 1;
+    }
+}
+
 int launch_gemm16(const unsigned short* A, size_t a_plane, const unsigned short* W, size_t w_plane,
                   const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
                   int M, int N, int K, int epilogue, float out_scale, int planes, bool bf, int variant,
@@ -428,19 +358,10 @@ int launch_gemm16(const unsigned short* A, size_t a_plane, const unsigned short*
     }
     if (planes == 2 && !bf) {
         if (Ch && (N % 32) != 0) { set_error("gemm16: split output needs N %% 32 == 0 (K-interleaved operand of the next GEMM), got %d", N); return PGMI_EINVAL; }
-        switch (variant) {
-            case 1: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 0, true, s);
-            case 2: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 3, true, s);
-            case 3: return launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 0, false, s);
-            // measured (profiles/r2/README.md): with buffer loads the DMA form wins for every output kind (FFN 368 -> 379 TFLOP/s
-            // against register staging for the fp32-output GEMMs)
-            default: {
-                g_group_m = (variant >= 101 && variant <= 164) ? variant - 100 : 0;      // 100 + g: the product kernel with g row panels per group
-                const int rc = launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, 1, true, s);
-                g_group_m = 0;
-                return rc;
-            }
-        }
+        set_tune(variant);
+        const int rc = launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s);
+        g_tune = GemmTune{};
+        return rc;
     }
     if (planes == 1 && bf) {
         if (out_scale != 1.0f) { set_error("gemm16: bf16 weights are not pre-scaled"); return PGMI_EINVAL; }
@@ -463,8 +384,10 @@ int launch_gemm16_qkv(const unsigned short* A, size_t a_plane, const unsigned sh
         return PGMI_EINVAL;
     }
     QkvOut qo{vt16, vt_plane, cos_t, sin_t, T, H, (T + 31) / 32 * 32, rotary, rot_halves};
-    return launch_gemm16x(A, W, bias, nullptr, nullptr, qk16, qk_plane, M, 3 * D, K, EPI_NONE, out_scale, (variant == 1 || variant == 3) ? 0 : 1,
-                          false, s, &qo);
+    set_tune(variant);
+    const int rc = launch_gemm16x(A, W, bias, nullptr, nullptr, qk16, qk_plane, M, 3 * D, K, EPI_NONE, out_scale, s, &qo);
+    g_tune = GemmTune{};
+    return rc;
 }
 
 // ---- fp32 -> 16-bit operands (weights at load time; activations in the op-level tests and the MSA tied-attention path) ----

@@ -264,8 +264,7 @@ class MSA_processing:
                 self.weights = np.load(file=weights_location)
             else:
                 from . import weights as _w
-                mapper = _w.map_from_alphabet(ALPHABET_PROTEIN_GAP, default=GAP)
-                mat = _w.map_matrix(np.vstack([np.array(list(s)) for s in trimmed.values()]), mapper)
+                mat = _w.encode_alignment(trimmed.values(), ALPHABET_PROTEIN_GAP, default=GAP)
                 self.weights = _w.calc_weights_fast(mat, identity_threshold=1 - theta, empty_value=0, num_cpus=num_cpus,
                                                     device=device)
                 np.save(file=weights_location, arr=self.weights)

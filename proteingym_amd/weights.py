@@ -1,15 +1,14 @@
-"""Host-side mirror of ``proteingym/utils/weights.py`` (sequence weights of an alignment) backed by
-the HIP pair-count kernel in libpgmi.so (``pgmi_msa_cluster_counts``, csrc/msa_weights.hip).
+"""Sequence weights of an alignment (the role of ``proteingym/utils/weights.py``) on the HIP pair-count kernel in
+libpgmi.so (``pgmi_msa_cluster_counts``, csrc/msa_weights.hip).
 
-Same function names and arguments as the reference (weights.py:13-53 ``calc_weights_fast``, :56-61
-``is_empty_sequence_matrix``, :64-93 ``map_from_alphabet``, :96-111 ``map_matrix``); ``num_cpus`` is
-accepted and ignored, ``device`` is additive.  There is no CPU path here: without the library or a
-GPU the call raises ``PgmiError``.
+``calc_weights_fast`` keeps the reference's name and arguments (weights.py:13-53; ``num_cpus`` is accepted and ignored,
+``device`` is additive).  The reference's EVcouplings helpers that turn letters into symbol indices (a defaultdict applied
+through ``np.vectorize``, weights.py:64-111) are replaced by one 256-entry byte table applied to the whole alignment at once
+(``encode_alignment``).  There is no CPU path here: without the library or a GPU the call raises ``PgmiError``.
 """
 from __future__ import annotations
 
 import ctypes as C
-from collections import defaultdict
 
 import numpy as np
 
@@ -17,23 +16,26 @@ from . import _lib
 from ._lib import PgmiError
 
 
-def is_empty_sequence_matrix(matrix, empty_value):
-    assert len(matrix.shape) == 2, f"Matrix must be 2D; shape={matrix.shape}"
-    assert isinstance(empty_value, (int, float)), f"empty_value must be a number; type={type(empty_value)}"
-    return np.all((matrix == empty_value), axis=1)
+def symbol_table(alphabet: str, default: str) -> np.ndarray:
+    """uint8[256]: byte of a letter -> its index in ``alphabet``; every other byte -> the index of ``default``."""
+    pos = alphabet.find(default)
+    if pos < 0 or len(default) != 1:
+        raise ValueError(f"Default {default} is not in alphabet {alphabet}")
+    table = np.full(256, pos, dtype=np.uint8)
+    table[np.frombuffer(alphabet.encode("ascii"), dtype=np.uint8)] = np.arange(len(alphabet), dtype=np.uint8)
+    return table
 
 
-def map_from_alphabet(alphabet, default):
-    map_ = {c: i for i, c in enumerate(alphabet)}
-    try:
-        default = map_[default]
-    except KeyError:
-        raise ValueError("Default {} is not in alphabet {}".format(default, alphabet))
-    return defaultdict(lambda: default, map_)
-
-
-def map_matrix(matrix, map_):
-    return np.vectorize(map_.__getitem__)(matrix)
+def encode_alignment(sequences, alphabet: str, default: str) -> np.ndarray:
+    """int8 [n_sequences, length] symbol indices of equal-length sequences (letters outside the alphabet count as ``default``)."""
+    sequences = list(sequences)
+    if not sequences:
+        return np.zeros((0, 0), dtype=np.int8)
+    width = len(sequences[0])
+    if any(len(s) != width for s in sequences):
+        raise ValueError("alignment rows differ in length")
+    raw = np.frombuffer("".join(sequences).encode("latin-1"), dtype=np.uint8).reshape(len(sequences), width)
+    return symbol_table(alphabet, default)[raw].astype(np.int8)
 
 
 def num_cluster_members(matrix_mapped, identity_threshold, invalid_value, device=0, return_ms=False):
@@ -57,8 +59,11 @@ def num_cluster_members(matrix_mapped, identity_threshold, invalid_value, device
 
 def calc_weights_fast(matrix_mapped, identity_threshold, empty_value, num_cpus=1, device=0):
     """weights.py:13-53: weight = 1 / cluster size, 0 for empty sequences."""
-    empty_idx = is_empty_sequence_matrix(matrix_mapped, empty_value=empty_value)
+    matrix_mapped = np.asarray(matrix_mapped)
+    if matrix_mapped.ndim != 2:
+        raise ValueError(f"Matrix must be 2D; shape={matrix_mapped.shape}")
     counts = num_cluster_members(matrix_mapped, identity_threshold, empty_value, device=device)
+    occupied = (matrix_mapped != empty_value).any(axis=1)           # a sequence of nothing but the empty symbol weighs 0
     weights = np.zeros(matrix_mapped.shape[0])
-    weights[~empty_idx] = 1.0 / counts[~empty_idx]
+    weights[occupied] = 1.0 / counts[occupied]
     return weights

@@ -14,7 +14,8 @@ rounds = int(sys.argv[1])
 variants = np.array([int(v) for v in sys.argv[2:]], dtype=np.int32)
 M = int(os.environ.get("GEMM_M", 82368))
 D = int(os.environ.get("GEMM_D", 1280))
-shapes = [("qkv", 3 * D, D, 0, 0), ("out", D, D, 0, 0), ("fc1", 4 * D, D, 1, 1), ("fc2", D, 4 * D, 0, 0)]
+# output kinds as in the product: fused QKV epilogue, in-place residual, GELU + split planes
+shapes = [("qkv", 3 * D, D, 0, 3), ("out", D, D, 0, 2), ("fc1", 4 * D, D, 1, 1), ("fc2", D, 4 * D, 0, 2)]
 ms = {}
 for name, N, K, epi, split in shapes:
     out = np.zeros(len(variants), dtype=np.float64)
@@ -25,4 +26,4 @@ for k, v in enumerate(variants):
     tot_ms = sum(ms[n][k] for n, *_ in shapes)
     tot_fl = sum(2.0 * M * N * K for _, N, K, _, _ in shapes)
     row = "  ".join(f"{n} {2.0 * M * N * K / ms[n][k] / 1e9:6.1f}" for n, N, K, _, _ in shapes)
-    print(f"variant {v:2d}: {row}   layer-sum {tot_fl / tot_ms / 1e9:6.1f} TF ({tot_ms:.2f} ms)", flush=True)
+    print(f"variant {v:4d}: {row}   layer-sum {tot_fl / tot_ms / 1e9:6.1f} TF ({tot_ms:.2f} ms)", flush=True)

@@ -9,7 +9,7 @@ from proteingym_amd import _lib
 
 lib = _lib.load()
 prec = sys.argv[1] if len(sys.argv) > 1 else "f16x3"
-variants = [int(v) for v in sys.argv[2:]] or [0, 1, 2, 3]
+variants = [int(v) for v in sys.argv[2:]] or [0]
 M = 82368
 shapes = [("qkv", 3840, 1280, 0, 0), ("out", 1280, 1280, 0, 0), ("fc1", 5120, 1280, 1, 1), ("fc2", 1280, 5120, 0, 0)]
 for v in variants:

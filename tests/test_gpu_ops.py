@@ -97,16 +97,20 @@ def test_attention_rotary(lib, prec):
     assert np.abs(ctx - ref).max() < 3e-5
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+GEMM_VARIANTS = [0,                  # the product's launch parameters (fp32 epilogue through the per-wave LDS transpose)
+                 1000]               # fp32 epilogue in accumulator order (the round-3 kernel's)
+
+
+@pytest.mark.parametrize("variant", GEMM_VARIANTS)
 @pytest.mark.parametrize("M,N,K,epi,res", [(300, 384, 128, 0, False), (257, 1280, 1280, 1, False),
                                             (513, 1280, 5120, 0, True), (1, 128, 256, 1, True),
-                                            (2300, 1280, 1280, 0, True),      # 45 tiles: every tile K-sliced (variants 0, 1)
+                                            (2300, 1280, 1280, 0, True),      # 45 tiles: every one as two half-height items
                                             (4200, 5120, 128, 1, False),      # 340 tiles on 256 CUs: a second item per workgroup
-                                            (15100, 1280, 256, 0, True)])     # 300 tiles: 256 full + 44 K-sliced x 2
+                                            (15100, 1280, 256, 0, True),      # 300 tiles: 256 full + 44 x 2 halves
+                                            (15100, 1284, 256, 0, True)])     # the same with a ragged last column tile (N % 256 = 4)
 def test_gemm_f16x3(lib, monkeypatch, variant, M, N, K, epi, res):
     """Split-fp16 3-pass GEMM: fp32-class accuracy (same bound as the fp32 kernel)."""
     monkeypatch.setenv("PGMI_GEMM_VARIANT", str(variant))
-    monkeypatch.setenv("PGMI_GEMM_SPLITK", "1" if variant in (1, 2) else "0")      # K-sliced tails (opt-in) with variants 1, 2
     rng = np.random.default_rng(4)
     A = (rng.standard_normal((M, K)) * rng.choice([0.01, 1.0, 30.0], size=(M, 1))).astype(np.float32)
     W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
@@ -136,7 +140,6 @@ def test_gemm_f16x3(lib, monkeypatch, variant, M, N, K, epi, res):
 def test_gemm_f16x3_half_tail_bit_identical(lib, monkeypatch, M, N, K, epi, res):
     """The half-height tail items (gemm_f16.hip: TilePlan.half) compute every element exactly as a full tile does."""
     monkeypatch.setenv("PGMI_GEMM_VARIANT", "0")
-    monkeypatch.setenv("PGMI_GEMM_SPLITK", "0")
     rng = np.random.default_rng(6)
     A = (rng.standard_normal((M, K)) * rng.choice([0.01, 1.0, 30.0], size=(M, 1))).astype(np.float32)
     W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
@@ -150,6 +153,26 @@ def test_gemm_f16x3_half_tail_bit_identical(lib, monkeypatch, M, N, K, epi, res)
         out[half] = C
     assert np.isfinite(out["1"]).all()
     assert np.array_equal(out["1"], out["0"])
+
+
+@pytest.mark.parametrize("M,N,K,epi,res", [(15100, 1280, 256, 0, True), (15100, 1284, 256, 1, True), (70000, 1280, 128, 0, True),
+                                            (300, 384, 128, 0, False)])
+def test_gemm_f16x3_launch_parameters_bit_identical(lib, monkeypatch, M, N, K, epi, res):
+    """The fp32 epilogue's path through LDS does not touch a row's arithmetic."""
+    rng = np.random.default_rng(8)
+    A = (rng.standard_normal((M, K)) * rng.choice([0.01, 1.0, 30.0], size=(M, 1))).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    R = rng.standard_normal((M, N)).astype(np.float32) if res else None
+    out = []
+    for variant in GEMM_VARIANTS:
+        monkeypatch.setenv("PGMI_GEMM_VARIANT", str(variant))
+        C = np.full((M, N), np.nan, np.float32)
+        _lib.check(lib.pgmi_op_gemm(0, _lib.PREC_F16X3, _p(A), _p(W), _p(bias), _p(R), M, N, K, epi, _p(C)))
+        out.append(C)
+    assert np.isfinite(out[0]).all()
+    for C in out[1:]:
+        assert np.array_equal(out[0], C)
 
 
 @pytest.mark.parametrize("M,N,K,epi,res", [(300, 384, 256, 0, False), (3600, 384, 128, 0, False),
