@@ -299,8 +299,6 @@ def score_msa_transformer(args, df, mutant_col, msa_start_index, MSA_weight_file
         if tdist.is_available() and tdist.is_initialized():
             shard_rank, shard_world = tdist.get_rank(), tdist.get_world_size()
     args.offset_idx = msa_start_index
-    mutants = [str(m) for m in df[mutant_col]]
-    cells = sorted({1 + int(one[1:-1]) - args.offset_idx for m in mutants for one in m.split(":")})   # +1: <cls>
     pad32 = lambda n: (n + 31) // 32 * 32
     for location in args.model_location:
         max_rows = pad32(min(args.msa_samples + (1 if pppl else 0), 1024)) * pad32(min(len(args.sequence) + 1, 1024))
@@ -323,8 +321,10 @@ def score_msa_transformer(args, df, mutant_col, msa_start_index, MSA_weight_file
             tokens = to_tokens([rows])[2][0]                      # [R, L+1]
             print(f"Batch sizes: {(1,) + tokens.shape}")
             if pppl:                                              # compute_fitness.py:403-417
+                # row-wise from the CURRENT frame (compute_fitness.py:405-409): after an earlier seed or run it is the on-disk frame,
+                # whose rows need not be the input file's in number or order
                 if "mutated_sequence" not in df:
-                    df["mutated_sequence"] = [get_mutated_sequence(m, args.sequence, args.offset_idx) for m in mutants]
+                    df["mutated_sequence"] = [get_mutated_sequence(str(m), args.sequence, args.offset_idx) for m in df[mutant_col]]
                 df[column] = [compute_pppl_msa(sq, model, alphabet, rows) for sq in df["mutated_sequence"]]
                 if on_disk is not None and not args.overwrite_prior_scores:
                     assert column not in on_disk.columns, f"Column {column} already exists in {out_csv}"
@@ -333,6 +333,7 @@ def score_msa_transformer(args, df, mutant_col, msa_start_index, MSA_weight_file
                 continue
             T = tokens.shape[1]
             # the reference forwards every column; only cells some mutant reads are needed (--all-positions restores it)
+            cells = sorted({1 + int(one[1:-1]) - args.offset_idx for m in df[mutant_col] for one in str(m).split(":")})   # +1: <cls>
             positions = list(range(T)) if args.all_positions else cells
             table = np.full((T, 33), np.nan, dtype=np.float32)
             # (seed, position) is the unit of work SURVEY 8e names for this path: with --shard-positions under torchrun every
@@ -345,7 +346,7 @@ def score_msa_transformer(args, df, mutant_col, msa_start_index, MSA_weight_file
                 from . import dist as pdist
                 import torch.distributed as tdist
                 table = pdist.gather_tables({0: table}, [T], device="cuda" if tdist.get_backend() == "nccl" else "cpu")[0]
-            df[column] = [label_row(m, args.sequence, table, alphabet, args.offset_idx) for m in mutants]
+            df[column] = [label_row(str(m), args.sequence, table, alphabet, args.offset_idx) for m in df[mutant_col]]   # the current frame's rows
             if on_disk is not None and not args.overwrite_prior_scores:
                 assert column not in on_disk.columns, f"Column {column} already exists in {out_csv}"
                 df = on_disk.merge(df[[column, "mutant"]], on="mutant")

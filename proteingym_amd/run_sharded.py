@@ -89,18 +89,56 @@ def plan_mutant_chunks(seq_lens, n_rows, world: int, max_chunk_rows: int = 0):
 
 
 def rows_per_assay(mapping, indices, data_folder):
-    """Row count of every assay file: the reference table's DMS_total_number_mutants where it has one, else the file's line
-    count.  Every rank must see the same numbers (they shape the all_gather); the rank that loads a file checks it."""
+    """Row count of every assay FILE (non-blank lines after the header), counted by every rank from the shared folder: the
+    numbers shape the chunk plan and the all_gather, so they must be the same everywhere and must be the files' own -- the
+    reference table's DMS_total_number_mutants is only a fallback for a file this rank cannot read (the rank that loads it
+    then fails that assay).  A file whose row count differs from the table is scored like the single-assay CLI scores it."""
     out = []
     for i in indices:
         row = mapping.iloc[i]
-        v = row["DMS_total_number_mutants"] if "DMS_total_number_mutants" in mapping.columns else float("nan")
-        if v == v:
-            out.append(int(v))
-        else:
+        try:
             with open(os.path.join(data_folder, str(row["DMS_filename"])), "rb") as f:
-                out.append(max(0, sum(1 for _ in f) - 1))
+                out.append(max(0, sum(1 for line in f if line.strip()) - 1))
+        except OSError:
+            v = row["DMS_total_number_mutants"] if "DMS_total_number_mutants" in mapping.columns else float("nan")
+            out.append(int(v) if v == v else 0)
     return out
+
+
+def shared_retrieval(ptr, retrieval_args, cache_dir, tag, wait_s=1800.0):
+    """``tranception.build_retrieval`` computed ONCE per assay across the ranks of a job: the chunks of a large assay land on
+    several ranks, each of which would otherwise re-read the alignment (and recompute sequence weights when no weight file
+    exists).  The rank that creates ``<tag>.lock`` first builds the log-prior and publishes it as ``<tag>.npy`` (atomic
+    rename); the others wait for the file.  The array is the builder's own output, so every rank scores with the same bits.
+    A waiter that times out (builder died) builds it itself."""
+    import numpy as np
+    if not retrieval_args:
+        return None
+    os.makedirs(cache_dir, exist_ok=True)
+    path, lock = os.path.join(cache_dir, tag + ".npy"), os.path.join(cache_dir, tag + ".lock")
+
+    def from_file():
+        return dict(log_prior=np.load(path), MSA_start=int(retrieval_args["MSA_start"]), MSA_end=int(retrieval_args["MSA_end"]),
+                    weight=float(retrieval_args.get("retrieval_inference_weight", 0.6)))
+    if os.path.exists(path):
+        return from_file()
+    try:
+        fd = os.open(lock, os.O_CREAT | os.O_EXCL | os.O_WRONLY)
+        os.close(fd)
+        builder = True
+    except FileExistsError:
+        builder = False
+    if not builder:
+        t_end = time.time() + wait_s
+        while time.time() < t_end:
+            if os.path.exists(path):
+                return from_file()
+            time.sleep(0.05)
+    r = ptr.build_retrieval(retrieval_args)
+    tmp = f"{path}.{os.getpid()}.tmp.npy"
+    np.save(tmp, r["log_prior"])
+    os.replace(tmp, path)
+    return r
 
 
 def chunk_row_scores(model, chunk, wild_type, scoring_mirror, indel_mode):
@@ -183,6 +221,14 @@ def main_tranception_mutants(own, rest, mapping, indices, rank, local_rank, worl
     mirror = not base.deactivate_scoring_mirror
     model = None
     local, failed, frames = {}, {}, {}
+    # one tag per job so that a later run (other weights, other alignment) never reads this one's priors: rank 0's start time
+    job_tag = str(int(t0 * 1000))
+    if world > 1:
+        import torch
+        import torch.distributed as tdist
+        stamp = torch.tensor([int(t0 * 1000)], dtype=torch.int64, device="cuda" if tdist.get_backend() == "nccl" else "cpu")
+        tdist.broadcast(stamp, 0)
+        job_tag = str(int(stamp.item()))
 
     def assay_inputs(k):
         args = cli.create_parser().parse_args(rest + ["--DMS_index", str(indices[k]), "--device", str(local_rank)])
@@ -197,13 +243,20 @@ def main_tranception_mutants(own, rest, mapping, indices, rank, local_rank, worl
             args, dms_id, wild_type, assay_file, msa = assay_inputs(k)
             frame = _assay_frame(args, assay_file, wild_type)
             if len(frame) != n_rows[k]:
-                raise ValueError(f"{assay_file} has {len(frame)} rows, the reference table says {n_rows[k]} (DMS_total_number_mutants): "
-                                 "the chunk plan of every rank is built from the table")
+                raise ValueError(f"{assay_file}: pandas reads {len(frame)} rows, the line count every rank planned with is {n_rows[k]}")
             frames[k] = frame
+            if n_rows[k] == 0:                               # a header-only file: nothing to score, the CSV below is header-only too
+                for j in js:
+                    local[j] = np.zeros(0)
+                continue
             if model is None:                                # one checkpoint load per rank
                 model = make_model(base.checkpoint, local_rank, base.scoring_window) if make_model is not None else \
                     ptr.from_pretrained(base.checkpoint, device=local_rank, scoring_window=base.scoring_window)
-            model.retrieval = ptr.build_retrieval(cli.retrieval_arguments(args, wild_type, msa))
+            if world > 1:                                    # an assay's chunks may sit on several ranks: one of them builds the prior
+                model.retrieval = shared_retrieval(ptr, cli.retrieval_arguments(args, wild_type, msa),
+                                                   os.path.join(args.output_scores_folder, ".retrieval_prior_cache"), f"{job_tag}_{dms_id}")
+            else:
+                model.retrieval = ptr.build_retrieval(cli.retrieval_arguments(args, wild_type, msa))
             for j in js:
                 _, r0, r1 = items[j]
                 local[j] = chunk_row_scores(model, frame.iloc[r0:r1], wild_type, mirror, args.indel_mode).ravel()
@@ -251,6 +304,14 @@ def main_tranception_mutants(own, rest, mapping, indices, rank, local_rank, worl
     if world > 1:
         import torch.distributed as tdist
         tdist.barrier()
+        if rank == 0:                                        # the job's shared priors have served every rank
+            cache = os.path.join(base.output_scores_folder, ".retrieval_prior_cache")
+            if os.path.isdir(cache):
+                for fn in os.listdir(cache):
+                    if fn.startswith(job_tag + "_"):
+                        os.remove(os.path.join(cache, fn))
+                if not os.listdir(cache):
+                    os.rmdir(cache)
         tdist.destroy_process_group()
     if n_failed:
         raise SystemExit(f"run_sharded: {n_failed} assay(s) failed (see the per-rank messages); their CSVs were not written")

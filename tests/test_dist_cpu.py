@@ -209,6 +209,82 @@ def test_tranception_mutant_chunks_world2_equal_the_unsharded_scorer(tmp_path, w
         assert a == open(os.path.join(workdir, "out1", r["DMS_id"] + ".csv")).read()
 
 
+def test_tranception_mutant_chunks_plan_from_the_files_not_the_table(tmp_path):
+    """The chunk plan counts the assay FILES' rows: a table whose DMS_total_number_mutants is stale (or missing) and a
+    header-only assay file are scored like the single-assay CLI scores them -- the former in full, the latter as a
+    header-only CSV without a scorer call -- on one process and on two gloo ranks."""
+    import pandas as pd
+    from proteingym_amd import run_sharded
+    workdir = str(tmp_path)
+    rows = _make_tranception_assays(workdir, indel=False)
+    table = pd.read_csv(os.path.join(workdir, "map.csv"))
+    true_n = [r["DMS_total_number_mutants"] for r in rows]
+    table.loc[0, "DMS_total_number_mutants"] = 650                 # the file has 700 rows
+    table.loc[1, "DMS_total_number_mutants"] = float("nan")
+    empty = pd.read_csv(os.path.join(workdir, "dms", "T3.csv")).iloc[:0]
+    empty.to_csv(os.path.join(workdir, "dms", "T3.csv"), index=False)          # header only; the table still says 5
+    true_n[3] = 0
+    table.to_csv(os.path.join(workdir, "map.csv"), index=False)
+    assert run_sharded.rows_per_assay(table, range(4), os.path.join(workdir, "dms")) == true_n
+    argv = _tranception_args(workdir, "optimal", False)
+    cli_part = argv[argv.index("--") + 1:]
+    cli_part[cli_part.index("--output_scores_folder") + 1] = os.path.join(workdir, "out1")
+    one = run_sharded.main(["tranception", "--", *cli_part], make_model=_fake_tranception)
+    assert one == [(k, 0, n) for k, n in enumerate(true_n)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_mutant_chunk_worker, args=(r, 2, port, workdir, "optimal", False, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sum(b - a for part in res.values() for _, a, b in part) == sum(true_n)
+    model = _fake_tranception("fake", 0, "optimal")
+    for k, r in enumerate(rows):
+        a = open(os.path.join(workdir, "out", r["DMS_id"] + ".csv")).read()
+        assert a == open(os.path.join(workdir, "out1", r["DMS_id"] + ".csv")).read()
+        got = pd.read_csv(os.path.join(workdir, "out", r["DMS_id"] + ".csv"), float_precision="round_trip")
+        if true_n[k] == 0:
+            assert len(got) == 0 and "avg_score" in got.columns
+        else:
+            want = model.score_mutants(DMS_data=pd.read_csv(os.path.join(workdir, "dms", r["DMS_filename"])), target_seq=r["target_seq"])
+            assert len(got) == len(want) and np.array_equal(got["avg_score"].to_numpy(), want["avg_score"].to_numpy())
+
+
+def _prior_worker(rank, cache, q):
+    from proteingym_amd import run_sharded
+
+    class P:                                                      # counts the builds through a file per call
+        @staticmethod
+        def build_retrieval(r):
+            import time as _t
+            open(os.path.join(cache, f"built_by_{rank}"), "w").close()
+            _t.sleep(0.5)
+            return dict(log_prior=np.arange(6, dtype=np.float32).reshape(2, 3) + 0.25, MSA_start=r["MSA_start"], MSA_end=r["MSA_end"], weight=0.6)
+    out = run_sharded.shared_retrieval(P, dict(MSA_start=1, MSA_end=3), cache, "job_T0")
+    q.put((rank, out["log_prior"].tolist(), out["MSA_start"], out["MSA_end"], out["weight"]))
+
+
+def test_retrieval_prior_is_built_once_for_the_ranks_that_share_an_assay(tmp_path):
+    """shared_retrieval: of the ranks that hold chunks of one assay exactly one builds the log-prior, the others read its file."""
+    cache = str(tmp_path / "cache")
+    os.makedirs(cache)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_prior_worker, args=(r, cache, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len([f for f in os.listdir(cache) if f.startswith("built_by_")]) == 1
+    assert all(r[1:] == res[0][1:] for r in res) and res[0][1] == [[0.25, 1.25, 2.25], [3.25, 4.25, 5.25]]
+
+
 def test_tranception_chunk_plan_balances_the_real_table():
     """Config 4 on 8 GPUs: whole assays give max/mean 2.08 on the real substitution table (one assay is 26 % of the
     cost); mutant chunks must bring every rank within 2 % of the mean, and keep the number of assays a rank touches (one
