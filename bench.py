@@ -430,6 +430,8 @@ def main():
         st = bench_scale.run(model, rank, world, args.steps, args.warmup, torch, dist,
                              max_assays=int(os.environ.get("PGMI_BENCH_217_ASSAYS", "0")))
         prof = model.profile()
+        from proteingym_amd import dist as pdist
+        rccl = pdist.collective_identity(local_rank)                  # a collective: every rank calls it
         if rank == 0:
             ffn_ms = prof["gemm_fc1"]["ms"] + prof["gemm_fc2"]["ms"]
             ffn_fl = prof["gemm_fc1"]["flops"] + prof["gemm_fc2"]["flops"]
@@ -454,6 +456,9 @@ def main():
                                         f"warm-up = the first {min(args.warmup, args.steps)} slices, untimed, then repeated inside the pass",
                            "one_gpu_point_of_this_curve": "the N = 1 line's secondary.benchmark_217_end_to_end: mutants / rank0_wall_clock.assay_run_s",
                            "precision": args.precision, "layers": args.layers},
+                "rccl": rccl,
+                "scaling_efficiency_formula": "value(N) / (N * one_gpu_same_workload_mutants_per_s of the N = 1 line) -- NOT value(N) / (N * value(1)): "
+                                              "value(1) is BASELINE configs[1] (one BLAT-shaped assay), this line is the 217-assay table",
                 "strong_scaling": st,
                 "weak_scaling": weak,
                 **({"REHEARSAL": "PGMI_BENCH_SHARE_GPU=1: ranks share a GPU and use gloo -- not a measurement"} if share else {}),
@@ -537,6 +542,12 @@ def main():
                         out["secondary"] = secondary(args.precision)
                 except Exception as e:                               # a secondary leg must never take the headline line down
                     out["secondary"] = {"error": repr(e)}
+                b217 = out["secondary"].get("benchmark_217_end_to_end") if isinstance(out["secondary"], dict) else None
+                if b217 and b217.get("rank0_wall_clock", {}).get("assay_run_s"):
+                    # the one-GPU point of the N > 1 strong-scaling curve (same workload, same timed region: mutants / seconds inside the scorer)
+                    out["one_gpu_same_workload_mutants_per_s"] = b217["mutants"] / b217["rank0_wall_clock"]["assay_run_s"]
+                    out["one_gpu_same_workload"] = ("the 217-assay-shaped table of the N > 1 lines on one GPU (secondary.benchmark_217_end_to_end: mutants / "
+                                                    "rank0_wall_clock.assay_run_s); scaling efficiency at N GPUs = value(N) / (N * this number)")
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

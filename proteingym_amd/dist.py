@@ -145,3 +145,43 @@ def init_from_env(backend: str = None):
             kw["device_id"] = torch.device("cuda", local_rank)
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
     return rank, local_rank, world
+
+
+def collective_identity(device=None):
+    """What the N > 1 bench line carries so that it proves which collective library saw how many ranks on which devices:
+    backend and world size as ``torch.distributed`` reports them, the library version, and one identity string per rank
+    (local device index, name, PCI bus id or UUID where this torch build exposes them) moved through the backend itself with
+    one fixed-stride all_gather -- ``world_size`` strings that differ pairwise mean ``world_size`` distinct devices took part."""
+    import torch
+    import torch.distributed as tdist
+    if not (tdist.is_available() and tdist.is_initialized()):
+        return {"backend": None, "world_size": 1, "devices": [], "version": None}
+    backend, world = tdist.get_backend(), tdist.get_world_size()
+    on_gpu = backend == "nccl" and torch.cuda.is_available()
+    ident = f"host-rank{tdist.get_rank()}"
+    if torch.cuda.is_available():
+        idx = torch.cuda.current_device() if device is None else int(device)
+        prop = torch.cuda.get_device_properties(idx)
+        parts = [f"cuda:{idx}", str(prop.name)]
+        for attr in ("pci_domain_id", "pci_bus_id", "pci_device_id"):
+            if hasattr(prop, attr):
+                parts.append(f"{attr}={getattr(prop, attr)}")
+        if hasattr(prop, "uuid"):
+            parts.append(f"uuid={prop.uuid}")
+        ident = " ".join(parts)
+    raw = ident.encode("utf-8")[:127]
+    mine = torch.zeros(128, dtype=torch.uint8)
+    mine[:len(raw)] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+    dev = "cuda" if on_gpu else "cpu"
+    allv = torch.zeros(world * 128, dtype=torch.uint8, device=dev)
+    tdist.all_gather_into_tensor(allv, mine.to(dev))
+    rows = allv.cpu().numpy().reshape(world, 128)
+    devices = [bytes(r[:int((r != 0).sum())]).decode("utf-8", "replace") for r in rows]
+    version = None
+    if backend == "nccl" and hasattr(torch.cuda, "nccl"):
+        try:
+            version = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:                                    # noqa: BLE001 -- a missing version string must not take a bench line down
+            version = None
+    return {"backend": backend, "world_size": world, "devices": devices, "distinct_devices": len(set(devices)), "version": version,
+            "library": "RCCL (torch.distributed backend 'nccl' on ROCm)" if backend == "nccl" else backend}

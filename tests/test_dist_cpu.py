@@ -56,6 +56,33 @@ def test_gloo_world2_partition_and_gather():
     assert res[0][2] == res[1][2]               # identical assignment on every rank
 
 
+def _identity_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    q.put((rank, pdist.collective_identity()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_collective_identity_reports_backend_world_and_one_string_per_rank():
+    """The `rccl` object of the N > 1 bench line: backend / world size from torch.distributed and one identity per rank moved
+    through the backend itself (gloo here; tests/test_gpu_dist.py runs it on a one-rank nccl group)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_identity_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == res[1]
+    assert res[0]["backend"] == "gloo" and res[0]["world_size"] == 2 and len(res[0]["devices"]) == 2
+    assert res[0]["distinct_devices"] == 2 and res[0]["devices"][0].endswith("rank0") and res[0]["devices"][1].endswith("rank1")
+
+
 def test_single_process_gather_is_identity():
     local = {0: np.arange(4.0), 1: np.zeros(0)}
     out = pdist.gather_score_vectors(local, [4, 0], [[0, 1]])

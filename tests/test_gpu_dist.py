@@ -38,6 +38,10 @@ def _worker(port, q):
         t = torch.tensor([1.5], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         ok = ok and bool(torch.equal(out, buf)) and float(t.item()) == 1.5
+        # the N > 1 bench line's `rccl` object: backend, world size, library version and the per-rank device identities
+        ident = pdist.collective_identity(0)
+        ok = ok and ident["backend"] == "nccl" and ident["world_size"] == 1 and len(ident["devices"]) == 1
+        ok = ok and ident["devices"][0].startswith("cuda:0 ") and ident["distinct_devices"] == 1 and bool(ident["version"])
         dist.barrier()
         dist.destroy_process_group()
         q.put(("ok" if ok else "mismatch", torch.cuda.nccl.version() if hasattr(torch.cuda, "nccl") else None))

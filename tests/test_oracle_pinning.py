@@ -649,3 +649,98 @@ def test_reference_merge_script_consumes_the_indel_csvs(tmp_path, monkeypatch):
     tr = pd.read_csv(scores / "Tranception_no_retrieval" / "Tranception_L" / "TOY_I.csv").drop_duplicates("mutated_sequence").set_index("mutated_sequence")
     assert len(merged) == len(assay) and not merged["Tranception_L_no_retrieval"].isna().any()
     assert np.allclose(merged["Tranception_L_no_retrieval"], tr.loc[merged["mutated_sequence"], "avg_score"].to_numpy())
+
+
+class _GoldenCliScorer:
+    """Stands in for the device with the scores the UNMODIFIED reference CLI wrote for the toy checkpoints (tests/golden/golden_esm.npz,
+    keys cli/<stem> and cli_long/<stem>): the CSVs run_benchmark writes then carry the reference's own numbers in the product's files."""
+    golden = None
+
+    def __init__(self, location):
+        self.stem = os.path.splitext(os.path.basename(location))[0]
+
+    def score(self, seq, mutants, offset):
+        key = ("cli_long/" if len(seq) > 1000 else "cli/") + self.stem
+        v = np.asarray(self.golden[key], dtype=np.float64)
+        assert len(v) == len(mutants)
+        return v
+
+    def close(self):
+        pass
+
+
+@pytest.mark.skipif(not rh.reference_available(), reason="/root/reference not present (GPU box)")
+def test_reference_performance_script_consumes_the_merged_scores(tmp_path, monkeypatch, golden_dir):
+    """The LAST consumer of the boundary (north star: "drops in under performance_DMS_benchmarks.py"): run_benchmark CSVs (ESM-1v
+    single + ensemble column, ESM2) of two toy assays -> the reference's merge.py -> the reference's performance_DMS_benchmarks.py
+    (performance_DMS_benchmarks.py:181-195 reads merged_scores/<DMS_id>.csv and the registry's score columns).  The per-assay Spearman
+    table it writes must equal scipy's spearmanr of the reference CLI's golden scores against DMS_score, at the 3 decimals the script
+    keeps (and the unrounded values agree to 1e-12 with what the product's CSVs hold).  tests/test_gpu_esm.py shows the device scores
+    give the same Spearman to 4 dp as these golden CLI scores.  The script's bootstrap (10 000 resamples) is cut to 20: only its
+    standard-error column depends on it."""
+    import importlib.util
+    import json
+    import shutil
+    import sys
+    from scipy.stats import spearmanr
+    from proteingym_amd import run_benchmark as rb
+    g = np.load(os.path.join(golden_dir, "golden_esm.npz"), allow_pickle=True)
+    _GoldenCliScorer.golden = g
+    dms = tmp_path / "dms"
+    dms.mkdir()
+    # four assays (the script's summary wants every taxon and every alignment-depth class present): the short and the long toy
+    # assay under two names each
+    layout = [("TOY_A", "TOY_DMS.csv", "seq", "Activity", "medium", "Human"), ("TOY_B", "TOY_LONG_DMS.csv", "seq_long", "Stability", "low", "Virus"),
+              ("TOY_C", "TOY_DMS.csv", "seq", "Binding", "high", "Eukaryote"), ("TOY_D", "TOY_LONG_DMS.csv", "seq_long", "Expression", "medium", "Prokaryote")]
+    ref_rows = []
+    for dms_id, src, seq_key, sel, neff, taxon in layout:
+        shutil.copy(os.path.join(golden_dir, src), dms / f"{dms_id}.csv")
+        ref_rows.append(dict(DMS_id=dms_id, DMS_filename=f"{dms_id}.csv", target_seq=str(g[seq_key]), DMS_total_number_mutants=len(pd.read_csv(dms / f"{dms_id}.csv")),
+                             UniProt_ID=dms_id + "_X", coarse_selection_type=sel, MSA_Neff_L_category=neff, taxon=taxon, MSA_start=1, MSA_end=len(str(g[seq_key]))))
+    pd.DataFrame(ref_rows).to_csv(tmp_path / "ref.csv", index=False)
+    registry = json.load(open("/root/reference/config.json"))["model_list_zero_shot_substitutions_DMS"]
+    models = {k: dict(registry[k]) for k in ("ESM1v_single", "ESM1v_ensemble", "ESM2_3B")}
+    models["ESM1v_single"]["input_score_name"] = "esm1v_toy_1"          # the toy checkpoints' file stems
+    models["ESM2_3B"]["input_score_name"] = "esm2_toy"
+    scores = tmp_path / "scores"
+    common = ["--dms_mapping", str(tmp_path / "ref.csv"), "--dms-input", str(dms)]
+    rb.main(rb.create_parser().parse_args(["--model-location", "/ckpt/esm1v_toy_1.pt", "--model_type", "ESM1v", *common,
+                                           "--dms-output", str(scores / models["ESM1v_ensemble"]["location"])]), make_model=_GoldenCliScorer)
+    rb.main(rb.create_parser().parse_args(["--model-location", "/ckpt/esm2_toy.pt", "--model_type", "ESM2", *common,
+                                           "--dms-output", str(scores / models["ESM2_3B"]["location"])]), make_model=_GoldenCliScorer)
+    json.dump({"model_list_zero_shot_substitutions_DMS": models}, open(tmp_path / "config.json", "w"))
+
+    def load(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    merge = load("pg_reference_merge_perf", "/root/reference/proteingym/merge.py")
+    monkeypatch.setattr(sys, "argv", ["merge.py", "--DMS_assays_location", str(dms), "--model_scores_location", str(scores),
+                                      "--DMS_reference_file", str(tmp_path / "ref.csv"), "--config_file", str(tmp_path / "config.json")])
+    merge.main()
+    perf = load("pg_reference_performance", "/root/reference/proteingym/performance_DMS_benchmarks.py")
+    slow = perf.compute_bootstrap_standard_error_functional_categories
+    monkeypatch.setattr(perf, "compute_bootstrap_standard_error_functional_categories", lambda df, number_assay_reshuffle=20: slow(df, 20))
+    outdir = tmp_path / "performance"
+    monkeypatch.setattr(sys, "argv", ["performance_DMS_benchmarks.py", "--input_scoring_files_folder", str(scores / "merged_scores"),
+                                      "--output_performance_file_folder", str(outdir), "--DMS_reference_file_path", str(tmp_path / "ref.csv"),
+                                      "--DMS_data_folder", str(dms), "--config_file", str(tmp_path / "config.json")])
+    perf.main()
+    table = pd.read_csv(outdir / "Spearman" / "DMS_substitutions_Spearman_DMS_level.csv", index_col="DMS ID")
+    clean = json.load(open("/root/reference/proteingym/constants.json"))["clean_names"]
+    short = {"ESM1v_single": g["cli/esm1v_toy_1"], "ESM1v_ensemble": g["cli/esm1v_toy_1"], "ESM2_3B": g["cli/esm2_toy"]}
+    long_ = {"ESM1v_single": g["cli_long/esm1v_toy_1"], "ESM1v_ensemble": g["cli_long/esm1v_toy_1"], "ESM2_3B": g["cli_long/esm2_toy"]}
+    want = {"TOY_A": short, "TOY_B": long_, "TOY_C": short, "TOY_D": long_}
+    for dms_id, by_model in want.items():
+        dms_score = pd.read_csv(dms / f"{dms_id}.csv")["DMS_score"]
+        merged = pd.read_csv(scores / "merged_scores" / f"{dms_id}.csv", float_precision="round_trip")
+        assert int(table.loc[dms_id, clean.get("number_mutants", "number_mutants")]) == len(dms_score)
+        for model, cli_scores in by_model.items():
+            rho = spearmanr(dms_score, np.asarray(cli_scores, dtype=np.float64))[0]
+            assert abs(spearmanr(merged["DMS_score"], merged[model])[0] - rho) < 1e-12          # what the product's files hold
+            assert float(table.loc[dms_id, clean.get(model, model)]) == round(rho, 3)            # what the reference's script reports
+    for metric in ("AUC", "MCC", "NDCG", "Top_recall"):
+        assert os.path.exists(outdir / metric / f"DMS_substitutions_{metric}_DMS_level.csv")
+    summary = [f for f in os.listdir(outdir / "Spearman") if f.startswith("Summary")]
+    assert summary, os.listdir(outdir / "Spearman")
