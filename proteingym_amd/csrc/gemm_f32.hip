@@ -132,6 +132,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(
         }
         const float* Ab = As + cur * BM * LDS_STRIDE + a_frag;
         const float* Bb = Bs + cur * BN * LDS_STRIDE + b_frag;
+        // Two-level sum: the 32 products of a K tile go through one MFMA chain that starts at 0 (`part`), and the tiles' partial
+        // sums are added in fp32 afterwards.  One chain over the whole K (2 560 dependent roundings at K = 5120) put this mode
+        // 2x further from exact arithmetic than the reference's blocked CPU GEMM on long sums (736-term pseudo-ppl sums, depth-5
+        // multi-mutants: VERDICT r3); K / 32 + 16 roundings per element are closer to what a blocked sgemm does.  The 64 adds per
+        // K tile issue under the 64 MFMAs of the next tile.
+        f32x16 part[2][2];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x4 af[2], bf[2];
@@ -146,9 +152,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e],
-                                                                         acc[i][j], 0, 0, 0);
+                        part[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e],
+                                                                          (g == 0 && e == 0) ? f32x16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f} : part[i][j], 0, 0, 0);
         }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[i][j][v] += part[i][j][v];
         if (more) {
             float* Aw = As + (cur ^ 1) * BM * LDS_STRIDE;
             float* Bw = Bs + (cur ^ 1) * BN * LDS_STRIDE;

@@ -87,6 +87,38 @@ def random_weights(cfg, seed: int, embed_std: float = 0.25) -> np.ndarray:
     return blob
 
 
+def outlier_weights(cfg, seed: int, n_outlier: int = 6, magnitude: float = 3000.0, max_ln_gain: float = 30.0,
+                    tail_df: float = 3.0, embed_std: float = 0.15, inject_layer: int = 2) -> np.ndarray:
+    """A checkpoint with the features real ESM / LLM checkpoints are known for and ``random_weights`` lacks (flat ABI blob):
+    * heavy-tailed Linear weights: Student-t(tail_df) scaled to nn.Linear's default variance (max / median of a matrix ~ 10^2-10^3,
+      so the per-tensor power-of-two pre-scale of the f16x3 weight planes leaves most entries far below the largest);
+    * ``n_outlier`` "massive" residual channels: the learned positions (ESM-1b/1v) carry +-magnitude there from the first layer on,
+      and layer ``inject_layer``'s FC2 bias adds +-magnitude as the feed-forward of real models does -- every LayerNorm after that
+      sees a row whose variance is a few channels, every residual add works at fp32's resolution AT that magnitude;
+    * LayerNorm gains up to ``max_ln_gain`` on a handful of channels of every LayerNorm (the outlier channels among them).
+    The tied embedding / LM-head rows stay N(0, embed_std^2): the log-likelihood ratios keep the size real checkpoints produce."""
+    rng = np.random.default_rng(seed)
+    blob = random_weights(cfg, seed=seed, embed_std=embed_std)
+    arrs = blob_to_arrays(cfg, blob)                       # views into blob
+    D = cfg["embed_dim"]
+    chans = rng.choice(D, size=n_outlier, replace=False)
+    signs = rng.choice([-1.0, 1.0], size=n_outlier)
+    for k, v in arrs.items():
+        if k == "lm_head.weight" or k.startswith("embed_tokens"):
+            continue
+        if v.ndim == 2 and not k.startswith("embed_"):
+            b = 1.0 / np.sqrt(v.shape[1])                  # U(-b, b) has variance b^2 / 3; t(df) has df / (df - 2)
+            v[:] = (rng.standard_t(tail_df, size=v.shape) * (b / np.sqrt(3.0) / np.sqrt(tail_df / (tail_df - 2.0)))).astype(np.float32)
+        elif "layer_norm" in k and k.endswith("weight"):
+            hot = np.concatenate([chans[:3], rng.choice(D, size=5, replace=False)])
+            v[hot] = rng.uniform(0.3 * max_ln_gain, max_ln_gain, size=hot.size).astype(np.float32)
+    if "embed_positions.weight" in arrs:
+        pe = arrs["embed_positions.weight"]
+        pe[:, chans] = (signs * magnitude * (1.0 + 0.1 * rng.standard_normal((pe.shape[0], n_outlier)))).astype(np.float32)
+    arrs[f"layers.{inject_layer}.fc2.bias"][chans] += (signs * magnitude).astype(np.float32)
+    return blob
+
+
 def blob_to_arrays(cfg, blob: np.ndarray) -> Dict[str, np.ndarray]:
     out, o = {}, 0
     for k, s in key_shapes(cfg):

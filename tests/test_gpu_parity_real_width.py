@@ -113,12 +113,14 @@ def test_esm2_650m_pppl_735_residues_vs_reference(lib, golden_dir, precision):
     model = pesm.EsmModel(cfg, blob, device=0, precision=precision)
     lib_ = pesm.SequenceLibrary(model, seqs)
     scores, terms = lib_.score(want_terms=True)
-    # The sum bar.  A flat 1e-4 on a 736-term sum is not a meaningful bar at this size: the UNMODIFIED reference's own fp32 sum is
-    # 2.6e-3 away from the same sum in exact (fp64) arithmetic (terms64/0 of the fixture: per-term 2.4e-5, i.e. the per-term
-    # differences do not average out over the sum).  Held instead: every TERM within the flat 1e-4; the sum within 3x the
-    # reference's own distance to fp64, against the reference AND against fp64.  Measured (profiles/r3/README.md): f16x3 is
-    # CLOSER to fp64 than the reference is (1.4e-3 vs 2.6e-3: an fp16 MFMA adds 16 exact products before its one fp32 rounding);
-    # the fp32 mode (v_mfma_f32_32x32x2: two products per rounding, one long chain over K) is 2.2x the reference's distance.
+    # The sum bar.  Config 5's per-mutant quantity is a SUM of ~736 terms, and the north star's flat 1e-4 cannot be stated against the
+    # reference for it: the UNMODIFIED reference's own fp32 sum is 2.6e-3 away from the same sum in exact (fp64) arithmetic (terms64/0
+    # of the fixture: per-term 2.4e-5; the per-term differences do not average out over the sum).  What is held, in BOTH modes:
+    #   * every TERM within the flat 1e-4 of the reference's;
+    #   * the sum CLOSER to exact (fp64) arithmetic than the reference's own sum is (e64 < the reference's distance), hence
+    #   * |sum - reference's sum| < 2 x that distance (triangle inequality) -- i.e. "within the reference's own fp32 noise", not 1e-4.
+    # Measured (profiles/r4/README.md): f16x3 1.4e-3 from fp64 (an fp16 MFMA adds 16 exact products before its one fp32 rounding), the
+    # fp32 mode 3.2e-4 since its GEMM sums per K tile first (round 3, one chain over K: 5.7e-3 = 2.2x the reference's distance).
     ref_noise = abs(float(g["sum/0"]) - g["terms64/0"].sum()) if "terms64/0" in g else 2.6e-3
     for r, s in enumerate(seqs):
         ref = g[f"terms/{r}"]
@@ -132,11 +134,11 @@ def test_esm2_650m_pppl_735_residues_vs_reference(lib, golden_dir, precision):
             e64 = abs(scores[r] - t64.sum())
             msg += (f"; the reference's own fp32 arithmetic vs fp64: per-term {np.abs(ref - t64).max():.2e}, sum {abs(float(g[f'sum/{r}']) - t64.sum()):.2e}"
                     f"; HIP vs fp64: per-term {np.abs(terms[r] - t64).max():.2e}, sum {e64:.2e}")
-            assert e64 < 3.0 * ref_noise
+            assert e64 < ref_noise
         print(msg)
         assert scores[r] == sum(float(v) for v in terms[r])                          # python's left-to-right double sum of the f32 terms
         assert e_term < TOL                                                          # flat 1e-4 on every term
-        assert e_sum < max(TOL, 3.0 * ref_noise)
+        assert e_sum < max(TOL, 2.0 * ref_noise)
     # a member scored alone (another batch composition: what a rank of run_indels sees) has the SAME BITS
     for r in range(len(seqs)):
         alone, t_alone = lib_.score(first=r, count=1, want_terms=True)
