@@ -14,6 +14,7 @@
 #include <vector>
 
 #include "common.h"
+#include "gemm16x_kernel.h"          // XMap (the tied row attention's operand maps); no kernel is instantiated here
 
 namespace pgmi {
 
@@ -663,13 +664,19 @@ int run_msa(pgmi_model* m, int R, int C, int keep_col = -1, bool* compacted = nu
     const int Rp = (R + 31) / 32 * 32, Cp = (C + 31) / 32 * 32;
     if ((int64_t)Rp * Cp > m->max_rows) { set_error("alignment of %d x %d tokens exceeds the workspace (%d rows): create the model with max_rows >= %lld", R, C, m->max_rows, (long long)Rp * Cp); return PGMI_EINVAL; }
     int rc = 0;
-    // split the (r, d) contraction of the tied scores so that the launch fills the chip: S divides R
+    // split the (r, d) contraction of the tied scores so that the launch fills the chip: S divides R, ~2 rounds of tiles at most
+    const int Kp = (C + 63) / 64 * 64;                      // the update GEMM's K (columns j), zero-padded
     int S = 1;
-    { const int tiles = ((C + 127) / 128) * ((C + 127) / 128) * H;
-      for (int cand = 1; cand <= 16; ++cand) if (R % cand == 0 && tiles * cand <= 2048) S = cand; }
-    rc = ensure_cap(m, &m->tied_part, &m->tied_part_cap, (size_t)H * S * C * Cp); if (rc) return rc;
-    rc = ensure_cap(m, &m->tied_p, &m->tied_p_cap, (size_t)H * C * Cp); if (rc) return rc;
-    rc = ensure_cap(m, &m->tied_vt, &m->tied_vt_cap, (size_t)H * R * 64 * Cp); if (rc) return rc;
+    { const int rows_last = C % 256, tm = (rows_last > 0 && rows_last <= 128) ? (C + 127) / 128 : (C + 255) / 256;
+      const int tiles = tm * ((C + 255) / 256) * H;
+      for (int cand = 1; cand <= 16; ++cand) if (R % cand == 0 && tiles * cand <= 640) S = cand; }
+    rc = ensure_cap(m, &m->tied_part, &m->tied_part_cap, (size_t)H * S * C * Kp); if (rc) return rc;
+    rc = ensure_cap(m, &m->tied_p, &m->tied_p_cap, (size_t)H * C * Kp); if (rc) return rc;           // split planes: 4 bytes per element like fp32
+    rc = ensure_cap(m, &m->tied_vt, &m->tied_vt_cap, (size_t)H * R * 64 * Kp); if (rc) return rc;
+    if ((unsigned long long)M * D * 4ull >= (1ull << 32) || (unsigned long long)H * R * 64 * Kp * 4ull >= (1ull << 32)) {
+        set_error("alignment of %d x %d tokens exceeds the 32-bit offset range of the tied row attention's operands", R, C);
+        return PGMI_EINVAL;
+    }
     if (R != m->msa_kv_R || C != m->msa_kv_C) {
         std::vector<int32_t> kv((size_t)C, R);
         PGMI_HIP(hipMemcpyAsync(m->msa_kv_len, kv.data(), (size_t)C * 4, hipMemcpyHostToDevice, s));
@@ -685,7 +692,6 @@ int run_msa(pgmi_model* m, int R, int C, int keep_col = -1, bool* compacted = nu
       launch_add_row_embedding(m->x, m->msa_pe, R, C, D, s);
       launch_layernorm(m->x, m->lnb_w, m->lnb_b, M, D, 1e-5f, m->x, s); }
     const double ln_bytes = 2.0 * M * D * 4;
-    const size_t ld3 = (size_t)3 * D;
     for (int l = 0; l < c.layers; ++l) {
         const Layer& L = m->layers[l];
         // ---- tied row attention (axial_attention.py:108-168) ----
@@ -695,26 +701,32 @@ int run_msa(pgmi_model* m, int R, int C, int keep_col = -1, bool* compacted = nu
           rc = linear(m, nullptr, m->h16, m->h16_plane, nullptr, L.wqkv16, L.bqkv, nullptr, m->qkv, nullptr, 0, M, 3 * D, D, EPI_NONE);
           if (rc) return rc; }
         { ProfScope p(m, PGMI_K_ATTENTION, 4.0 * (double)C * C * R * D, 0);
-          GemmF32Ex g1;                                    // scores: batch = (head, K split)
-          g1.lda = g1.ldw = (int64_t)ld3; g1.ldc = Cp;
-          g1.kblock = 64; g1.a_kbstride = g1.w_kbstride = (int64_t)C * ld3;
-          g1.nbatch = H * S; g1.inner = S;
-          g1.a_s0 = g1.w_s0 = (int64_t)(R / S) * C * ld3; g1.a_s1 = g1.w_s1 = 64;
-          g1.c_s0 = (int64_t)C * Cp; g1.c_s1 = (int64_t)S * C * Cp;
-          rc = launch_gemm_f32_ex(m->qkv, m->qkv + D, m->tied_part, C, C, (R / S) * 64, g1, s);
+          // operands for the 16-bit pipe (msa_transformer.hip): q -> m->h16 (free once the projection has read it), k -> m->g16, V^T
+          unsigned short* q16 = m->h16;
+          unsigned short* k16 = m->g16;
+          unsigned short* vt16 = reinterpret_cast<unsigned short*>(m->tied_vt);
+          unsigned short* p16 = reinterpret_cast<unsigned short*>(m->tied_p);
+          launch_tied_prep_qk(m->qkv, M, D, q16, k16, s);
+          launch_pack_vt16(m->qkv, R, C, Kp, H, vt16, s);
+          XMap g1{};                                       // scores: batch = (head, K split); K walks (r, d): runs of 64 d a row of tokens apart
+          g1.a_row_bytes = g1.w_row_bytes = (unsigned int)D * 4u;
+          g1.a_bytes = g1.w_bytes = (unsigned int)((size_t)M * D * 4);
+          g1.k_run_log2 = 1; g1.a_run_bytes = g1.w_run_bytes = (unsigned int)((size_t)C * D * 4);
+          g1.batch_inner = S;
+          g1.a_b0 = g1.w_b0 = (unsigned int)((size_t)(R / S) * C * D * 4); g1.a_b1 = g1.w_b1 = 64u * 4u;
+          g1.c_b0 = (long long)C * Kp; g1.c_b1 = (long long)S * C * Kp; g1.ldc = Kp;
+          rc = launch_gemm16_ex(q16, k16, m->tied_part, nullptr, C, (C + 3) / 4 * 4, (R / S) * 64, 1.0f / tied_w_scale(), g1, H * S, s);
           if (rc) return rc;
-          rc = launch_tied_softmax(m->tied_part, H, S, C, Cp, 1.0f / sqrtf((float)R), m->tied_p, s);
+          rc = launch_tied_softmax16(m->tied_part, H, S, C, Kp, 1.0f / sqrtf((float)R), p16, s);
           if (rc) return rc;
-          launch_pack_vt(m->qkv, R, C, Cp, H, m->tied_vt, s);
-          GemmF32Ex g2;                                    // update: batch = head, output scattered to [r, i, h, d]
-          g2.lda = Cp; g2.ldw = Cp; g2.ldc = D;
-          g2.kblock = Cp; g2.a_kbstride = g2.w_kbstride = Cp;
-          g2.nblock = 64; g2.c_nbstride = (int64_t)C * D;
-          g2.nbatch = H; g2.inner = H;
-          g2.a_s0 = (int64_t)C * Cp; g2.w_s0 = (int64_t)R * 64 * Cp; g2.c_s0 = 64;
-          rc = launch_gemm_f32_ex(m->tied_p, m->tied_vt, m->h, C, R * 64, Cp, g2, s);
-          if (rc) return rc;
-          launch_split16(m->h, (int64_t)M * D, 1.0f, 2, D, m->h16, s); }
+          XMap g2{};                                       // update: batch = head, output scattered to the context rows [r, i] x columns [h, d]
+          g2.a_row_bytes = g2.w_row_bytes = (unsigned int)Kp * 4u;
+          g2.a_bytes = (unsigned int)((size_t)H * C * Kp * 4); g2.w_bytes = (unsigned int)((size_t)H * R * 64 * Kp * 4);
+          g2.batch_inner = H;
+          g2.a_b0 = (unsigned int)((size_t)C * Kp * 4); g2.w_b0 = (unsigned int)((size_t)R * 64 * Kp * 4);
+          g2.o_ld = D; g2.o_rows_per_n64 = C; g2.o_col_per_batch = 64;
+          rc = launch_gemm16_ex(p16, vt16, nullptr, m->h16, C, R * 64, Kp, 1.0f / tied_w_scale(), g2, H, s);
+          if (rc) return rc; }
         if (keep_col >= 0 && m->keep_rows && l == c.layers - 1) {
             ProfScope p(m, PGMI_K_KEPT_ROWS, 2.0 * R * D * (2.0 * D + 3.0 * D) + 4.0 * R * R * D + 4.0 * D * F, 0);
             // the column's tokens (r, keep_col), r = 0 .. R-1: rows r * C + keep_col of the (r, c) order

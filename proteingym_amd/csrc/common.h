@@ -103,20 +103,12 @@ void launch_pppl_sum(const float* terms, const int64_t* rp, const int32_t* sid, 
 void launch_msa_window_tokens(const int32_t* full, int R, int Tfull, int start, int Tw, int mask_col, int32_t* out, hipStream_t s);
 void launch_add_row_embedding(float* x, const float* pe, int R, int C, int D, hipStream_t s);
 void launch_permute_rows(const float* src, float* dst, int A, int B, int D, hipStream_t s);
-int launch_tied_softmax(const float* part, int H, int S, int C, int Cp, float scale, float* P, hipStream_t s);
-void launch_pack_vt(const float* qkv, int R, int C, int Cp, int H, float* Vt, hipStream_t s);
+// tied row attention operands for the 16-bit pipe (msa_transformer.hip)
+void launch_tied_prep_qk(const float* qkv, int64_t M, int D, unsigned short* q16, unsigned short* k16, hipStream_t s);
+void launch_pack_vt16(const float* qkv, int R, int C, int Kp, int H, unsigned short* Vt, hipStream_t s);
+int launch_tied_softmax16(const float* part, int H, int S, int C, int Kp, float scale, unsigned short* P, hipStream_t s);
+float tied_w_scale();
 
-// Strided / batched fp32 GEMM: C_b = A_b W_b^T for b in [0, nbatch); b = bo * inner + bi.
-struct GemmF32Ex {
-    int64_t lda = 0, ldw = 0, ldc = 0;                 // row strides (elements)
-    int kblock = 32;                                   // K axis = runs of kblock contiguous elements ...
-    int64_t a_kbstride = 0, w_kbstride = 0;            // ... this far apart (== kblock for a dense row)
-    int nblock = 1 << 30;                              // output N axis = runs of nblock columns ...
-    int64_t c_nbstride = 0;                            // ... this far apart
-    int nbatch = 1, inner = 1;
-    int64_t a_s0 = 0, a_s1 = 0, w_s0 = 0, w_s1 = 0, c_s0 = 0, c_s1 = 0;   // per-batch base offsets (inner, outer)
-};
-int launch_gemm_f32_ex(const float* A, const float* W, float* C, int M, int N, int K, const GemmF32Ex& ex, hipStream_t s);
 int launch_gemm_f32(const float* A, const float* W, const float* bias, const float* residual,
                     float* C, int M, int N, int K, int epilogue, hipStream_t s);
 
@@ -133,6 +125,9 @@ int launch_gemm16_qkv(const unsigned short* A, size_t a_plane, const unsigned sh
                       const float* bias, int M, int D, int K, float out_scale, unsigned short* qk16, size_t qk_plane,
                       unsigned short* vt16, size_t vt_plane, const float* cos_t, const float* sin_t, int rotary,
                       int T, int H, int variant, hipStream_t s, int rot_halves = 1);
+struct XMap;                                       // gemm16x_kernel.h: batched / strided operand and output maps
+int launch_gemm16_ex(const unsigned short* A, const unsigned short* W, float* Cf, unsigned short* Ch, int M, int N, int K,
+                     float out_scale, XMap xm, int nbatch, hipStream_t s);
 // x [n/K rows][K] fp32 -> mode 0: f16x3 weight (hi/lo of x*scale), 1: bf16 plane, 2: f16x3 activation split; the
 // f16x3 forms are written K-interleaved (ki_off)
 void launch_split16(const float* x, int64_t n, float scale, int mode, int K, unsigned short* out, hipStream_t s);

@@ -83,8 +83,28 @@ struct TilePlan {
     int tiles_m, tiles_n;
     int n_main;       // items [0, n_main): one full tile each (XCD-aware grouped order); workgroup b runs b, b + G, ...
     int n_tail;       // tail items n_main + h, h < n_tail, one per workgroup at most (half = 1: halves of the last round's tiles)
-    int half;         // 1: tail item h is the upper (h even) or lower (h odd) 128 rows of tile n_main + h / 2
+    int half;         // 1: tail item h is the upper (h even) or lower (h odd) 128 rows of tile n_main + h / 2;
+                      // 2: EVERY item is a 128-row tile (tiles_m counts 128-row panels, n_main = 0, n_tail = all of them): M just above a
+                      //    multiple of 128 (the tied row attention's C = 287 columns) wastes a third of a 256-row panel less
     int group_m;      // row panels per group of the grouped tile order (gemm_f16.hip kGroupM)
+};
+
+// How the GEMM's indices map onto memory when an operand is not a dense [rows][K] matrix / the output not a dense [M][N] one: the tied
+// row attention of the MSA Transformer (axial_attention.py:112-168) contracts over (alignment row r, head dim d) with q, k used in
+// place -- K runs of 64 elements a row stride apart --, one batch per (head, K split), and scatters its update back to [r, i, h, d].
+// All zero = dense, one batch.
+struct XMap {
+    unsigned int a_row_bytes, w_row_bytes;     // byte stride between consecutive operand rows (0: 4 K)
+    unsigned int a_bytes, w_bytes;             // extent of the operand arrays for the buffer descriptors (0: rows x 4 K)
+    int k_run_log2;                            // K tiles (of 32) per contiguous run, log2 (0 with a_run_bytes == 0: one run = dense)
+    unsigned int a_run_bytes, w_run_bytes;     // byte stride between runs
+    int tiles_per_batch, batch_inner;          // tiles per batch (0: one batch); batch b = outer * batch_inner + inner
+    unsigned int a_b0, a_b1, w_b0, w_b1;       // operand byte offsets per inner / outer batch index
+    long long c_b0, c_b1;                      // fp32 output: element offsets per inner / outer batch index
+    int ldc;                                   // fp32 output: row pitch in elements (0: N)
+    int o_ld;                                  // split-plane output scatter (0: dense [M][N]): row pitch in columns, ...
+    int o_rows_per_n64;                        // ... output row = m + (n / 64) * o_rows_per_n64, ...
+    int o_col_per_batch;                       // ... column = batch * o_col_per_batch + n % 64
 };
 
 constexpr int XBM = 256, XBN = 256, XNT = 512, XCPR = 8;   // 8 chunks = one 128-byte line per row and K tile (hi | lo)
@@ -104,11 +124,13 @@ __device__ __forceinline__ void x_tile_coords(int wgid, int tiles_m, int tiles_n
 // OUT 0: fp32 [M,N] (+ residual); 1: split fp16 planes, K-interleaved (the next GEMM's operand); 2: attention operands (QkvOut).
 // CEPI (OUT 0 only): the fp32 epilogue goes through a per-wave LDS transpose so that 16 lanes cover 256 contiguous bytes of a
 // row (4 rows = 8 full lines per load / store instruction; the accumulator layout gives 32 rows x 32 bytes per instruction).
-template <int EPI, int OUT, bool CEPI>
+// XM: the batched / strided form (XMap); false = dense operands, one batch: xm is ignored (and costs nothing).
+template <int EPI, int OUT, bool CEPI, bool XM = false>
 __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
     const unsigned short* __restrict__ A, const unsigned short* __restrict__ W, const float* __restrict__ bias,
     const float* residual, float* Cf, unsigned short* Ch, size_t c_plane, int M, int N, int K, float out_scale,
-    TilePlan tp, QkvOut qo) {
+    TilePlan tp, QkvOut qo, XMap xm_arg) {
+    const XMap xm = XM ? xm_arg : XMap{};                         // dense instantiations: every xm test below folds away
     constexpr int WN = 4, TMX = 4, TN = 2, LD = 4;               // TMX: 32-row MFMA tiles per wave of a full item (a half item: 2)
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];  // [2][X_STAGE] + patches
     const int tid = threadIdx.x, lane = tid & 63;
@@ -127,43 +149,61 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
     const int csrc = c8 ^ sw8;
     // buffer descriptors built from kernel arguments only (provably wave-uniform): loads take a 32-bit per-lane byte offset
     // and the K-tile offset as an SGPR -- no 64-bit address arithmetic in the memory phases
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(A), 0, (int)((unsigned int)M * (unsigned int)K * 4u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(W), 0, (int)((unsigned int)N * (unsigned int)K * 4u), 0x00020000);
+    const unsigned int a_row_bytes = xm.a_row_bytes ? xm.a_row_bytes : (unsigned int)K * 4u;
+    const unsigned int w_row_bytes = xm.w_row_bytes ? xm.w_row_bytes : (unsigned int)K * 4u;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(A), 0, (int)(xm.a_bytes ? xm.a_bytes : (unsigned int)M * (unsigned int)K * 4u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(W), 0, (int)(xm.w_bytes ? xm.w_bytes : (unsigned int)N * (unsigned int)K * 4u), 0x00020000);
     unsigned int a_off[LD], w_off[LD];
-    int m0 = 0, n0 = 0, a_ld = LD;
-    bool half_item = false;                                       // the upper or lower 128 rows of a tile (tail of the item list)
+    int m0 = 0, n0 = 0, a_ld = LD, batch = 0;
+    unsigned int a_base = 0, w_base = 0;                          // the batch's operand offsets (SGPRs)
+    bool half_item = false;                                       // a 128-row item: half of a tile (tail of the item list), or every item (half == 2)
     const int nk = K / 32;
-    auto decode = [&](int item) {                                 // sets m0, n0, half_item and the source offsets
+    const int n_items = tp.n_main + tp.n_tail;
+    auto decode = [&](int item) {                                 // sets m0, n0, half_item, batch and the source offsets
+        const bool all_half = tp.half == 2;
         int wgid;
-        if (item < tp.n_main) {
+        if (item < tp.n_main || all_half) {
             // XCD-aware order: item i runs on XCD i % 8 (grid size is a multiple of 8); every XCD walks a contiguous
             // run of the grouped tile order so that its L2 keeps the live A panels and W tiles
-            const int nwg = tp.n_main, xcd = item & 7, q = nwg >> 3, r8 = nwg & 7;
+            const int nwg = all_half ? n_items : tp.n_main, xcd = item & 7, q = nwg >> 3, r8 = nwg & 7;
             wgid = (xcd < r8 ? xcd * (q + 1) : r8 * (q + 1) + (xcd - r8) * q) + (item >> 3);
         } else {
             wgid = tp.n_main + ((item - tp.n_main) >> 1);
         }
+        batch = 0;
+        if (xm.tiles_per_batch) {
+            batch = wgid / xm.tiles_per_batch;
+            wgid -= batch * xm.tiles_per_batch;
+            const int bi = batch % xm.batch_inner, bo = batch / xm.batch_inner;
+            a_base = __builtin_amdgcn_readfirstlane((unsigned int)bi * xm.a_b0 + (unsigned int)bo * xm.a_b1);
+            w_base = __builtin_amdgcn_readfirstlane((unsigned int)bi * xm.w_b0 + (unsigned int)bo * xm.w_b1);
+            batch = __builtin_amdgcn_readfirstlane(batch);
+        }
         int tm, tn;
         x_tile_coords(wgid, tp.tiles_m, tp.tiles_n, tm, tn, tp.group_m);
-        half_item = tp.half && item >= tp.n_main;
+        half_item = all_half || (tp.half && item >= tp.n_main);
         a_ld = half_item ? LD / 2 : LD;                           // A rows staged per K tile: 64 per instruction
-        m0 = __builtin_amdgcn_readfirstlane(tm * XBM + (half_item ? ((item - tp.n_main) & 1) * (XBM / 2) : 0));
+        m0 = __builtin_amdgcn_readfirstlane(all_half ? tm * (XBM / 2) : tm * XBM + (half_item ? ((item - tp.n_main) & 1) * (XBM / 2) : 0));
         n0 = __builtin_amdgcn_readfirstlane(tn * XBN);
 #pragma unroll
-        for (int i = 0; i < LD; ++i) {                            // row pitch 4 K bytes; the launcher guarantees rows * 4 K < 4 GiB
-            a_off[i] = (unsigned int)min(m0 + row_lo + 64 * i, M - 1) * (unsigned int)K * 4u + (unsigned int)csrc * 16u;
-            w_off[i] = (unsigned int)min(n0 + row_lo + 64 * i, N - 1) * (unsigned int)K * 4u + (unsigned int)csrc * 16u;
+        for (int i = 0; i < LD; ++i) {                            // the launcher guarantees that every offset stays below 4 GiB
+            a_off[i] = (unsigned int)min(m0 + row_lo + 64 * i, M - 1) * a_row_bytes + (unsigned int)csrc * 16u;
+            w_off[i] = (unsigned int)min(n0 + row_lo + 64 * i, N - 1) * w_row_bytes + (unsigned int)csrc * 16u;
         }
     };
     auto issue_tile = [&](int kt, int buf) {                      // 1 KiB per wave-instruction, wave-uniform LDS base
         u32x4* base = lds + buf * X_STAGE + wave * 64;
+        // K tile kt of the item: dense rows: 128 kt; K runs (xm): run kt >> k_run_log2, tile kt & mask inside it
+        const int run = kt >> xm.k_run_log2, in_run = kt - (run << xm.k_run_log2);
+        const int ka = (int)(a_base + (xm.a_run_bytes ? (unsigned int)run * xm.a_run_bytes + (unsigned int)in_run * 128u : (unsigned int)kt * 128u));
+        const int kw = (int)(w_base + (xm.w_run_bytes ? (unsigned int)run * xm.w_run_bytes + (unsigned int)in_run * 128u : (unsigned int)kt * 128u));
 #pragma unroll
         for (int i = 0; i < LD; ++i)
             if (i < a_ld)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(base + XNT * i), 16, (int)a_off[i], kt * 128, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(base + XNT * i), 16, (int)a_off[i], ka, 0, 0);
 #pragma unroll
         for (int i = 0; i < LD; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(base + X_OP_CH + XNT * i), 16, (int)w_off[i], kt * 128, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(base + X_OP_CH + XNT * i), 16, (int)w_off[i], kw, 0, 0);
     };
     // phase boundary: everything issued before stays before, this wave's LDS traffic has landed; VMEM stays in flight
     auto phase = [&]() {
@@ -233,8 +273,7 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
         __builtin_amdgcn_sched_group_barrier(0x008, 3 * TN * TM - 8, 0);
     };
 
-    // ---- this workgroup's item list: b, b + G, ... below n_main, then at most one tail item ----
-    const int n_items = tp.n_main + tp.n_tail;
+    // ---- this workgroup's item list: b, b + G, ... (items >= n_main are 128-row items) ----
     int item = blockIdx.x;
     if (item >= n_items) return;
     decode(item);
@@ -281,7 +320,7 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
 
         // ---- the item just finished: both K-tile buffers are free after the last phase barrier; the next item's first K
         //      tile is in flight while this item's epilogue runs ----
-        const int em0 = m0, en0 = n0;
+        const int em0 = m0, en0 = n0, eb = batch;
         item += gridDim.x;
         const bool more = item < n_items;
         if (more) {
@@ -403,8 +442,10 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
             unsigned char* patch = patches + wave * (32 * 128);
             const int cc = lane & 7, rq = lane >> 3;
             const unsigned int kOob = 0x80000000u;                // the launcher keeps M N 4 below 2^31
-            const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(Cf, 0, (int)((unsigned int)M * (unsigned int)N * 4u), 0x00020000);
-            const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual ? residual : Cf), 0, (int)((unsigned int)M * (unsigned int)N * 4u), 0x00020000);
+            const unsigned int ldc = xm.ldc ? (unsigned int)xm.ldc : (unsigned int)N;
+            const long long cb = xm.tiles_per_batch ? (long long)(eb % xm.batch_inner) * xm.c_b0 + (long long)(eb / xm.batch_inner) * xm.c_b1 : 0;
+            const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(Cf + cb, 0, (int)((unsigned int)M * ldc * 4u), 0x00020000);
+            const __amdgpu_buffer_rsrc_t rsR = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(residual ? residual : Cf) + cb, 0, (int)((unsigned int)M * ldc * 4u), 0x00020000);
             unsigned int coff[TN];                                // byte offset of the lane's four columns inside a row, or out of range
             f32x4 bv[TN];
 #pragma unroll
@@ -416,7 +457,7 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
 #pragma unroll
             for (int j = 0; j < TN; ++j) asm volatile("" :: "v"(bv[j]));                     // waited for HERE, not inside the block loop
             auto c_off = [&](int m, int j) -> int {
-                return (int)((m < M && coff[j] != kOob) ? (unsigned int)m * (unsigned int)N * 4u + coff[j] : kOob);
+                return (int)((m < M && coff[j] != kOob) ? (unsigned int)m * ldc * 4u + coff[j] : kOob);
             };
             // residual rows of block i + 1 are loaded before block i is processed: one memory latency per item, not per block
             u32x4 rv[2][TN][4];
@@ -543,8 +584,13 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
                         const int q = lane + 64 * k;                 // 16-byte chunk: row q/16, chunk q%16 of the 256-byte run
                         const int row = q >> 4, cc = q & 15;
                         const u32x4 v = *reinterpret_cast<const u32x4*>(patch + row * SP + cc * 16);
-                        if (m_base + row < M)
-                            *reinterpret_cast<u32x4*>(Ch + (size_t)(m_base + row) * (2 * (size_t)N) + ncol0 * 2 + cc * 8) = v;
+                        if (m_base + row < M) {
+                            if (xm.o_ld)      // scatter (XMap): the wave's 64 columns are one (n / 64) block of the batch's output columns
+                                *reinterpret_cast<u32x4*>(Ch + ((size_t)(m_base + row) + (ncol0 >> 6) * (size_t)xm.o_rows_per_n64) * (2 * (size_t)xm.o_ld) +
+                                                          (size_t)eb * (size_t)xm.o_col_per_batch * 2 + cc * 8) = v;
+                            else
+                                *reinterpret_cast<u32x4*>(Ch + (size_t)(m_base + row) * (2 * (size_t)N) + ncol0 * 2 + cc * 8) = v;
+                        }
                     }
                     __builtin_amdgcn_wave_barrier();
                 }

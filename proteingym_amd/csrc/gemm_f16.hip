@@ -273,6 +273,7 @@ static int launch_gemm16x_one(const unsigned short* A, const unsigned short* W,
     const dim3 grid(std::min(G, n_items)), block(XNT);
     QkvOut qo{};
     if (qkv) qo = *qkv;
+    const XMap xmap{};
 #define PGMI_LAUNCH16X(EPI_, OUT_, CEPI_)                                                                 \
     do {                                                                                                 \
         auto kfn = gemm16x_kernel<EPI_, OUT_, CEPI_>;                                                     \
@@ -281,7 +282,7 @@ static int launch_gemm16x_one(const unsigned short* A, const unsigned short* W,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);  \
         if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PGMI_EHIP; } \
         hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, A, W, bias, residual, Cf, Ch, c_plane, M, N, K,  \
-                           out_scale, tp, qo);                                                           \
+                           out_scale, tp, qo, xmap);                                                     \
     } while (0)
 #define PGMI_LAUNCH16X_O(EPI_) do { if (Ch) PGMI_LAUNCH16X(EPI_, 1, false); else if (tune.cepi) PGMI_LAUNCH16X(EPI_, 0, true); \
         else PGMI_LAUNCH16X(EPI_, 0, false); } while (0)
@@ -291,6 +292,45 @@ static int launch_gemm16x_one(const unsigned short* A, const unsigned short* W,
     else PGMI_LAUNCH16X_O(EPI_NONE);
 #undef PGMI_LAUNCH16X_O
 #undef PGMI_LAUNCH16X
+    PGMI_HIP(hipGetLastError());
+    return PGMI_OK;
+}
+
+// Batched / strided form (XMap, gemm16x_kernel.h): the MSA Transformer's tied row attention.  M, N, K are ONE batch's; nbatch batches
+// share the launch (xm.tiles_per_batch is filled in here).  fp32 output (Cf; always through the LDS-transpose epilogue) or split
+// planes (Ch; dense or scattered by xm.o_*).  M just above a multiple of 128: 128-row tiles throughout (TilePlan.half = 2).
+int launch_gemm16_ex(const unsigned short* A, const unsigned short* W, float* Cf, unsigned short* Ch, int M, int N, int K,
+                     float out_scale, XMap xm, int nbatch, hipStream_t s) {
+    if (M <= 0 || N <= 0 || K <= 0 || (K % 64) != 0 || (N % 4) != 0 || (!Cf && !Ch) || (Cf && Ch) || nbatch < 1 ||
+        (Ch && (N % 64) != 0) || (xm.a_run_bytes && (K / 32) % (1 << xm.k_run_log2) != 0)) {
+        set_error("gemm16_ex: unsupported shape/args M=%d N=%d K=%d batches=%d", M, N, K, nbatch);
+        return PGMI_EINVAL;
+    }
+    TilePlan tp{};
+    tp.group_m = kGroupM;
+    const int rows_last = M % XBM;                                // rows in the last 256-row panel
+    const bool all_half = rows_last > 0 && rows_last <= XBM / 2;  // ... at most half of it: 128-row tiles waste less
+    tp.tiles_m = all_half ? (M + XBM / 2 - 1) / (XBM / 2) : (M + XBM - 1) / XBM;
+    tp.tiles_n = (N + XBN - 1) / XBN;
+    const int per = tp.tiles_m * tp.tiles_n, T = per * nbatch, G = x_num_cus();
+    xm.tiles_per_batch = per;
+    if (xm.batch_inner < 1) xm.batch_inner = 1;
+    if (all_half) { tp.half = 2; tp.n_main = 0; tp.n_tail = T; } else { tp.n_main = T; }
+    const dim3 grid(std::min(G, T)), block(XNT);
+    QkvOut qo{};
+    const float* nobias = nullptr;
+    const size_t lds_bytes = X_LDS_BYTES;
+#define PGMI_LAUNCH16X_EX(OUT_, CEPI_)                                                                    \
+    do {                                                                                                 \
+        auto kfn = gemm16x_kernel<EPI_NONE, OUT_, CEPI_, true>;                                           \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                           \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);  \
+        if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PGMI_EHIP; } \
+        hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, A, W, nobias, nobias, Cf, Ch, (size_t)0, M, N, K,  \
+                           out_scale, tp, qo, xm);                                                       \
+    } while (0)
+    if (Ch) PGMI_LAUNCH16X_EX(1, false); else PGMI_LAUNCH16X_EX(0, true);
+#undef PGMI_LAUNCH16X_EX
     PGMI_HIP(hipGetLastError());
     return PGMI_OK;
 }

@@ -33,14 +33,10 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return x * 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
-// EX = strided / batched form (GemmF32Ex in common.h): per-batch base offsets, row strides lda/ldw/ldc,
-// a K axis made of `kblock`-element contiguous runs `kbstride` apart (so an operand like q[r, i, h, :]
-// summed over (r, d) needs no packing), and an N axis of `nblock`-wide runs `c_nbstride` apart on the
-// output.  EX = false is the plain nn.Linear form and compiles to the same code as before.
-template <int EPI, bool EX>
+template <int EPI>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(
     const float* __restrict__ A, const float* __restrict__ W, const float* __restrict__ bias,
-    const float* residual, float* C, int M, int N, int K, int tiles_m, int tiles_n, GemmF32Ex ex) {
+    const float* residual, float* C, int M, int N, int K, int tiles_m, int tiles_n) {
     __shared__ __attribute__((aligned(16))) float lds[2 * 2 * BM * LDS_STRIDE];
     float* As = lds;                         // [2][BM][LDS_STRIDE]
     float* Bs = lds + 2 * BM * LDS_STRIDE;   // [2][BN][LDS_STRIDE]
@@ -63,24 +59,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int r = lane & 31, kh = lane >> 5;
-    const int64_t lda = EX ? ex.lda : K, ldw = EX ? ex.ldw : K;
-    if (EX) {
-        const int bo = blockIdx.y / ex.inner, bi = blockIdx.y % ex.inner;
-        A += bo * ex.a_s1 + bi * ex.a_s0;
-        W += bo * ex.w_s1 + bi * ex.w_s0;
-        C += bo * ex.c_s1 + bi * ex.c_s0;
-    }
-    // element offset of K tile kt inside a row
-    auto koff_a = [&](int kt) -> int64_t {
-        if (!EX) return (int64_t)kt * BK;
-        const int k = kt * BK;
-        return (int64_t)(k / ex.kblock) * ex.a_kbstride + (k % ex.kblock);
-    };
-    auto koff_w = [&](int kt) -> int64_t {
-        if (!EX) return (int64_t)kt * BK;
-        const int k = kt * BK;
-        return (int64_t)(k / ex.kblock) * ex.w_kbstride + (k % ex.kblock);
-    };
+    const int64_t lda = K, ldw = K;
+    auto koff_a = [&](int kt) -> int64_t { return (int64_t)kt * BK; };     // element offset of K tile kt inside a row
+    auto koff_w = [&](int kt) -> int64_t { return (int64_t)kt * BK; };
 
     // --- global -> register staging: 4 float4 of A and 4 of W per thread per K tile ------
     const float* a_src[4];
@@ -188,8 +169,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(
                 if (m < M) {
                     float val = acc[i][j][v] + bv;
                     if (EPI == EPI_GELU) val = gelu_erf(val);
-                    const size_t o = EX ? (size_t)m * ex.ldc + (size_t)(n / ex.nblock) * ex.c_nbstride + (n % ex.nblock)
-                                        : (size_t)m * N + n;
+                    const size_t o = (size_t)m * N + n;
                     if (residual) val = residual[o] + val;
                     C[o] = val;
                 }
@@ -206,25 +186,10 @@ int launch_gemm_f32(const float* A, const float* W, const float* bias, const flo
     }
     const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     const dim3 grid(tiles_m * tiles_n), block(256);
-    const GemmF32Ex none{};
     if (epilogue == EPI_GELU)
-        hipLaunchKernelGGL((gemm_f32_kernel<EPI_GELU, false>), grid, block, 0, s, A, W, bias, residual, C, M, N, K, tiles_m, tiles_n, none);
+        hipLaunchKernelGGL((gemm_f32_kernel<EPI_GELU>), grid, block, 0, s, A, W, bias, residual, C, M, N, K, tiles_m, tiles_n);
     else
-        hipLaunchKernelGGL((gemm_f32_kernel<EPI_NONE, false>), grid, block, 0, s, A, W, bias, residual, C, M, N, K, tiles_m, tiles_n, none);
-    PGMI_HIP(hipGetLastError());
-    return PGMI_OK;
-}
-
-int launch_gemm_f32_ex(const float* A, const float* W, float* C, int M, int N, int K, const GemmF32Ex& ex, hipStream_t s) {
-    if (M <= 0 || N <= 0 || K <= 0 || (K % BK) != 0 || ex.kblock <= 0 || (ex.kblock % BK) != 0 || (K % ex.kblock) != 0 ||
-        ex.nblock <= 0 || ex.nbatch <= 0 || ex.inner <= 0 || (ex.nbatch % ex.inner) != 0 || (ex.lda % 4) || (ex.ldw % 4) ||
-        (ex.a_kbstride % 4) || (ex.w_kbstride % 4) || (ex.a_s0 % 4) || (ex.a_s1 % 4) || (ex.w_s0 % 4) || (ex.w_s1 % 4)) {
-        set_error("gemm_f32_ex: unsupported shape/strides M=%d N=%d K=%d kblock=%d", M, N, K, ex.kblock);
-        return PGMI_EINVAL;
-    }
-    const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-    const dim3 grid(tiles_m * tiles_n, ex.nbatch), block(256);
-    hipLaunchKernelGGL((gemm_f32_kernel<EPI_NONE, true>), grid, block, 0, s, A, W, nullptr, nullptr, C, M, N, K, tiles_m, tiles_n, ex);
+        hipLaunchKernelGGL((gemm_f32_kernel<EPI_NONE>), grid, block, 0, s, A, W, bias, residual, C, M, N, K, tiles_m, tiles_n);
     PGMI_HIP(hipGetLastError());
     return PGMI_OK;
 }
