@@ -87,7 +87,6 @@ struct pgmi_model {
     int32_t* nonfinite = nullptr;
     int gemm_variant = 0;
     int keep_rows = 1;                                 // last layer's row-local stages on the kept rows only (PGMI_KEEP_ROWS)
-    int att16 = 3;        // f16x3 attention: 0 fp32 pipe, 1 in-kernel split, 2 prep pass + DMA ring, 3 QKV epilogue + DMA ring (default)
     int last_B = 0, last_T = 0;
     int dh = kHeadDim;    // true head dim; heads are laid out in 64-lane slot groups (pgmi_model_create)
     int rot_halves = 1;   // slot groups per head: 1, or 2 for head_dim 128
@@ -350,8 +349,7 @@ int run_encoder(pgmi_model* m, int B, int T, const int32_t* keep = nullptr, int 
         { ProfScope p(m, PGMI_K_LAYERNORM, 0, ln_bytes);
           if (prec == PGMI_PREC_FP32) launch_layernorm(m->x, L.ln1_w, L.ln1_b, M, D, 1e-5f, m->h, s);
           else launch_layernorm16(m->x, L.ln1_w, L.ln1_b, M, D, 1e-5f, m->h16, m->h16_plane, mode16, s); }
-        const bool fused_qkv = prec == PGMI_PREC_F16X3 && m->att16 == 3;
-        if (m->rot_halves > 1 && !fused_qkv && prec == PGMI_PREC_F16X3) { set_error("head_dim 128 in precision f16x3 needs the fused QKV + DMA-ring attention path (PGMI_ATT16=3)"); return PGMI_EINVAL; }
+        const bool fused_qkv = prec == PGMI_PREC_F16X3;          // attention operands straight from the QKV projection's epilogue
         { ProfScope p(m, PGMI_K_GEMM_QKV, 2.0 * M * 3 * D * D, 0);
           if (fused_qkv)
               rc = launch_gemm16_qkv(m->h16, m->h16_plane, L.wqkv16.p, L.wqkv16.plane, L.bqkv, M, Da, D, L.wqkv16.out_scale,
@@ -361,14 +359,12 @@ int run_encoder(pgmi_model* m, int B, int T, const int32_t* keep = nullptr, int 
               rc = linear(m, m->h, m->h16, m->h16_plane, L.wqkv, L.wqkv16, L.bqkv, nullptr, m->qkv, nullptr, 0, M, 3 * Da, D, EPI_NONE);
           if (rc) return rc; }
         { ProfScope p(m, PGMI_K_ATTENTION, 4.0 * M * T * D, 0);
-          const bool v2 = prec == PGMI_PREC_F16X3 && m->att16 >= 2;
+          const bool v2 = prec == PGMI_PREC_F16X3;
           if (c.arch == PGMI_ARCH_ESM2 && !v2) launch_rotary(m->qkv, m->rot_cos, m->rot_sin, M, T, m->Hs, s, m->rot_halves);
           if (v2)
               rc = launch_attention_f16x3_v2(fused_qkv ? nullptr : m->qkv, m->kv_len, m->rot_cos, m->rot_sin, c.arch == PGMI_ARCH_ESM2, B, T, H,
                                              m->qk16, m->qk16_plane, m->vt16, m->vt16_plane, nullptr, m->h16,
                                              m->h16_plane, 1, s, nullptr, nullptr, m->rot_halves * kHeadDim);
-          else if (prec == PGMI_PREC_F16X3 && m->att16 == 1)
-              rc = launch_attention_f16x3(m->qkv, m->kv_len, B, T, H, m->h, m->h16, m->h16_plane, 1, s);
           else
               rc = launch_attention_f32(m->qkv, m->kv_len, B, T, H, m->h, m->h16, m->h16_plane,
                                         prec == PGMI_PREC_FP32 ? 0 : mode16, s, m->rot_halves * kHeadDim);
@@ -961,7 +957,6 @@ int pgmi_model_create(const pgmi_config* cfg, const float* w, int64_t n_weights,
     }
     TRY(dev_alloc(m->allocs, &m->nonfinite, (size_t)1));
     PGMI_HIP(hipMemset(m->nonfinite, 0, 4));
-    m->att16 = env_int("PGMI_ATT16", 3);
     if (cfg->precision == PGMI_PREC_F16X3) {
         m->qk16_plane = R * 2 * Da;
         m->vt16_plane = R * Da;
@@ -1664,7 +1659,7 @@ int pgmi_op_attention(int device, int precision, const float* qkv, const int32_t
     pgmi_model tmp;
     tmp.cfg.arch = PGMI_ARCH_ESM2;
     if (rotary) rc = ensure_rotary(&tmp, T);
-    if (!rc && precision == PGMI_PREC_F16X3 && env_int("PGMI_ATT16", 2) == 2) {
+    if (!rc && precision == PGMI_PREC_F16X3) {
         const size_t Tp = (size_t)(T + 31) / 32 * 32;
         unsigned short *qk = nullptr, *vt = nullptr;
         rc = dev_alloc(pool, &qk, (size_t)B * T * 2 * D * 2);
@@ -1673,8 +1668,7 @@ int pgmi_op_attention(int device, int precision, const float* qkv, const int32_t
                                                 vt, (size_t)B * Tp * D, dc, nullptr, 0, 0, nullptr);
     } else if (!rc) {
         if (rotary) launch_rotary(dq, tmp.rot_cos, tmp.rot_sin, B * T, T, H, nullptr);
-        rc = (precision == PGMI_PREC_F16X3) ? launch_attention_f16x3(dq, dl, B, T, H, dc, nullptr, 0, 0, nullptr)
-                                            : launch_attention_f32(dq, dl, B, T, H, dc, nullptr, 0, 0, nullptr);
+        rc = launch_attention_f32(dq, dl, B, T, H, dc, nullptr, 0, 0, nullptr);
     }
     hipDeviceSynchronize();
     for (void* p : tmp.allocs) hipFree(p);

@@ -1,19 +1,15 @@
 // Fused multi-head self-attention on the 16-bit matrix pipe with split-fp16 (f16x3) operands.
 //
-// Same math and interface as attention_f32.hip (q k^T, fp32 softmax, P v; reference:
-// /root/reference/proteingym/baselines/esm/esm/multihead_attention.py:357-387), same wave/lane
-// arrangement (one wave = 32 queries of one head, S^T = K Q^T so the query lives in the lane, P is
-// consumed straight from the accumulator registers), but every product is evaluated as
+// Math: q k^T, fp32 softmax, P v (reference: /root/reference/proteingym/baselines/esm/esm/multihead_attention.py:357-387;
+// Tranception: tranception/model_pytorch.py:155-183).  One wave = 32 queries of one head, S^T = K Q^T so the query lives in the
+// lane, P is consumed straight from the accumulator registers.  Every product is evaluated as
 //     x y  ~=  x_hi y_hi + 2^-11 (x_hi y_lo + x_lo y_hi),   x_hi = fp16(x), x_lo = fp16((x - x_hi) 2^11)
-// with v_mfma_f32_32x32x16_f16: 24 MFMAs of 32 cycles per (32q x 32k) tile instead of 64 MFMAs of
-// 64 cycles on the fp32 pipe.  The 2^-11 terms are kept in their own accumulators and folded in
-// fp32 (S = main + corr/2048 before the softmax, O likewise at the end), so no fp16 subnormal is
-// ever produced.  fp32 q/k/v tiles are split on the fly while they are staged into LDS:
-//   K planes   [32 keys][64 d]   row-major, 16-byte chunks XOR-swizzled           -> MFMA A operand of S^T
-//   V^T planes [64 d][32 keys]   keys stored in the order the S^T accumulator holds them (bits 2
-//                                and 3 of the key index swapped), so the packed P registers and one
-//                                ds_read_b128 of V^T agree on the k order of the 16-deep MFMA.
-// Roofline: after the switch the kernel is VALU-bound (exp, splits, rescale), not MFMA-bound.
+// with v_mfma_f32_32x32x16_f16: 24 MFMAs per (32q x 32k) tile.  The 2^-11 terms are kept in their own accumulators and folded in
+// fp32 (S = main + corr/2048 before the softmax, O likewise at the end), so no fp16 subnormal is ever produced.
+// Operands arrive already split (from the fused QKV projection's epilogue, gemm16x_kernel.h OUT 2, or from the prep passes below):
+//   qk16 [plane][M][2D]      q | k, row-major (hi plane, lo 2^11 plane); q carries head_dim^-1/2 log2(e)
+//   vt16 [plane][B*H*64][Tp] V transposed per (sequence, head), keys of each 32-key tile stored with bits 2 and 3 of the key index
+//                            swapped (the order the S^T accumulator holds them), pad keys = 0
 #include <stdlib.h>
 #include <algorithm>
 
@@ -27,8 +23,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int AKT = 32;                       // keys per tile
-constexpr int kAttTuneDefault = 0;            // attention_f16x3_v2_kernel `tune` bits used when PGMI_ATT_TUNE is not set
-constexpr float kAttDeferDefault = 4.0f;      // ... and its `defer_thr` (PGMI_ATT_DEFER): measured +3.5 % (T = 288) / +4.5 % (T = 1024) over 0
+constexpr float kAttDefer = 4.0f;             // lag allowed before O is rescaled (base-2 units; see the rescale in the kernel): +3.5 % (T = 288) / +4.5 % (T = 1024) over 0
 constexpr int K_CH = AKT * 8;                 // chunks per K plane
 constexpr int V_CH = 64 * 4;                  // chunks per V^T plane
 constexpr int A_STAGE = 2 * K_CH + 2 * V_CH;  // chunks per buffer (hi+lo planes of K and V^T) = 16 KB
@@ -40,243 +35,12 @@ __device__ __forceinline__ unsigned int pack_h2(_Float16 a, _Float16 b) {
 __device__ __forceinline__ f32x16 mfma_h(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
 }
-// split 8 floats into packed hi / lo (scaled by 2^11) fragments
-__device__ __forceinline__ void split8(const float (&x)[8], u32x4& hi, u32x4& lo) {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        _Float16 h0, l0, h1, l1;
-        split_act(x[2 * e], h0, l0);
-        split_act(x[2 * e + 1], h1, l1);
-        hi[e] = pack_h2(h0, h1);
-        lo[e] = pack_h2(l0, l1);
-    }
-}
 
-template <int WPB, int OUT>
-__global__ __launch_bounds__(WPB * 64) void attention_f16x3_kernel(
-    const float* __restrict__ qkv, const int32_t* __restrict__ kv_len, int T, int H,
-    float* __restrict__ ctx, unsigned short* __restrict__ ctx16, size_t plane) {
-    constexpr int NT = WPB * 64;
-    constexpr int NLK = (512 + NT - 1) / NT;          // K units (one float4 each) per thread per tile
-    constexpr int NLV = (256 + NT - 1) / NT;          // V units (two float4: a key pair) per thread per tile
-    __shared__ __attribute__((aligned(16))) u32x4 lds[2 * A_STAGE];
-
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 31, kh = lane >> 5;
-    const int D = H * kHeadDim;
-    const size_t RS = (size_t)3 * D;
-    const float* base = qkv + (size_t)b * T * RS + (size_t)h * kHeadDim;
-    const int Tk = kv_len ? kv_len[b] : T;
-    const int q0 = (blockIdx.x * WPB + wave) * 32;
-    const bool active = q0 < T;
-
-    // Q fragments (B operand of S^T = K Q^T): lane (r,kh) holds Q[q0+r][16s + 8kh .. +7]
-    u32x4 qh[4], ql[4];
-    {
-        const int qrow = min(q0 + r, T - 1);
-        const float* qp = base + (size_t)qrow * RS + kh * 8;
-#pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const f32x4 a = *reinterpret_cast<const f32x4*>(qp + s * 16);
-            const f32x4 c = *reinterpret_cast<const f32x4*>(qp + s * 16 + 4);
-            const float x[8] = {a[0], a[1], a[2], a[3], c[0], c[1], c[2], c[3]};
-            split8(x, qh[s], ql[s]);
-        }
-    }
-
-    // ---- staging: fp32 global tiles -> split fp16 planes in LDS ---------------------------------
-    f32x4 k_st[NLK], v_st[NLV][2];
-    auto stage_load = [&](int kt) {
-#pragma unroll
-        for (int i = 0; i < NLK; ++i) {
-            const int f = tid + NT * i;
-            if (f < 512) {
-                const int key = kt * AKT + (f >> 4), c4 = f & 15;
-                k_st[i] = (key < T) ? *reinterpret_cast<const f32x4*>(base + (size_t)key * RS + D + c4 * 4)
-                                    : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NLV; ++i) {
-            const int f = tid + NT * i;
-            if (f < 256) {
-                const int key = kt * AKT + 2 * (f >> 4), c4 = f & 15;
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    v_st[i][u] = (key + u < T) ? *reinterpret_cast<const f32x4*>(base + (size_t)(key + u) * RS + 2 * D + c4 * 4)
-                                               : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-        }
-    };
-    auto stage_store = [&](int buf) {
-        char* kb = reinterpret_cast<char*>(lds + buf * A_STAGE);                 // K hi plane, lo plane follows
-        char* vb = reinterpret_cast<char*>(lds + buf * A_STAGE + 2 * K_CH);      // V^T hi plane, lo plane follows
-#pragma unroll
-        for (int i = 0; i < NLK; ++i) {
-            const int f = tid + NT * i;
-            if (f < 512) {
-                const int key = f >> 4, c4 = f & 15, c8 = c4 >> 1;
-                _Float16 hh[4], ll[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float xe = k_st[i][e];
-                    split_act(xe, hh[e], ll[e]);
-                }
-                const int off = (key * 8 + (c8 ^ ((key >> 1) & 7))) * 16 + (c4 & 1) * 8;
-                *reinterpret_cast<u32x2*>(kb + off) = u32x2{pack_h2(hh[0], hh[1]), pack_h2(hh[2], hh[3])};
-                *reinterpret_cast<u32x2*>(kb + K_CH * 16 + off) = u32x2{pack_h2(ll[0], ll[1]), pack_h2(ll[2], ll[3])};
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < NLV; ++i) {
-            const int f = tid + NT * i;
-            if (f < 256) {
-                const int key = 2 * (f >> 4), c4 = f & 15;                       // keys (key, key+1), d = 4*c4 .. +3
-                const int pos = (key & 0x13) | ((key & 4) << 1) | ((key & 8) >> 1);   // swap bits 2 and 3
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float x0 = v_st[i][0][e], x1 = v_st[i][1][e];
-                    _Float16 h0, l0, h1, l1;
-                    split_act(x0, h0, l0);
-                    split_act(x1, h1, l1);
-                    const int d = c4 * 4 + e;
-                    const int off = (d * 4 + ((pos >> 3) ^ ((d >> 2) & 3))) * 16 + (pos & 7) * 2;
-                    *reinterpret_cast<unsigned int*>(vb + off) = pack_h2(h0, h1);
-                    *reinterpret_cast<unsigned int*>(vb + V_CH * 16 + off) = pack_h2(l0, l1);
-                }
-            }
-        }
-    };
-
-    const int nkt = (Tk + AKT - 1) / AKT;
-    stage_load(0);
-    stage_store(0);
-    __syncthreads();
-
-    f32x16 om[2], oc[2];
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int v = 0; v < 16; ++v) { om[dt][v] = 0.f; oc[dt][v] = 0.f; }
-    float m_run = -INFINITY, l_run = 0.f;
-    constexpr float kInvLo = 1.0f / kLoScale;
-
-    int cur = 0;
-    for (int kt = 0; kt < nkt; ++kt) {
-        const bool more = kt + 1 < nkt;
-        if (more) stage_load(kt + 1);
-        if (active) {
-            const u32x4* Kb = lds + cur * A_STAGE;
-            const u32x4* Vb = Kb + 2 * K_CH;
-            f32x16 sm, sc;
-#pragma unroll
-            for (int v = 0; v < 16; ++v) { sm[v] = 0.f; sc[v] = 0.f; }
-#pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const int ci = r * 8 + ((2 * s + kh) ^ ((r >> 1) & 7));
-                const u32x4 kfh = Kb[ci], kfl = Kb[K_CH + ci];
-                sc = mfma_h(kfh, ql[s], sc);
-                sc = mfma_h(kfl, qh[s], sc);
-                sm = mfma_h(kfh, qh[s], sm);
-            }
-            float st[16];
-#pragma unroll
-            for (int v = 0; v < 16; ++v) st[v] = fmaf(sc[v], kInvLo, sm[v]);
-            if (kt * AKT + AKT > Tk) {
-#pragma unroll
-                for (int v = 0; v < 16; ++v) {
-                    const int key = kt * AKT + (v & 3) + 8 * (v >> 2) + 4 * kh;
-                    if (key >= Tk) st[v] = -INFINITY;
-                }
-            }
-            float mloc = st[0];
-#pragma unroll
-            for (int v = 1; v < 16; ++v) mloc = fmaxf(mloc, st[v]);
-            mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-            const float m_new = fmaxf(m_run, mloc);
-            const float alpha = expf(m_run - m_new);
-            float psum = 0.f;
-#pragma unroll
-            for (int v = 0; v < 16; ++v) {
-                st[v] = expf(st[v] - m_new);
-                psum += st[v];
-            }
-            l_run = l_run * alpha + psum;
-            m_run = m_new;
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) { om[dt][v] *= alpha; oc[dt][v] *= alpha; }
-            // P fragments: registers 8m .. 8m+7 are exactly the k order of MFMA step m
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-                const float x[8] = {st[8 * m], st[8 * m + 1], st[8 * m + 2], st[8 * m + 3],
-                                    st[8 * m + 4], st[8 * m + 5], st[8 * m + 6], st[8 * m + 7]};
-                u32x4 ph, pl;
-                split8(x, ph, pl);
-#pragma unroll
-                for (int dt = 0; dt < 2; ++dt) {
-                    const int d = dt * 32 + r;
-                    const int ci = d * 4 + ((2 * m + kh) ^ ((d >> 2) & 3));
-                    const u32x4 vfh = Vb[ci], vfl = Vb[V_CH + ci];
-                    oc[dt] = mfma_h(vfh, pl, oc[dt]);
-                    oc[dt] = mfma_h(vfl, ph, oc[dt]);
-                    om[dt] = mfma_h(vfh, ph, om[dt]);
-                }
-            }
-        }
-        if (more) stage_store(cur ^ 1);
-        __syncthreads();
-        cur ^= 1;
-    }
-
-    if (active) {
-        const float l_tot = l_run + __shfl_xor(l_run, 32);
-        if (q0 + r < T) {
-            const float inv = 1.0f / l_tot;
-            const size_t off = ((size_t)b * T + q0 + r) * D + (size_t)h * kHeadDim + 4 * kh;
-#pragma unroll
-            for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    float val[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) val[e] = fmaf(oc[dt][4 * g + e], kInvLo, om[dt][4 * g + e]) * inv;
-                    const size_t oo = off + dt * 32 + 8 * g;
-                    if constexpr (OUT == 0) {
-                        *reinterpret_cast<f32x4*>(ctx + oo) = f32x4{val[0], val[1], val[2], val[3]};
-                    } else {
-                        _Float16 hh[4], ll[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) split_act(val[e], hh[e], ll[e]);
-                        // K-interleaved GEMM operand (common.h ki_off): column h*64 + dt*32 + 8g + 4kh of a row of D
-                        unsigned short* dst = ctx16 + ((size_t)b * T + q0 + r) * (size_t)(2 * D) + (size_t)(2 * h + dt) * 64 + 8 * g + 4 * kh;
-                        *reinterpret_cast<u32x2*>(dst) = u32x2{pack_h2(hh[0], hh[1]), pack_h2(hh[2], hh[3])};
-                        *reinterpret_cast<u32x2*>(dst + 32) = u32x2{pack_h2(ll[0], ll[1]), pack_h2(ll[2], ll[3])};
-                    }
-                }
-        }
-    }
-}
-
-
-// =================================================================================================
-// v2: operands arrive already split.  qkv_prep_kernel turns the fp32 q|k|v rows written by the QKV
-// GEMM into attention-ready fp16 planes once per layer (and applies the ESM2 rotary on the way):
-//   qk16 [plane][M][2D]                 q | k, row-major (hi plane, lo*2^11 plane)
-//   vt16 [plane][B*H*64][Tp]            V transposed per (sequence, head), keys of each 32-key tile
-//                                       stored with bits 2 and 3 of the key index swapped, pad keys = 0
-// attention_f16x3_v2_kernel then moves K / V^T tiles global -> LDS with global_load_lds (swizzle on
-// the source chunk) and does no conversion work at all: per (32q x 32k) tile 24 MFMAs + ~150 VALU.
-// =================================================================================================
-// `conv` (Tranception, tranception/model_pytorch.py:73-88,240-251): per (q|k|v, head group h / (H/4),
-// channel) a causal 7-tap depth-wise filter + bias, conv[((which*4 + group)*64 + d)*8 + j]; taps are
-// right-aligned (kernel sizes 3/5/7 have leading zeros, group 0 is the identity), tap j multiplies
-// the token t-6+j of the same sequence (zero before the sequence start); entry 7 is the bias.
+// Prep pass for operands that do NOT come from the fused QKV projection (the op-level entry pgmi_op_attention): fp32 q|k|v rows
+// [M][3D] -> the planes above, ESM2 rotary applied on the way (rotary_embedding.py:11-20).
 __global__ __launch_bounds__(256) void qkv_prep_kernel(
     const float* __restrict__ qkv, const float* __restrict__ cos_t, const float* __restrict__ sin_t,
-    int rotary, const float* __restrict__ conv, int T, int H, int Tp, unsigned short* __restrict__ qk16,
+    int rotary, int T, int H, int Tp, unsigned short* __restrict__ qk16,
     size_t qk_plane, unsigned short* __restrict__ vt16, size_t vt_plane) {
     const int b = blockIdx.z, h = blockIdx.y, t0 = blockIdx.x * 32;
     const int tid = threadIdx.x;
@@ -290,28 +54,8 @@ __global__ __launch_bounds__(256) void qkv_prep_kernel(
         const int t = t0 + tok;
         if (t < T) {
             const float* src = qkv + ((size_t)b * T + t) * RS + (size_t)which * D + h * kHeadDim + 4 * c;
-            f32x4 x1, x2;
-            if (conv) {
-                const float* cw = conv + ((size_t)(which * 4 + h / (H / 4)) * kHeadDim + 4 * c) * 8;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { x1[e] = cw[e * 8 + 7]; x2[e] = cw[(32 + e) * 8 + 7]; }
-#pragma unroll
-                for (int j = 0; j < 7; ++j) {
-                    const int tt = t - 6 + j;
-                    if (tt >= 0) {
-                        const f32x4 a1 = *reinterpret_cast<const f32x4*>(src - (size_t)(6 - j) * RS);
-                        const f32x4 a2 = *reinterpret_cast<const f32x4*>(src - (size_t)(6 - j) * RS + 32);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            x1[e] = fmaf(cw[e * 8 + j], a1[e], x1[e]);
-                            x2[e] = fmaf(cw[(32 + e) * 8 + j], a2[e], x2[e]);
-                        }
-                    }
-                }
-            } else {
-                x1 = *reinterpret_cast<const f32x4*>(src);
-                x2 = *reinterpret_cast<const f32x4*>(src + 32);
-            }
+            f32x4 x1 = *reinterpret_cast<const f32x4*>(src);
+            f32x4 x2 = *reinterpret_cast<const f32x4*>(src + 32);
             if (rotary) {           // rotary_embedding.py:11-20: x*cos + rotate_half(x)*sin
                 const f32x4 c1 = *reinterpret_cast<const f32x4*>(cos_t + t * 64 + 4 * c);
                 const f32x4 s1 = *reinterpret_cast<const f32x4*>(sin_t + t * 64 + 4 * c);
@@ -350,29 +94,11 @@ __global__ __launch_bounds__(256) void qkv_prep_kernel(
         const int d = tid & 63, kq = tid >> 6;
         _Float16 hh[8], ll[8];
         const float* vsrc = qkv + ((size_t)b * T) * RS + 2 * D + h * kHeadDim + d;
-        if (conv) {
-            const float* cw = conv + ((size_t)(2 * 4 + h / (H / 4)) * kHeadDim + d) * 8;
-            float win[14];                                    // tokens t0+8kq-6 .. t0+8kq+7
 #pragma unroll
-            for (int j = 0; j < 14; ++j) {
-                const int t = t0 + 8 * kq - 6 + j;
-                win[j] = (t >= 0 && t < T) ? vsrc[(size_t)t * RS] : 0.0f;
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float y = cw[7];
-#pragma unroll
-                for (int j = 0; j < 7; ++j) y = fmaf(cw[j], win[e + j], y);
-                if (t0 + 8 * kq + e >= T) y = 0.0f;
-                split_act(y, hh[e], ll[e]);
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int t = t0 + 8 * kq + e;
-                const float x = (t < T) ? vsrc[(size_t)t * RS] : 0.0f;
-                split_act(x, hh[e], ll[e]);
-            }
+        for (int e = 0; e < 8; ++e) {
+            const int t = t0 + 8 * kq + e;
+            const float x = (t < T) ? vsrc[(size_t)t * RS] : 0.0f;
+            split_act(x, hh[e], ll[e]);
         }
         // key 8kq+e -> position with bits 2,3 swapped: 16(kq>>1) + 8(e>>2) + 4(kq&1) + (e&3)
         unsigned short* row = vt16 + (((size_t)b * H + h) * kHeadDim + d) * Tp + t0 + 16 * (kq >> 1) + 4 * (kq & 1);
@@ -383,10 +109,13 @@ __global__ __launch_bounds__(256) void qkv_prep_kernel(
     }
 }
 
+// `conv` (Tranception, tranception/model_pytorch.py:73-88,240-251): per (q|k|v, head group h / (H/4), channel) a causal 7-tap
+// depth-wise filter + bias, conv[((which*4 + group)*64 + d)*8 + j]; taps are right-aligned (kernel sizes 3/5/7 have leading zeros,
+// group 0 is the identity), tap j multiplies the token t-6+j of the same sequence (zero before the sequence start); entry 7 is the bias.
 // Tranception flavour of the prep pass (conv != nullptr, no rotary): the 38 token rows a 32-token tile
 // needs (6 rows of causal history) are staged ONCE in LDS with coalesced float4 loads and the 7-tap
 // filters are read from an LDS copy, instead of 7 strided global loads per output and per-tap scalar weight
-// loads (the generic kernel above ran at 2.3 TB/s; this pass is HBM-bound: 4 B in + 4 B out per element).
+// loads (computing the taps from global memory ran at 2.3 TB/s; this pass is HBM-bound: 4 B in + 4 B out per element).
 __global__ __launch_bounds__(256) void qkv_prep_conv_kernel(
     const float* __restrict__ qkv, const float* __restrict__ conv, int T, int H, int Tp,
     unsigned short* __restrict__ qk16, size_t qk_plane, unsigned short* __restrict__ vt16, size_t vt_plane) {
@@ -494,10 +223,8 @@ template <int WPB, int OUT, int NSTG, int DH = 64>
 __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
     const unsigned short* __restrict__ qk16, size_t qk_plane, const unsigned short* __restrict__ vt16,
     size_t vt_plane, const int32_t* __restrict__ kv_len, const float* __restrict__ slopes, int T, int H,
-    int Tp, float* __restrict__ ctx, unsigned short* __restrict__ ctx16, size_t plane, int tune, float defer_thr) {
-    // tune (A/B switches, see launch_attention_f16x3_v2): 1 = static priority for the waves in odd hardware wave slots, 2 = the
-    // lane <-> lane + 32 max exchange through LDS (ds_bpermute) instead of v_permlane32_swap, 4 = 8-byte epilogue stores (the old
-    // form) instead of 16-byte ones, 8 = Q fragments straight from global memory (the old form).  defer_thr: see the rescale below.
+    int Tp, float* __restrict__ ctx, unsigned short* __restrict__ ctx16, size_t plane) {
+    constexpr float defer_thr = kAttDefer;
     // slopes != nullptr selects the Tranception flavour (tranception/model_pytorch.py:155-183): causal
     // mask (key <= query) and the grouped-ALiBi bias slope[h] * key added to the scaled scores.
     constexpr int NT = WPB * 64;
@@ -520,18 +247,16 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
     const int Tk = kv_len ? kv_len[b] : T;
     const int q0 = (blockIdx.x * WPB + wave) * 32;
     const bool active = q0 < T;
-    // Two workgroups share a CU, one wave of each per SIMD, both running this same loop: with equal priorities the pair tends to
-    // sit in the same kind of phase (both in the softmax's VALU chain, then both in the MFMAs).  A static priority for the wave in
-    // the odd hardware slot lets it run unimpeded while its partner fills the unit it leaves idle.
-    if ((tune & 1) && (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1)) __builtin_amdgcn_s_setprio(2);
+    // (Two workgroups share a CU, one wave of each per SIMD.  Measured and not kept, profiles/r3: a static priority for the wave in
+    // the odd hardware slot, -3 %; the lane <-> lane + 32 max exchange through LDS instead of v_permlane32_swap, -1.3 %; 8-byte
+    // epilogue stores, -8 %; Q fragments straight from global memory, -2 %.)
 
     // Q fragments: lane (r,kh) holds Q[q0+r][16s + 8kh .. +7] of both planes.  Loaded straight from the planes each of the 2 NS
     // 16-byte loads of a wave touches 32 different rows (one per lane pair): 8 x 32 row segments for an 8 KB tile.  With
     // kQviaLds the wave's Q tile is instead moved like a K tile -- 8 lanes per 128-byte row, DMA into LDS in the K tile's swizzled
     // image (ring stages 1 and 2 are still free) -- and the fragments are read from there: a quarter of the row segments on the
     // texture-address path, which this kernel keeps busy (9 % of wave-cycles with its FIFO full).
-    constexpr bool kQviaLds = NSTG >= 3;
-    const bool q_lds = kQviaLds && !(tune & 8);
+    constexpr bool q_lds = NSTG >= 3;
     u32x4 qh[NS], ql[NS];
     if (!q_lds) {
         const int qrow = min(q0 + r, T - 1);
@@ -585,10 +310,6 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
             voff[i] = voff_last[i] = d * Tp * 2 + c * 16;
             sbase[i] = (int)((unsigned int)p * (unsigned int)vt_plane * 2u);
             sstep[i] = (AKT / 8) * 16;
-            if (tune & 16) {        // TIMING PROBE ONLY (wrong numbers): a V^T tile read as one contiguous 4 KB block of the same (sequence, head) region
-                voff[i] = voff_last[i] = g * 16;
-                sstep[i] = DH * 64;
-            }
         }
     }
     auto issue_tile = [&](int kt, int buf) {
@@ -705,9 +426,7 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
             float mloc = st[0];
 #pragma unroll
             for (int v = 1; v < 16; ++v) mloc = fmaxf(mloc, st[v]);
-            if (tune & 2) {
-                mloc = fmaxf(mloc, __shfl_xor(mloc, 32));
-            } else {                                      // v_permlane32_swap: both halves of the query's row without an LDS round trip
+            {                                             // v_permlane32_swap: both halves of the query's row without an LDS round trip
                 const unsigned int mu = __builtin_bit_cast(unsigned int, mloc);
                 const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
                 const unsigned int s0 = sw[0], s1 = sw[1];
@@ -772,7 +491,7 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
 
     if (active) {
         const float l_tot = l_run + __shfl_xor(l_run, 32);
-        if (OUT == 1 && !(tune & 4)) {
+        if (OUT == 1) {
             // Split-plane output, 16-byte stores: lane (r, kh) holds columns 8g + 4kh .. + 3 of its query row for g = 0 .. 3; one
             // v_permlane32_swap per dword hands lane (r, 0) its partner's half of an even g and lane (r, 1) its partner's half of
             // the following odd g, so every lane owns 8 consecutive columns = one dwordx4 per plane: 8 store instructions per
@@ -839,22 +558,13 @@ template <int WPB, int OUT, int NSTG, int DH>
 static int launch_att16v2_one(dim3 grid, const unsigned short* qk16, size_t qk_plane, const unsigned short* vt16, size_t vt_plane,
                               const int32_t* kv_len, const float* slopes, int T, int H, int Tp, float* ctx, unsigned short* ctx16,
                               size_t plane, hipStream_t s) {
-    // tuning switches, read per launch (the A/B scripts toggle them inside one process): PGMI_ATT_TUNE bit 0 = asymmetric static
-    // priority, bit 1 = ds_bpermute max exchange (the old form); PGMI_ATT_DEFER = lag allowed before O is rescaled (0 .. 5)
-    const char* et = getenv("PGMI_ATT_TUNE");
-    const char* ed = getenv("PGMI_ATT_DEFER");
-    const int tune = et ? atoi(et) : kAttTuneDefault;
-    float defer_thr = ed ? (float)atof(ed) : kAttDeferDefault;
-    if (!(defer_thr >= 0.0f)) defer_thr = 0.0f;
-    if (defer_thr > 5.0f) defer_thr = 5.0f;                             // P 2^(10 + thr) must stay below fp16's 65504
     constexpr size_t lds_bytes = (size_t)NSTG * (DH * 16) * 16;          // stage = DH * 16 chunks of 16 B
     auto kfn = attention_f16x3_v2_kernel<WPB, OUT, NSTG, DH>;
     if (lds_bytes > 65536) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PGMI_EHIP; }
     }
-    hipLaunchKernelGGL(kfn, grid, dim3(WPB * 64), lds_bytes, s, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane,
-                       tune, defer_thr);
+    hipLaunchKernelGGL(kfn, grid, dim3(WPB * 64), lds_bytes, s, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane);
     return PGMI_OK;
 }
 
@@ -909,49 +619,19 @@ int launch_attention_f16x3_v2(const float* qkv, const int32_t* kv_len, const flo
         PGMI_HIP(hipGetLastError());
         return PGMI_OK;
     }
-    static const bool old_prep = getenv("PGMI_PREP_OLD") != nullptr;
-    if (qkv && conv && !rotary && !old_prep)      // Tranception: LDS-staged depth-wise conv + split
+    if (qkv && conv && rotary) { set_error("attention_f16x3_v2: depth-wise convolution and rotary together are not a model this library knows"); return PGMI_EINVAL; }
+    if (qkv && conv)       // Tranception: LDS-staged depth-wise conv + split
         hipLaunchKernelGGL(qkv_prep_conv_kernel, dim3(n32, H, B), dim3(256), 0, s, qkv, conv, T, H, Tp, qk16, qk_plane, vt16, vt_plane);
-    else if (qkv)      // operands not prepared by the fused QKV epilogue: run the prep pass
-        hipLaunchKernelGGL(qkv_prep_kernel, dim3(n32, H, B), dim3(256), 0, s, qkv, cos_t, sin_t, rotary, conv, T, H, Tp,
+    else if (qkv)          // operands not prepared by the fused QKV epilogue: run the prep pass
+        hipLaunchKernelGGL(qkv_prep_kernel, dim3(n32, H, B), dim3(256), 0, s, qkv, cos_t, sin_t, rotary, T, H, Tp,
                            qk16, qk_plane, vt16, vt_plane);
     const int nblk = (n32 + 3) / 4;
     int wpb = (n32 + nblk - 1) / nblk;
     if (wpb == 3) wpb = 4;                        // measured: a 4th (idle) wave that only helps loading beats 3-wave blocks
-    const int wpb_env = getenv("PGMI_ATT_WPB") ? atoi(getenv("PGMI_ATT_WPB")) : 0;   // tuning only (read per launch: scripts/att_bench.py)
-    dim3 grid(nblk, H, B);
-    if (wpb_env >= 1 && wpb_env <= 4) { wpb = wpb_env; grid.x = (n32 + wpb - 1) / wpb; }
+    const dim3 grid(nblk, H, B);
     if (out_mode == 0) rc = launch_att16v2_mode<0, 3>(wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane, s);
     else rc = launch_att16v2_mode<1, 3>(wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane, s);
     if (rc) return rc;
-    PGMI_HIP(hipGetLastError());
-    return PGMI_OK;
-}
-
-template <int OUT>
-static void launch_att16_mode(int wpb, dim3 grid, const float* qkv, const int32_t* kv_len, int T, int H,
-                              float* ctx, unsigned short* ctx16, size_t plane, hipStream_t s) {
-    switch (wpb) {
-        case 1: hipLaunchKernelGGL((attention_f16x3_kernel<1, OUT>), grid, dim3(64), 0, s, qkv, kv_len, T, H, ctx, ctx16, plane); break;
-        case 2: hipLaunchKernelGGL((attention_f16x3_kernel<2, OUT>), grid, dim3(128), 0, s, qkv, kv_len, T, H, ctx, ctx16, plane); break;
-        case 3: hipLaunchKernelGGL((attention_f16x3_kernel<3, OUT>), grid, dim3(192), 0, s, qkv, kv_len, T, H, ctx, ctx16, plane); break;
-        default: hipLaunchKernelGGL((attention_f16x3_kernel<4, OUT>), grid, dim3(256), 0, s, qkv, kv_len, T, H, ctx, ctx16, plane); break;
-    }
-}
-
-// out_mode 0: fp32 ctx; 1: fp16 hi/lo planes (the f16x3 out-projection operand)
-int launch_attention_f16x3(const float* qkv, const int32_t* kv_len, int B, int T, int H, float* ctx,
-                           unsigned short* ctx16, size_t plane, int out_mode, hipStream_t s) {
-    if (B <= 0 || T <= 0 || H <= 0 || out_mode < 0 || out_mode > 1) {
-        set_error("attention_f16x3: bad arguments B=%d T=%d H=%d out=%d", B, T, H, out_mode);
-        return PGMI_EINVAL;
-    }
-    const int n32 = (T + 31) / 32;
-    const int nblk = (n32 + 3) / 4;
-    const int wpb = (n32 + nblk - 1) / nblk;
-    const dim3 grid(nblk, H, B);
-    if (out_mode == 0) launch_att16_mode<0>(wpb, grid, qkv, kv_len, T, H, ctx, ctx16, plane, s);
-    else launch_att16_mode<1>(wpb, grid, qkv, kv_len, T, H, ctx, ctx16, plane, s);
     PGMI_HIP(hipGetLastError());
     return PGMI_OK;
 }

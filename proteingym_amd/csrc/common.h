@@ -139,12 +139,8 @@ int launch_attention_f32(const float* qkv, const int32_t* kv_len, int B, int T, 
                          unsigned short* ctx16, size_t plane, int out_mode, hipStream_t s, int head_dim = 64);   // 128: heads of two adjacent slot groups
 
 // ---- attention_f16.hip -------------------------------------------------------------------
-// Same interface as launch_attention_f32, split-fp16 (f16x3) arithmetic on the 16-bit MFMA pipe.
-// out_mode 0: fp32 ctx; 1: fp16 hi/lo planes.
-int launch_attention_f16x3(const float* qkv, const int32_t* kv_len, int B, int T, int H, float* ctx,
-                           unsigned short* ctx16, size_t plane, int out_mode, hipStream_t s);
-// v2: a prep pass writes attention-ready fp16 planes (rotary fused), the attention kernel moves tiles
-// with direct-to-LDS loads.  Scratch: qk16 (2 planes, stride qk_plane >= B*T*2*H*64 halfs) and vt16
+// Split-fp16 (f16x3) attention on the 16-bit MFMA pipe: operands as attention-ready fp16 planes (from the fused QKV projection, or
+// from a prep pass over qkv != nullptr: rotary / Tranception depth-wise conv fused), tiles moved with direct-to-LDS loads.  Scratch: qk16 (2 planes, stride qk_plane >= B*T*2*H*64 halfs) and vt16
 // (2 planes, stride vt_plane >= B*H*64*roundup(T,32) halfs).
 int launch_attention_f16x3_v2(const float* qkv, const int32_t* kv_len, const float* cos_t, const float* sin_t,
                               int rotary, int B, int T, int H, unsigned short* qk16, size_t qk_plane,

@@ -1,7 +1,8 @@
-"""Attention-kernel A/B inside one process (PGMI_ATT_TUNE / PGMI_ATT_DEFER are read per launch): ms per launch and algorithmic
-TFLOP/s of the attention class at several (sequences, tokens) shapes of the ESM-1v 650M layer, rounds interleaved.
+"""Attention-kernel timing: ms per launch and algorithmic TFLOP/s of the attention class at several (sequences, tokens) shapes of the
+ESM-1v 650M layer; configurations (values of the environment variable PGMI_ATT_VARIANT, read per launch by the library when it was
+built with tuning variants) are interleaved round by round inside one process.
 
-    python scripts/att_bench.py [--rounds 5] [--configs 0:0:0,0:4:0,1:0:0,1:4:0,2:0:0,0:4:3]        (config = TUNE:DEFER:WPB:SPLIT, WPB 0 = default)
+    python scripts/att_bench.py [--rounds 5] [--configs 0,1]
 """
 import argparse
 import json
@@ -18,12 +19,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--layers", type=int, default=4)
-    ap.add_argument("--configs", default="0:4:0:0,14:0:0:0")
+    ap.add_argument("--configs", default="0")
     ap.add_argument("--shapes", default="286x286,90x1100,150x150,600x120")      # positions x residues
     a = ap.parse_args()
     cfg = dict(synthetic.ESM1V_650M, layers=a.layers)
     model = pesm.EsmModel(cfg, synthetic.random_weights(cfg, seed=1), device=0)
-    confs = [tuple(c.split(":")) for c in a.configs.split(",")]
+    confs = a.configs.split(",")
     out = {}
     for shp in a.shapes.split(","):
         P, L = (int(v) for v in shp.split("x"))
@@ -38,7 +39,7 @@ def main():
         res = {c: [] for c in confs}
         for _ in range(a.rounds):
             for c in confs:
-                os.environ["PGMI_ATT_TUNE"], os.environ["PGMI_ATT_DEFER"], os.environ["PGMI_ATT_WPB"], os.environ["PGMI_ATT_SPLIT"] = c
+                os.environ["PGMI_ATT_VARIANT"] = c
                 model.profile_reset()
                 model.profile_enable(True)
                 assay.run_device_only()
@@ -50,8 +51,8 @@ def main():
             ms = float(np.median([r[0] for r in res[c]]))
             tf = float(np.median([r[1] for r in res[c]]))
             ref = ref or ms
-            out[f"{shp} tune={c[0]} defer={c[1]} wpb={c[2]} split={c[3]}"] = {"ms_per_launch": round(ms, 4), "tflops": round(tf, 1), "vs_first": round(ref / ms, 3)}
-            print(f"{shp:>10s} T={assay.T:4d} seqs={len(assay.positions):4d}  tune={c[0]} defer={c[1]} wpb={c[2]} split={c[3]}: {ms:.4f} ms/launch  {tf:6.1f} TFLOP/s  x{ref / ms:.3f}", flush=True)
+            out[f"{shp} variant={c}"] = {"ms_per_launch": round(ms, 4), "tflops": round(tf, 1), "vs_first": round(ref / ms, 3)}
+            print(f"{shp:>10s} T={assay.T:4d} seqs={len(assay.positions):4d}  variant={c}: {ms:.4f} ms/launch  {tf:6.1f} TFLOP/s  x{ref / ms:.3f}", flush=True)
         assay.close()
     print(json.dumps(out))
     model.close()

@@ -152,6 +152,57 @@ def test_wider_shape_vs_oracle(lib):
     m.close()
 
 
+def _real_shape_fixture(golden_dir):
+    import importlib.util
+    path = os.path.join(golden_dir, "golden_msa_real_shape.npz")
+    if not os.path.exists(path):
+        pytest.skip("golden_msa_real_shape.npz not generated (tests/golden/make_golden_msa_real_shape.py)")
+    spec = importlib.util.spec_from_file_location("make_golden_msa_real_shape", os.path.join(golden_dir, "make_golden_msa_real_shape.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)                       # token_grid / seeds: the fixture's inputs are regenerated, only oracle outputs are stored
+    return np.load(path), gen
+
+
+def test_real_shape_400_rows_287_columns_vs_oracle(lib, golden_dir):
+    """esm_msa1b at its REAL shape -- 12 layers x 768 x 12 heads, 400 sampled rows x 287 columns (a BLAT-sized alignment, forwarded
+    whole like the reference does: axial_attention.py:81-110 only chunks beyond max_tokens_per_msa at inference) -- against the CPU
+    oracle's frozen rows: all 287 log-prob rows of the query from the unmasked forward and three masked-marginals rows
+    (compute_fitness.py:380-394), flat 1e-4.  The fixture also holds the oracle in fp64: the reference's own fp32 distance."""
+    from proteingym_amd import synthetic
+    g, gen = _real_shape_fixture(golden_dir)
+    cfg = dict(synthetic.MSA_1B)
+    arrays = synthetic.random_msa_transformer_arrays(cfg, seed=gen.SEED_W)
+    tok = gen.token_grid(287, 1)
+    m = pmsa.MsaTransformerModel(cfg, pmsa.pack_state_dict(cfg, arrays), max_rows=416 * 288)
+    lp = m.token_logprobs(tok)
+    err_all = float(np.abs(lp[0] - g["c287/row0_logprobs"]).max())
+    err64 = float(np.abs(lp[0] - g["c287/row0_logprobs_fp64"]).max())
+    pos = [int(p) for p in g["c287/positions"]]
+    rows = m.masked_logprobs(tok, np.array(pos), seq_len=286)
+    err_mm = float(np.abs(rows - g["c287/mm_rows"]).max())
+    print(f"MSA Transformer 12 x 768 x 12, 400 x 287: query-row log-probs max|err| {err_all:.2e} vs the fp32 oracle ({err64:.2e} vs fp64; the "
+          f"oracle's own fp32 vs fp64: {float(g['c287/fp32_vs_fp64'][0]):.2e}); masked-marginals rows {err_mm:.2e}")
+    m.close()
+    assert err_all < TOL and err_mm < TOL
+
+
+def test_real_shape_1024_column_window_vs_oracle(lib, golden_dir):
+    """The same model on a 400 x 1100 alignment: position 700's optimal window (utils/scoring_utils.py:43-52) is a 400 x 1024 forward --
+    the tied row attention's 1024 x 1024 score matrix per head, the operand planes at 1.26 GB -- against the oracle's frozen row."""
+    from proteingym_amd import synthetic
+    g, gen = _real_shape_fixture(golden_dir)
+    cfg = dict(synthetic.MSA_1B)
+    arrays = synthetic.random_msa_transformer_arrays(cfg, seed=gen.SEED_W)
+    tok = gen.token_grid(1101, 2)
+    m = pmsa.MsaTransformerModel(cfg, pmsa.pack_state_dict(cfg, arrays), max_rows=416 * 1024)
+    i = int(g["c1100/position"][0])
+    row = m.masked_logprobs(tok, np.array([i]), seq_len=1100)
+    err = float(np.abs(row - g["c1100/mm_row"]).max())
+    print(f"MSA Transformer 12 x 768 x 12, 400 x 1024-column window (position {i} of 1100): masked row max|err| {err:.2e}")
+    m.close()
+    assert err < TOL
+
+
 def test_errors(model, gold):
     from proteingym_amd import _lib
     tok = gold["sampled/seed1"].copy()
