@@ -219,6 +219,10 @@ __global__ __launch_bounds__(256) void qkv_prep_conv_kernel(
 
 // DH = 64: one head = 64 lanes of the operand planes (head dims below 64 arrive zero-padded).  DH = 128 (ESM2-15B): a head is two
 // adjacent 64-lane slot groups of the planes; S sums 8 k16 steps instead of 4, O has 4 d tiles instead of 2.
+// Measured and NOT kept (round 4, scripts/att_bench.py, profiles/r4/README.md): one workgroup of 8 / 9 waves per (sequence, head)
+// (K / V^T read once instead of once per query block; every query tile of T = 288 in one block) -4 % / -36 %; the score MFMAs of key
+// tile kt + 1 issued inside the softmax of tile kt (own accumulators, 4-stage ring, 235 VGPRs) -3 ... -5 % at every shape.  Two
+// waves share a SIMD's matrix pipe AND its VALU issue: work moved between them, or between a wave's own phases, does not net.
 template <int WPB, int OUT, int NSTG, int DH = 64>
 __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
     const unsigned short* __restrict__ qk16, size_t qk_plane, const unsigned short* __restrict__ vt16,
@@ -373,29 +377,36 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
     float m_run = -INFINITY, l_run = 0.f;
     constexpr float kInvLo = 1.0f / kLoScale;
 
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto wanted = [&](int kt) -> bool { return active && !(causal && kt * AKT > q0 + 31); };   // causal: tiles above the diagonal are skipped
+    // S^T = K Q^T of one key tile: main and 2^-11 correction accumulators
+    auto scores = [&](int buf, f32x16& sm, f32x16& sc) {
+        const u32x4* Kb = lds + buf * STG_CH;
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int ci = r * KCPR + ((2 * s + kh) ^ (DH == 64 ? ((r >> 1) & 7) : (r & 15)));
+            const u32x4 kfh = Kb[ci], kfl = Kb[KCH + ci];
+            sc = mfma_h(kfh, ql[s], s == 0 ? zero16 : sc);       // s == 0: the accumulator operand is the inline constant 0
+            sc = mfma_h(kfl, qh[s], sc);
+            sm = mfma_h(kfh, qh[s], s == 0 ? zero16 : sm);
+        }
+    };
+    // tile t of this wave's DMA share has landed once at most `younger` tiles issued after it remain in flight
+    auto wait_tile = [&](int younger) {
+        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
+        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
     int cur = 0;
     for (int kt = 0; kt < nkt; ++kt) {
-        // tile kt landed for this wave once at most `pending` younger tiles remain in flight
-        const int pending = min(NSTG - 2, nkt - 1 - kt);
-        if (pending >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
-        else if (pending == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wait_tile(min(NSTG - 2, nkt - 1 - kt));
         __builtin_amdgcn_s_barrier();          // tile kt visible to all waves; slot of tile kt-1 is free
         asm volatile("" ::: "memory");
         if (kt + NSTG - 1 < nkt) issue_tile(kt + NSTG - 1, (cur == 0) ? NSTG - 1 : cur - 1);
-        if (active && !(causal && kt * AKT > q0 + 31)) {
-            const u32x4* Kb = lds + cur * STG_CH;
-            const u32x4* Vb = Kb + 2 * KCH;
+        if (wanted(kt)) {
+            const u32x4* Vb = lds + cur * STG_CH + 2 * KCH;
             f32x16 sm, sc;
-            const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const int ci = r * KCPR + ((2 * s + kh) ^ (DH == 64 ? ((r >> 1) & 7) : (r & 15)));
-                const u32x4 kfh = Kb[ci], kfl = Kb[KCH + ci];
-                sc = mfma_h(kfh, ql[s], s == 0 ? zero16 : sc);       // s == 0: the accumulator operand is the inline constant 0
-                sc = mfma_h(kfl, qh[s], sc);
-                sm = mfma_h(kfh, qh[s], s == 0 ? zero16 : sm);
-            }
+            scores(cur, sm, sc);
             float st[16];
             if (causal) {
                 // ALiBi: slope * key index (model_pytorch.py:167-168), key = 32 kt + 4 kh + c_v with c_v a compile-time constant per
