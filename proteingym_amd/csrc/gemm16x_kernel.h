@@ -352,6 +352,18 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
                 const bool row_ok = m < M;
                 if (!staged_q && !row_ok) continue;
                 const int bb = m / qo.T, t = m - bb * qo.T;
+                // ESM2: the row's rotary table entries for all four column groups, loaded TOGETHER before the group loop (loads inside it
+                // were waited for one group at a time, and the wait -- vmcnt counts stores too -- included the V^T stores just issued)
+                // (a table row holds every angle twice: slots i and 32 + i are the pair (j, j + dh / 2) of one frequency -- api.hip ensure_rotary)
+                f32x4 rc[4], rs[4];
+                if (which < 2 && qo.rotary) {
+                    const int tr = (min(t, qo.T - 1) * qo.rot_halves + (hh % qo.rot_halves)) * 64;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        rc[g] = *reinterpret_cast<const f32x4*>(qo.cos_t + tr + 8 * g + 4 * kh);
+                        rs[g] = *reinterpret_cast<const f32x4*>(qo.sin_t + tr + 8 * g + 4 * kh);
+                    }
+                }
                 if (row_ok)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -369,11 +381,7 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
                     }
                     if (which < 2) {
                         if (qo.rotary) {                       // rotary_embedding.py:11-20
-                            const int tr = (t * qo.rot_halves + (hh % qo.rot_halves)) * 64;
-                            const f32x4 c1 = *reinterpret_cast<const f32x4*>(qo.cos_t + tr + d0);
-                            const f32x4 s1 = *reinterpret_cast<const f32x4*>(qo.sin_t + tr + d0);
-                            const f32x4 c2 = *reinterpret_cast<const f32x4*>(qo.cos_t + tr + 32 + d0);
-                            const f32x4 s2 = *reinterpret_cast<const f32x4*>(qo.sin_t + tr + 32 + d0);
+                            const f32x4 c1 = rc[g], s1 = rs[g], c2 = rc[g], s2 = rs[g];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
                                 const float y0 = x0[e] * c1[e] + (-x1[e]) * s1[e];
