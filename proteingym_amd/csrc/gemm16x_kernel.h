@@ -122,10 +122,8 @@ __device__ __forceinline__ void x_tile_coords(int wgid, int tiles_m, int tiles_n
 }
 
 // OUT 0: fp32 [M,N] (+ residual); 1: split fp16 planes, K-interleaved (the next GEMM's operand); 2: attention operands (QkvOut).
-// CEPI (OUT 0 only): the fp32 epilogue goes through a per-wave LDS transpose so that 16 lanes cover 256 contiguous bytes of a
-// row (4 rows = 8 full lines per load / store instruction; the accumulator layout gives 32 rows x 32 bytes per instruction).
 // XM: the batched / strided form (XMap); false = dense operands, one batch: xm is ignored (and costs nothing).
-template <int EPI, int OUT, bool CEPI, bool XM = false>
+template <int EPI, int OUT, bool XM = false>
 __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
     const unsigned short* __restrict__ A, const unsigned short* __restrict__ W, const float* __restrict__ bias,
     const float* residual, float* Cf, unsigned short* Ch, size_t c_plane, int M, int N, int K, float out_scale,
@@ -438,7 +436,7 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
                 }
             }
             }
-        } else if constexpr (OUT == 0 && CEPI) {
+        } else if constexpr (OUT == 0) {
             // fp32 (+ residual) output through a per-wave LDS transpose, one 32 x 32 accumulator tile at a time.  Patch: 32 rows
             // x 128 B, the 16-byte chunk index XORed with row & 7: the accumulator-order writes (ds_write_b128: 8 rows of one
             // chunk column per group) and the row-order reads (ds_read_b128: four rows of 4 chunks per group) are conflict-free.
@@ -512,11 +510,11 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
                 }
             }
         } else {
-            // lane holds column m = m_base + r of C^T, rows n = (v&3) + 8(v>>2) + 4kh; split-plane output leaves through a
+            // OUT 1.  Lane holds column m = m_base + r of C^T, rows n = (v&3) + 8(v>>2) + 4kh; split-plane output leaves through a
             // per-wave LDS transpose as full 128-byte row segments
             // per-wave LDS patch: 32 rows x (256 B in OUTPUT order: group 0 hi | group 0 lo | group 1 hi | group 1 lo) + 16 B pad
             constexpr int SP = 272;
-            const bool staged = (OUT == 1) && (N % 8 == 0) && (en0 + (wn * TN + TN) * 32 <= N);
+            const bool staged = (N % 8 == 0) && (en0 + (wn * TN + TN) * 32 <= N);
             unsigned char* patch = patches + wave * (32 * SP);
             // the wave's bias values, once per item (see OUT 2 above)
             f32x4 bvs[TN][4];
@@ -552,15 +550,7 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
                             if (EPI == EPI_SQRELU) { t = fmaxf(t, 0.0f); t = t * t; }     // tranception/activations.py:79-84
                             val[e] = t;
                         }
-                        const size_t o = (size_t)m * N + n;
-                        if constexpr (OUT == 0) {
-                            if (residual) {
-                                const f32x4 rv = *reinterpret_cast<const f32x4*>(residual + o);
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) val[e] = rv[e] + val[e];
-                            }
-                            *reinterpret_cast<f32x4*>(Cf + o) = val;
-                        } else {
+                        {
                             h4 hi, lo;
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
@@ -581,7 +571,7 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
                         }
                     }
                 }
-                if (OUT == 1 && staged) {
+                if (staged) {
                     // K-interleaved output: the wave's 64 columns are two 32-column groups = 2 x (64 B hi | 64 B lo) = 256
                     // contiguous bytes per row: 16 lanes write one row
                     __builtin_amdgcn_wave_barrier();

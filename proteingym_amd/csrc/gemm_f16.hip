@@ -238,10 +238,9 @@ static int x_num_cus() {
 // FC1 (N = 5120: 20 column panels) runs at the same speed with 4 and with 8 but fetches less with 8 (3.26 vs 3.47 GB per launch: with
 // 20 column panels a group of 4 rows is 80 tiles = 2.5 rounds of an XCD, and the partial rounds straddle two groups): wide outputs keep 8.
 constexpr int kGroupM = 4, kGroupMWide = 8, kWideTilesN = 16;
-// Launch parameters, product defaults; variants >= 1000 of launch_gemm16 override them for the interleaved A/B of
-// scripts/gemm_ab.py.  None of them touches a row's arithmetic: same bits.
-constexpr int kCoalescedEpilogue = 1;                             // fp32 epilogue through the per-wave LDS transpose
-struct GemmTune { int group_m = 0, cepi = kCoalescedEpilogue; };
+// Launch parameters: variants >= 1000 of launch_gemm16 override the row panels per group for the interleaved A/B of
+// scripts/gemm_ab.py (tile order does not touch a row's arithmetic: same bits).
+struct GemmTune { int group_m = 0; };
 static thread_local GemmTune g_tune;
 
 static int launch_gemm16x_one(const unsigned short* A, const unsigned short* W,
@@ -274,9 +273,9 @@ static int launch_gemm16x_one(const unsigned short* A, const unsigned short* W,
     QkvOut qo{};
     if (qkv) qo = *qkv;
     const XMap xmap{};
-#define PGMI_LAUNCH16X(EPI_, OUT_, CEPI_)                                                                 \
+#define PGMI_LAUNCH16X(EPI_, OUT_)                                                                        \
     do {                                                                                                 \
-        auto kfn = gemm16x_kernel<EPI_, OUT_, CEPI_>;                                                     \
+        auto kfn = gemm16x_kernel<EPI_, OUT_>;                                                            \
         const size_t lds_bytes = X_LDS_BYTES;                                                            \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                           \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);  \
@@ -284,9 +283,8 @@ static int launch_gemm16x_one(const unsigned short* A, const unsigned short* W,
         hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, A, W, bias, residual, Cf, Ch, c_plane, M, N, K,  \
                            out_scale, tp, qo, xmap);                                                     \
     } while (0)
-#define PGMI_LAUNCH16X_O(EPI_) do { if (Ch) PGMI_LAUNCH16X(EPI_, 1, false); else if (tune.cepi) PGMI_LAUNCH16X(EPI_, 0, true); \
-        else PGMI_LAUNCH16X(EPI_, 0, false); } while (0)
-    if (qkv) PGMI_LAUNCH16X(EPI_NONE, 2, false);
+#define PGMI_LAUNCH16X_O(EPI_) do { if (Ch) PGMI_LAUNCH16X(EPI_, 1); else PGMI_LAUNCH16X(EPI_, 0); } while (0)
+    if (qkv) PGMI_LAUNCH16X(EPI_NONE, 2);
     else if (epilogue == EPI_GELU) PGMI_LAUNCH16X_O(EPI_GELU);
     else if (epilogue == EPI_SQRELU) PGMI_LAUNCH16X_O(EPI_SQRELU);
     else PGMI_LAUNCH16X_O(EPI_NONE);
@@ -320,16 +318,16 @@ int launch_gemm16_ex(const unsigned short* A, const unsigned short* W, float* Cf
     QkvOut qo{};
     const float* nobias = nullptr;
     const size_t lds_bytes = X_LDS_BYTES;
-#define PGMI_LAUNCH16X_EX(OUT_, CEPI_)                                                                    \
+#define PGMI_LAUNCH16X_EX(OUT_)                                                                           \
     do {                                                                                                 \
-        auto kfn = gemm16x_kernel<EPI_NONE, OUT_, CEPI_, true>;                                           \
+        auto kfn = gemm16x_kernel<EPI_NONE, OUT_, true>;                                                  \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                           \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);  \
         if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PGMI_EHIP; } \
         hipLaunchKernelGGL(kfn, grid, block, lds_bytes, s, A, W, nobias, nobias, Cf, Ch, (size_t)0, M, N, K,  \
                            out_scale, tp, qo, xm);                                                       \
     } while (0)
-    if (Ch) PGMI_LAUNCH16X_EX(1, false); else PGMI_LAUNCH16X_EX(0, true);
+    if (Ch) PGMI_LAUNCH16X_EX(1); else PGMI_LAUNCH16X_EX(0);
 #undef PGMI_LAUNCH16X_EX
     PGMI_HIP(hipGetLastError());
     return PGMI_OK;
@@ -376,14 +374,12 @@ static int launch_gemm16x(const unsigned short* A, const unsigned short* W,
 }
 
 // variant (tuning; everything below 1000 is the product's configuration): 1000 + t sets the round-4 launch parameters for the
-// interleaved A/B of scripts/gemm_ab.py -- t bits 0-3: row panels per group (0: by shape), bit 9: fp32 epilogue through the
-// LDS transpose (the product's) or in accumulator order.
+// interleaved A/B of scripts/gemm_ab.py -- t bits 0-3: row panels per group (0: by shape).
 static void set_tune(int variant) {
     g_tune = GemmTune{};
     if (variant >= 1000) {
         const int t = variant - 1000;
         g_tune.group_m = t & 15;
-        g_tune.cepi = (t >> 9) & 1;
     }
 }
 

@@ -97,8 +97,8 @@ def test_attention_rotary(lib, prec):
     assert np.abs(ctx - ref).max() < 3e-5
 
 
-GEMM_VARIANTS = [0,                  # the product's launch parameters (fp32 epilogue through the per-wave LDS transpose)
-                 1000]               # fp32 epilogue in accumulator order (the round-3 kernel's)
+GEMM_VARIANTS = [0,                  # the product's launch parameters
+                 1002, 1008]         # 2 / 8 row panels per group of the tile order (the product: 4, or 8 for wide outputs)
 
 
 @pytest.mark.parametrize("variant", GEMM_VARIANTS)
@@ -158,7 +158,7 @@ def test_gemm_f16x3_half_tail_bit_identical(lib, monkeypatch, M, N, K, epi, res)
 @pytest.mark.parametrize("M,N,K,epi,res", [(15100, 1280, 256, 0, True), (15100, 1284, 256, 1, True), (70000, 1280, 128, 0, True),
                                             (300, 384, 128, 0, False)])
 def test_gemm_f16x3_launch_parameters_bit_identical(lib, monkeypatch, M, N, K, epi, res):
-    """The fp32 epilogue's path through LDS does not touch a row's arithmetic."""
+    """The tile order does not touch a row's arithmetic."""
     rng = np.random.default_rng(8)
     A = (rng.standard_normal((M, K)) * rng.choice([0.01, 1.0, 30.0], size=(M, 1))).astype(np.float32)
     W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
