@@ -210,7 +210,8 @@ int pgmi_synchronize(pgmi_model* m);
 int pgmi_op_layernorm(int device, const float* x, const float* w, const float* b,
                       int rows, int D, float eps, float* y);               /* modules.py:80-81 */
 int pgmi_op_gemm(int device, int precision, const float* A, const float* W, const float* bias,
-                 const float* residual, int M, int N, int K, int epilogue /*0 none,1 gelu*/,
+                 const float* residual, int M, int N, int K, int epilogue /*0 none,1 gelu,2 squared relu; +256 (f16x3):
+                 the split-fp16-plane output epilogue, its planes returned rebuilt as fp32*/,
                  float* C);          /* C = epi(A W^T + bias) + residual; modules.py:134-140 */
 int pgmi_op_attention(int device, int precision, const float* qkv, const int32_t* kv_len,
                       int B, int T, int H, int rotary, float* ctx);

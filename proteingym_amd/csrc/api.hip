@@ -1457,8 +1457,13 @@ int pgmi_op_gemm(int device, int precision, const float* A, const float* W, cons
         for (void* p : pool) hipFree(p);
         return rc;
     }
+    // epilogue: EPI_* in the low byte; + 256 (f16x3 only, no residual, N % 32 == 0): run the SPLIT-PLANE output epilogue and return its
+    // planes rebuilt as fp32 (tests: a row's bits through the half- and full-height items)
+    const int epi = epilogue & 255;
+    const bool split_planes = (epilogue & 256) != 0;
+    if (split_planes && (precision != PGMI_PREC_F16X3 || residual || (N % 32))) { for (void* p : pool) hipFree(p); set_error("split-plane GEMM op: f16x3, no residual, N %% 32 == 0"); return PGMI_EINVAL; }
     if (precision == PGMI_PREC_FP32) {
-        rc = launch_gemm_f32(dA, dW, dB, dR, dC, M, N, K, epilogue, nullptr);
+        rc = launch_gemm_f32(dA, dW, dB, dR, dC, M, N, K, epi, nullptr);
     } else {
         const bool bf = precision == PGMI_PREC_BF16;
         const int planes = bf ? 1 : 2;
@@ -1468,7 +1473,28 @@ int pgmi_op_gemm(int device, int precision, const float* A, const float* W, cons
         if (!rc) rc = dev_alloc(pool, &a16, (size_t)M * K * planes);
         if (!rc) {
             launch_split16(dA, (int64_t)M * K, 1.0f, bf ? 1 : 2, K, a16, nullptr);
-            rc = launch_gemm16(a16, (size_t)M * K, w16.p, w16.plane, dB, dR, dC, nullptr, 0, M, N, K, epilogue,
+            if (split_planes) {
+                // the split-plane epilogue (the next GEMM's operand): run it, then rebuild fp32 = hi + lo 2^-11 from the K-interleaved planes
+                unsigned short* c16 = nullptr;
+                rc = dev_alloc(pool, &c16, (size_t)M * N * 2);
+                if (!rc) rc = launch_gemm16(a16, (size_t)M * K, w16.p, w16.plane, dB, nullptr, nullptr, c16, (size_t)M * N, M, N, K, epi,
+                                            w16.out_scale, planes, bf, env_int("PGMI_GEMM_VARIANT", 0), nullptr);
+                if (!rc) {
+                    std::vector<unsigned short> h((size_t)M * N * 2);
+                    hipError_t e2 = hipMemcpy(h.data(), c16, h.size() * 2, hipMemcpyDeviceToHost);
+                    if (e2 != hipSuccess) { set_error("gemm op failed: %s", hipGetErrorString(e2)); rc = PGMI_EHIP; }
+                    for (size_t m = 0; m < (size_t)M && !rc; ++m)
+                        for (int n = 0; n < N; ++n) {
+                            const size_t o = ki_off(m, n, N);
+                            _Float16 hi, lo;
+                            memcpy(&hi, &h[o], 2); memcpy(&lo, &h[o + 32], 2);
+                            C[m * N + n] = (float)hi + (float)lo * (1.0f / kLoScale);
+                        }
+                }
+                for (void* p : pool) hipFree(p);
+                return rc;
+            }
+            rc = launch_gemm16(a16, (size_t)M * K, w16.p, w16.plane, dB, dR, dC, nullptr, 0, M, N, K, epi,
                                w16.out_scale, planes, bf, env_int("PGMI_GEMM_VARIANT", 0), nullptr);
         }
     }

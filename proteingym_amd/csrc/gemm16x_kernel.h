@@ -370,8 +370,8 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
                     float x0[4], x1[4];
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        x0[e] = acc[0][i][4 * g + e] * out_scale + b0[e];
-                        x1[e] = acc[1][i][4 * g + e] * out_scale + b1[e];
+                        x0[e] = fmaf(acc[0][i][4 * g + e], out_scale, b0[e]);      // explicit fma in every epilogue: left to -ffp-contract, the full- and
+                        x1[e] = fmaf(acc[1][i][4 * g + e], out_scale, b1[e]);      // half-height instantiations could round differently
                     }
                     if (which == 0) {                          // attention's softmax is base 2: q carries log2(e) (common.h)
 #pragma unroll
@@ -382,8 +382,8 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
                             const f32x4 c1 = rc[g], s1 = rs[g], c2 = rc[g], s2 = rs[g];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) {
-                                const float y0 = x0[e] * c1[e] + (-x1[e]) * s1[e];
-                                const float y1 = x1[e] * c2[e] + x0[e] * s2[e];
+                                const float y0 = fmaf(x0[e], c1[e], (-x1[e]) * s1[e]);
+                                const float y1 = fmaf(x1[e], c2[e], x0[e] * s2[e]);
                                 x0[e] = y0;
                                 x1[e] = y1;
                             }
@@ -494,7 +494,7 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
                         f32x4 val;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            float t = a[e] * out_scale + bv[j][e];
+                            float t = fmaf(a[e], out_scale, bv[j][e]);
                             if (EPI == EPI_GELU) t = gelu_erf16(t);
                             if (EPI == EPI_SQRELU) { t = fmaxf(t, 0.0f); t = t * t; }     // tranception/activations.py:79-84
                             val[e] = t;
@@ -511,7 +511,11 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
             }
         } else {
             // OUT 1.  Lane holds column m = m_base + r of C^T, rows n = (v&3) + 8(v>>2) + 4kh; split-plane output leaves through a
-            // per-wave LDS transpose as full 128-byte row segments
+            // per-wave LDS transpose as full 128-byte row segments.  (Round 4 tried whole 16-byte chunks per lane -- one
+            // v_permlane32_swap per dword between the lane pair (r, kh = 0 / 1), ds_write_b128 into an XOR-swizzled 256-byte row,
+            // no bank conflicts: FC1 -0.8 % -- and did not keep it: the full- and the half-height instantiations then disagreed in the
+            // last bits on rows holding values below fp16's normal range (tests/test_gpu_tranception.py::test_token_logprobs_do_not_…),
+            // although every op-level comparison on random data was bit-identical.)
             // per-wave LDS patch: 32 rows x (256 B in OUTPUT order: group 0 hi | group 0 lo | group 1 hi | group 1 lo) + 16 B pad
             constexpr int SP = 272;
             const bool staged = (N % 8 == 0) && (en0 + (wn * TN + TN) * 32 <= N);
@@ -545,7 +549,7 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
                         f32x4 val;
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            float t = acc[j][i][4 * g + e] * out_scale + bv[e];
+                            float t = fmaf(acc[j][i][4 * g + e], out_scale, bv[e]);
                             if (EPI == EPI_GELU) t = gelu_erf16(t);
                             if (EPI == EPI_SQRELU) { t = fmaxf(t, 0.0f); t = t * t; }     // tranception/activations.py:79-84
                             val[e] = t;

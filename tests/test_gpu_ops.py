@@ -155,6 +155,32 @@ def test_gemm_f16x3_half_tail_bit_identical(lib, monkeypatch, M, N, K, epi, res)
     assert np.array_equal(out["1"], out["0"])
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(2300, 1280, 128, 1),        # 45 tiles: every one of them as two half-height items
+                                        (15100, 1280, 256, 2),       # 300 tiles on 256 CUs: 256 full + 44 x 2 halves; squared ReLU
+                                        (4300, 5120, 128, 1),        # 340 tiles: 256 + 84 x 2; the FC1 kind (GELU)
+                                        (200, 1344, 384, 1),         # rows past M in the lower halves; the last column tile holds one wave's worth of columns
+                                        (600, 1312, 128, 2)])        # N % 64 != 0: the 8-byte store path
+def test_gemm_f16x3_split_plane_epilogue_bit_identical_across_item_kinds(lib, monkeypatch, M, N, K, epi):
+    """The split-plane (next GEMM's operand) epilogue through the full-height and the half-height items: same bits, and the
+    values of the fp32 epilogue's to the operand's 22 bits."""
+    monkeypatch.setenv("PGMI_GEMM_VARIANT", "0")
+    rng = np.random.default_rng(7)
+    A = (rng.standard_normal((M, K)) * rng.choice([0.01, 1.0, 30.0], size=(M, 1))).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    out = {}
+    for half in ("1", "0"):
+        monkeypatch.setenv("PGMI_GEMM_HALF_TAIL", half)
+        C = np.full((M, N), np.nan, np.float32)
+        _lib.check(lib.pgmi_op_gemm(0, _lib.PREC_F16X3, _p(A), _p(W), _p(bias), None, M, N, K, epi + 256, _p(C)))
+        out[half] = C
+    assert np.isfinite(out["1"]).all()
+    assert np.array_equal(out["1"], out["0"])
+    F = np.empty((M, N), np.float32)
+    _lib.check(lib.pgmi_op_gemm(0, _lib.PREC_F16X3, _p(A), _p(W), _p(bias), None, M, N, K, epi, _p(F)))
+    assert np.abs(out["1"] - F).max() <= np.abs(F).max() * 2.0 ** -21
+
+
 @pytest.mark.parametrize("M,N,K,epi,res", [(15100, 1280, 256, 0, True), (15100, 1284, 256, 1, True), (70000, 1280, 128, 0, True),
                                             (300, 384, 128, 0, False)])
 def test_gemm_f16x3_launch_parameters_bit_identical(lib, monkeypatch, M, N, K, epi, res):

@@ -175,6 +175,25 @@ def test_run_sharded_mutant_chunks_equal_the_cli(lib, gold, golden_dir, tmp_path
         assert open(tmp_path / "sharded" / f"{name}.csv").read() == open(tmp_path / "single" / f"{name}.csv").read()
 
 
+def test_token_logprobs_do_not_depend_on_the_batch_or_on_the_gemm_item_kind(lib, golden_dir, monkeypatch):
+    """The first sequences of a batch of 7 / 100 / 200: the small launches run every GEMM tile as two half-height items, the
+    200-sequence one as full-height items (2 x 228 tiles do not fit one round of CUs), PGMI_GEMM_HALF_TAIL=0 forces full-height
+    items at every size -- the same bits in all of them, through the split-plane (c_fc, squared ReLU) and the fp32 epilogues.
+    (Round 4: a rewrite of the split-plane epilogue passed every op-level comparison on random data and differed here, on rows
+    holding values below fp16's normal range.)"""
+    m = ptr.from_pretrained(os.path.join(golden_dir, "Tranception_toy"), device=0)
+    rng = np.random.default_rng(0)
+    seqs = ["".join(rng.choice(list("ACDEFGHIKLMNPQRSTVWY"), size=70)) for _ in range(200)]
+    ids, _ = m.encode_batch(seqs)
+    monkeypatch.setenv("PGMI_GEMM_HALF_TAIL", "1")
+    base = m.token_logprobs(ids[:7])
+    for half in ("0", "1"):
+        monkeypatch.setenv("PGMI_GEMM_HALF_TAIL", half)
+        for B in (7, 100, 200):
+            assert np.array_equal(m.token_logprobs(ids[:B])[:7], base), (half, B)
+    m.close()
+
+
 def test_context_edges_around_1022_residues_vs_oracle(lib):
     """The Tranception context holds 1 022 residues + [CLS] / [SEP] (scoring_utils.py:152-203: a protein that fits is scored
     whole, a longer one through the optimal window of every mutant, Delta to the wild type OF THE SAME WINDOW): proteins of
