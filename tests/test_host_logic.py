@@ -389,3 +389,37 @@ def test_drop_in_launchers_read_the_zero_shot_config_and_build_a_valid_command_l
         a = tcli.create_parser().parse_args(argv)
         assert a.DMS_index == 7 and bool(a.indel_mode) == ("indels" in script) and bool(a.inference_time_retrieval) == ("no_retrieval" not in script)
         assert a.DMS_reference_file_path.endswith("DMS_indels.csv" if "indels" in script else "DMS_substitutions.csv")
+
+
+def test_product_path_never_touches_the_oracle():
+    """oracle/ is test infrastructure: no module of the product package names it, bench.py only inside its cpu_baseline leg,
+    __graft_entry__ only in build() (compiling the checker) and smoke() (checking against it)."""
+    import ast
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def oracle_imports(path):
+        tree = ast.parse(open(path).read())
+        hits = []
+        for node in ast.walk(tree):
+            names = []
+            if isinstance(node, ast.Import):
+                names = [a.name for a in node.names]
+            elif isinstance(node, ast.ImportFrom):
+                names = [node.module or ""]
+            if any(n == "oracle" or n.startswith("oracle.") for n in names):
+                hits.append(node.lineno)
+        return tree, hits
+    pkg = os.path.join(root, "proteingym_amd")
+    for fn in sorted(os.listdir(pkg)):
+        if fn.endswith(".py"):
+            assert oracle_imports(os.path.join(pkg, fn))[1] == [], fn
+    for fn in sorted(os.listdir(os.path.join(pkg, "csrc"))):
+        if fn.endswith((".hip", ".h")):
+            assert "oracle" not in open(os.path.join(pkg, "csrc", fn)).read(), fn
+    tree, hits = oracle_imports(os.path.join(root, "bench.py"))
+    spans = {f.name: (f.lineno, f.end_lineno) for f in ast.walk(tree) if isinstance(f, ast.FunctionDef)}
+    lo, hi = spans["cpu_baseline"]
+    assert hits and all(lo <= h <= hi for h in hits), (hits, spans["cpu_baseline"])
+    tree, hits = oracle_imports(os.path.join(root, "__graft_entry__.py"))
+    spans = {f.name: (f.lineno, f.end_lineno) for f in ast.walk(tree) if isinstance(f, ast.FunctionDef)}
+    assert all(any(lo <= h <= hi for lo, hi in (spans["build"], spans["smoke"])) for h in hits), hits
