@@ -306,6 +306,26 @@ def test_real_small_esm2_shapes_load_and_match_oracle(lib):
         m.close()
 
 
+@pytest.mark.parametrize("arch", ["ESM1V_650M", "ESM2_650M"])
+def test_token_logprobs_do_not_depend_on_the_batch_or_on_the_gemm_item_kind(lib, monkeypatch, arch):
+    """The first sequences of a batch of 4 / 60 / 230 (4 layers at the 650M width: 1280 x 20 heads x 5120, T = 72): the small launches
+    run every GEMM tile as two half-height items, the larger ones as full-height items (+ a half-height tail), PGMI_GEMM_HALF_TAIL=0
+    forces full-height items everywhere -- the same bits in all of them, through the fused QKV (rotary for ESM2), the split-plane
+    (FC1 + GELU) and the fp32 + residual epilogues."""
+    cfg = dict(getattr(synthetic, arch), layers=4)
+    m = pesm.EsmModel(cfg, synthetic.random_weights(cfg, seed=3, embed_std=0.15), device=0)
+    rng = np.random.default_rng(1)
+    tok = rng.integers(4, 24, size=(230, 72)).astype(np.int32)
+    tok[:, 0], tok[:, -1] = 0, 2
+    monkeypatch.setenv("PGMI_GEMM_HALF_TAIL", "1")
+    base = m.token_logprobs(tok[:4])
+    for half in ("0", "1"):
+        monkeypatch.setenv("PGMI_GEMM_HALF_TAIL", half)
+        for B in (4, 60, 230):
+            assert np.array_equal(m.token_logprobs(tok[:B])[:4], base), (half, B)
+    m.close()
+
+
 def test_spearman_vs_dms_score_identical_to_reference(models, golden, golden_dir):
     """the downstream metric (per-assay Spearman against DMS_score, 4 decimals --
     performance_DMS_benchmarks.py) computed from the HIP scores equals the one from the reference CLI's scores."""
