@@ -744,3 +744,61 @@ def test_reference_performance_script_consumes_the_merged_scores(tmp_path, monke
         assert os.path.exists(outdir / metric / f"DMS_substitutions_{metric}_DMS_level.csv")
     summary = [f for f in os.listdir(outdir / "Spearman") if f.startswith("Summary")]
     assert summary, os.listdir(outdir / "Spearman")
+
+
+@pytest.mark.skipif(not rh.reference_available(), reason="/root/reference not present (GPU box)")
+def test_reference_performance_script_consumes_the_indel_csvs(tmp_path, monkeypatch):
+    """The same for the indel benchmark (`performance_DMS_benchmarks.py --indel_mode`, key mutated_sequence): four toy indel libraries
+    scored by run_sharded tranception --indel_mode (device stand-in), merged by the reference's merge.py --mutation_type indels, then
+    the reference's performance script: its per-assay Spearman equals scipy's on the runner's own scores."""
+    import importlib.util
+    import json
+    import sys
+    from scipy.stats import spearmanr
+    from proteingym_amd import run_sharded, synthetic
+    from test_dist_cpu import _fake_tranception
+    dms = tmp_path / "dms"
+    dms.mkdir()
+    ref_rows = []
+    layout = [("IND_A", 48, 40, "Activity", "medium", "Human"), ("IND_B", 60, 36, "Stability", "low", "Virus"),
+              ("IND_C", 52, 30, "Binding", "high", "Eukaryote"), ("IND_D", 45, 44, "Expression", "medium", "Prokaryote")]
+    rng = np.random.default_rng(12)
+    for k, (dms_id, L, n, sel, neff, taxon) in enumerate(layout):
+        wt, lib_ = synthetic.random_indel_library(20 + k, L, n)
+        score = rng.standard_normal(len(lib_))
+        pd.DataFrame({"mutant": lib_, "mutated_sequence": lib_, "DMS_score": score, "DMS_score_bin": (score > 0).astype(int)}).to_csv(dms / f"{dms_id}.csv", index=False)
+        ref_rows.append(dict(DMS_id=dms_id, DMS_filename=f"{dms_id}.csv", target_seq=wt, DMS_total_number_mutants=len(lib_), UniProt_ID=dms_id + "_X",
+                             coarse_selection_type=sel, MSA_Neff_L_category=neff, taxon=taxon))
+    pd.DataFrame(ref_rows).to_csv(tmp_path / "ref.csv", index=False)
+    registry = json.load(open("/root/reference/config.json"))["model_list_zero_shot_indels_DMS"]
+    models = {"Tranception_L_no_retrieval": registry["Tranception_L_no_retrieval"]}
+    scores = tmp_path / "scores"
+    run_sharded.main(["tranception", "--", "--checkpoint", "fake", "--DMS_reference_file_path", str(tmp_path / "ref.csv"), "--DMS_data_folder", str(dms),
+                      "--output_scores_folder", str(scores / models["Tranception_L_no_retrieval"]["location"]), "--indel_mode"], make_model=_fake_tranception)
+    json.dump({"model_list_zero_shot_indels_DMS": models}, open(tmp_path / "config.json", "w"))
+
+    def load(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        return mod
+    merge = load("pg_reference_merge_perf_indels", "/root/reference/proteingym/merge.py")
+    monkeypatch.setattr(sys, "argv", ["merge.py", "--DMS_assays_location", str(dms), "--model_scores_location", str(scores), "--mutation_type", "indels",
+                                      "--DMS_reference_file", str(tmp_path / "ref.csv"), "--config_file", str(tmp_path / "config.json")])
+    merge.main()
+    perf = load("pg_reference_performance_indels", "/root/reference/proteingym/performance_DMS_benchmarks.py")
+    slow = perf.compute_bootstrap_standard_error_functional_categories
+    monkeypatch.setattr(perf, "compute_bootstrap_standard_error_functional_categories", lambda df, number_assay_reshuffle=20: slow(df, 20))
+    outdir = tmp_path / "performance"
+    monkeypatch.setattr(sys, "argv", ["performance_DMS_benchmarks.py", "--input_scoring_files_folder", str(scores / "merged_scores"),
+                                      "--output_performance_file_folder", str(outdir), "--DMS_reference_file_path", str(tmp_path / "ref.csv"),
+                                      "--DMS_data_folder", str(dms), "--config_file", str(tmp_path / "config.json"), "--indel_mode"])
+    perf.main()
+    table = pd.read_csv(outdir / "Spearman" / "DMS_indels_Spearman_DMS_level.csv", index_col="DMS ID")
+    clean = json.load(open("/root/reference/proteingym/constants.json"))["clean_names"]
+    col = clean.get("Tranception_L_no_retrieval", "Tranception_L_no_retrieval")
+    for dms_id, *_ in layout:
+        ours = pd.read_csv(scores / "Tranception_no_retrieval" / "Tranception_L" / f"{dms_id}.csv").drop_duplicates("mutated_sequence").set_index("mutated_sequence")
+        assay = pd.read_csv(dms / f"{dms_id}.csv")
+        rho = spearmanr(assay["DMS_score"], ours.loc[assay["mutated_sequence"], "avg_score"].to_numpy())[0]
+        assert float(table.loc[dms_id, col]) == round(rho, 3), (dms_id, table.loc[dms_id, col], rho)
