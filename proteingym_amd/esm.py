@@ -24,32 +24,26 @@ import numpy as np
 from . import _lib
 from ._lib import PgmiError, Config
 
-# esm/constants.py:8
-proteinseq_toks = {
-    'toks': ['L', 'A', 'G', 'V', 'S', 'E', 'R', 'T', 'I', 'D', 'P', 'K', 'Q', 'N', 'F', 'Y', 'M',
-             'H', 'W', 'C', 'X', 'B', 'U', 'Z', 'O', '.', '-']
-}
+# The 33 symbols of the ESM-1b / ESM2 / MSA Transformer vocabulary in index order -- the checkpoint's embedding rows ARE this order
+# (esm/constants.py:8 between the four leading specials, one filler up to a multiple of 8, and <mask>; esm/data.py:92-174).
+VOCABULARY = ("<cls>", "<pad>", "<eos>", "<unk>",
+              *"LAGVSERTIDPKQNFYMHWCXBUZO.-",
+              "<null_1>", "<mask>")
+assert len(VOCABULARY) == 33
+_INDEX = {tok: i for i, tok in enumerate(VOCABULARY)}
 
 
 class Alphabet:
-    """The 33-symbol ESM-1b / ESM2 alphabet (esm/data.py:92-174, arch "roberta_large"/"ESM-1b")."""
+    """The ESM-1b / ESM2 alphabet as one constant table; attribute names are the ones the reference's callers read
+    (``mask_idx``, ``padding_idx``, ``all_toks``, ``get_idx`` ...; arch "roberta_large" / "ESM-1b")."""
 
-    def __init__(self):
-        self.standard_toks = list(proteinseq_toks["toks"])
-        self.prepend_toks = ["<cls>", "<pad>", "<eos>", "<unk>"]
-        self.append_toks = ["<mask>"]
-        self.prepend_bos = True
-        self.append_eos = True
-        self.all_toks = list(self.prepend_toks) + self.standard_toks
-        for i in range((8 - (len(self.all_toks) % 8)) % 8):
-            self.all_toks.append(f"<null_{i + 1}>")
-        self.all_toks.extend(self.append_toks)
-        self.tok_to_idx = {tok: i for i, tok in enumerate(self.all_toks)}
-        self.unk_idx = self.tok_to_idx["<unk>"]
-        self.padding_idx = self.get_idx("<pad>")
-        self.cls_idx = self.get_idx("<cls>")
-        self.mask_idx = self.get_idx("<mask>")
-        self.eos_idx = self.get_idx("<eos>")
+    all_toks = list(VOCABULARY)
+    tok_to_idx = _INDEX
+    cls_idx, padding_idx, eos_idx, unk_idx = _INDEX["<cls>"], _INDEX["<pad>"], _INDEX["<eos>"], _INDEX["<unk>"]
+    mask_idx = _INDEX["<mask>"]
+    prepend_bos = append_eos = True                      # <cls> before and <eos> after every sequence
+    _single = frozenset(filter(lambda t: len(t) == 1, VOCABULARY))
+    _multi = sorted(filter(lambda t: len(t) > 1, VOCABULARY), key=len, reverse=True)
 
     @classmethod
     def from_architecture(cls, name: str) -> "Alphabet":
@@ -58,25 +52,23 @@ class Alphabet:
         raise ValueError("Unknown architecture selected")
 
     def __len__(self):
-        return len(self.all_toks)
+        return len(VOCABULARY)
 
     def get_idx(self, tok):
+        """Index of a token; anything outside the vocabulary is <unk> (mutant letters go through here)."""
         return self.tok_to_idx.get(tok, self.unk_idx)
 
     def get_tok(self, ind):
-        return self.all_toks[ind]
+        return VOCABULARY[ind]
 
     def to_dict(self):
-        return self.tok_to_idx.copy()
+        return dict(self.tok_to_idx)
 
     def tokenize(self, text: str) -> List[str]:
         """Behaviour of the reference tokenizer (esm/data.py:178-251; every vocabulary entry is a no-split token): the text
         is cut at every vocabulary token -- the single residue letters and literal special tokens such as "<mask>" --
         whitespace between tokens is dropped, and whatever is left (a run of characters outside the vocabulary: lower
         case, 'J', '*', ...) stays ONE token, which ``encode`` then fails on exactly like the reference."""
-        if not hasattr(self, "_single"):
-            self._single = frozenset(t for t in self.all_toks if len(t) == 1)
-            self._multi = sorted((t for t in self.all_toks if len(t) > 1), key=len, reverse=True)
         if all(ch in self._single for ch in text):
             return list(text)
         out, run, i, n = [], [], 0, len(text)

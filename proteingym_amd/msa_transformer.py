@@ -17,12 +17,11 @@ import ctypes as C
 import itertools
 import os
 import random
-from collections import defaultdict
 from typing import List, Sequence, Tuple
 
 import numpy as np
 
-from . import _lib
+from . import _lib, alignment
 from ._lib import Config, PgmiError
 from . import esm as pesm
 
@@ -35,10 +34,8 @@ ALPHABET_PROTEIN_GAP = GAP + ALPHABET_PROTEIN_NOGAP
 class MsaAlphabet(pesm.Alphabet):
     """Same 33 symbols as ESM-1b; <cls> is prepended, no <eos> (esm/data.py:158-164)."""
 
-    def __init__(self):
-        super().__init__()
-        self.append_eos = False
-        self.use_msa = True
+    append_eos = False
+    use_msa = True
 
     def get_batch_converter(self, truncation_seq_length: int = None):
         return MSABatchConverter(self)
@@ -225,46 +222,22 @@ class MSA_processing:
         self.alphabet = ALPHABET_PROTEIN_NOGAP
         self.use_weights = use_weights
         self.device = device
-        seqs = defaultdict(str)
-        name = ""
-        with open(MSA_location, "r") as f:
-            for i, line in enumerate(f):
-                line = line.rstrip()
-                if line.startswith(">"):
-                    name = line
-                    if i == 0:
-                        self.focus_seq_name = name
-                else:
-                    seqs[name] += line
-        if preprocess_MSA:
-            names = list(seqs.keys())
-            up = [seqs[n].replace(".", "-").upper() for n in names]
-            wt = up[names.index(self.focus_seq_name)]
-            keep = np.array([aa != "-" for aa in wt])
-            arr = np.array([list(s) for s in up])[:, keep]
-            gaps = arr == "-"
-            seq_ok = gaps.mean(axis=1) <= threshold_sequence_frac_gaps
-            col_ok = gaps[seq_ok].mean(axis=0) <= threshold_focus_cols_frac_gaps
-            seqs = {n: "".join(a.upper() if c else a.lower() for a, c in zip(row, col_ok))
-                    for n, row, ok in zip(names, arr, seq_ok) if ok}
-        self.focus_seq = seqs[self.focus_seq_name]
-        self.focus_cols = [ix for ix, s in enumerate(self.focus_seq) if s == s.upper() and s != "-"]
-        self.focus_seq_trimmed = "".join(self.focus_seq[ix] for ix in self.focus_cols)
+        al = alignment.FocusAlignment(MSA_location, preprocess_MSA, threshold_sequence_frac_gaps, threshold_focus_cols_frac_gaps,
+                                      remove_sequences_with_indeterminate_AA_in_focus_cols)
+        self.focus_seq_name, self.focus_seq = al.focus_name, al.focus_seq
+        self.focus_cols = al.focus_cols.tolist()
+        self.focus_seq_trimmed = "".join(self.focus_seq[c] for c in self.focus_cols)
         self.seq_len = len(self.focus_cols)
         self.alphabet_size = len(self.alphabet)
-        self.raw_seq_name_to_sequence = dict(seqs)
-        trimmed = {n: "".join(s.replace(".", "-")[ix].upper() for ix in self.focus_cols) for n, s in seqs.items()}
-        if remove_sequences_with_indeterminate_AA_in_focus_cols:
-            ok = set(self.alphabet)
-            trimmed = {n: s for n, s in trimmed.items() if all((l in ok or l == "-") for l in s)}
-        self.seq_name_to_sequence = trimmed
-        self.num_sequences = len(trimmed)
+        self.raw_seq_name_to_sequence = al.raw
+        self.seq_name_to_sequence = dict(zip(al.names, alignment.to_strings(al.trimmed)))
+        self.num_sequences = len(al.names)
         if use_weights:
             if os.path.isfile(str(weights_location)):
                 self.weights = np.load(file=weights_location)
             else:
                 from . import weights as _w
-                mat = _w.encode_alignment(trimmed.values(), ALPHABET_PROTEIN_GAP, default=GAP)
+                mat = _w.symbol_table(ALPHABET_PROTEIN_GAP, default=GAP)[al.trimmed].astype(np.int8)
                 self.weights = _w.calc_weights_fast(mat, identity_threshold=1 - theta, empty_value=0, num_cpus=num_cpus,
                                                     device=device)
                 np.save(file=weights_location, arr=self.weights)
@@ -273,7 +246,7 @@ class MSA_processing:
         self.Neff = np.sum(self.weights)
         assert self.weights.shape[0] == self.num_sequences, \
             f"Expected {self.num_sequences} sequences, loaded weights have {self.weights.shape[0]}"
-        self.seq_name_to_weight = {n: self.weights[i] for i, n in enumerate(trimmed.keys())}
+        self.seq_name_to_weight = {n: self.weights[i] for i, n in enumerate(al.names)}
 
 
 def read_fasta_records(filename):

@@ -17,13 +17,12 @@ import ctypes as C
 import json
 import os
 import re
-from collections import defaultdict
 from typing import Dict, Optional, Sequence
 
 import numpy as np
 import pandas as pd
 
-from . import _lib
+from . import _lib, alignment
 from ._lib import PgmiError, Config
 
 VOCAB = {'[UNK]': 0, '[CLS]': 1, '[SEP]': 2, '[PAD]': 3, '[MASK]': 4, 'A': 5, 'C': 6, 'D': 7, 'E': 8, 'F': 9,
@@ -110,25 +109,16 @@ def get_sequence_slices(df, target_seq, model_context_len, start_idx=1, scoring_
 
 # ---- retrieval prior (tranception/utils/msa_utils.py:28-138) -------------------------------------
 def process_msa_data(MSA_data_file):
-    msa_data = defaultdict(str)
-    sequence_name = ""
-    with open(MSA_data_file, "r") as msa_file:
-        for line in msa_file:
-            line = line.rstrip()
-            if line.startswith(">"):
-                sequence_name = line
-            else:
-                msa_data[sequence_name] += line.upper()
-    return msa_data
+    """{header line -> upper-case sequence} (msa_utils.py:28-43)."""
+    return alignment.read_records(MSA_data_file, upper=True)[1]
 
 
 class MSA_processing:
-    """EVE-style alignment pre-processing and sequence weights (tranception/utils/msa_utils.py:194-368,
-    same constructor arguments and attributes the scorer reads: focus_seq_name, seq_name_to_sequence,
-    seq_name_to_weight, weights, Neff).  Weights are loaded from ``weights_location`` when the file
-    exists, otherwise computed (1 / number of sequences within Hamming distance theta over the focus
-    columns, vectorised over blocks of sequences instead of the reference's per-sequence python map)
-    and saved there, as the reference does."""
+    """EVE-style alignment pre-processing and sequence weights (tranception/utils/msa_utils.py:194-368): the reference's constructor
+    arguments, and the attributes its callers read.  The pre-processing itself is ``alignment.FocusAlignment`` (numpy over the byte
+    matrix).  Weights are loaded from ``weights_location`` when the file exists, otherwise computed (1 / number of sequences within
+    Hamming distance theta over the focus columns: HIP kernel with ``device``, blocked numpy without) and saved there, as the
+    reference does."""
 
     def __init__(self, MSA_location="", theta=0.2, use_weights=True, weights_location="./data/weights",
                  preprocess_MSA=True, threshold_sequence_frac_gaps=0.5, threshold_focus_cols_frac_gaps=1.0,
@@ -138,7 +128,7 @@ class MSA_processing:
         self.MSA_location = MSA_location
         self.weights_location = weights_location
         self.theta = theta
-        self.alphabet = "ACDEFGHIKLMNPQRSTVWY"
+        self.alphabet = alignment.AMINO_ACIDS
         self.use_weights = use_weights
         self.preprocess_MSA = preprocess_MSA
         self.threshold_sequence_frac_gaps = threshold_sequence_frac_gaps
@@ -147,70 +137,31 @@ class MSA_processing:
         self.gen_alignment()
 
     def gen_alignment(self):
+        al = alignment.FocusAlignment(self.MSA_location, self.preprocess_MSA, self.threshold_sequence_frac_gaps,
+                                      self.threshold_focus_cols_frac_gaps, self.remove_sequences_with_indeterminate_AA_in_focus_cols)
         self.aa_dict = {aa: i for i, aa in enumerate(self.alphabet)}
-        self.seq_name_to_sequence = defaultdict(str)
-        name = ""
-        with open(self.MSA_location, "r") as msa_data:
-            for i, line in enumerate(msa_data):
-                line = line.rstrip()
-                if line.startswith(">"):
-                    name = line
-                    if i == 0:
-                        self.focus_seq_name = name
-                else:
-                    self.seq_name_to_sequence[name] += line
-        if self.preprocess_MSA:
-            names = list(self.seq_name_to_sequence.keys())
-            seqs = [self.seq_name_to_sequence[n].replace(".", "-").upper() for n in names]
-            wt = seqs[names.index(self.focus_seq_name)]
-            keep_cols = np.array([aa != '-' for aa in wt])
-            arr = np.array([list(s) for s in seqs])[:, keep_cols]
-            gaps = arr == '-'
-            seq_ok = gaps.mean(axis=1) <= self.threshold_sequence_frac_gaps
-            col_ok = gaps[seq_ok].mean(axis=0) <= self.threshold_focus_cols_frac_gaps
-            self.seq_name_to_sequence = defaultdict(str)
-            for n, row, ok in zip(names, arr, seq_ok):
-                if ok:
-                    self.seq_name_to_sequence[n] = ''.join(a.upper() if c else a.lower() for a, c in zip(row, col_ok))
-        self.focus_seq = self.seq_name_to_sequence[self.focus_seq_name]
-        self.focus_cols = [ix for ix, s in enumerate(self.focus_seq) if s == s.upper() and s != '-']
-        self.focus_seq_trimmed = [self.focus_seq[ix] for ix in self.focus_cols]
-        self.seq_len = len(self.focus_cols)
         self.alphabet_size = len(self.alphabet)
-        try:
-            start, stop = self.focus_seq_name.split("/")[-1].split("-")
-            self.focus_start_loc, self.focus_stop_loc = int(start), int(stop)
-        except Exception:
-            start, stop = 1, len(self.focus_seq)
-            self.focus_start_loc, self.focus_stop_loc = 1, len(self.focus_seq)
-        self.uniprot_focus_col_to_wt_aa_dict = {c + int(start): self.focus_seq[c] for c in self.focus_cols}
-        self.uniprot_focus_col_to_focus_idx = {c + int(start): c for c in self.focus_cols}
-        self.raw_seq_name_to_sequence = self.seq_name_to_sequence.copy()
-        for seq_name, sequence in self.seq_name_to_sequence.items():
-            sequence = sequence.replace(".", "-")
-            self.seq_name_to_sequence[seq_name] = [sequence[ix].upper() for ix in self.focus_cols]
-        if self.remove_sequences_with_indeterminate_AA_in_focus_cols:
-            alphabet_set = set(self.alphabet)
-            for seq_name in [n for n, sq in self.seq_name_to_sequence.items()
-                             if any((l not in alphabet_set and l != "-") for l in sq)]:
-                del self.seq_name_to_sequence[seq_name]
-        names = list(self.seq_name_to_sequence.keys())
-        # integer encoding: AA index 0..19, -1 for gaps (zero one-hot rows in the reference)
-        enc = np.full((len(names), len(self.focus_cols)), -1, dtype=np.int8)
-        for i, n in enumerate(names):
-            enc[i] = [self.aa_dict.get(l, -1) for l in self.seq_name_to_sequence[n]]
-        self.encoded = enc
+        self.focus_seq_name, self.focus_seq = al.focus_name, al.focus_seq
+        self.focus_cols = al.focus_cols.tolist()
+        self.focus_seq_trimmed = [self.focus_seq[c] for c in self.focus_cols]
+        self.seq_len = len(self.focus_cols)
+        self.focus_start_loc, self.focus_stop_loc = al.focus_range()
+        self.uniprot_focus_col_to_wt_aa_dict = {c + self.focus_start_loc: self.focus_seq[c] for c in self.focus_cols}
+        self.uniprot_focus_col_to_focus_idx = {c + self.focus_start_loc: c for c in self.focus_cols}
+        self.raw_seq_name_to_sequence = al.raw
+        self.seq_name_to_sequence = {n: list(s) for n, s in zip(al.names, alignment.to_strings(al.trimmed))}
+        self.encoded = al.residue_codes(gap=-1)          # 0..19, -1 for gaps (the reference's all-zero one-hot rows)
+        self.num_sequences = len(al.names)
         if self.use_weights:
             try:
                 self.weights = np.load(file=self.weights_location)
             except Exception:
-                self.weights = compute_sequence_weights(enc, self.theta, device=self.device)
+                self.weights = compute_sequence_weights(self.encoded, self.theta, device=self.device)
                 np.save(file=self.weights_location, arr=self.weights)
         else:
-            self.weights = np.ones(len(names))
+            self.weights = np.ones(self.num_sequences)
         self.Neff = np.sum(self.weights)
-        self.num_sequences = len(names)
-        self.seq_name_to_weight = {n: self.weights[i] for i, n in enumerate(names)}
+        self.seq_name_to_weight = {n: self.weights[i] for i, n in enumerate(al.names)}
 
 
 def compute_sequence_weights(enc: np.ndarray, theta: float, block: int = 256, device=None) -> np.ndarray:

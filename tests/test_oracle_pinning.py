@@ -802,3 +802,66 @@ def test_reference_performance_script_consumes_the_indel_csvs(tmp_path, monkeypa
         assay = pd.read_csv(dms / f"{dms_id}.csv")
         rho = spearmanr(assay["DMS_score"], ours.loc[assay["mutated_sequence"], "avg_score"].to_numpy())[0]
         assert float(table.loc[dms_id, col]) == round(rho, 3), (dms_id, table.loc[dms_id, col], rho)
+
+
+@pytest.mark.skipif(not rh.reference_available(), reason="/root/reference not present (GPU box)")
+@pytest.mark.parametrize("kwargs", [
+    {},
+    {"threshold_sequence_frac_gaps": 0.2, "threshold_focus_cols_frac_gaps": 0.3},
+    {"preprocess_MSA": False},
+    {"remove_sequences_with_indeterminate_AA_in_focus_cols": False},
+    {"preprocess_MSA": False, "remove_sequences_with_indeterminate_AA_in_focus_cols": False},
+])
+def test_alignment_preprocessing_vs_live_reference(tmp_path, kwargs):
+    """alignment.FocusAlignment (byte-matrix numpy) against the reference's own ``MSA_processing`` (string / pandas code,
+    tranception/utils/msa_utils.py:230-340) on an alignment with insert columns, '.', gappy rows and columns, X / B / Z residues and
+    a sequence spread over several lines -- every attribute a caller can read, for the reference's switches on and off."""
+    from proteingym_amd import tranception as ptr, msa_transformer as pmsa
+    rh.load_reference_tranception()
+    from tranception.utils import msa_utils
+    rng = np.random.default_rng(11)
+    aa = np.array(list("ACDEFGHIKLMNPQRSTVWY"))
+    width, focus = 60, None
+    lines = []
+    col_kind = rng.choice(3, size=width, p=[0.75, 0.15, 0.10])               # 0 match column, 1 insert column (focus '.' / lower), 2 gappy
+    for i in range(40):
+        row = aa[rng.integers(0, 20, width)].copy()
+        if i == 0:
+            row[col_kind == 1] = "-" if kwargs.get("preprocess_MSA", True) else "."
+            if not kwargs.get("preprocess_MSA", True):
+                low = rng.random(width) < 0.1
+                row = np.where(low & (col_kind == 0), np.char.lower(row), row)
+        else:
+            row[rng.random(width) < (0.9 if i % 7 == 3 else 0.12)] = "-"
+            row[(col_kind == 2) & (rng.random(width) < 0.8)] = "-"
+            ins = col_kind == 1
+            row[ins] = np.where(rng.random(ins.sum()) < 0.5, ".", np.char.lower(row[ins]))
+            if i % 9 == 4:
+                row[rng.integers(0, width)] = "X"
+            if i % 11 == 5:
+                row[rng.integers(0, width)] = "b"
+        s = "".join(row)
+        lines.append(f">seq{i}/10-{9 + width}" if i else ">FOCUS/10-69")
+        lines += [s[:25], s[25:]] if i % 3 == 1 else [s]
+    a2m = tmp_path / "t.a2m"
+    a2m.write_text("\n".join(lines) + "\n")
+    ref = msa_utils.MSA_processing(MSA_location=str(a2m), use_weights=False, **kwargs)
+    for mine in (ptr.MSA_processing(MSA_location=str(a2m), use_weights=False, **kwargs),
+                 pmsa.MSA_processing(MSA_location=str(a2m), use_weights=False, **kwargs)):
+        assert mine.focus_seq_name == ref.focus_seq_name and mine.focus_seq == ref.focus_seq
+        assert list(mine.focus_cols) == list(ref.focus_cols) and mine.seq_len == ref.seq_len
+        assert "".join(mine.focus_seq_trimmed) == "".join(ref.focus_seq_trimmed)
+        assert dict(mine.raw_seq_name_to_sequence) == dict(ref.raw_seq_name_to_sequence)
+        assert list(mine.seq_name_to_sequence) == list(ref.seq_name_to_sequence)
+        for n in ref.seq_name_to_sequence:
+            assert "".join(mine.seq_name_to_sequence[n]) == "".join(ref.seq_name_to_sequence[n]), n
+        assert mine.num_sequences == ref.num_sequences and np.array_equal(mine.weights, ref.weights) and mine.Neff == ref.Neff
+        assert list(mine.seq_name_to_weight) == list(ref.seq_name_to_weight)
+    tr = ptr.MSA_processing(MSA_location=str(a2m), use_weights=False, **kwargs)
+    assert (tr.focus_start_loc, tr.focus_stop_loc) == (ref.focus_start_loc, ref.focus_stop_loc)
+    assert tr.uniprot_focus_col_to_wt_aa_dict == ref.uniprot_focus_col_to_wt_aa_dict
+    assert tr.uniprot_focus_col_to_focus_idx == ref.uniprot_focus_col_to_focus_idx
+    onehot = np.zeros((tr.num_sequences, tr.seq_len, 20))
+    i, j = np.nonzero(tr.encoded >= 0)
+    onehot[i, j, tr.encoded[i, j]] = 1.0
+    assert np.array_equal(onehot, ref.one_hot_encoding)
