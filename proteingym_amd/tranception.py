@@ -189,45 +189,61 @@ def compute_sequence_weights(enc: np.ndarray, theta: float, block: int = 256, de
 
 
 def get_msa_prior(MSA_data_file, MSA_weight_file_name, MSA_start, MSA_end, len_target_seq, vocab=VOCAB,
-                  retrieval_aggregation_mode="aggregate_substitution", filter_MSA=True, seq_name_to_weight=None):
+                  retrieval_aggregation_mode="aggregate_substitution", filter_MSA=True, seq_name_to_weight=None,
+                  block_bytes=64 << 20):
     """Per-position amino-acid distribution of the retrieved alignment with 1e-5 pseudo-counts, [len_target_seq, V],
     zero outside [MSA_start, MSA_end) -- the quantity msa_utils.py:63-138 builds.  Sequences sharing less than 20 %
     of the query's symbols are dropped (:83-91); with ``MSA_weight_file_name`` the EVE weights come from
     ``MSA_processing`` and sequences without a weight are dropped (:100-115); ``seq_name_to_weight`` injects weights
-    directly.  The float expression of the reference is kept term by term so the result is bit-identical."""
+    directly (additive, like ``block_bytes``: the size of the float64 working set).  The float expression of the reference
+    is kept term by term so the result is bit-identical."""
     V = len(vocab)
-    alignment = process_msa_data(MSA_data_file)
-    names = list(alignment.keys())
+    records = process_msa_data(MSA_data_file)
+    names = list(records)
     width = MSA_end - MSA_start
-
-    def encode(seq):                                      # vocabulary index per column, -1 = not in the vocabulary
-        return np.array([vocab.get(ch, -1) for ch in seq], dtype=np.int64)
-    codes = {n: encode(alignment[n]) for n in names}
+    table = np.full(256, -1, dtype=np.int64)              # byte -> vocabulary index, -1 = not in the vocabulary
+    for symbol, index in vocab.items():
+        if len(symbol) == 1:
+            table[ord(symbol)] = index
+    codes = table[alignment.to_matrix([records[n] for n in names])]
+    keep = np.ones(len(names), dtype=bool)
     if filter_MSA:
-        query = codes[names[0]]
+        query = codes[0]
         n_query = float((query >= 0).sum())
-        names = [n for n in names
-                 if not (float(((codes[n] == query) & (query >= 0)).sum()) / n_query < 0.2)]
+        keep &= ~(((codes == query) & (query >= 0)).sum(axis=1) / n_query < 0.2)
     if MSA_weight_file_name is not None and seq_name_to_weight is None:
         assert os.path.exists(MSA_weight_file_name), "Weights file not located on disk."
         seq_name_to_weight = MSA_processing(MSA_location=MSA_data_file, use_weights=True,
                                             weights_location=MSA_weight_file_name).seq_name_to_weight
     if seq_name_to_weight is not None:
-        names = [n for n in names if n in seq_name_to_weight]
-        weights = np.array([seq_name_to_weight[n] for n in names])
+        keep &= np.array([n in seq_name_to_weight for n in names], dtype=bool)
+        weights = np.array([seq_name_to_weight[n] for n, k in zip(names, keep) if k])
     else:
-        weights = np.array([1] * len(names))
+        weights = np.array([1] * int(keep.sum()))
     if retrieval_aggregation_mode not in ("aggregate_substitution", "aggregate_indel"):
         return np.ones((len_target_seq, V)) / V
-    one_hots = np.zeros((len(names), width, V))
-    for i, n in enumerate(names):
-        c = codes[n]
-        cols = np.nonzero(c >= 0)[0]
-        one_hots[i, cols, c[cols]] = 1.0
-    counts = (one_hots + np.ones_like(one_hots) * 1e-5) * np.expand_dims(weights, axis=(1, 2))
-    total = counts.sum(axis=-1).sum(axis=0)
+    codes = codes[keep]
+    if codes.shape[1] > width:
+        if (codes[:, width:] >= 0).any():
+            raise IndexError(f"the alignment has residues beyond column {width} = MSA_end - MSA_start")
+        codes = codes[:, :width]
+    # The reference materialises one_hots [sequences, width, V] in float64 (and two temporaries of that size) and reduces over the
+    # sequences.  Same expressions here on blocks of sequences: numpy reduces a leading axis by adding the slices one after the other,
+    # so carrying the running sum in as slice 0 of the next block gives the same bits with memory bounded by the block.
+    acc = np.zeros((width, V))
+    total = np.zeros(width)
+    rows_per_block = max(1, block_bytes // max(1, width * V * 8))
+    for lo in range(0, codes.shape[0], rows_per_block):
+        c = codes[lo:lo + rows_per_block]
+        one_hots = np.zeros((c.shape[0], width, V))
+        i, j = np.nonzero(c >= 0)
+        one_hots[i, j, c[i, j]] = 1.0
+        counts = (one_hots + np.ones_like(one_hots) * 1e-5) * np.expand_dims(weights[lo:lo + rows_per_block], axis=(1, 2))
+        first = lo == 0
+        total = np.add.reduce(counts.sum(axis=-1) if first else np.concatenate([total[None], counts.sum(axis=-1)]), axis=0)
+        acc = np.add.reduce(counts if first else np.concatenate([acc[None], counts]), axis=0)
     prior = np.zeros((len_target_seq, V))
-    prior[MSA_start:MSA_end, :] = counts.sum(axis=0) / np.tile(total.reshape(-1, 1), (1, V))
+    prior[MSA_start:MSA_end, :] = acc / np.tile(total.reshape(-1, 1), (1, V))
     return prior
 
 

@@ -865,3 +865,35 @@ def test_alignment_preprocessing_vs_live_reference(tmp_path, kwargs):
     i, j = np.nonzero(tr.encoded >= 0)
     onehot[i, j, tr.encoded[i, j]] = 1.0
     assert np.array_equal(onehot, ref.one_hot_encoding)
+
+
+@pytest.mark.skipif(not rh.reference_available(), reason="/root/reference not present (GPU box)")
+@pytest.mark.parametrize("weighted", [False, True])
+def test_msa_prior_in_blocks_equals_live_reference_bitwise(tmp_path, weighted):
+    """get_msa_prior reduces the alignment in blocks of sequences (bounded memory); the bits must be the reference's, which reduces
+    one [sequences, width, V] array (msa_utils.py:63-138) -- 300 sequences in 24 blocks, with and without EVE weights."""
+    from proteingym_amd import tranception as ptr
+    rh.load_reference_tranception()
+    from tranception.utils import msa_utils
+    rng = np.random.default_rng(5)
+    aa = np.array(list("ACDEFGHIKLMNPQRSTVWY"))
+    width = 48
+    focus = aa[rng.integers(0, 20, width)]
+    lines = [">FOCUS/3-50", "".join(focus)]
+    for i in range(1, 300):
+        row = np.where(rng.random(width) < (0.95 if i % 13 == 0 else 0.4), aa[rng.integers(0, 20, width)], focus)
+        row[rng.random(width) < 0.15] = "-"
+        if i % 17 == 0:
+            row[rng.integers(0, width)] = "X"
+        lines += [f">s{i}", "".join(row)]
+    a2m = tmp_path / "p.a2m"
+    a2m.write_text("\n".join(lines) + "\n")
+    wfile = None
+    if weighted:
+        wfile = str(tmp_path / "w.npy")
+        msa_utils.MSA_processing(MSA_location=str(a2m), use_weights=True, weights_location=wfile)      # the reference computes and saves
+    want = msa_utils.get_msa_prior(MSA_data_file=str(a2m), MSA_weight_file_name=wfile, MSA_start=2, MSA_end=50, len_target_seq=60,
+                                   vocab=ptr.VOCAB, verbose=False)
+    got = ptr.get_msa_prior(str(a2m), wfile, 2, 50, 60, block_bytes=13 * width * 25 * 8)
+    assert np.array_equal(got, want)
+    assert np.array_equal(ptr.get_msa_prior(str(a2m), wfile, 2, 50, 60), want)
