@@ -12,24 +12,27 @@ typedef __bf16 b8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-// erf-GELU (modules.py:17-24, nn.GELU) without calling erff: 17 VALU ops instead of ~38 per value, which matters
-// because the FC1 epilogue runs while the matrix pipe idles (18 % of FC1 at K = 1280, 30 % at K = 768).
-//   gelu(x) = max(x,0) - 0.5|x| erfc(|x|/sqrt2),   erfc(z) ~= t Q(t) exp(-z^2),  t = 1/(1 + p z)
-// (Abramowitz-Stegun 7.1.26 form, Q of degree 5 re-fitted by minimax to the product 0.5|x| erfc: fit error 3.7e-9).
-// The erfc form has no 1 + erf cancellation for x < 0: against fp64 the fp32 evaluation is within 2.4e-7 abs
-// (torch's fp32 gelu: 1.2e-6), mean 1.9e-8 (torch: 4.6e-8) -- scripts/fit_gelu.py.
-__device__ __forceinline__ float gelu_erf16(float x) {
-    const float ax = fabsf(x);
-    const float z = fminf(ax * 0.70710678118654752440f, 13.0f);
-    const float t = __builtin_amdgcn_rcpf(fmaf(3.973660903e-01f, z, 1.0f));
-    float q = -2.134610164e-01f;
-    q = fmaf(q, t, 7.781763039e-01f);
-    q = fmaf(q, t, -4.744764895e-01f);
-    q = fmaf(q, t, 5.422912625e-01f);
-    q = fmaf(q, t, 1.330677808e-01f);
-    q = fmaf(q, t, 2.344017484e-01f);
-    const float e = __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);
-    return fmaf(-0.5f * ax, t * q * e, fmaxf(x, 0.0f));
+// erf-GELU (modules.py:17-24, nn.GELU) in 10 VALU instructions per value, ONE of them quarter-rate.  The FC1 epilogue runs while
+// the matrix pipe idles and its cost is VALU issue: two waves per SIMD x 128 values per lane; erff costs ~38 instructions, the round-2
+// form (Abramowitz-Stegun t = 1 / (1 + p z), Q(t) exp(-z^2): 17 instructions, an rcp AND an exp) ~78 issue cycles per value, this ~38.
+//   gelu(x) = max(x, 0) - a Phi(-a),  a = min(|x|, 6),  Phi(-a) = 2^P(a)
+// P of degree 6, fitted by reweighted least squares to the ABSOLUTE error of a 2^P(a) on [0, 6] (5.1e-8; beyond 6 the term is below
+// 6e-9 and held there); written in b = -a so that the last step is one fma.  No 1 + erf cancellation for x < 0.  Against fp64 the fp32
+// evaluation is within 2.8e-7 abs on [-10, 10] (torch's fp32 gelu: 1.2e-6), mean 3.0e-8 (torch: 6.1e-8) -- scripts/fit_gelu.py.
+// Four values at a time so that the seven fmas are PACKED instructions (v_pk_fma_f32: two values per issue slot; from scalar code
+// hipcc prefers v_fmaak_f32 with a literal, one value per slot).
+__device__ __forceinline__ f32x4 gelu_erf16(f32x4 x) {
+    auto all = [](float v) { return f32x4{v, v, v, v}; };
+    const f32x4 b = __builtin_elementwise_max(-__builtin_elementwise_abs(x), all(-6.0f));
+    f32x4 q = all(3.309269596e-05f);
+    q = __builtin_elementwise_fma(q, b, all(7.692188374e-04f));
+    q = __builtin_elementwise_fma(q, b, all(8.080714382e-03f));
+    q = __builtin_elementwise_fma(q, b, all(5.341210216e-02f));
+    q = __builtin_elementwise_fma(q, b, all(-4.587709904e-01f));
+    q = __builtin_elementwise_fma(q, b, all(1.151201725e+00f));
+    q = __builtin_elementwise_fma(q, b, all(-9.999930859e-01f));
+    const f32x4 e = {__builtin_amdgcn_exp2f(q[0]), __builtin_amdgcn_exp2f(q[1]), __builtin_amdgcn_exp2f(q[2]), __builtin_amdgcn_exp2f(q[3])};
+    return __builtin_elementwise_fma(b, e, __builtin_elementwise_max(x, all(0.0f)));
 }
 
 // Attention operands straight from the fused QKV projection (OUT 2): q|k as split planes qk16 [2][M][2D] (ESM2 rotary
@@ -493,12 +496,11 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
                         const f32x4 a = *reinterpret_cast<const f32x4*>(patch + row * 128 + ((cc ^ (row & 7)) << 4));
                         f32x4 val;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float t = fmaf(a[e], out_scale, bv[j][e]);
-                            if (EPI == EPI_GELU) t = gelu_erf16(t);
-                            if (EPI == EPI_SQRELU) { t = fmaxf(t, 0.0f); t = t * t; }     // tranception/activations.py:79-84
-                            val[e] = t;
-                        }
+                        for (int e = 0; e < 4; ++e) val[e] = fmaf(a[e], out_scale, bv[j][e]);
+                        if (EPI == EPI_GELU) val = gelu_erf16(val);
+                        if (EPI == EPI_SQRELU)   // tranception/activations.py:79-84
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const float t = fmaxf(val[e], 0.0f); val[e] = t * t; }
                         if (residual) {
                             const f32x4 rr = __builtin_bit_cast(f32x4, rv[i & 1][j][k]);
 #pragma unroll
@@ -548,12 +550,11 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
                         const f32x4 bv = bvs[j][g];
                         f32x4 val;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float t = fmaf(acc[j][i][4 * g + e], out_scale, bv[e]);
-                            if (EPI == EPI_GELU) t = gelu_erf16(t);
-                            if (EPI == EPI_SQRELU) { t = fmaxf(t, 0.0f); t = t * t; }     // tranception/activations.py:79-84
-                            val[e] = t;
-                        }
+                        for (int e = 0; e < 4; ++e) val[e] = fmaf(acc[j][i][4 * g + e], out_scale, bv[e]);
+                        if (EPI == EPI_GELU) val = gelu_erf16(val);
+                        if (EPI == EPI_SQRELU)   // tranception/activations.py:79-84
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const float t = fmaxf(val[e], 0.0f); val[e] = t * t; }
                         {
                             h4 hi, lo;
 #pragma unroll

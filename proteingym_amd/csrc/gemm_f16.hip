@@ -157,12 +157,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(
                 const f32x4 bv = bias ? *reinterpret_cast<const f32x4*>(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
                 f32x4 val;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float t = acc[j][i][4 * g + e] + bv[e];
-                    if (EPI == EPI_GELU) t = gelu_erf16(t);
-                    if (EPI == EPI_SQRELU) { t = fmaxf(t, 0.0f); t = t * t; }
-                    val[e] = t;
-                }
+                for (int e = 0; e < 4; ++e) val[e] = acc[j][i][4 * g + e] + bv[e];
+                if (EPI == EPI_GELU) val = gelu_erf16(val);
+                if (EPI == EPI_SQRELU)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { const float t = fmaxf(val[e], 0.0f); val[e] = t * t; }
                 const size_t o = (size_t)m * N + n;
                 if (residual) {
                     const f32x4 rv = *reinterpret_cast<const f32x4*>(residual + o);
