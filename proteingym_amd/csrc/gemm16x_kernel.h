@@ -12,7 +12,7 @@ typedef __bf16 b8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
-// erf-GELU (modules.py:17-24, nn.GELU) in 10 VALU instructions per value, ONE of them quarter-rate.  The FC1 epilogue runs while
+// erf-GELU (modules.py:17-24, nn.GELU) in 10 VALU issue slots per 2 values + one quarter-rate exp2 per value.  The FC1 epilogue runs while
 // the matrix pipe idles and its cost is VALU issue: two waves per SIMD x 128 values per lane; erff costs ~38 instructions, the round-2
 // form (Abramowitz-Stegun t = 1 / (1 + p z), Q(t) exp(-z^2): 17 instructions, an rcp AND an exp) ~78 issue cycles per value, this ~38.
 //   gelu(x) = max(x, 0) - a Phi(-a),  a = min(|x|, 6),  Phi(-a) = 2^P(a)
@@ -24,7 +24,9 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x4 gelu_erf16(f32x4 x) {
     auto all = [](float v) { return f32x4{v, v, v, v}; };
     const f32x4 b = __builtin_elementwise_max(-__builtin_elementwise_abs(x), all(-6.0f));
-    f32x4 q = all(3.309269596e-05f);
+    // x * 0 in the first step: a NaN or an infinity in x must come out as NaN (max / min return their OTHER operand for a NaN, so b and
+    // max(x, 0) alone would turn NaN into -6e-9: the LM head's GELU would swallow the non-finite values the fp16 range guard looks for)
+    f32x4 q = __builtin_elementwise_fma(x, all(0.0f), all(3.309269596e-05f));
     q = __builtin_elementwise_fma(q, b, all(7.692188374e-04f));
     q = __builtin_elementwise_fma(q, b, all(8.080714382e-03f));
     q = __builtin_elementwise_fma(q, b, all(5.341210216e-02f));

@@ -155,6 +155,30 @@ def test_gemm_f16x3_half_tail_bit_identical(lib, monkeypatch, M, N, K, epi, res)
     assert np.array_equal(out["1"], out["0"])
 
 
+@pytest.mark.parametrize("planes", [0, 256])
+def test_gemm_f16x3_gelu_epilogue_keeps_non_finite_values(lib, planes):
+    """The fp16 range guard (PGMI_EOVERFLOW) looks for non-finite log-probabilities at the END of the network, and the LM head has a
+    GELU in front of them: a NaN or an infinity that enters the GELU epilogue has to come out non-finite (a form built from max / min,
+    which return their other operand for a NaN, would hand on a finite number), for the fp32 and the split-plane output alike; the
+    finite rows next to it are untouched."""
+    M, N, K = 300, 1280, 128
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((M, K)).astype(np.float32)
+    W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
+    bias = rng.standard_normal(N).astype(np.float32)
+    clean = np.zeros((M, N), np.float32)
+    _lib.check(lib.pgmi_op_gemm(0, _lib.PREC_F16X3, _p(A), _p(W), _p(bias), None, M, N, K, 1 + planes, _p(clean)))
+    assert np.isfinite(clean).all()
+    bad_bias = bias.copy()
+    bad_bias[[5, 600, 1279]] = [np.nan, np.inf, -np.inf]
+    out = np.zeros((M, N), np.float32)
+    _lib.check(lib.pgmi_op_gemm(0, _lib.PREC_F16X3, _p(A), _p(W), _p(bad_bias), None, M, N, K, 1 + planes, _p(out)))
+    assert not np.isfinite(out[:, [5, 600, 1279]]).any()
+    keep = np.ones(N, bool)
+    keep[[5, 600, 1279]] = False
+    assert np.array_equal(out[:, keep], clean[:, keep])
+
+
 @pytest.mark.parametrize("M,N,K,epi", [(2300, 1280, 128, 1),        # 45 tiles: every one of them as two half-height items
                                         (15100, 1280, 256, 2),       # 300 tiles on 256 CUs: 256 full + 44 x 2 halves; squared ReLU
                                         (4300, 5120, 128, 1),        # 340 tiles: 256 + 84 x 2; the FC1 kind (GELU)
