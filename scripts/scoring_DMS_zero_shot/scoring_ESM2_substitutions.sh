@@ -1,8 +1,5 @@
 #!/bin/bash
 # MI355X drop-in for ProteinGym's scripts/scoring_DMS_zero_shot/scoring_ESM2_substitutions.sh (same zero_shot_config.sh, same variables, same CSVs).
 source "$(dirname "${BASH_SOURCE[0]}")/_pgmi_env.sh"
-: "${model_checkpoint:=/path/to/esm2_t33_650M_UR50D.pt}" "${esm2_size:=650M}" "${dms_output_folder:=${DMS_output_score_folder_subs}/ESM2/${esm2_size}}"
-: "${scoring_strategy:=masked-marginals}" "${DMS_index:=0}"
-pgmi_run proteingym_amd.compute_fitness --model-location ${model_checkpoint} --dms_index "${DMS_index}" \
-    --dms_mapping "${DMS_reference_file_path_subs}" --dms-input "${DMS_data_folder_subs}" --dms-output "${dms_output_folder}" \
-    --scoring-strategy "${scoring_strategy}" --model_type ESM2
+: "${model_checkpoint:=/path/to/esm2_t33_650M_UR50D.pt}" "${dms_output_folder:=${DMS_output_score_folder_subs}/ESM2/${esm2_size:-650M}}"
+pgmi_esm ESM2
