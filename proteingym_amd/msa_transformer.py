@@ -12,12 +12,11 @@ through the C ABI (``pgmi_msa_token_logprobs`` / ``pgmi_msa_masked_logprobs``); 
 """
 from __future__ import annotations
 
-import argparse
 import ctypes as C
 import itertools
 import os
 import random
-from typing import List, Sequence, Tuple
+from typing import List, Tuple
 
 import numpy as np
 

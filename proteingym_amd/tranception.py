@@ -17,7 +17,7 @@ import ctypes as C
 import json
 import os
 import re
-from typing import Dict, Optional, Sequence
+from typing import Optional, Sequence
 
 import numpy as np
 import pandas as pd

@@ -13,7 +13,6 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import PgmiError
 
 
 def symbol_table(alphabet: str, default: str) -> np.ndarray:

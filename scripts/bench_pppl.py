@@ -14,7 +14,6 @@ import os
 import sys
 import time
 
-import numpy as np
 
 sys.path.insert(0, os.getcwd())
 from proteingym_amd import dist as pdist, esm as pesm, synthetic  # noqa: E402

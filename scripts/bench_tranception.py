@@ -8,7 +8,6 @@ import os
 import sys
 import time
 
-import numpy as np
 import pandas as pd
 
 sys.path.insert(0, os.getcwd())

@@ -1,6 +1,5 @@
 """Within-process interleaved A/B of GEMM variants (perf deltas come from interleaved rounds in ONE process on ONE set of
 operands).   python scripts/gemm_ab.py ROUNDS v1 v2 ...   -> per shape median TFLOP/s per variant + layer-sum"""
-import ctypes as C
 import os
 import sys
 

@@ -1,6 +1,5 @@
 """What the FC1-class epilogue costs: the same GEMM (M x 5120 x 1280, and the FC2 shape for reference) with each output kind.
     python scripts/gemm_epilogue_cost.py"""
-import ctypes as C
 import os
 import sys
 

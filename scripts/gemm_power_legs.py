@@ -3,7 +3,6 @@ back to back for a few seconds while `rocm-smi --showpower --showclocks` is samp
 
     python scripts/gemm_power_legs.py SHAPE v1 v2 ...      SHAPE: qkv | out | fc1 | fc2   (BLAT shape, ESM-1v 650M layer)
 """
-import ctypes as C
 import os
 import re
 import subprocess
