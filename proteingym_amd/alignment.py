@@ -39,14 +39,19 @@ def read_records(path: str, upper: bool = False) -> Tuple[str, Dict[str, str]]:
     return first, {n: "".join(c) for n, c in chunks.items()}
 
 
-def to_matrix(sequences: List[str]) -> np.ndarray:
-    """uint8 [n, width] of equal-length ASCII sequences."""
+def to_matrix(sequences: List[str], columns: np.ndarray = None) -> np.ndarray:
+    """uint8 [n, width] of equal-length ASCII sequences; with ``columns`` (bool [width]) only those columns, picked row by row so that
+    the full-width matrix of a large alignment (10^5 - 10^6 sequences x thousands of raw columns) never exists."""
     if not sequences:
         return np.zeros((0, 0), dtype=np.uint8)
     width = len(sequences[0])
     if any(len(s) != width for s in sequences):
         raise ValueError("alignment rows differ in length")
-    return np.frombuffer("".join(sequences).encode("ascii"), dtype=np.uint8).reshape(len(sequences), width).copy()
+    out = np.empty((len(sequences), width if columns is None else int(columns.sum())), dtype=np.uint8)
+    for i, s in enumerate(sequences):
+        row = np.frombuffer(s.encode("ascii"), dtype=np.uint8)
+        out[i] = row if columns is None else row[columns]
+    return out
 
 
 def to_strings(matrix: np.ndarray) -> List[str]:
@@ -60,11 +65,17 @@ def _is_lower(m):
 
 
 def _upper(m):
-    return np.where(_is_lower(m), m - 32, m).astype(np.uint8)
+    """Upper case, in place for an array this module owns."""
+    m[_is_lower(m)] -= 32
+    return m
 
 
-def _lower(m):
-    return np.where((m >= ord("A")) & (m <= ord("Z")), m + 32, m).astype(np.uint8)
+def _lower_where(m, columns):
+    """Lower case in the columns flagged (bool [width]), in place."""
+    sub = m[:, columns]
+    sub[(sub >= ord("A")) & (sub <= ord("Z"))] += 32
+    m[:, columns] = sub
+    return m
 
 
 class FocusAlignment:
@@ -82,21 +93,23 @@ class FocusAlignment:
         if self.focus_name is None:
             raise ValueError(f"{path}: the first line is not a '>' header")
         names = list(records)
-        m = to_matrix([records[n] for n in names])
+        rows = [records[n] for n in names]
         if preprocess:
-            m = _upper(m)
+            focus = _upper(np.frombuffer(records[self.focus_name].encode("ascii"), dtype=np.uint8).copy())
+            m = _upper(to_matrix(rows, columns=(focus != _GAP) & (focus != _DOT)))
             m[m == _DOT] = _GAP
-            m = m[:, m[names.index(self.focus_name)] != _GAP]
             gaps = m == _GAP
             seq_ok = gaps.mean(axis=1) <= max_seq_gaps
             col_ok = gaps[seq_ok].mean(axis=0) <= max_col_gaps
-            m = np.where(col_ok[None, :], m, _lower(m))[seq_ok]
+            m = _lower_where(m[seq_ok], ~col_ok)
             names = [n for n, ok in zip(names, seq_ok) if ok]
+        else:
+            m = to_matrix(rows)
         self.raw = dict(zip(names, to_strings(m)))
         self.focus_seq = self.raw[self.focus_name]
         f = m[names.index(self.focus_name)]
         self.focus_cols = np.flatnonzero(~_is_lower(f) & (f != _GAP))
-        t = _upper(m[:, self.focus_cols])
+        t = _upper(m[:, self.focus_cols])                     # fancy indexing: a copy
         t[t == _DOT] = _GAP
         if drop_indeterminate:
             known = np.zeros(256, dtype=bool)
