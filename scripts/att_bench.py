@@ -1,8 +1,8 @@
 """Attention-kernel timing: ms per launch and algorithmic TFLOP/s of the attention class at several (sequences, tokens) shapes of the
-ESM-1v 650M layer; configurations (values of the environment variable PGMI_ATT_VARIANT, read per launch by the library when it was
-built with tuning variants) are interleaved round by round inside one process.
+ESM-1v 650M layer (median over rounds, measured by the library's own per-class HIP events).  Two builds of the kernel are compared with
+scripts/lib_ab.sh, not from here.
 
-    python scripts/att_bench.py [--rounds 5] [--configs 0,1]
+    python scripts/att_bench.py [--rounds 5]
 """
 import argparse
 import json
@@ -19,12 +19,10 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--layers", type=int, default=4)
-    ap.add_argument("--configs", default="0")
     ap.add_argument("--shapes", default="286x286,90x1100,150x150,600x120")      # positions x residues
     a = ap.parse_args()
     cfg = dict(synthetic.ESM1V_650M, layers=a.layers)
     model = pesm.EsmModel(cfg, synthetic.random_weights(cfg, seed=1), device=0)
-    confs = a.configs.split(",")
     out = {}
     for shp in a.shapes.split(","):
         P, L = (int(v) for v in shp.split("x"))
@@ -36,23 +34,17 @@ def main():
             muts = muts * (P // L + 1)
         assay = pesm.Assay(model, seq, muts)
         assay.run_device_only()
-        res = {c: [] for c in confs}
+        res = []
         for _ in range(a.rounds):
-            for c in confs:
-                os.environ["PGMI_ATT_VARIANT"] = c
-                model.profile_reset()
-                model.profile_enable(True)
-                assay.run_device_only()
-                model.profile_enable(False)
-                pr = model.profile()["attention"]
-                res[c].append((pr["ms"] / pr["launches"], pr["flops"] / (pr["ms"] * 1e-3) / 1e12))
-        ref = None
-        for c in confs:
-            ms = float(np.median([r[0] for r in res[c]]))
-            tf = float(np.median([r[1] for r in res[c]]))
-            ref = ref or ms
-            out[f"{shp} variant={c}"] = {"ms_per_launch": round(ms, 4), "tflops": round(tf, 1), "vs_first": round(ref / ms, 3)}
-            print(f"{shp:>10s} T={assay.T:4d} seqs={len(assay.positions):4d}  variant={c}: {ms:.4f} ms/launch  {tf:6.1f} TFLOP/s  x{ref / ms:.3f}", flush=True)
+            model.profile_reset()
+            model.profile_enable(True)
+            assay.run_device_only()
+            model.profile_enable(False)
+            pr = model.profile()["attention"]
+            res.append((pr["ms"] / pr["launches"], pr["flops"] / (pr["ms"] * 1e-3) / 1e12))
+        ms, tf = float(np.median([r[0] for r in res])), float(np.median([r[1] for r in res]))
+        out[shp] = {"T": assay.T, "sequences": len(assay.positions), "ms_per_launch": round(ms, 4), "tflops": round(tf, 1)}
+        print(f"{shp:>10s} T={assay.T:4d} seqs={len(assay.positions):4d}: {ms:.4f} ms/launch  {tf:6.1f} TFLOP/s", flush=True)
         assay.close()
     print(json.dumps(out))
     model.close()
