@@ -117,14 +117,13 @@ class MSA_processing:
     """EVE-style alignment pre-processing and sequence weights (tranception/utils/msa_utils.py:194-368): the reference's constructor
     arguments, and the attributes its callers read.  The pre-processing itself is ``alignment.FocusAlignment`` (numpy over the byte
     matrix).  Weights are loaded from ``weights_location`` when the file exists, otherwise computed (1 / number of sequences within
-    Hamming distance theta over the focus columns: HIP kernel with ``device``, blocked numpy without) and saved there, as the
-    reference does."""
+    Hamming distance theta over the focus columns, by the HIP pair-count kernel on ``device``) and saved there, as the reference does."""
 
     def __init__(self, MSA_location="", theta=0.2, use_weights=True, weights_location="./data/weights",
                  preprocess_MSA=True, threshold_sequence_frac_gaps=0.5, threshold_focus_cols_frac_gaps=1.0,
-                 remove_sequences_with_indeterminate_AA_in_focus_cols=True, device=None):
+                 remove_sequences_with_indeterminate_AA_in_focus_cols=True, device=0):
         np.random.seed(2021)
-        self.device = device                 # additive: HIP device for the O(N^2 L) weight computation
+        self.device = device                 # additive: HIP device of the O(N^2 L) weight computation
         self.MSA_location = MSA_location
         self.weights_location = weights_location
         self.theta = theta
@@ -164,28 +163,13 @@ class MSA_processing:
         self.seq_name_to_weight = {n: self.weights[i] for i, n in enumerate(al.names)}
 
 
-def compute_sequence_weights(enc: np.ndarray, theta: float, block: int = 256, device=None) -> np.ndarray:
-    """msa_utils.py:341-352: weight_i = 1 / #{j : <x_j, x_i> / <x_i, x_i> > 1 - theta} on one-hot
-    encodings, i.e. matches over the non-gap positions of i (0 for an all-gap sequence).  With
-    ``device`` the pair count runs in the HIP kernel (``pgmi_msa_cluster_counts``); without, on the
-    host in numpy like the reference's own CPU loop."""
-    if device is not None:
-        from . import weights as _w
-        counts = _w.num_cluster_members(enc, 1 - theta, -1, device=device)
-        return np.where(counts > 0, 1.0 / np.maximum(counts, 1), 0.0)
-    n = enc.shape[0]
-    w = np.zeros(n)
-    valid = enc >= 0
-    nonempty = valid.sum(1)
-    for i0 in range(0, n, block):
-        a = enc[i0:i0 + block]
-        match = ((a[:, None, :] == enc[None, :, :]) & valid[i0:i0 + block, None, :]).sum(-1)     # [b, n]
-        ne = nonempty[i0:i0 + block]
-        with np.errstate(divide="ignore", invalid="ignore"):
-            frac = match / ne[:, None]
-        cnt = (frac > 1 - theta).sum(1)
-        w[i0:i0 + block] = np.where(ne > 0, 1.0 / np.maximum(cnt, 1), 0.0)
-    return w
+def compute_sequence_weights(enc: np.ndarray, theta: float, device: int = 0) -> np.ndarray:
+    """msa_utils.py:341-352: weight_i = 1 / #{j : <x_j, x_i> / <x_i, x_i> > 1 - theta} on one-hot encodings, i.e. matches over the
+    non-gap positions of i (0 for an all-gap sequence).  The O(N^2 L) pair count is the HIP kernel ``pgmi_msa_cluster_counts``
+    (csrc/msa_weights.hip); there is no host version in this package (``PgmiError`` without the library or a GPU)."""
+    from . import weights as _w
+    counts = _w.num_cluster_members(enc, 1 - theta, -1, device=device)
+    return np.where(counts > 0, 1.0 / np.maximum(counts, 1), 0.0)
 
 
 def get_msa_prior(MSA_data_file, MSA_weight_file_name, MSA_start, MSA_end, len_target_seq, vocab=VOCAB,

@@ -86,3 +86,8 @@ def test_msa_processing_on_device_matches_reference_weights(lib, golden_dir, tmp
     mp = ptr.MSA_processing(MSA_location=os.path.join(golden_dir, "TOY_MSA_GAPPY.a2m"), use_weights=True,
                             weights_location=str(tmp_path / "w.npy"), device=0)
     assert np.array_equal(mp.weights, g["weights"])
+    assert list(mp.seq_name_to_weight.keys()) == list(g["names"]) and abs(mp.Neff - float(g["Neff"])) < 1e-12
+    assert np.array_equal(np.load(str(tmp_path / "w.npy")), g["weights"])          # computed once, saved where the reference saves it
+    again = ptr.MSA_processing(MSA_location=os.path.join(golden_dir, "TOY_MSA_GAPPY.a2m"), use_weights=True,
+                               weights_location=str(tmp_path / "w.npy"))             # default device; the file is loaded
+    assert np.array_equal(again.weights, g["weights"])
