@@ -892,3 +892,28 @@ def test_msa_prior_in_blocks_equals_live_reference_bitwise(tmp_path, weighted):
     got = ptr.get_msa_prior(str(a2m), wfile, 2, 50, 60, block_bytes=13 * width * 25 * 8)
     assert np.array_equal(got, want)
     assert np.array_equal(ptr.get_msa_prior(str(a2m), wfile, 2, 50, 60), want)
+
+
+@pytest.mark.skipif(not rh.reference_available(), reason="/root/reference not present (GPU box)")
+def test_alignment_reader_oddities_vs_live_reference(tmp_path):
+    """alignment.read_records against the reference's two readers (msa_utils.py:28-43 ``process_msa_data``; the loop at the top of
+    ``MSA_processing.gen_alignment``) on what real a2m files occasionally hold: a sequence over several lines, a repeated header, blank
+    lines, trailing blanks, lower case and '.', a header without a sequence."""
+    from proteingym_amd import tranception as ptr, alignment
+    rh.load_reference_tranception()
+    from tranception.utils import msa_utils
+    text = (">FOCUS/1-8\nACDE\nFGHI  \n\n>two\nac.eF-HI\n>empty\n>three\nACDEFGHI\n>two\nKLMNPQRS\n>four \nA-DE\n\nFG-I\n")
+    p = tmp_path / "odd.a2m"
+    p.write_text(text)
+    want = msa_utils.process_msa_data(str(p))
+    got = ptr.process_msa_data(str(p))
+    assert list(got.items()) == list(want.items())
+    first, raw = alignment.read_records(str(p))
+    ref = msa_utils.MSA_processing.__new__(msa_utils.MSA_processing)           # only the reading loop is wanted: drive gen_alignment's own state
+    ref.MSA_location, ref.alphabet, ref.preprocess_MSA, ref.use_weights = str(p), "ACDEFGHIKLMNPQRSTVWY", False, False
+    ref.remove_sequences_with_indeterminate_AA_in_focus_cols, ref.weights_location, ref.theta = False, None, 0.2
+    ref.gen_alignment()                                                          # no pre-processing: the records as read
+    assert first == ref.focus_seq_name
+    assert list(raw.items()) == list(ref.raw_seq_name_to_sequence.items())
+    with pytest.raises(ValueError, match="differ in length"):                  # '>two' was extended by its second record: ragged
+        alignment.FocusAlignment(str(p), preprocess=False)
