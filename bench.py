@@ -75,6 +75,44 @@ def ffn_traffic(precision, M, D, F):
     return fc1["fetch_bytes"] + fc1["write_bytes"], detail
 
 
+def box_state(step, seconds=2.0):
+    """Shader clock and socket power WHILE the hot path runs (untimed extra steps in a thread, `rocm-smi` sampled beside them):
+    boxes of this pool differ by +-3 % under the 1 400 W cap, and the line should say which kind of box it was measured on.
+    Never raises: {"unavailable": reason} instead."""
+    import re
+    import subprocess
+    import threading
+    try:
+        stop = threading.Event()
+
+        def spin():
+            while not stop.is_set():
+                step()
+        th = threading.Thread(target=spin, daemon=True)
+        th.start()
+        clocks, watts = [], []
+        t_end = time.perf_counter() + seconds
+        try:
+            while time.perf_counter() < t_end:
+                txt = subprocess.run(["rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=10).stdout
+                c = re.search(r"sclk clock level:?\s*\d*:?\s*\(?(\d+)\s*Mhz", txt, re.I)
+                w = re.search(r"Power \(W\):\s*([\d.]+)", txt)
+                if c:
+                    clocks.append(int(c.group(1)))
+                if w:
+                    watts.append(float(w.group(1)))
+        finally:
+            stop.set()
+            th.join()
+        if not clocks and not watts:
+            return {"unavailable": "rocm-smi printed neither a shader clock nor a socket power"}
+        return {"sclk_mhz": round(sum(clocks) / len(clocks)) if clocks else None,
+                "socket_power_w": round(sum(watts) / len(watts)) if watts else None, "samples": max(len(clocks), len(watts)),
+                "what": "rocm-smi --showpower --showclocks sampled during untimed extra steps of the same assay, after the timed region"}
+    except Exception as e:                                             # noqa: BLE001 -- monitoring must never take the line down
+        return {"unavailable": repr(e)}
+
+
 def usable_cores() -> int:
     """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota
     (the GPU box shows 256 logical CPUs but grants a 16-CPU quota; oversubscribing it with 256
@@ -343,6 +381,7 @@ def main():
                     help="score with N checkpoints per step and average (ESM-1v ensemble rate; the headline is 1)")
     ap.add_argument("--variant", type=int, default=None, help="debug: PGMI_GEMM_VARIANT tile configuration")
     ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` object (other configs; ~1 min after the headline)")
+    ap.add_argument("--no-box-state", action="store_true", help="skip the `box` object (shader clock / socket power during ~2 s of untimed extra steps)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -479,6 +518,7 @@ def main():
         return
 
     prof = model.profile()
+    box = box_state(step) if not args.no_box_state else None          # after the timed region and the profile read-out
     if rank == 0:
         ffn_ms = prof["gemm_fc1"]["ms"] + prof["gemm_fc2"]["ms"]
         ffn_fl = prof["gemm_fc1"]["flops"] + prof["gemm_fc2"]["flops"]
@@ -523,6 +563,8 @@ def main():
                          "whole_step_tflops": total_fl / dt / 1e12},
             "kernels": kern,
         }
+        if box is not None:
+            out["box"] = box
         if world == 1 and args.cpu_seconds > 0:
             _, gpu_table = assay.run(want_table=True)                 # outside the timed region
             for m2, a2, _ in extra:

@@ -13,7 +13,7 @@ if [ "$1" != "quick" ]; then
 fi
 timeout 900 python bench.py > $O/bench_f16x3.json 2> $O/bench_f16x3.err; echo "bench rc $?"
 timeout 400 python bench.py --gpus 1 --steps 20 --warmup 5 --no-secondary > $O/bench_driver_command_headline.json 2> $O/bench_driver.err
-timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_f16x3 -o p -- python bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-secondary > $O/prof_f16x3.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_f16x3 -o p -- python bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-secondary --no-box-state > $O/prof_f16x3.log 2>&1
 if [ "$1" != "quick" ]; then
   bash scripts/pmc_profile.sh r4 > $O/pmc.log 2>&1; cp gpurun_out/pmc_r4/summary.txt $O/pmc_summary.txt; cp gpurun_out/pmc_r4/pmc_traffic.json $O/pmc_traffic.json
 fi

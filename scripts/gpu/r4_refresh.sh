@@ -10,7 +10,7 @@ timeout 120 python -m pytest tests/test_gpu_outliers.py tests/test_gpu_ops.py -q
 bash scripts/pmc_profile.sh r4 > $O/pmc.log 2>&1; cp gpurun_out/pmc_r4/summary.txt $O/pmc_summary.txt; cp gpurun_out/pmc_r4/pmc_traffic.json $O/pmc_traffic.json
 cp gpurun_out/pmc_r4/pmc_traffic.json profiles/r4/pmc_traffic.json
 timeout 200 python bench.py --gpus 1 --steps 20 --warmup 5 --no-secondary > $O/bench_driver_command_headline.json 2> $O/bench_driver.err
-timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_f16x3 -o p -- python bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-secondary > $O/prof_f16x3.log 2>&1
+timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_f16x3 -o p -- python bench.py --steps 2 --warmup 1 --cpu-seconds 0 --no-secondary --no-box-state > $O/prof_f16x3.log 2>&1
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete; find $O -name "*.db" -delete
 timeout 100 python scripts/bench_msa_transformer.py > $O/bench_msa_transformer.json 2> $O/bench_msa.err
 timeout 400 python bench.py > $O/bench_f16x3.json 2> $O/bench_f16x3.err

@@ -4,7 +4,7 @@
 #   scripts/pmc_profile.sh <tag> [bench args...]
 set -u
 TAG=${1:-r1}; shift || true
-ARGS=${@:-"--steps 1 --warmup 0 --cpu-seconds 0 --layers 4"}
+ARGS=${@:-"--steps 1 --warmup 0 --cpu-seconds 0 --layers 4 --no-box-state"}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 # every dispatch of a kernel at the full row count: the per-dispatch means below must not mix in the kept-rows launches of the last layer
 export PGMI_KEEP_ROWS=0
