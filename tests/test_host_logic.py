@@ -423,3 +423,22 @@ def test_product_path_never_touches_the_oracle():
     tree, hits = oracle_imports(os.path.join(root, "__graft_entry__.py"))
     spans = {f.name: (f.lineno, f.end_lineno) for f in ast.walk(tree) if isinstance(f, ast.FunctionDef)}
     assert all(any(lo <= h <= hi for lo, hi in (spans["build"], spans["smoke"])) for h in hits), hits
+
+
+def test_bench_box_state_never_raises(monkeypatch):
+    """bench.box_state reports the shader clock / socket power beside the line; without a GPU (or rocm-smi) it must say
+    'unavailable' -- and a step that fails must not take the bench line down either."""
+    import importlib.util
+    import time
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(__file__), "..", "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    calls = [0]
+
+    def step():
+        calls[0] += 1
+        time.sleep(0.005)
+    out = bench.box_state(step, seconds=0.3)
+    assert calls[0] > 0 and ("unavailable" in out or {"sclk_mhz", "socket_power_w", "samples"} <= set(out))
+    monkeypatch.setenv("PATH", "/nonexistent")                       # no rocm-smi at all
+    assert "unavailable" in bench.box_state(step, seconds=0.1)
