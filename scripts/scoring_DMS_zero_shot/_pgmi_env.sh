@@ -36,11 +36,10 @@ pgmi_esm() {
         --dms_index "${DMS_index:=0}" --dms-input "${DMS_data_folder_subs}" --dms_mapping "${DMS_reference_file_path_subs}" \
         --scoring-strategy "${scoring_strategy:=masked-marginals}" "$@"
 }
-# pgmi_tranception subs|indels [more flags]: assay ${DMS_index} of that benchmark through score_tranception_proteingym with ${checkpoint}
+# pgmi_tranception <mapping csv> <data folder> [more flags]: assay ${DMS_index} through score_tranception_proteingym with ${checkpoint}
 pgmi_tranception() {
-    local which="$1"; shift
-    local mapping="DMS_reference_file_path_${which}" folder="DMS_data_folder_${which}"
+    local mapping="$1" folder="$2"; shift 2
     pgmi_run proteingym_amd.score_tranception_proteingym --checkpoint "${checkpoint:=/path/to/Tranception_Large}" --DMS_index "${DMS_index:=0}" \
-        --DMS_data_folder "${!folder}" --DMS_reference_file_path "${!mapping}" --output_scores_folder "${output_scores_folder}" "$@"
+        --DMS_data_folder "${folder}" --DMS_reference_file_path "${mapping}" --output_scores_folder "${output_scores_folder}" "$@"
 }
 ESM1V_FIVE="${model_checkpoint1:-/path/to/esm1v_t33_650M_UR90S_1.pt} ${model_checkpoint2:-/path/to/esm1v_t33_650M_UR90S_2.pt} ${model_checkpoint3:-/path/to/esm1v_t33_650M_UR90S_3.pt} ${model_checkpoint4:-/path/to/esm1v_t33_650M_UR90S_4.pt} ${model_checkpoint5:-/path/to/esm1v_t33_650M_UR90S_5.pt}"

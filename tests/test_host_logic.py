@@ -391,6 +391,39 @@ def test_drop_in_launchers_read_the_zero_shot_config_and_build_a_valid_command_l
         assert a.DMS_reference_file_path.endswith("DMS_indels.csv" if "indels" in script else "DMS_substitutions.csv")
 
 
+@pytest.mark.parametrize("script", ["scoring_Tranception.sh", "scoring_ESM1b_substitutions.sh"])
+def test_clinical_launchers_build_a_valid_command_line(script, tmp_path):
+    """scripts/scoring_clinical_zero_shot/*.sh read the clinical_* variables of zero_shot_config.sh."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg_dir = tmp_path / "scripts"
+    (cfg_dir / "scoring_clinical_zero_shot").mkdir(parents=True)
+    (cfg_dir / "zero_shot_config.sh").write_text(
+        'export clinical_reference_file_path_subs=/data/pg/reference_files/clinical_substitutions.csv\n'
+        'export clinical_data_folder_subs=/data/pg/clinical_ProteinGym_substitutions\n'
+        'export clinical_MSA_data_folder_subs=/data/pg/clinical_msa_files\n'
+        'export clinical_MSA_weights_folder_subs=/data/pg/clinical_msa_weights\n'
+        'export clinical_output_score_folder_subs=/data/pg/zero_shot_clinical_substitutions_scores\n')
+    env = dict(os.environ, ZERO_SHOT_CONFIG=str(cfg_dir / "zero_shot_config.sh"), PGMI_LAUNCH_ECHO="1", DMS_index="11")
+    out = subprocess.run(["bash", os.path.join(root, "scripts", "scoring_clinical_zero_shot", script)], env=env, capture_output=True, text=True,
+                         cwd=str(tmp_path))
+    assert out.returncode == 0, out.stderr
+    module, *argv = out.stdout.strip().split("\n")
+    if script == "scoring_Tranception.sh":
+        from proteingym_amd import score_tranception_proteingym as tcli
+        assert module == "proteingym_amd.score_tranception_proteingym"
+        a = tcli.create_parser().parse_args(argv)
+        assert a.DMS_index == 11 and a.inference_time_retrieval and not a.indel_mode
+        assert a.DMS_reference_file_path.endswith("clinical_substitutions.csv") and a.MSA_folder == "/data/pg/clinical_msa_files"
+        assert a.MSA_weights_folder == "/data/pg/clinical_msa_weights" and a.output_scores_folder.endswith("Tranception/Tranception_L")
+    else:
+        from proteingym_amd import run_benchmark as rb
+        assert module == "proteingym_amd.run_benchmark"
+        a = rb.create_parser().parse_args(argv)
+        assert a.scoring_strategy == "wt-marginals" and a.scoring_window == "overlapping"
+        assert str(a.dms_mapping).endswith("clinical_substitutions.csv")
+
+
 def test_product_path_never_touches_the_oracle():
     """oracle/ is test infrastructure: no module of the product package names it, bench.py only inside its cpu_baseline leg,
     __graft_entry__ only in build() (compiling the checker) and smoke() (checking against it)."""
