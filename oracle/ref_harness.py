@@ -180,6 +180,27 @@ REF_TRANCEPTION = os.path.join(REF_ROOT, "proteingym", "baselines", "tranception
 _tr = None
 
 
+def torch_cuda_available() -> bool:
+    import torch
+    return torch.cuda.is_available()
+
+
+class _ClustalOmegaCommandline:
+    """Biopython is not installed here.  The reference only builds ``ClustalOmegaCommandline(cmd=<executable>, profile1=..., profile2=...,
+    outfile=..., force=True)`` and calls it (msa_utils.py:167-172); Biopython turns that into
+    ``<executable> --profile1 A --profile2 B -o OUT --force`` and returns (stdout, stderr).  Same here."""
+
+    def __init__(self, cmd="clustalo", **options):
+        self.cmd, self.options = cmd, options
+
+    def __call__(self):
+        import subprocess
+        o = self.options
+        argv = [self.cmd, "--profile1", o["profile1"], "--profile2", o["profile2"], "-o", o["outfile"]] + (["--force"] if o.get("force") else [])
+        done = subprocess.run(argv, capture_output=True, text=True, check=True)
+        return done.stdout, done.stderr
+
+
 def load_reference_tranception():
     """Returns (tranception package, tokenizer) from the unmodified reference."""
     global _tr
@@ -206,7 +227,12 @@ def load_reference_tranception():
         sys.modules["transformers.utils.model_parallel_utils"] = mp
     for n in ["Bio", "Bio.Align", "Bio.Align.Applications"]:
         sys.modules.setdefault(n, types.ModuleType(n))
-    sys.modules["Bio.Align.Applications"].ClustalOmegaCommandline = object
+    sys.modules["Bio.Align.Applications"].ClustalOmegaCommandline = _ClustalOmegaCommandline
+    if not torch_cuda_available():
+        # msa_utils.update_retrieved_MSA_log_prior_indel builds its zero row with .cuda() (msa_utils.py:183): on a machine without a GPU
+        # that call is the identity here, so the reference's own walk runs instead of falling into its bare except
+        import torch
+        torch.Tensor.cuda = lambda self, *a, **k: self
     if not getattr(mu.PreTrainedModel, "_pgmi_patched", False):
         _orig_iw = mu.PreTrainedModel.init_weights
 

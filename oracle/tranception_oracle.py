@@ -325,11 +325,79 @@ def get_sequence_slices(df, target_seq, model_context_len, start_idx=1, scoring_
     return pd.concat([df, wt], axis=0).drop_duplicates()
 
 
-def sequence_scores(cfg, W, sliced, window_start, window_end, reverse=False, retrieval=None, batch=20):
+def clustal_aligner(MSA_filename, clustal_omega_location, work_dir, tag="oracle", num_sequences_kept=100000):
+    """The file protocol around the aligner (msa_utils.py:148-173): once per alignment, its (at most 100 000: the first + a
+    ``random.sample`` of the rest) sequences are written upper case with '.' as '-', 80 characters per line, the first one renamed
+    >REFERENCE_SEQUENCE; per scored sequence a one-record file >SEQ_TO_SCORE; the executable is called as Biopython's
+    ClustalOmegaCommandline calls it (``--profile1 A --profile2 B -o OUT --force``); the rows >SEQ_TO_SCORE and >REFERENCE_SEQUENCE of
+    its output (read upper case) come back.  Returns ``aligner(sequence) -> (aligned sequence, aligned reference)``."""
+    import random
+    import subprocess
+    os.makedirs(work_dir, exist_ok=True)
+    base = os.path.basename(MSA_filename)
+    sampled = os.path.join(work_dir, f"Sampled_{tag}_{base}")
+    if not os.path.exists(sampled):
+        msa = process_msa_data(MSA_filename)
+        names = list(msa)
+        if len(names) > num_sequences_kept:
+            names = [names[0]] + random.sample(names[1:], k=num_sequences_kept - 1)
+        with open(sampled, "w") as f:
+            for i, n in enumerate(names):
+                sq = msa[n].upper().replace(".", "-")
+                f.write((">REFERENCE_SEQUENCE" if i == 0 else n) + "\n" + "\n".join(sq[k:k + 80] for k in range(0, len(sq), 80)) + "\n")
+    to_align = os.path.join(work_dir, f"Seq_to_align_{tag}_{base}")
+    expanded = os.path.join(work_dir, f"Expanded_{tag}_{base}")
+
+    def aligner(sequence):
+        with open(to_align, "w") as f:
+            f.write("\n".join([">SEQ_TO_SCORE"] + [sequence[k:k + 80] for k in range(0, len(sequence), 80)]) + "\n")
+        subprocess.run([clustal_omega_location, "--profile1", sampled, "--profile2", to_align, "-o", expanded, "--force"], check=True,
+                       capture_output=True)
+        rows = process_msa_data(expanded)
+        return rows[">SEQ_TO_SCORE"], rows[">REFERENCE_SEQUENCE"]
+    return aligner
+
+
+def update_prior_indel(log_prior, MSA_start, MSA_end, aligned_seq, aligned_ref):
+    """msa_utils.py:174-191: the walk over the two aligned rows (the sequence to score, the alignment's reference sequence) that edits the
+    log-prior [rows, V] of the family alignment for ONE sequence.  Column by column: both gaps -> nothing; a gap in the sequence -> that
+    prior row is dropped; a gap in the reference (an inserted residue) -> a ZERO row is inserted, at the index of the ALIGNMENT COLUMN (the
+    reference indexes the prior with the column counter, so columns skipped as 'both gaps' shift every later insertion); then
+    MSA_end = MSA_start + rows.  When the mask and the prior disagree in length the reference's bare ``except`` prints and returns the prior
+    as edited so far with the OLD MSA_end; so does this."""
+    prior = log_prior
+    try:
+        keep = []
+        for col in range(len(aligned_seq)):
+            a, b = aligned_seq[col], aligned_ref[col]
+            if a == "-" and b == "-":
+                continue
+            if a == "-":
+                keep.append(False)
+            elif b == "-":
+                prior = torch.cat((prior[:col], torch.zeros(1, prior.shape[1], dtype=prior.dtype), prior[col:]), dim=0)
+                keep.append(True)
+            else:
+                keep.append(True)
+        prior = prior[torch.tensor(keep, dtype=torch.bool)]
+        MSA_end = MSA_start + len(prior)
+    except Exception:
+        pass
+    return prior, MSA_start, MSA_end
+
+
+def sequence_scores(cfg, W, sliced, window_start, window_end, reverse=False, retrieval=None, batch=20, mutated=None):
     """Sum over positions of log p(token t+1 | tokens <= t) for each sliced sequence
     (scoring_utils.py:97-128), with the MSA-prior fusion of model_pytorch.py:806-830 when
-    ``retrieval`` = dict(log_prior [L,25], MSA_start, MSA_end, weight) is given."""
+    ``retrieval`` = dict(log_prior [L,25], MSA_start, MSA_end, weight) is given.  With ``retrieval["aligner"]`` (indel scoring with
+    retrieval, model_pytorch.py:794-799, 832-839; one sequence per forward): ``aligner(full mutated sequence)`` returns the two aligned rows
+    (sequence, reference), the prior is edited for that sequence (``update_prior_indel``), and positions whose prior row sums to exactly 0
+    -- the inserted residues -- and the last position keep the network's own log-probabilities; a prior slice that does not span the
+    scored window is an IndexError, as in the reference."""
     out = []
+    indel = retrieval is not None and retrieval.get("aligner") is not None
+    if indel:
+        batch = 1
     with torch.no_grad():
         for b0 in range(0, len(sliced), batch):
             seqs = list(sliced[b0:b0 + batch])
@@ -339,18 +407,26 @@ def sequence_scores(cfg, W, sliced, window_start, window_end, reverse=False, ret
             if retrieval is not None:
                 fused = lp.clone()
                 a = retrieval["weight"]
+                log_prior, m_start, m_end = retrieval["log_prior"], retrieval["MSA_start"], retrieval["MSA_end"]
+                if indel:
+                    row_seq, row_ref = retrieval["aligner"](mutated[b0])
+                    log_prior, m_start, m_end = update_prior_indel(torch.as_tensor(log_prior, dtype=lp.dtype), m_start, m_end, row_seq, row_ref)
+                pr = None
                 for s in range(len(seqs)):
                     st, en = int(window_start[b0 + s]), int(window_end[b0 + s])
-                    lo, hi = max(st, retrieval["MSA_start"]), min(en, retrieval["MSA_end"])
+                    lo, hi = max(st, m_start), min(en, m_end)
                     if hi <= lo:
                         continue
-                    pr = torch.as_tensor(retrieval["log_prior"][lo:hi], dtype=lp.dtype)
+                    pr = torch.as_tensor(log_prior[lo:hi], dtype=lp.dtype)
                     if reverse:
                         pr = torch.flip(pr, dims=(0,))
-                        a0 = max(0, en - retrieval["MSA_end"])
+                        a0 = max(0, en - m_end)
                     else:
-                        a0 = max(0, retrieval["MSA_start"] - st)
+                        a0 = max(0, m_start - st)
                     fused[s, a0:a0 + (hi - lo)] = (1 - a) * lp[s, a0:a0 + (hi - lo)] + a * pr
+                if indel:
+                    inserted = torch.tensor([bool(pr[i].sum() == 0) for i in range(len(pr))] + [True])
+                    fused[:, inserted, :] = lp[:, inserted, :]          # IndexError when the slice (+1) and the positions differ in length
                 lp = fused
             tgt = torch.as_tensor(ids[:, 1:])
             ll = torch.gather(lp, 2, tgt.unsqueeze(-1)).squeeze(-1)
@@ -377,7 +453,7 @@ def score_mutants(cfg, W, df, target_seq, scoring_mirror=True, retrieval=None, s
         s = sl.copy()
         seqs = s["sliced_mutated_sequence"].apply(lambda x: x[::-1]) if rev else s["sliced_mutated_sequence"]
         s["score"] = sequence_scores(cfg, W, list(seqs), list(s["window_start"]), list(s["window_end"]), reverse=rev,
-                                     retrieval=retrieval)
+                                     retrieval=retrieval, mutated=list(s["mutated_sequence"]))
         if scoring_window == "sliding":
             s = s[["mutated_sequence", "score"]].groupby("mutated_sequence").sum().reset_index()
         s["score"] = s["score"] / s["mutated_sequence"].map(len)

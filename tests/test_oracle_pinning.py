@@ -917,3 +917,96 @@ def test_alignment_reader_oddities_vs_live_reference(tmp_path):
     assert list(raw.items()) == list(ref.raw_seq_name_to_sequence.items())
     with pytest.raises(ValueError, match="differ in length"):                  # '>two' was extended by its second record: ragged
         alignment.FocusAlignment(str(p), preprocess=False)
+
+
+# ---- Tranception: indel scoring WITH retrieval (the aligner is the user's executable; here a deterministic stand-in) ------------------
+STAND_IN_ALIGNER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stand_in_clustalo.py")
+
+
+def _indel_retrieval(to, golden_dir, a2m, ms, me, L, work):
+    prior = to.get_msa_prior(os.path.join(golden_dir, a2m), ms, me, L)
+    with np.errstate(divide="ignore"):
+        log_prior = torch.log(torch.tensor(prior).float()).numpy()
+    return dict(log_prior=log_prior, MSA_start=ms, MSA_end=me, weight=0.6,
+                aligner=to.clustal_aligner(os.path.join(golden_dir, a2m), STAND_IN_ALIGNER, str(work)))
+
+
+def test_tranception_oracle_indels_with_retrieval_reproduces_golden(golden_dir, tmp_path):
+    """tests/golden/make_golden_tranception_indel_retrieval.py ran the unmodified reference (model_pytorch.py:794-840,
+    msa_utils.py:141-192) with the stand-in aligner: the oracle's restatement -- aligner file protocol, the walk that edits the prior, the
+    zero-row fusion rule, both directions, wild-type delta -- gives the same three columns, gets the same aligned rows from the stand-in,
+    and fails the way the reference fails on an alignment that does not cover the scored window."""
+    from oracle import tranception_oracle as to
+    g = np.load(os.path.join(golden_dir, "golden_tranception_indel_retrieval.npz"))
+    seq = str(g["seq"])
+    cfg, W = to.load_checkpoint(os.path.join(golden_dir, "Tranception_toy"))
+    df = pd.read_csv(os.path.join(golden_dir, "TOY_TRANCEPTION_INDEL_RETRIEVAL_DMS.csv"))
+    retr = _indel_retrieval(to, golden_dir, "TOY_MSA_INDEL_FULL.a2m", 0, len(seq), len(seq), tmp_path / "full")
+    for k, s in enumerate(df["mutated_sequence"]):
+        assert list(retr["aligner"](s)) == [str(v) for v in g[f"aligned/{k}"]], k
+    r = to.score_mutants(cfg, W, df[["mutant", "mutated_sequence"]], seq, retrieval=retr, indel_mode=True)
+    key = r["mutated_sequence"].fillna(r["mutant"]) if "mutant" in r else r["mutated_sequence"]
+    m = pd.merge(df[["mutated_sequence"]], r.assign(key=key), left_on="mutated_sequence", right_on="key", how="left")
+    for c in ("avg_score_L_to_R", "avg_score_R_to_L", "avg_score"):
+        assert np.abs(m[c].to_numpy(dtype=np.float64) - g[f"full/{c}"]).max() < 2e-5, c
+    assert float(m["avg_score"][0]) == 0.0                                       # the wild type is in the library: its zero row
+    assert str(g["partial_alignment"]).startswith("IndexError")
+    part = _indel_retrieval(to, golden_dir, "TOY_MSA.a2m", 10, 60, len(seq), tmp_path / "part")
+    with pytest.raises(IndexError):
+        to.score_mutants(cfg, W, df[["mutant", "mutated_sequence"]].iloc[:3], seq, retrieval=part, indel_mode=True)
+
+
+def test_update_prior_indel_walk():
+    """The walk of msa_utils.py:174-191 on hand-made rows: a deleted residue drops its row, an inserted one gets a zero row, 'both gaps'
+    columns are skipped but still advance the insertion index (the reference's own indexing), MSA_end follows the row count; a mask
+    that does not fit leaves the prior as edited so far and MSA_end untouched (the reference's bare except)."""
+    from oracle import tranception_oracle as to
+    V = 5
+    prior = torch.arange(1, 7, dtype=torch.float32).view(6, 1).repeat(1, V)            # rows 1..6
+    out, ms, me = to.update_prior_indel(prior, 0, 6, "AB-DEFX", "ABCDEF-")              # C deleted (col 2), X inserted after F (col 6)
+    assert (ms, me) == (0, 6) and out[:, 0].tolist() == [1, 2, 4, 5, 6, 0]
+    out, ms, me = to.update_prior_indel(prior, 0, 6, "A-BXCDEF", "A-B-CDEF")            # col 1 both gaps: skipped; X at col 3 -> zero row at index 3
+    assert out[:, 0].tolist() == [1, 2, 3, 0, 4, 5, 6] and me == 7
+    out, ms, me = to.update_prior_indel(prior, 0, 6, "ABC", "ABC")                      # 3 mask entries for 6 rows: IndexError inside, swallowed
+    assert out[:, 0].tolist() == [1, 2, 3, 4, 5, 6] and me == 6
+
+
+@pytest.mark.skipif(not rh.reference_available(), reason="/root/reference not present (GPU box)")
+def test_update_prior_indel_vs_live_reference(tmp_path):
+    """The same walk through the reference's own function (msa_utils.update_retrieved_MSA_log_prior_indel driven with a stand-in model object
+    and the stand-in aligner) on random indels of a random family, incl. an alignment whose reference row has gaps."""
+    from oracle import tranception_oracle as to
+    rh.load_reference_tranception()
+    from tranception.utils import msa_utils
+    import types
+    rng = np.random.default_rng(8)
+    aa = list("ACDEFGHIKLMNPQRSTVWY")
+    for case in range(3):
+        L = 40
+        ref = "".join(rng.choice(aa, size=L))
+        rows = [ref if case < 2 else ref[:10] + "--" + ref[12:]]                          # case 2: gaps in the reference row itself
+        for _ in range(6):
+            s = list(ref)
+            for p_ in rng.choice(L, size=6, replace=False):
+                s[p_] = rng.choice(aa + ["-"])
+            rows.append("".join(s))
+        folder = tmp_path / f"fam{case}"
+        folder.mkdir()
+        a2m = folder / "fam.a2m"
+        a2m.write_text("".join(f">s{i}/1-{L}\n{r}\n" for i, r in enumerate(rows)))
+        model = types.SimpleNamespace(MSA_folder=str(folder), MSA_filename=str(a2m),
+                                      config=types.SimpleNamespace(clustal_omega_location=STAND_IN_ALIGNER))
+        prior = torch.log(torch.rand(L, 25, generator=torch.Generator().manual_seed(case)))
+        aligner = to.clustal_aligner(str(a2m), STAND_IN_ALIGNER, str(tmp_path / f"work{case}"))
+        for trial in range(6):
+            s = list(ref.replace("-", ""))
+            for _ in range(int(rng.integers(1, 4))):
+                p_ = int(rng.integers(1, len(s) - 1))
+                if rng.random() < 0.5:
+                    del s[p_]
+                else:
+                    s.insert(p_, rng.choice(aa))
+            s = "".join(s)
+            want, ws, we = msa_utils.update_retrieved_MSA_log_prior_indel(model, prior.clone(), 0, L, s, "hash")
+            got, gs, ge = to.update_prior_indel(prior.clone(), 0, L, *aligner(s))
+            assert (gs, ge) == (ws, we) and got.shape == want.shape and torch.equal(got, want), (case, trial)
