@@ -114,6 +114,8 @@ def shared_retrieval(ptr, retrieval_args, cache_dir, tag, wait_s=1800.0):
     import numpy as np
     if not retrieval_args:
         return None
+    if retrieval_args.get("retrieval_aggregation_mode") == "aggregate_indel":
+        return ptr.build_retrieval(retrieval_args)        # carries a per-rank aligner (files of its own under <alignment folder>/Sampled)
     os.makedirs(cache_dir, exist_ok=True)
     path, lock = os.path.join(cache_dir, tag + ".npy"), os.path.join(cache_dir, tag + ".lock")
 

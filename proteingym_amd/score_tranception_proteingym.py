@@ -43,7 +43,7 @@ _FLAGS = [
     ("--retrieval_inference_weight", dict(type=float, default=0.6, help="alpha: weight of the alignment prior in the fusion")),
     ("--MSA_folder", dict(type=str, default=".", help="folder holding the alignments")),
     ("--MSA_weights_folder", dict(type=str, default=None, help="folder holding the sequence-weight files")),
-    ("--clustal_omega_location", dict(type=str, default=None, help="only used by indel scoring with retrieval (not built here)")),
+    ("--clustal_omega_location", dict(type=str, default=None, help="Clustal Omega executable: indel scoring with retrieval re-aligns every sequence with it")),
     ("--device", dict(type=int, default=int(os.environ.get("LOCAL_RANK", "0")), help="[additive] GPU index")),
 ]
 
@@ -88,10 +88,13 @@ def retrieval_arguments(args, wild_type, msa):
     --inference_time_retrieval)."""
     if msa is None:
         return None
-    if args.indel_mode:
-        raise NotImplementedError("indel scoring with retrieval needs Clustal Omega re-alignment (not built)")
-    return dict(MSA_filename=msa[0], MSA_weight_file_name=msa[1], MSA_start=msa[2], MSA_end=msa[3],
-                full_protein_length=len(wild_type), retrieval_inference_weight=args.retrieval_inference_weight)
+    out = dict(MSA_filename=msa[0], MSA_weight_file_name=msa[1], MSA_start=msa[2], MSA_end=msa[3],
+               full_protein_length=len(wild_type), retrieval_inference_weight=args.retrieval_inference_weight)
+    if args.indel_mode:                                   # score_tranception_proteingym.py:87-99: every sequence is re-aligned with Clustal Omega
+        if not args.clustal_omega_location:
+            raise ValueError("--indel_mode with --inference_time_retrieval needs --clustal_omega_location <Clustal Omega executable>")
+        out.update(retrieval_aggregation_mode="aggregate_indel", clustal_omega_location=args.clustal_omega_location)
+    return out
 
 
 def main(args=None):

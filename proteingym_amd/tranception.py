@@ -231,6 +231,69 @@ def get_msa_prior(MSA_data_file, MSA_weight_file_name, MSA_start, MSA_end, len_t
     return prior
 
 
+# ---- indel scoring with retrieval: one re-alignment per scored sequence (msa_utils.py:141-192) ------
+class SequenceAligner:
+    """Aligns one sequence to the family alignment with the user's Clustal Omega executable, the way the reference drives it: the
+    alignment's sequences (the first one renamed >REFERENCE_SEQUENCE; at most 100 000 of them, the rest sampled once with python's
+    ``random``) upper case with '.' as '-' in ``<alignment folder>/Sampled/Sampled_<id>_<name>``, the sequence as >SEQ_TO_SCORE in a file
+    next to it, ``<executable> --profile1 <sampled> --profile2 <sequence> -o <expanded> --force`` (Biopython's ClustalOmegaCommandline
+    line), and the rows >SEQ_TO_SCORE / >REFERENCE_SEQUENCE of the output read back upper case.  One subprocess per sequence, as in the
+    reference: this path is bound by the aligner, not by the GPU."""
+
+    def __init__(self, MSA_filename: str, clustal_omega_location: str, max_sequences: int = 100000):
+        import uuid
+        if not clustal_omega_location:
+            raise ValueError("indel scoring with retrieval re-aligns every sequence: --clustal_omega_location <executable> is required")
+        self.executable = clustal_omega_location
+        folder = os.path.join(os.path.dirname(MSA_filename) or ".", "Sampled")
+        os.makedirs(folder, exist_ok=True)
+        name, tag = os.path.basename(MSA_filename), str(uuid.uuid4())
+        self.sampled, self.query, self.expanded = (os.path.join(folder, f"{kind}_{tag}_{name}") for kind in ("Sampled", "Seq_to_align", "Expanded"))
+        records = process_msa_data(MSA_filename)
+        names = list(records)
+        if len(names) > max_sequences:
+            import random
+            names = names[:1] + random.sample(names[1:], k=max_sequences - 1)
+        with open(self.sampled, "w") as f:
+            for k, n in enumerate(names):
+                f.write((">REFERENCE_SEQUENCE" if k == 0 else n) + "\n" + _wrap(records[n].replace(".", "-"), 80) + "\n")
+
+    def __call__(self, sequence: str):
+        import subprocess
+        with open(self.query, "w") as f:
+            f.write(">SEQ_TO_SCORE\n" + _wrap(sequence, 80) + "\n")
+        done = subprocess.run([self.executable, "--profile1", self.sampled, "--profile2", self.query, "-o", self.expanded, "--force"],
+                              capture_output=True, text=True)
+        if done.returncode != 0:
+            raise RuntimeError(f"{self.executable} failed ({done.returncode}): {done.stderr.strip()[-500:]}")
+        rows = process_msa_data(self.expanded)
+        return rows[">SEQ_TO_SCORE"], rows[">REFERENCE_SEQUENCE"]
+
+
+def _wrap(text: str, width: int) -> str:
+    return "\n".join(text[k:k + width] for k in range(0, len(text), width))
+
+
+def realigned_prior_rows(n_rows: int, aligned_seq: str, aligned_ref: str):
+    """Which row of the family log-prior stands at each position of ONE re-aligned sequence (msa_utils.py:174-191): an int array of prior
+    row indices with -1 for an inserted residue (the reference puts an all-zero row there), or None where the reference's own bookkeeping
+    breaks.  The reference walks the alignment columns: both rows gaps -> skipped; a gap in the sequence -> that prior row goes; a gap in
+    the reference row -> a zero row is put in AT THE COLUMN'S INDEX in the prior as edited so far (so every 'both gaps' column before it
+    shifts it: kept as is); at the end the keep / drop marks must be exactly as many as the rows, else the reference logs an error, keeps
+    the half-edited prior and fails in the forward -- None here, and the caller raises."""
+    a = np.frombuffer(aligned_seq.encode("ascii"), dtype=np.uint8) == ord("-")
+    b = np.frombuffer(aligned_ref.encode("ascii"), dtype=np.uint8) == ord("-")
+    if a.shape != b.shape:
+        return None
+    rows = list(range(n_rows))
+    for col in np.flatnonzero(b & ~a):                   # inserted residues, left to right (list.insert clamps like the reference's slices)
+        rows.insert(int(col), -1)
+    marks = ~a[~(a & b)]                                  # one mark per column that is not 'both gaps': keep unless the sequence has a gap
+    if marks.size != len(rows):
+        return None
+    return np.asarray(rows, dtype=np.int64)[marks]
+
+
 # ---- checkpoint ------------------------------------------------------------------------------------
 def expected_keys(n_layer):
     keys = ["transformer.wte.weight"]
@@ -340,12 +403,16 @@ class TranceptionModel:
         _lib.check(_lib.load().pgmi_tr_token_logprobs(self._h, _lib.ptr(t, _lib._i32p), B, T, _lib.ptr(out, _lib._f32p)))
         return out
 
-    def sequence_loglik(self, sliced_sequences, window_start=None, window_end=None, reverse=False) -> np.ndarray:
+    def sequence_loglik(self, sliced_sequences, window_start=None, window_end=None, reverse=False, mutated_sequences=None) -> np.ndarray:
         """sum_t log p(token_{t+1} | tokens_{<=t}) per sliced sequence (scoring_utils.py:97-128), fused
-        with the retrieval prior (model_pytorch.py:806-830) when the model was built with one."""
+        with the retrieval prior (model_pytorch.py:806-830) when the model was built with one.  ``mutated_sequences`` (the full
+        sequences the slices were cut from) are what indel scoring with retrieval re-aligns (model_pytorch.py:794-799)."""
         lib = _lib.load()
         seqs = list(sliced_sequences)
         n = len(seqs)
+        if self.retrieval is not None and self.retrieval.get("aligner") is not None:
+            return np.array([self._realigned_loglik(seqs[i], int(window_start[i]), int(window_end[i]), reverse, mutated_sequences[i])
+                             for i in range(n)], dtype=np.float32)
         out = np.empty(n, dtype=np.float32)
         order = np.argsort([len(s) for s in seqs], kind="stable")
         r = self.retrieval
@@ -384,13 +451,55 @@ class TranceptionModel:
             start = end
         return out
 
+    def _realigned_loglik(self, sliced, start, end, reverse, mutated_sequence) -> float:
+        """Indel scoring with retrieval, one sequence (model_pytorch.py:794-839): the family log-prior is re-indexed through the
+        sequence's own alignment (a row dropped per deleted residue, none for an inserted one), fused over the scored window, and the
+        positions of inserted residues keep the network's log-probabilities.  The device reduction fuses ONE contiguous run of
+        positions per sequence, and the log-likelihood is a sum over positions, so the sequence goes through it once per run of
+        positions that have a prior row plus once without any prior:  sum_runs S(run) - (runs - 1) S(no prior)."""
+        r = self.retrieval
+        rows = realigned_prior_rows(r["log_prior"].shape[0], *r["aligner"](mutated_sequence))
+        if rows is None:
+            raise IndexError("indel scoring with retrieval: the alignment's reference sequence does not span the protein the log-prior "
+                             "was built for (the reference fails on the same input, model_pytorch.py:836)")
+        m_start, m_end = r["MSA_start"], r["MSA_start"] + len(rows)
+        lo, hi = max(start, m_start), min(end, m_end)
+        if hi <= lo:
+            raise IndexError(f"indel scoring with retrieval: no overlap between the scored window [{start}, {end}) and the alignment")
+        window = rows[lo:hi][::-1] if reverse else rows[lo:hi]           # prior row per fused position, in scoring order
+        if len(window) + 1 != len(sliced) + 1:                           # the reference's mask (+ the end token) against the scored positions
+            raise IndexError(f"indel scoring with retrieval: the prior covers {len(window)} of the window's {len(sliced)} residues "
+                             "(the reference raises here: model_pytorch.py:836)")
+        first = max(0, end - m_end) if reverse else max(0, m_start - start)
+        has_prior = window >= 0
+        edges = np.flatnonzero(np.diff(np.concatenate([[False], has_prior, [False]]).astype(np.int8)))
+        runs = list(zip(edges[0::2], edges[1::2]))                       # [i0, i1) runs of positions with a prior row
+        prior = np.zeros((len(window) + 1, r["log_prior"].shape[1]), dtype=np.float32)
+        prior[:len(window)][has_prior] = r["log_prior"][window[has_prior]]   # this sequence's prior, already in scoring order: never flipped below
+        ids, lens = self.encode_batch([sliced])                          # encoded ONCE: X / B / J / Z are replaced at random
+        ids, lens = np.repeat(ids, len(runs) + 1, axis=0), np.repeat(lens, len(runs) + 1)
+        B, T = ids.shape
+        a0 = np.array([first + i0 for i0, _ in runs] + [0], dtype=np.int32)
+        row0 = np.array([i0 for i0, _ in runs] + [0], dtype=np.int32)
+        count = np.array([i1 - i0 for i0, i1 in runs] + [0], dtype=np.int32)
+        flip = np.zeros(B, dtype=np.int32)
+        res = np.empty(B, dtype=np.float32)
+        lp = _lib.as_f32(prior)
+        _lib.check(_lib.load().pgmi_tr_sequence_loglik(self._h, _lib.ptr(ids, _lib._i32p), _lib.ptr(lens, _lib._i32p), B, T,
+                                                       _lib.ptr(lp, _lib._f32p), lp.shape[0], _lib.ptr(a0, _lib._i32p), _lib.ptr(row0, _lib._i32p),
+                                                       _lib.ptr(count, _lib._i32p), _lib.ptr(flip, _lib._i32p), float(r["weight"]),
+                                                       _lib.ptr(res, _lib._f32p)))
+        plain = float(res[-1])
+        return float(np.sum(res[:-1], dtype=np.float64) - (len(runs) - 1) * plain) if runs else plain
+
     # -- scoring (scoring_utils.py:77-150) ----------------------------------------------------------------
     def _scores(self, slices, column, target_seq, reverse=False):
         """Per-sequence score of one reading direction (scoring_utils.py:129-150): window log-likelihoods from the
         device, summed per sequence in 'sliding' mode, divided by the FULL sequence length, then (with a target)
         the wild type's value for the same window start (optimal) / the single wild-type total (sliding) subtracted."""
+        realign = dict(mutated_sequences=list(slices['mutated_sequence'])) if (self.retrieval or {}).get("aligner") else {}
         loglik = self.sequence_loglik(slices['sliced_mutated_sequence'], slices['window_start'].to_numpy(),
-                                      slices['window_end'].to_numpy(), reverse=reverse)
+                                      slices['window_end'].to_numpy(), reverse=reverse, **realign)
         per = pd.DataFrame({'mutated_sequence': list(slices['mutated_sequence']),
                             'sliced_mutated_sequence': list(slices['sliced_mutated_sequence']),
                             'window_start': list(slices['window_start']), 'window_end': list(slices['window_end']),
@@ -470,8 +579,12 @@ def build_retrieval(retrieval: Optional[dict]) -> Optional[dict]:
         return None
     prior = get_msa_prior(retrieval["MSA_filename"], retrieval.get("MSA_weight_file_name"), retrieval["MSA_start"],
                           retrieval["MSA_end"], retrieval["full_protein_length"],
+                          retrieval_aggregation_mode=retrieval.get("retrieval_aggregation_mode", "aggregate_substitution"),
                           seq_name_to_weight=retrieval.get("seq_name_to_weight"))
     import torch
     log_prior = torch.log(torch.tensor(prior).float()).numpy()              # same rounding as the reference (:662-672)
-    return dict(log_prior=log_prior, MSA_start=int(retrieval["MSA_start"]), MSA_end=int(retrieval["MSA_end"]),
-                weight=float(retrieval.get("retrieval_inference_weight", 0.6)))
+    state = dict(log_prior=log_prior, MSA_start=int(retrieval["MSA_start"]), MSA_end=int(retrieval["MSA_end"]),
+                 weight=float(retrieval.get("retrieval_inference_weight", 0.6)))
+    if retrieval.get("retrieval_aggregation_mode") == "aggregate_indel":    # every scored sequence is re-aligned (model_pytorch.py:794-799)
+        state["aligner"] = SequenceAligner(retrieval["MSA_filename"], retrieval.get("clustal_omega_location"))
+    return state

@@ -220,3 +220,38 @@ def test_context_edges_around_1022_residues_vs_oracle(lib):
         print(f"Tranception, {L} residues: avg scores max|err| {worst:.2e}")
         assert worst < TOL
     model.close()
+
+
+def test_indels_with_retrieval_vs_reference(lib, golden_dir, tmp_path):
+    """Indel scoring WITH inference-time retrieval through the CLI (score_tranception_proteingym --indel_mode --inference_time_retrieval
+    --clustal_omega_location ...): every sequence re-aligned (here by tests/golden/stand_in_clustalo.py, the aligner the unmodified
+    reference was given when tests/golden/make_golden_tranception_indel_retrieval.py froze its columns), the prior re-indexed per
+    sequence, inserted residues left to the network; an alignment that does not span the protein fails like the reference (IndexError)."""
+    import shutil
+    import stat
+    from proteingym_amd import score_tranception_proteingym as cli
+    g = np.load(os.path.join(golden_dir, "golden_tranception_indel_retrieval.npz"))
+    seq = str(g["seq"])
+    aligner = tmp_path / "clustalo"                                     # an executable of our own: mode bits need not survive the trip to the box
+    aligner.write_text('#!/bin/sh\nexec python3 "%s" "$@"\n' % os.path.join(golden_dir, "stand_in_clustalo.py"))
+    aligner.chmod(aligner.stat().st_mode | stat.S_IXUSR)
+    msa = tmp_path / "msa"
+    msa.mkdir()
+    shutil.copy(os.path.join(golden_dir, "TOY_MSA_INDEL_FULL.a2m"), msa / "TOY_MSA_INDEL_FULL.a2m")
+    shutil.copy(os.path.join(golden_dir, "TOY_MSA.a2m"), msa / "TOY_MSA.a2m")
+    df = pd.read_csv(os.path.join(golden_dir, "TOY_TRANCEPTION_INDEL_RETRIEVAL_DMS.csv"))
+    common = ["--checkpoint", os.path.join(golden_dir, "Tranception_toy"), "--DMS_data_folder", golden_dir,
+              "--DMS_file_name", "TOY_TRANCEPTION_INDEL_RETRIEVAL_DMS.csv", "--target_seq", seq, "--indel_mode", "--inference_time_retrieval",
+              "--MSA_folder", str(msa), "--clustal_omega_location", str(aligner), "--batch_size_inference", "1"]
+    cli.main(cli.create_parser().parse_args(common + ["--MSA_filename", "TOY_MSA_INDEL_FULL.a2m", "--MSA_start", "1", "--MSA_end", str(len(seq)),
+                                                      "--output_scores_folder", str(tmp_path / "out")]))
+    r = pd.read_csv(tmp_path / "out" / "TOY_TRANCEPTION_INDEL_RETRIEVAL_DMS.csv", float_precision="round_trip")
+    key = r["mutated_sequence"].fillna(r["mutant"]) if "mutant" in r else r["mutated_sequence"]      # the wild type's zero row sits under 'mutant'
+    m = pd.merge(df[["mutated_sequence"]], r.assign(key=key), left_on="mutated_sequence", right_on="key", how="left")
+    for c in ("avg_score_L_to_R", "avg_score_R_to_L", "avg_score"):
+        err = np.abs(m[c].to_numpy(dtype=np.float64) - g[f"full/{c}"]).max()
+        print(f"indels with retrieval, {c}: max|err| {err:.2e}")
+        assert err < TOL, c
+    with pytest.raises(IndexError):
+        cli.main(cli.create_parser().parse_args(common + ["--MSA_filename", "TOY_MSA.a2m", "--MSA_start", "11", "--MSA_end", "60",
+                                                          "--output_scores_folder", str(tmp_path / "out2")]))

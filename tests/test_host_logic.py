@@ -340,7 +340,7 @@ def test_runner_groups_short_assays_and_keeps_every_csv(tmp_path):
 
 LAUNCHERS = ["scoring_ESM1v_substitutions.sh", "scoring_ESM1b_substitutions.sh", "scoring_ESM2_substitutions.sh",
              "scoring_MSA_transformer_substitutions.sh", "scoring_Tranception_substitutions.sh",
-             "scoring_Tranception_substitutions_no_retrieval.sh", "scoring_Tranception_indels_no_retrieval.sh"]
+             "scoring_Tranception_substitutions_no_retrieval.sh", "scoring_Tranception_indels_no_retrieval.sh", "scoring_Tranception_indels.sh"]
 
 
 @pytest.mark.parametrize("script", LAUNCHERS)
@@ -389,9 +389,10 @@ def test_drop_in_launchers_read_the_zero_shot_config_and_build_a_valid_command_l
         a = tcli.create_parser().parse_args(argv)
         assert a.DMS_index == 7 and bool(a.indel_mode) == ("indels" in script) and bool(a.inference_time_retrieval) == ("no_retrieval" not in script)
         assert a.DMS_reference_file_path.endswith("DMS_indels.csv" if "indels" in script else "DMS_substitutions.csv")
+        assert bool(a.clustal_omega_location) == (script == "scoring_Tranception_indels.sh")      # indels WITH retrieval: the aligner
 
 
-@pytest.mark.parametrize("script", ["scoring_Tranception.sh", "scoring_ESM1b_substitutions.sh"])
+@pytest.mark.parametrize("script", ["scoring_Tranception.sh", "scoring_Tranception_indels.sh", "scoring_ESM1b_substitutions.sh"])
 def test_clinical_launchers_build_a_valid_command_line(script, tmp_path):
     """scripts/scoring_clinical_zero_shot/*.sh read the clinical_* variables of zero_shot_config.sh."""
     import subprocess
@@ -403,19 +404,27 @@ def test_clinical_launchers_build_a_valid_command_line(script, tmp_path):
         'export clinical_data_folder_subs=/data/pg/clinical_ProteinGym_substitutions\n'
         'export clinical_MSA_data_folder_subs=/data/pg/clinical_msa_files\n'
         'export clinical_MSA_weights_folder_subs=/data/pg/clinical_msa_weights\n'
-        'export clinical_output_score_folder_subs=/data/pg/zero_shot_clinical_substitutions_scores\n')
+        'export clinical_output_score_folder_subs=/data/pg/zero_shot_clinical_substitutions_scores\n'
+        'export clinical_reference_file_path_indels=/data/pg/reference_files/clinical_indels.csv\n'
+        'export clinical_data_folder_indels=/data/pg/clinical_ProteinGym_indels\n'
+        'export clinical_MSA_data_folder_indels=/data/pg/clinical_msa_files_indels\n'
+        'export clinical_MSA_weights_folder_indels=/data/pg/clinical_msa_weights_indels\n'
+        'export clinical_output_score_folder_indels=/data/pg/zero_shot_clinical_indels_scores\n')
     env = dict(os.environ, ZERO_SHOT_CONFIG=str(cfg_dir / "zero_shot_config.sh"), PGMI_LAUNCH_ECHO="1", DMS_index="11")
     out = subprocess.run(["bash", os.path.join(root, "scripts", "scoring_clinical_zero_shot", script)], env=env, capture_output=True, text=True,
                          cwd=str(tmp_path))
     assert out.returncode == 0, out.stderr
     module, *argv = out.stdout.strip().split("\n")
-    if script == "scoring_Tranception.sh":
+    if script.startswith("scoring_Tranception"):
         from proteingym_amd import score_tranception_proteingym as tcli
         assert module == "proteingym_amd.score_tranception_proteingym"
         a = tcli.create_parser().parse_args(argv)
-        assert a.DMS_index == 11 and a.inference_time_retrieval and not a.indel_mode
-        assert a.DMS_reference_file_path.endswith("clinical_substitutions.csv") and a.MSA_folder == "/data/pg/clinical_msa_files"
-        assert a.MSA_weights_folder == "/data/pg/clinical_msa_weights" and a.output_scores_folder.endswith("Tranception/Tranception_L")
+        indels = "indels" in script
+        assert a.DMS_index == 11 and a.inference_time_retrieval and bool(a.indel_mode) == indels and bool(a.clustal_omega_location) == indels
+        assert a.DMS_reference_file_path.endswith("clinical_indels.csv" if indels else "clinical_substitutions.csv")
+        assert a.MSA_folder == ("/data/pg/clinical_msa_files_indels" if indels else "/data/pg/clinical_msa_files")
+        assert a.MSA_weights_folder == ("/data/pg/clinical_msa_weights_indels" if indels else "/data/pg/clinical_msa_weights")
+        assert a.output_scores_folder.endswith("Tranception/Tranception_L")
     else:
         from proteingym_amd import run_benchmark as rb
         assert module == "proteingym_amd.run_benchmark"

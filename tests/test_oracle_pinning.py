@@ -1010,3 +1010,74 @@ def test_update_prior_indel_vs_live_reference(tmp_path):
             want, ws, we = msa_utils.update_retrieved_MSA_log_prior_indel(model, prior.clone(), 0, L, s, "hash")
             got, gs, ge = to.update_prior_indel(prior.clone(), 0, L, *aligner(s))
             assert (gs, ge) == (ws, we) and got.shape == want.shape and torch.equal(got, want), (case, trial)
+
+
+class _OracleBackedDevice:
+    """``pgmi_tr_sequence_loglik`` with the ABI's semantics (include/pgmi.h: per sequence ONE contiguous run of logit rows
+    [a0, a0 + n) fused with log_prior rows row0 + i, or row0 + n - 1 - i when flipped) computed by the oracle's forward -- lets
+    the product's indel-with-retrieval host logic (re-indexed prior, runs of positions, sum over copies) execute on CPU."""
+
+    def __init__(self, cfg, W):
+        self.cfg, self.W = cfg, W
+        self.calls = []
+
+    def pgmi_tr_sequence_loglik(self, handle, tokens, lens, B, T, log_prior, P, a0, row0, count, flip, alpha, out):
+        from oracle import tranception_oracle as to
+        ids = np.ctypeslib.as_array(tokens, shape=(B, T)).astype(np.int64)
+        ln = np.ctypeslib.as_array(lens, shape=(B,))
+        res = np.ctypeslib.as_array(out, shape=(B,))
+        mask = (np.arange(T)[None, :] < ln[:, None]).astype(np.int64)
+        with torch.no_grad():
+            lp = torch.log_softmax(to.forward_logits(self.cfg, self.W, ids, mask)[:, :-1, :], dim=-1)
+        if log_prior:
+            prior = torch.as_tensor(np.ctypeslib.as_array(log_prior, shape=(P, lp.shape[-1])).copy())
+            A0, R0, N, F = (np.ctypeslib.as_array(p_, shape=(B,)) for p_ in (a0, row0, count, flip))
+            self.calls.append((B, N.tolist()))
+            for b in range(B):
+                if N[b] > 0:
+                    rows = prior[R0[b]:R0[b] + N[b]]
+                    rows = torch.flip(rows, dims=(0,)) if F[b] else rows
+                    lp[b, A0[b]:A0[b] + N[b]] = (1 - alpha) * lp[b, A0[b]:A0[b] + N[b]] + alpha * rows
+        ll = torch.gather(lp, 2, torch.as_tensor(ids[:, 1:]).unsqueeze(-1)).squeeze(-1)
+        res[:] = (ll * torch.as_tensor(mask[:, 1:]).to(ll.dtype)).sum(1).numpy()
+        return 0
+
+
+def test_tranception_product_indels_with_retrieval_host_logic_on_cpu(golden_dir, tmp_path, monkeypatch):
+    """The product's side of indel scoring with retrieval (tranception.SequenceAligner, realigned_prior_rows,
+    TranceptionModel._realigned_loglik, the CLI's retrieval arguments) against the unmodified reference's goldens, with the device
+    reduction served by the oracle through the ABI's own semantics.  An inserted residue splits the fused positions into runs: the
+    sequence then goes through the reduction once per run plus once without a prior."""
+    import shutil
+    from oracle import tranception_oracle as to
+    from proteingym_amd import tranception as ptr, _lib, score_tranception_proteingym as cli
+    g = np.load(os.path.join(golden_dir, "golden_tranception_indel_retrieval.npz"))
+    seq = str(g["seq"])
+    cfg, W = to.load_checkpoint(os.path.join(golden_dir, "Tranception_toy"))
+    df = pd.read_csv(os.path.join(golden_dir, "TOY_TRANCEPTION_INDEL_RETRIEVAL_DMS.csv"))
+    a2m = shutil.copy(os.path.join(golden_dir, "TOY_MSA_INDEL_FULL.a2m"), tmp_path / "TOY_MSA_INDEL_FULL.a2m")   # the aligner writes next to it
+    args = cli.create_parser().parse_args(["--checkpoint", "x", "--DMS_data_folder", "x", "--indel_mode", "--inference_time_retrieval",
+                                           "--clustal_omega_location", STAND_IN_ALIGNER])
+    retrieval = ptr.build_retrieval(cli.retrieval_arguments(args, seq, (str(a2m), None, 0, len(seq))))
+    assert isinstance(retrieval["aligner"], ptr.SequenceAligner)
+    for k, s in enumerate(df["mutated_sequence"]):
+        assert list(retrieval["aligner"](s)) == [str(v) for v in g[f"aligned/{k}"]], k
+    device = _OracleBackedDevice(cfg, W)
+    monkeypatch.setattr(_lib, "load", lambda: device)
+    model = object.__new__(ptr.TranceptionModel)
+    model._h, model.n_ctx, model.scoring_window, model.retrieval, model.cfg = None, cfg["n_ctx"], "optimal", retrieval, cfg
+    r = model.score_mutants(DMS_data=df, target_seq=seq, scoring_mirror=True, indel_mode=True)
+    key = r["mutated_sequence"].fillna(r["mutant"]) if "mutant" in r else r["mutated_sequence"]
+    m = pd.merge(df[["mutated_sequence"]], r.assign(key=key), left_on="mutated_sequence", right_on="key", how="left")
+    for c in ("avg_score_L_to_R", "avg_score_R_to_L", "avg_score"):
+        assert np.abs(m[c].to_numpy(dtype=np.float64) - g[f"full/{c}"]).max() < 3e-5, c
+    assert max(b for b, _ in device.calls) >= 3 and min(b for b, _ in device.calls) == 2      # insertions inside: 2+ runs; none: 1 run + the plain copy
+    with pytest.raises(ValueError, match="clustal_omega_location"):
+        cli.retrieval_arguments(cli.create_parser().parse_args(["--checkpoint", "x", "--DMS_data_folder", "x", "--indel_mode",
+                                                                "--inference_time_retrieval"]), seq, (str(a2m), None, 0, len(seq)))
+    part = shutil.copy(os.path.join(golden_dir, "TOY_MSA.a2m"), tmp_path / "TOY_MSA.a2m")
+    model.retrieval = ptr.build_retrieval(dict(MSA_filename=str(part), MSA_weight_file_name=None, MSA_start=10, MSA_end=60,
+                                               full_protein_length=len(seq), retrieval_aggregation_mode="aggregate_indel",
+                                               clustal_omega_location=STAND_IN_ALIGNER))
+    with pytest.raises(IndexError):                                            # the reference raises IndexError on this input too (golden)
+        model.score_mutants(DMS_data=df.iloc[:3], target_seq=seq, scoring_mirror=True, indel_mode=True)
