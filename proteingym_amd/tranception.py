@@ -467,7 +467,7 @@ class TranceptionModel:
         if hi <= lo:
             raise IndexError(f"indel scoring with retrieval: no overlap between the scored window [{start}, {end}) and the alignment")
         window = rows[lo:hi][::-1] if reverse else rows[lo:hi]           # prior row per fused position, in scoring order
-        if len(window) + 1 != len(sliced) + 1:                           # the reference's mask (+ the end token) against the scored positions
+        if len(window) != len(sliced):                                   # the reference's mask (one entry per prior row + the end token) against the scored positions
             raise IndexError(f"indel scoring with retrieval: the prior covers {len(window)} of the window's {len(sliced)} residues "
                              "(the reference raises here: model_pytorch.py:836)")
         first = max(0, end - m_end) if reverse else max(0, m_start - start)
