@@ -1081,3 +1081,39 @@ def test_tranception_product_indels_with_retrieval_host_logic_on_cpu(golden_dir,
                                                clustal_omega_location=STAND_IN_ALIGNER))
     with pytest.raises(IndexError):                                            # the reference raises IndexError on this input too (golden)
         model.score_mutants(DMS_data=df.iloc[:3], target_seq=seq, scoring_mirror=True, indel_mode=True)
+
+
+def test_run_sharded_tranception_indels_with_retrieval_in_chunks_on_cpu(golden_dir, tmp_path, monkeypatch):
+    """``run_sharded tranception`` (mutant chunks, resident model, per-assay retrieval swapped in) with --indel_mode
+    --inference_time_retrieval --clustal_omega_location: the assay cut into three chunks gives the unmodified reference's columns (the
+    device call served by the oracle through the ABI's semantics)."""
+    import shutil
+    from oracle import tranception_oracle as to
+    from proteingym_amd import tranception as ptr, _lib, run_sharded
+    g = np.load(os.path.join(golden_dir, "golden_tranception_indel_retrieval.npz"))
+    seq = str(g["seq"])
+    cfg, W = to.load_checkpoint(os.path.join(golden_dir, "Tranception_toy"))
+    device = _OracleBackedDevice(cfg, W)
+    monkeypatch.setattr(_lib, "load", lambda: device)
+
+    def make_model(checkpoint, dev, scoring_window):
+        m = object.__new__(ptr.TranceptionModel)
+        m._h, m.n_ctx, m.scoring_window, m.retrieval, m.cfg = None, cfg["n_ctx"], scoring_window, None, cfg
+        m.close = lambda: None
+        return m
+    (tmp_path / "msa").mkdir()
+    (tmp_path / "data").mkdir()
+    shutil.copy(os.path.join(golden_dir, "TOY_MSA_INDEL_FULL.a2m"), tmp_path / "msa" / "TOY_MSA_INDEL_FULL.a2m")
+    shutil.copy(os.path.join(golden_dir, "TOY_TRANCEPTION_INDEL_RETRIEVAL_DMS.csv"), tmp_path / "data" / "A.csv")
+    pd.DataFrame({"DMS_id": ["A"], "DMS_filename": ["A.csv"], "target_seq": [seq], "MSA_filename": ["TOY_MSA_INDEL_FULL.a2m"], "MSA_start": [1],
+                  "MSA_end": [len(seq)], "weight_file_name": ["none.npy"]}).to_csv(tmp_path / "ref.csv", index=False)
+    run_sharded.main(["tranception", "--max-chunk-rows", "6", "--", "--checkpoint", "x", "--DMS_reference_file_path", str(tmp_path / "ref.csv"),
+                      "--DMS_data_folder", str(tmp_path / "data"), "--output_scores_folder", str(tmp_path / "out"), "--indel_mode",
+                      "--inference_time_retrieval", "--MSA_folder", str(tmp_path / "msa"), "--clustal_omega_location", STAND_IN_ALIGNER],
+                     make_model=make_model)
+    r = pd.read_csv(tmp_path / "out" / "A.csv", float_precision="round_trip")
+    df = pd.read_csv(tmp_path / "data" / "A.csv")
+    key = r["mutated_sequence"].fillna(r["mutant"]) if "mutant" in r else r["mutated_sequence"]
+    m = pd.merge(df[["mutated_sequence"]], r.assign(key=key), left_on="mutated_sequence", right_on="key", how="left")
+    for c in ("avg_score_L_to_R", "avg_score_R_to_L", "avg_score"):
+        assert np.abs(m[c].to_numpy(dtype=np.float64) - g[f"full/{c}"]).max() < 3e-5, c
