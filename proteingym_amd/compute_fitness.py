@@ -46,7 +46,7 @@ _FLAGS = [
     ("--msa-samples", dict(type=int, default=400, help="rows sampled from the alignment per seed")),
     ("--msa-weights-folder", dict(type=str, default=None, help="folder of sequence-weight .npy files (sequence-reweighting)")),
     ("--seeds", dict(type=int, nargs="+", default=1, help="one sampled alignment and one score column per seed")),
-    ("--filter-msa", dict(action="store_true", help="hhfilter pre-filtering (external binary: not available here)")),
+    ("--filter-msa", dict(action="store_true", help="filter the alignment with hhfilter (--path-to-hhfilter) before sampling")),
     ("--hhfilter-min-cov", dict(type=int, default=75, help="hhfilter -cov")),
     ("--hhfilter-max-seq-id", dict(type=int, default=90, help="hhfilter -id")),
     ("--hhfilter-min-seq-id", dict(type=int, default=0, help="hhfilter -qid")),
@@ -306,8 +306,10 @@ def score_msa_transformer(args, df, mutant_col, msa_start_index, MSA_weight_file
         stem = checkpoint_stem(location)
         print("Transferred model to GPU")
         to_tokens = alphabet.get_batch_converter()
-        alignment = pmsa.process_msa(filename=str(args.msa_path), weight_filename=MSA_weight_file_name,
-                                     filter_msa=args.filter_msa, device=args.device)
+        alignment = pmsa.process_msa(filename=str(args.msa_path), weight_filename=MSA_weight_file_name, filter_msa=args.filter_msa,
+                                     path_to_hhfilter=args.path_to_hhfilter, hhfilter_min_cov=args.hhfilter_min_cov,
+                                     hhfilter_max_seq_id=args.hhfilter_max_seq_id, hhfilter_min_seq_id=args.hhfilter_min_seq_id,
+                                     device=args.device)
         for seed in seeds:
             column = f"{stem}_seed{seed}"
             on_disk = pd.read_csv(out_csv) if os.path.exists(out_csv) else None

@@ -290,8 +290,34 @@ def sample_msa(filename, nseq: int, sampling_strategy: str, random_seed: int, we
     return [(desc, seq.upper()) for desc, seq in msa]
 
 
-def process_msa(filename, weight_filename, filter_msa=False, device=0, **_):
-    """compute_fitness.py:76-97.  hhfilter pre-filtering shells out to an external binary: not available here."""
+def hhfilter_alignment(filename, path_to_hhfilter, min_cov=75, max_seq_id=100, min_seq_id=0) -> str:
+    """compute_fitness.py:77-89: the alignment with every '.' turned into '-' and every byte upper case (headers included, as the
+    reference's ``tr`` and ``dd conv=ucase`` do) is written to ``<folder>/preprocessed/<name>_UC.a2m`` and handed to the user's
+    ``<path_to_hhfilter>/bin/hhfilter -cov C -id I -qid Q -i ... -o <folder>/hhfiltered/<name>_hhfiltered_cov_C_maxid_I_minid_Q.a2m``;
+    returns that output path.  (The reference APPENDS to its intermediate file, so a second run filters every sequence twice; here
+    the file is rewritten.)"""
+    import subprocess
+    folder, name = os.path.dirname(filename), os.path.basename(filename).split(".")[0]
+    for sub in ("preprocessed", "hhfiltered"):
+        os.makedirs(os.path.join(folder, sub), exist_ok=True)
+    upper = os.path.join(folder, "preprocessed", name + "_UC.a2m")
+    with open(filename) as f, open(upper, "w") as g:
+        g.write(f.read().replace(".", "-").upper())
+    out = os.path.join(folder, "hhfiltered", f"{name}_hhfiltered_cov_{min_cov}_maxid_{max_seq_id}_minid_{min_seq_id}.a2m")
+    exe = os.path.join(str(path_to_hhfilter), "bin", "hhfilter")
+    try:
+        done = subprocess.run([exe, "-cov", str(min_cov), "-id", str(max_seq_id), "-qid", str(min_seq_id), "-i", upper, "-o", out],
+                              capture_output=True, text=True)
+    except OSError as e:
+        raise RuntimeError(f"--filter-msa: cannot run {exe} ({e}); --path-to-hhfilter must point at an hh-suite installation") from e
+    if done.returncode != 0 or not os.path.exists(out):
+        raise RuntimeError(f"--filter-msa: {exe} failed ({done.returncode}): {done.stderr.strip()[-500:]}")
+    return out
+
+
+def process_msa(filename, weight_filename, filter_msa=False, path_to_hhfilter=None, hhfilter_min_cov=75, hhfilter_max_seq_id=100,
+                hhfilter_min_seq_id=0, device=0):
+    """compute_fitness.py:76-97: optional hhfilter pre-filtering (the user's executable), then the EVE pre-processing and weights."""
     if filter_msa:
-        raise NotImplementedError("--filter-msa needs the external hhfilter binary")
+        filename = hhfilter_alignment(filename, path_to_hhfilter, hhfilter_min_cov, hhfilter_max_seq_id, hhfilter_min_seq_id)
     return MSA_processing(MSA_location=filename, use_weights=True, weights_location=weight_filename, device=device)

@@ -1117,3 +1117,44 @@ def test_run_sharded_tranception_indels_with_retrieval_in_chunks_on_cpu(golden_d
     m = pd.merge(df[["mutated_sequence"]], r.assign(key=key), left_on="mutated_sequence", right_on="key", how="left")
     for c in ("avg_score_L_to_R", "avg_score_R_to_L", "avg_score"):
         assert np.abs(m[c].to_numpy(dtype=np.float64) - g[f"full/{c}"]).max() < 3e-5, c
+
+
+@pytest.mark.skipif(not rh.reference_available(), reason="/root/reference not present (GPU box)")
+def test_filter_msa_vs_live_reference(tmp_path, monkeypatch):
+    """--filter-msa (compute_fitness.py:76-97): the reference rewrites the alignment ('.' -> '-', upper case, headers included), shells out
+    to <path>/bin/hhfilter and pre-processes what comes back.  The product does the same through subprocess; with the stand-in filter
+    (tests/golden/stand_in_hhfilter.py) in place of hh-suite both hand the SAME filtered file (same relative path, same bytes) to
+    MSA_processing -- whose own parity is test_alignment_preprocessing_vs_live_reference."""
+    import stat
+    from proteingym_amd import msa_transformer as pmsa
+    ref_cf = rh.load_reference()
+    rng = np.random.default_rng(21)
+    aa = np.array(list("ACDEFGHIKLMNPQRSTVWY"))
+    width = 50
+    focus = aa[rng.integers(0, 20, width)]
+    lines = [">Target.prot/1-50", "".join(focus)]
+    for i in range(1, 60):
+        row = np.where(rng.random(width) < (0.97 if i % 5 == 0 else 0.5), focus, aa[rng.integers(0, 20, width)])
+        row[rng.random(width) < (0.6 if i % 7 == 0 else 0.1)] = "-"
+        lines += [f">UniRef100_x{i}.v/1-50", "".join(row)]
+    root = tmp_path / "hhsuite"
+    (root / "bin").mkdir(parents=True)
+    exe = root / "bin" / "hhfilter"
+    exe.write_text('#!/bin/sh\nexec python3 "%s" "$@"\n' % os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "stand_in_hhfilter.py"))
+    exe.chmod(exe.stat().st_mode | stat.S_IXUSR)
+    seen = {}
+    for who, fn, mod in (("ref", ref_cf.process_msa, ref_cf), ("mine", pmsa.process_msa, pmsa)):
+        folder = tmp_path / who
+        folder.mkdir()
+        (folder / "fam.a2m").write_text("\n".join(lines) + "\n")
+        import types
+        monkeypatch.setattr(mod, "MSA_processing",                                                 # record what the pre-processing is given
+                            lambda MSA_location, **kw: types.SimpleNamespace(focus_seq_name="recorded", MSA_location=MSA_location))
+        out = fn(filename=str(folder / "fam.a2m"), weight_filename=None, filter_msa=True, path_to_hhfilter=str(root), hhfilter_min_cov=75,
+                 hhfilter_max_seq_id=90, hhfilter_min_seq_id=0).MSA_location
+        seen[who] = (os.path.relpath(out, folder), open(out).read())
+    assert seen["mine"] == seen["ref"]
+    kept = seen["ref"][1].count(">")
+    assert 1 < kept < 60 and ">TARGET-PROT/1-50" in seen["ref"][1]                # filtered; headers went through tr and ucase too
+    with pytest.raises(RuntimeError, match="hhfilter"):
+        pmsa.process_msa(filename=str(tmp_path / "mine" / "fam.a2m"), weight_filename=None, filter_msa=True, path_to_hhfilter=str(tmp_path / "nowhere"))
