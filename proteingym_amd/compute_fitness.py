@@ -76,23 +76,40 @@ def create_parser():
     return parser
 
 
-def label_row(row, sequence, token_probs, alphabet, offset_idx):
-    """compute_fitness.py:240-250 on a host table (token_probs [1, L+2, 33] or [L+2, 33])."""
+def label_rows(mutants, sequence, token_probs, offset_idx):
+    """``label_row`` (compute_fitness.py:240-250) for a whole mutant column on a host table (token_probs [1, L+2, 33] or [L+2, 33]):
+    the strings go through the library's parser (``pgmi_parse_mutants``: the reference's wild-type assertion, same text), the
+    look-ups are ``esm.score_parsed`` -- an f32 difference per substitution added up in double in the order of the string, the
+    arithmetic of the reference's ``.item()`` sum and of the device kernel.  Residue letters have the same indices in the ESM and
+    the MSA Transformer alphabets (esm/data.py:142-174), so one parser serves both."""
     tp = token_probs[0] if token_probs.ndim == 3 else token_probs
-    score = 0
-    for mutation in row.split(":"):
-        wt, idx, mt = mutation[0], int(mutation[1:-1]) - offset_idx, mutation[-1]
-        assert sequence[idx] == wt, "The listed wildtype does not match the provided sequence"
-        wt_encoded, mt_encoded = alphabet.get_idx(wt), alphabet.get_idx(mt)
-        score += float(tp[1 + idx, mt_encoded] - tp[1 + idx, wt_encoded])     # add 1 for BOS
-    return score
+    return pesm.score_from_table(tp, [str(m) for m in mutants], sequence, offset_idx)
+
+
+def label_row(row, sequence, token_probs, alphabet, offset_idx):
+    """compute_fitness.py:240-250, the seam function by name: one row of ``label_rows``."""
+    return float(label_rows([row], sequence, token_probs, offset_idx)[0])
+
+
+def mutated_sequences(mutants, wt_sequence, offset_idx):
+    """``get_mutated_sequence`` (compute_fitness.py:252-257) for a column of SINGLE substitutions ('A25G'): wild-type copies as one
+    byte matrix, one assignment.  A string that is not letter-integer-letter fails in ``int`` as in the reference."""
+    mutants = [str(m) for m in mutants]
+    wt = np.frombuffer(wt_sequence.encode("ascii"), dtype=np.uint8)
+    idx = np.array([int(m[1:-1]) for m in mutants], dtype=np.int64) - int(offset_idx)
+    if ((idx >= len(wt)) | (idx < -len(wt))).any():
+        raise IndexError("string index out of range")
+    listed = np.frombuffer("".join(m[0] for m in mutants).encode("ascii"), dtype=np.uint8)
+    assert (wt[idx] == listed).all(), "The listed wildtype does not match the provided sequence"
+    out = np.tile(wt, (len(mutants), 1))
+    out[np.arange(len(mutants)), idx] = np.frombuffer("".join(m[-1] for m in mutants).encode("ascii"), dtype=np.uint8)
+    flat = out.tobytes().decode("ascii")
+    return [flat[i * len(wt):(i + 1) * len(wt)] for i in range(len(mutants))]
 
 
 def get_mutated_sequence(row, wt_sequence, offset_idx):
-    """compute_fitness.py:252-257 (single substitution, as the reference)."""
-    wt, idx, mt = row[0], int(row[1:-1]) - offset_idx, row[-1]
-    assert wt_sequence[idx] == wt, "The listed wildtype does not match the provided sequence"
-    return wt_sequence[:idx] + mt + wt_sequence[(idx + 1):]
+    """compute_fitness.py:252-257 (one single substitution)."""
+    return mutated_sequences([row], wt_sequence, offset_idx)[0]
 
 
 def compute_pppl_batch(sequences, model, alphabet):
@@ -261,7 +278,7 @@ def main(args):
         print("Transferred model to GPU")
         if args.scoring_strategy == "wt-marginals":            # one forward (or blended windows), then table look-ups
             table = wt_marginals_table(model, alphabet, args.sequence, args.scoring_window)
-            df[column] = [label_row(m, args.sequence, table, alphabet, args.offset_idx) for m in mutants]
+            df[column] = label_rows(mutants, args.sequence, table, args.offset_idx)
         elif args.scoring_strategy == "masked-marginals":      # the hot path: one device-resident assay
             print("Scoring with masked-marginals and model {}".format(column))
             if len(args.sequence) + 2 > 1024 and args.scoring_window == "overlapping":
@@ -273,7 +290,7 @@ def main(args):
             assay.close()
         else:                                                  # pseudo-ppl
             if "mutated_sequence" not in df:
-                df["mutated_sequence"] = [get_mutated_sequence(m, args.sequence, args.offset_idx) for m in mutants]
+                df["mutated_sequence"] = mutated_sequences(mutants, args.sequence, args.offset_idx)
             df[column] = compute_pppl_batch(list(df["mutated_sequence"]), model, alphabet)
         model.close()
     if "ESM1v" in args.model_type:                             # plain mean of the checkpoint columns (:530-537)
@@ -326,7 +343,7 @@ def score_msa_transformer(args, df, mutant_col, msa_start_index, MSA_weight_file
                 # row-wise from the CURRENT frame (compute_fitness.py:405-409): after an earlier seed or run it is the on-disk frame,
                 # whose rows need not be the input file's in number or order
                 if "mutated_sequence" not in df:
-                    df["mutated_sequence"] = [get_mutated_sequence(str(m), args.sequence, args.offset_idx) for m in df[mutant_col]]
+                    df["mutated_sequence"] = mutated_sequences(df[mutant_col], args.sequence, args.offset_idx)
                 df[column] = [compute_pppl_msa(sq, model, alphabet, rows) for sq in df["mutated_sequence"]]
                 if on_disk is not None and not args.overwrite_prior_scores:
                     assert column not in on_disk.columns, f"Column {column} already exists in {out_csv}"
@@ -348,7 +365,7 @@ def score_msa_transformer(args, df, mutant_col, msa_start_index, MSA_weight_file
                 from . import dist as pdist
                 import torch.distributed as tdist
                 table = pdist.gather_tables({0: table}, [T], device="cuda" if tdist.get_backend() == "nccl" else "cpu")[0]
-            df[column] = [label_row(str(m), args.sequence, table, alphabet, args.offset_idx) for m in df[mutant_col]]   # the current frame's rows
+            df[column] = label_rows(df[mutant_col], args.sequence, table, args.offset_idx)   # the current frame's rows
             if on_disk is not None and not args.overwrite_prior_scores:
                 assert column not in on_disk.columns, f"Column {column} already exists in {out_csv}"
                 df = on_disk.merge(df[[column, "mutant"]], on="mutant")

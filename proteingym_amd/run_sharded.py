@@ -89,20 +89,40 @@ def plan_mutant_chunks(seq_lens, n_rows, world: int, max_chunk_rows: int = 0):
 
 
 def rows_per_assay(mapping, indices, data_folder):
-    """Row count of every assay FILE (non-blank lines after the header), counted by every rank from the shared folder: the
-    numbers shape the chunk plan and the all_gather, so they must be the same everywhere and must be the files' own -- the
-    reference table's DMS_total_number_mutants is only a fallback for a file this rank cannot read (the rank that loads it
-    then fails that assay).  A file whose row count differs from the table is scored like the single-assay CLI scores it."""
+    """Row count of every assay FILE as the scorer's own parser sees it (``pd.read_csv``: quoted fields with embedded newlines,
+    whitespace-only lines and footers count the way ``_assay_frame`` will count them), -1 for a file that cannot be read or
+    parsed.  The numbers shape the chunk plan and the all_gather, so they must be the same on every rank: rank 0 counts and
+    ``planned_rows`` broadcasts.  The reference table's DMS_total_number_mutants stands in for an unreadable file only so
+    that the plan has a cost for it; the rank that then loads it fails that assay (a file nobody can read is a failed assay,
+    not an empty one)."""
     out = []
     for i in indices:
         row = mapping.iloc[i]
         try:
-            with open(os.path.join(data_folder, str(row["DMS_filename"])), "rb") as f:
-                out.append(max(0, sum(1 for line in f if line.strip()) - 1))
-        except OSError:
-            v = row["DMS_total_number_mutants"] if "DMS_total_number_mutants" in mapping.columns else float("nan")
-            out.append(int(v) if v == v else 0)
+            out.append(len(pd.read_csv(os.path.join(data_folder, str(row["DMS_filename"])), usecols=[0], low_memory=False)))
+        except Exception:
+            out.append(-1)
     return out
+
+
+def planned_rows(mapping, indices, data_folder, rank, world):
+    """(rows per assay for the plan, readable flags): counted once, by rank 0, and broadcast -- every rank plans from the same
+    numbers even if the folder looks different from another rank's mount."""
+    counts = rows_per_assay(mapping, indices, data_folder) if rank == 0 else None
+    if world > 1:
+        import torch.distributed as tdist
+        box = [counts]
+        tdist.broadcast_object_list(box, src=0)
+        counts = box[0]
+    readable = [c >= 0 for c in counts]
+    table = mapping["DMS_total_number_mutants"] if "DMS_total_number_mutants" in mapping.columns else None
+    rows = []
+    for i, c in zip(indices, counts):
+        if c < 0:
+            v = table.iloc[i] if table is not None else float("nan")
+            c = int(v) if v == v else 0
+        rows.append(c)
+    return rows, readable
 
 
 def shared_retrieval(ptr, retrieval_args, cache_dir, tag, wait_s=1800.0):
@@ -110,22 +130,41 @@ def shared_retrieval(ptr, retrieval_args, cache_dir, tag, wait_s=1800.0):
     several ranks, each of which would otherwise re-read the alignment (and recompute sequence weights when no weight file
     exists).  The rank that creates ``<tag>.lock`` first builds the log-prior and publishes it as ``<tag>.npy`` (atomic
     rename); the others wait for the file.  The array is the builder's own output, so every rank scores with the same bits.
-    A waiter that times out (builder died) builds it itself."""
+    A builder that FAILS (missing alignment or weight file, ragged a2m ...) publishes ``<tag>.failed`` with the message: the
+    failure is deterministic, so the waiters raise it at once instead of polling for ``wait_s`` and rebuilding into the same
+    error.  A waiter whose builder vanished without either file (killed: the lock's pid is gone, or ``wait_s`` is over) builds
+    the prior itself."""
     import numpy as np
     if not retrieval_args:
         return None
     if retrieval_args.get("retrieval_aggregation_mode") == "aggregate_indel":
         return ptr.build_retrieval(retrieval_args)        # carries a per-rank aligner (files of its own under <alignment folder>/Sampled)
     os.makedirs(cache_dir, exist_ok=True)
-    path, lock = os.path.join(cache_dir, tag + ".npy"), os.path.join(cache_dir, tag + ".lock")
+    path, lock, failed = (os.path.join(cache_dir, tag + ext) for ext in (".npy", ".lock", ".failed"))
 
     def from_file():
         return dict(log_prior=np.load(path), MSA_start=int(retrieval_args["MSA_start"]), MSA_end=int(retrieval_args["MSA_end"]),
                     weight=float(retrieval_args.get("retrieval_inference_weight", 0.6)))
+
+    def builder_alive():
+        try:
+            pid = int(open(lock).read().strip() or 0)
+        except (OSError, ValueError):
+            return True                                   # lock just created, pid not written yet (or unreadable): keep waiting
+        if pid <= 0:
+            return True
+        try:
+            os.kill(pid, 0)                               # one node: the ranks share a pid namespace
+        except ProcessLookupError:
+            return False
+        except OSError:
+            return True
+        return True
     if os.path.exists(path):
         return from_file()
     try:
         fd = os.open(lock, os.O_CREAT | os.O_EXCL | os.O_WRONLY)
+        os.write(fd, str(os.getpid()).encode())
         os.close(fd)
         builder = True
     except FileExistsError:
@@ -135,8 +174,20 @@ def shared_retrieval(ptr, retrieval_args, cache_dir, tag, wait_s=1800.0):
         while time.time() < t_end:
             if os.path.exists(path):
                 return from_file()
+            if os.path.exists(failed):
+                raise RuntimeError(f"retrieval prior of {tag}: the building rank failed: {open(failed).read().strip()}")
+            if not builder_alive():
+                break
             time.sleep(0.05)
-    r = ptr.build_retrieval(retrieval_args)
+    try:
+        r = ptr.build_retrieval(retrieval_args)
+    except BaseException as e:
+        if not isinstance(e, KeyboardInterrupt):
+            tmp = f"{failed}.{os.getpid()}.tmp"
+            with open(tmp, "w") as f:
+                f.write(f"{type(e).__name__}: {e}")
+            os.replace(tmp, failed)
+        raise
     tmp = f"{path}.{os.getpid()}.tmp.npy"
     np.save(tmp, r["log_prior"])
     os.replace(tmp, path)
@@ -190,7 +241,7 @@ def _assay_frame(args, assay_file, wild_type):
     if key not in df:               # the single-assay scorer ends in DMS_data[key] (model_pytorch.py:915-919): same failure, before the work
         raise KeyError(key)
     if "mutated_sequence" not in df and not args.indel_mode:
-        df["mutated_sequence"] = [ptr.get_mutated_sequence(wild_type, m) for m in df["mutant"]]
+        df["mutated_sequence"] = ptr.mutated_sequences(wild_type, df["mutant"])
     assert ("mutated_sequence" in df), "DMS file to score does not have mutated_sequence column"
     if "mutant" not in df:
         df["mutant"] = df["mutated_sequence"]
@@ -207,7 +258,7 @@ def main_tranception_mutants(own, rest, mapping, indices, rank, local_rank, worl
     base = cli.create_parser().parse_args(rest + ["--device", str(local_rank)])
     if base.model_framework != "pytorch":
         raise NotImplementedError("only --model_framework pytorch has an MI355X backend")
-    n_rows = rows_per_assay(mapping, indices, base.DMS_data_folder)
+    n_rows, readable = planned_rows(mapping, indices, base.DMS_data_folder, rank, world)
     items, assignment, costs = plan_mutant_chunks([len(str(mapping.iloc[i]["target_seq"])) for i in indices], n_rows, world,
                                                   max_chunk_rows=own.max_chunk_rows)
     mine = assignment[rank]
@@ -243,9 +294,11 @@ def main_tranception_mutants(own, rest, mapping, indices, rank, local_rank, worl
     for k, js in by_assay.items():
         try:
             args, dms_id, wild_type, assay_file, msa = assay_inputs(k)
+            if not readable[k]:
+                raise OSError(f"{assay_file}: the assay file could not be read when the job was planned")
             frame = _assay_frame(args, assay_file, wild_type)
             if len(frame) != n_rows[k]:
-                raise ValueError(f"{assay_file}: pandas reads {len(frame)} rows, the line count every rank planned with is {n_rows[k]}")
+                raise ValueError(f"{assay_file}: {len(frame)} rows now, {n_rows[k]} when the job was planned (rank 0's count)")
             frames[k] = frame
             if n_rows[k] == 0:                               # a header-only file: nothing to score, the CSV below is header-only too
                 for j in js:

@@ -16,7 +16,6 @@ from __future__ import annotations
 import ctypes as C
 import json
 import os
-import re
 from typing import Optional, Sequence
 
 import numpy as np
@@ -33,41 +32,77 @@ AA_vocab = "ACDEFGHIKLMNPQRSTVWY"
 
 
 # ---- scoring_utils mirrors ----------------------------------------------------------------------
+def _parse_substitutions(mutants, start_idx):
+    """The 'A25G:K30R' strings of a whole column as flat arrays: (row of each substitution, 0-based position, from byte, to byte)."""
+    rows, pos, frm, to = [], [], bytearray(), bytearray()
+    for i, m in enumerate(mutants):
+        for one in m.split(":"):
+            rows.append(i)
+            pos.append(int(one[1:-1]) - start_idx)
+            frm += one[0].encode()
+            to += one[-1].encode()
+    return (np.asarray(rows, dtype=np.int64), np.asarray(pos, dtype=np.int64),
+            np.frombuffer(bytes(frm), dtype=np.uint8), np.frombuffer(bytes(to), dtype=np.uint8))
+
+
+def mutated_sequences(focus_seq, mutants, start_idx=1, AA_vocab=AA_vocab):
+    """``get_mutated_sequence`` (scoring_utils.py:16-31) for a whole 'mutant' column: one [rows, L] byte matrix of wild-type copies,
+    every substitution written with one fancy assignment (a later substitution at the same position wins, as in the reference's
+    loop).  Same checks in the same order -- per substitution: the from letter against the UNMUTATED sequence, then the to letter
+    against the amino-acid alphabet -- with the reference's messages; negative positions index from the end like python strings."""
+    mutants = list(mutants)
+    wt = np.frombuffer(focus_seq.encode("ascii"), dtype=np.uint8)
+    rows, pos, frm, to = _parse_substitutions(mutants, start_idx)
+    if ((pos >= len(wt)) | (pos < -len(wt))).any():
+        raise IndexError("string index out of range")
+    known = np.zeros(256, dtype=bool)
+    known[np.frombuffer(AA_vocab.encode("ascii"), dtype=np.uint8)] = True
+    bad = np.flatnonzero((wt[pos] != frm) | ~known[to])
+    if bad.size:
+        k = int(bad[0])
+        label = mutants[rows[k]].split(":")[int(k - np.searchsorted(rows, rows[k]))]
+        if wt[pos[k]] != frm[k]:
+            raise AssertionError("Invalid from_AA or mutant position: " + label + " from_AA: " + chr(frm[k]) + " relative pos: " +
+                                 str(int(pos[k])) + " focus_seq: " + str(focus_seq))
+        raise AssertionError("Mutant to_AA is invalid: " + label)
+    out = np.tile(wt, (len(mutants), 1))
+    out[rows, pos] = to
+    return alignment.to_strings(out)
+
+
 def get_mutated_sequence(focus_seq, mutant, start_idx=1, AA_vocab=AA_vocab):
-    """scoring_utils.py:16-31."""
-    mutated_seq = list(focus_seq)
-    for mutation in mutant.split(":"):
-        from_AA, position, to_AA = mutation[0], int(mutation[1:-1]), mutation[-1]
-        relative_position = position - start_idx
-        assert (from_AA == focus_seq[relative_position]), "Invalid from_AA or mutant position: " + str(mutation) + \
-            " from_AA: " + str(from_AA) + " relative pos: " + str(relative_position) + " focus_seq: " + str(focus_seq)
-        assert (to_AA in AA_vocab), "Mutant to_AA is invalid: " + str(mutation)
-        mutated_seq[relative_position] = to_AA
-    return "".join(mutated_seq)
+    """scoring_utils.py:16-31 (one mutant; columns go through ``mutated_sequences``)."""
+    return mutated_sequences(focus_seq, [mutant], start_idx, AA_vocab)[0]
 
 
 def get_optimal_window(mutation_position_relative, seq_len_wo_special, model_window):
-    """scoring_utils.py:47-60 (same function as proteingym/utils/scoring_utils.py:43-52)."""
-    half = model_window // 2
-    if seq_len_wo_special <= model_window:
-        return [0, seq_len_wo_special]
-    elif mutation_position_relative < half:
-        return [0, model_window]
-    elif mutation_position_relative >= seq_len_wo_special - half:
-        return [seq_len_wo_special - model_window, seq_len_wo_special]
-    return [max(0, mutation_position_relative - half), min(seq_len_wo_special, mutation_position_relative + half)]
+    """scoring_utils.py:47-60 -- the same rule as proteingym/utils/scoring_utils.py:43-52: the library's ``pgmi_optimal_window``."""
+    from .esm import get_optimal_window as c_window
+    return c_window(mutation_position_relative, seq_len_wo_special, model_window)
+
+
+def optimal_windows(centres, seq_len_wo_special, model_window):
+    """``get_optimal_window`` for an array of positions: int64 [n, 2] of (start, end)."""
+    c = np.asarray(centres, dtype=np.int64)
+    n, w, half = int(seq_len_wo_special), int(model_window), int(model_window) // 2
+    if n <= w:
+        return np.tile(np.array([0, n], dtype=np.int64), (len(c), 1))
+    lo = np.where(c < half, 0, np.where(c >= n - half, n - w, np.maximum(0, c - half)))
+    hi = np.where(c < half, w, np.where(c >= n - half, n, np.minimum(n, c + half)))
+    return np.stack([lo, hi], axis=1)
 
 
 def sequence_replace_single(sequence, char_to_replace, char_replacements):
-    """scoring_utils.py:62-69 (random replacement via np.random.choice, as the reference)."""
-    positions = [m.start() for m in re.finditer(char_to_replace, sequence)]
-    if not positions:
+    """scoring_utils.py:62-69: every ``char_to_replace`` becomes a letter drawn by ONE ``np.random.choice`` call over all of its
+    positions (the reference's draw, so a seeded run replaces the same letters)."""
+    codes = np.frombuffer(sequence.encode("ascii"), dtype=np.uint8)
+    where = np.flatnonzero(codes == ord(char_to_replace))
+    if not where.size:
         return sequence
-    replacements = np.random.choice(a=list(char_replacements), size=len(positions), replace=True)
-    sequence = list(sequence)
-    for idx, position in enumerate(positions):
-        sequence[position] = replacements[idx]
-    return ''.join(sequence)
+    drawn = np.random.choice(a=list(char_replacements), size=where.size, replace=True)
+    codes = codes.copy()
+    codes[where] = np.frombuffer("".join(drawn).encode("ascii"), dtype=np.uint8)
+    return codes.tobytes().decode("ascii")
 
 
 def get_sequence_slices(df, target_seq, model_context_len, start_idx=1, scoring_window="optimal", indel_mode=False):
@@ -92,8 +127,10 @@ def get_sequence_slices(df, target_seq, model_context_len, start_idx=1, scoring_
             win_mut = [(0, len(s)) for s in seqs]
             win_wt = [(0, L)] * len(seqs)
         else:                                               # window centred on the mean mutated position
-            centres = [int(np.mean([int(one[1:-1]) - start_idx for one in m.split(":")])) for m in base["mutant"]]
-            win_mut = [tuple(get_optimal_window(c, L, model_context_len)) for c in centres]
+            rows, pos, _, _ = _parse_substitutions(base["mutant"], start_idx)
+            depth = np.bincount(rows, minlength=len(seqs))
+            centres = (np.bincount(rows, weights=pos, minlength=len(seqs)) / depth).astype(np.int64)   # int(np.mean(...)): exact sums of small integers
+            win_mut = [(int(a), int(b)) for a, b in optimal_windows(centres, L, model_context_len)]
             win_wt = win_mut
         blocks = [block(seqs, win_mut), block([target_seq] * len(seqs), win_wt)]
     elif scoring_window == "sliding":                       # consecutive context-sized chunks, mutated then wild type
@@ -185,11 +222,22 @@ def get_msa_prior(MSA_data_file, MSA_weight_file_name, MSA_start, MSA_end, len_t
     records = process_msa_data(MSA_data_file)
     names = list(records)
     width = MSA_end - MSA_start
-    table = np.full(256, -1, dtype=np.int64)              # byte -> vocabulary index, -1 = not in the vocabulary
+    table = np.full(256, -1, dtype=np.int8)               # byte -> vocabulary index (25 symbols), -1 = not in the vocabulary
     for symbol, index in vocab.items():
         if len(symbol) == 1:
             table[ord(symbol)] = index
-    codes = table[alignment.to_matrix([records[n] for n in names])]
+    rows = [records[n] for n in names]
+    lengths = np.array([len(r) for r in rows], dtype=np.int64)
+    if filter_MSA and len(rows) and (lengths != lengths[0]).any():
+        # the reference's similarity filter takes np.dot of two flattened one-hot rows (:83-91): rows of another length end there
+        k = int(np.flatnonzero(lengths != lengths[0])[0])
+        raise ValueError(f"shapes ({lengths[0] * V},) and ({lengths[k] * V},) not aligned: alignment row {k} differs in length from the query")
+    # one byte per alignment cell; short rows (tolerated by the reference without the filter: their tail stays all-zero, :44-52) are
+    # padded with a byte outside the vocabulary
+    full = int(lengths.max()) if len(rows) else 0
+    codes = np.full((len(rows), full), -1, dtype=np.int8)
+    for i, r in enumerate(rows):
+        codes[i, :len(r)] = table[np.frombuffer(r.encode("ascii"), dtype=np.uint8)]
     keep = np.ones(len(names), dtype=bool)
     if filter_MSA:
         query = codes[0]
@@ -211,14 +259,17 @@ def get_msa_prior(MSA_data_file, MSA_weight_file_name, MSA_start, MSA_end, len_t
         if (codes[:, width:] >= 0).any():
             raise IndexError(f"the alignment has residues beyond column {width} = MSA_end - MSA_start")
         codes = codes[:, :width]
+    elif codes.shape[1] < width:                          # an alignment narrower than the declared range: the missing columns hold no counts
+        codes = np.concatenate([codes, np.full((codes.shape[0], width - codes.shape[1]), -1, dtype=np.int8)], axis=1)
     # The reference materialises one_hots [sequences, width, V] in float64 (and two temporaries of that size) and reduces over the
     # sequences.  Same expressions here on blocks of sequences: numpy reduces a leading axis by adding the slices one after the other,
-    # so carrying the running sum in as slice 0 of the next block gives the same bits with memory bounded by the block.
+    # so carrying the running sum in as slice 0 of the next block gives the same bits with memory bounded by the block (the byte
+    # matrix is widened to an index type one block at a time).
     acc = np.zeros((width, V))
     total = np.zeros(width)
     rows_per_block = max(1, block_bytes // max(1, width * V * 8))
     for lo in range(0, codes.shape[0], rows_per_block):
-        c = codes[lo:lo + rows_per_block]
+        c = codes[lo:lo + rows_per_block].astype(np.intp)
         one_hots = np.zeros((c.shape[0], width, V))
         i, j = np.nonzero(c >= 0)
         one_hots[i, j, c[i, j]] = 1.0
@@ -246,7 +297,13 @@ class SequenceAligner:
             raise ValueError("indel scoring with retrieval re-aligns every sequence: --clustal_omega_location <executable> is required")
         self.executable = clustal_omega_location
         folder = os.path.join(os.path.dirname(MSA_filename) or ".", "Sampled")
-        os.makedirs(folder, exist_ok=True)
+        try:                                              # the reference's place; a read-only alignment folder gets a temporary one
+            os.makedirs(folder, exist_ok=True)
+            if not os.access(folder, os.W_OK):
+                raise PermissionError(folder)
+        except OSError:
+            import tempfile
+            folder = tempfile.mkdtemp(prefix="pgmi_sampled_")
         name, tag = os.path.basename(MSA_filename), str(uuid.uuid4())
         self.sampled, self.query, self.expanded = (os.path.join(folder, f"{kind}_{tag}_{name}") for kind in ("Sampled", "Seq_to_align", "Expanded"))
         records = process_msa_data(MSA_filename)
@@ -257,6 +314,21 @@ class SequenceAligner:
         with open(self.sampled, "w") as f:
             for k, n in enumerate(names):
                 f.write((">REFERENCE_SEQUENCE" if k == 0 else n) + "\n" + _wrap(records[n].replace(".", "-"), 80) + "\n")
+
+    def close(self):
+        """Removes this aligner's three files (the reference leaves one set per model behind; a sharded job builds one aligner per
+        rank and assay, so they are taken away with the retrieval state they belong to)."""
+        for path in (self.sampled, self.query, self.expanded):
+            try:
+                os.remove(path)
+            except OSError:
+                pass
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def __call__(self, sequence: str):
         import subprocess
@@ -530,7 +602,7 @@ class TranceptionModel:
         run_sharded when an assay's rows are scored in chunks) leaves that row to the caller."""
         frame = DMS_data.copy()
         if 'mutated_sequence' not in frame and not indel_mode:
-            frame['mutated_sequence'] = [get_mutated_sequence(target_seq, m) for m in frame['mutant']]
+            frame['mutated_sequence'] = mutated_sequences(target_seq, frame['mutant'])
         assert ('mutated_sequence' in frame), "DMS file to score does not have mutated_sequence column"
         if 'mutant' not in frame:
             frame['mutant'] = frame['mutated_sequence']

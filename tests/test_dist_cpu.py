@@ -2,6 +2,7 @@
 all_gather the GPU ranks run over RCCL."""
 import os
 import socket
+import time
 
 import numpy as np
 import pytest
@@ -253,6 +254,12 @@ def test_tranception_mutant_chunks_plan_from_the_files_not_the_table(tmp_path):
     true_n[3] = 0
     table.to_csv(os.path.join(workdir, "map.csv"), index=False)
     assert run_sharded.rows_per_assay(table, range(4), os.path.join(workdir, "dms")) == true_n
+    # counted by the parser that scores: a quoted field with an embedded newline and a blank-looking line are pandas' rows, not lines
+    odd = pd.DataFrame({"mutant": ["A1C", "A1D"], "note": ["two\nlines", " "]})
+    odd.to_csv(os.path.join(workdir, "dms", "odd.csv"), index=False)
+    probe = pd.DataFrame({"DMS_filename": ["odd.csv", "absent.csv", "absent.csv"], "DMS_total_number_mutants": [9, 12, float("nan")]})
+    assert run_sharded.rows_per_assay(probe, range(3), os.path.join(workdir, "dms")) == [2, -1, -1]
+    assert run_sharded.planned_rows(probe, range(3), os.path.join(workdir, "dms"), 0, 1) == ([2, 12, 0], [True, False, False])
     argv = _tranception_args(workdir, "optimal", False)
     cli_part = argv[argv.index("--") + 1:]
     cli_part[cli_part.index("--output_scores_folder") + 1] = os.path.join(workdir, "out1")
@@ -310,6 +317,62 @@ def test_retrieval_prior_is_built_once_for_the_ranks_that_share_an_assay(tmp_pat
         assert p.exitcode == 0
     assert len([f for f in os.listdir(cache) if f.startswith("built_by_")]) == 1
     assert all(r[1:] == res[0][1:] for r in res) and res[0][1] == [[0.25, 1.25, 2.25], [3.25, 4.25, 5.25]]
+
+
+def _failing_prior_worker(rank, cache, q):
+    from proteingym_amd import run_sharded
+
+    class P:
+        @staticmethod
+        def build_retrieval(r):
+            import time as _t
+            open(os.path.join(cache, f"built_by_{rank}"), "w").close()
+            _t.sleep(0.5)
+            raise FileNotFoundError("no alignment for this assay")
+    t0 = time.time()
+    try:
+        run_sharded.shared_retrieval(P, dict(MSA_start=1, MSA_end=3), cache, "job_T1", wait_s=600.0)
+        q.put((rank, "no error", time.time() - t0))
+    except BaseException as e:
+        q.put((rank, f"{type(e).__name__}: {e}", time.time() - t0))
+
+
+def test_failing_retrieval_builder_fails_the_waiting_ranks_at_once(tmp_path):
+    """A builder that raises publishes <tag>.failed: the ranks waiting for its prior raise the same message within the poll
+    interval (not after wait_s, and without rebuilding into the same deterministic error)."""
+    cache = str(tmp_path / "cache")
+    os.makedirs(cache)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_failing_prior_worker, args=(r, cache, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert len([f for f in os.listdir(cache) if f.startswith("built_by_")]) == 1          # nobody rebuilt
+    assert all("no alignment for this assay" in r[1] for r in res), res
+    assert max(r[2] for r in res) < 30.0
+
+
+def test_retrieval_waiter_takes_over_from_a_dead_builder(tmp_path):
+    """A lock whose pid is gone (builder killed) does not cost the waiter wait_s: it builds the prior itself."""
+    from proteingym_amd import run_sharded
+    cache = str(tmp_path / "cache")
+    os.makedirs(cache)
+    dead = mp.get_context("spawn").Process(target=int)
+    dead.start()
+    dead.join()
+    open(os.path.join(cache, "job_T2.lock"), "w").write(str(dead.pid))
+
+    class P:
+        @staticmethod
+        def build_retrieval(r):
+            return dict(log_prior=np.ones((2, 3), np.float32), MSA_start=1, MSA_end=3, weight=0.6)
+    t0 = time.time()
+    out = run_sharded.shared_retrieval(P, dict(MSA_start=1, MSA_end=3), cache, "job_T2", wait_s=600.0)
+    assert time.time() - t0 < 30.0 and out["log_prior"].shape == (2, 3)
 
 
 def test_tranception_chunk_plan_balances_the_real_table():

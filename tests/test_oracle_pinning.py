@@ -1158,3 +1158,63 @@ def test_filter_msa_vs_live_reference(tmp_path, monkeypatch):
     assert 1 < kept < 60 and ">TARGET-PROT/1-50" in seen["ref"][1]                # filtered; headers went through tr and ucase too
     with pytest.raises(RuntimeError, match="hhfilter"):
         pmsa.process_msa(filename=str(tmp_path / "mine" / "fam.a2m"), weight_filename=None, filter_msa=True, path_to_hhfilter=str(tmp_path / "nowhere"))
+
+
+@pytest.mark.skipif(not rh.reference_available(), reason="/root/reference not present (GPU box)")
+def test_tranception_host_helpers_vs_live_reference():
+    """The column-wise helpers of tranception.py against the reference's per-string functions (scoring_utils.py:16-31,47-69): mutated
+    sequences incl. repeated positions and negative indices, the two assertion texts in the reference's order of checks, windows at
+    every position of proteins around the context length, and the random replacement consuming numpy's stream like the reference."""
+    from proteingym_amd import synthetic, tranception as ptr
+    rh.load_reference_tranception()
+    from tranception.utils import scoring_utils as ref
+    seq, muts, _ = synthetic.random_assay(seed=3, L=90, n_single=60, n_multi=140)
+    w0 = seq[4]
+    muts += [f"{w0}5A:{w0}5C", f"{seq[-1]}0G", f"{seq[9]}10W:{seq[0]}1Y:{seq[9]}10H"]        # same position twice; position 0 = index -1
+    assert ptr.mutated_sequences(seq, muts) == [ref.get_mutated_sequence(seq, m) for m in muts]
+    assert ptr.get_mutated_sequence(seq, muts[7], start_idx=1) == ref.get_mutated_sequence(seq, muts[7], start_idx=1)
+    other = "A" if seq[2] != "A" else "C"
+    for bad in ([muts[0], f"{other}3G"], [f"{seq[2]}3B", muts[1]], [f"{seq[2]}3G:{other}3G:{seq[4]}5B"], [f"{seq[2]}3B:{other}3G"]):
+        with pytest.raises(AssertionError) as want:
+            [ref.get_mutated_sequence(seq, m) for m in bad]
+        with pytest.raises(AssertionError) as got:
+            ptr.mutated_sequences(seq, bad)
+        assert str(got.value) == str(want.value)
+    with pytest.raises(IndexError):
+        ptr.mutated_sequences(seq, [f"{seq[0]}500A"])
+    for n, w in ((50, 1022), (1022, 1022), (1023, 1022), (1500, 1022), (77, 20), (78, 21)):
+        pos = np.arange(n)
+        want = np.array([ref.get_optimal_window(int(p), n, w) for p in pos])
+        assert np.array_equal(ptr.optimal_windows(pos, n, w), want)
+        assert all(ptr.get_optimal_window(int(p), n, w) == list(want[p]) for p in (0, n // 2, n - 1))
+    text = "MXKBXZJAXXB"
+    for ch, choices in (("X", "ACDEFGHIKLMNPQRSTVWY"), ("B", "DN"), ("J", "IL"), ("Q", "EQ")):
+        np.random.seed(11)
+        want = ref.sequence_replace_single(text, ch, choices)
+        want_next = np.random.random()
+        np.random.seed(11)
+        assert ptr.sequence_replace_single(text, ch, choices) == want
+        assert np.random.random() == want_next or ch == "Q"           # no occurrence: the reference still calls choice(size=0)
+
+
+@pytest.mark.skipif(not rh.reference_available(), reason="/root/reference not present (GPU box)")
+def test_msa_prior_ragged_alignment_like_the_live_reference(tmp_path):
+    """Rows shorter than the query: the reference tolerates them without the similarity filter (their tail holds no counts) and fails
+    with ValueError in the filter's np.dot; rows longer than MSA_end - MSA_start with residues there: IndexError in both."""
+    from proteingym_amd import tranception as ptr
+    rh.load_reference_tranception()
+    from tranception.utils import msa_utils
+    a2m = tmp_path / "r.a2m"
+    a2m.write_text(">Q/1-12\nACDEFGHIKLMN\n>a\nACDEFGHI\n>b\nAC-EFGHIKLMN\n>c\nACD\n")
+    kw = dict(MSA_data_file=str(a2m), MSA_weight_file_name=None, MSA_start=0, MSA_end=12, len_target_seq=14, vocab=ptr.VOCAB)
+    want = msa_utils.get_msa_prior(filter_MSA=False, verbose=False, **kw)
+    assert np.array_equal(ptr.get_msa_prior(str(a2m), None, 0, 12, 14, filter_MSA=False), want)
+    with pytest.raises(ValueError):
+        msa_utils.get_msa_prior(filter_MSA=True, verbose=False, **kw)
+    with pytest.raises(ValueError):
+        ptr.get_msa_prior(str(a2m), None, 0, 12, 14, filter_MSA=True)
+    with pytest.raises(IndexError):
+        msa_utils.get_msa_prior(MSA_data_file=str(a2m), MSA_weight_file_name=None, MSA_start=0, MSA_end=8, len_target_seq=14, vocab=ptr.VOCAB,
+                                filter_MSA=False, verbose=False)
+    with pytest.raises(IndexError):
+        ptr.get_msa_prior(str(a2m), None, 0, 8, 14, filter_MSA=False)
