@@ -312,11 +312,20 @@ def secondary(precision, budget_note="bounded: every leg is a few seconds of GPU
         df["mutated_sequence"] = df["mutant"].apply(lambda m: ptr.get_mutated_sequence(sq, m))
         df = df.drop_duplicates("mutated_sequence")
         mt.score_mutants(DMS_data=df.iloc[:32], target_seq=sq)
-        t0 = time.perf_counter()
-        mt.score_mutants(DMS_data=df, target_seq=sq, scoring_mirror=True)
-        dt = time.perf_counter() - t0
+        timing = {}
+        for share in (False, True):                 # the reference's loop (every sequence in full), then prefix-shared: same bits
+            mt.share_prefix = share
+            mt.rows_forwarded = mt.rows_full = 0
+            t0 = time.perf_counter()
+            mt.score_mutants(DMS_data=df, target_seq=sq, scoring_mirror=True)
+            timing[share] = (time.perf_counter() - t0, mt.rows_forwarded, mt.rows_full)
+        dt = timing[True][0]
         out["tranception_l_one_batch"] = {"mutants_per_s": len(df) / dt, "seconds": dt, "mutants": len(df),
-                                          "what": "config 4 model shape (36 x 1280 x 20), 286-residue protein, both directions, no retrieval"}
+                                          "full_forward_mutants_per_s": len(df) / timing[False][0],
+                                          "rows_forwarded": timing[True][1], "rows_of_the_full_forwards": timing[True][2],
+                                          "what": "config 4 model shape (36 x 1280 x 20), 286-residue protein, both directions, no retrieval; "
+                                                  "prefix-shared (rows from the first mutated token's tile on; bit-identical to "
+                                                  "full_forward_mutants_per_s' path, which forwards every sequence in full like the reference)"}
         with tempfile.TemporaryDirectory() as d:
             rng = np.random.default_rng(11)
             n_seq, aa = 4000, np.array(list(synthetic.AA))
@@ -343,11 +352,13 @@ def secondary(precision, budget_note="bounded: every leg is a few seconds of GPU
             mt.retrieval = ptr.build_retrieval(dict(MSA_filename=os.path.join(d, "synth.a2m"), MSA_weight_file_name=wfile, MSA_start=0,
                                                     MSA_end=L_BLAT, full_protein_length=L_BLAT, retrieval_inference_weight=0.6))
             t_p = time.perf_counter() - t0 - t_w
+            mt.rows_forwarded = mt.rows_full = 0
             res = mt.score_mutants(DMS_data=full, target_seq=sq, scoring_mirror=True)
             dt = time.perf_counter() - t0
         out["tranception_l_whole_assay_with_retrieval"] = {
             "mutants_per_s": len(full) / dt, "seconds": dt, "mutants": len(full), "scored_sequences": int(len(res)),
             "sequence_weights_s": t_w, "prior_s": t_p, "scoring_s": dt - t_w - t_p,
+            "rows_forwarded": mt.rows_forwarded, "rows_of_the_full_forwards": mt.rows_full,
             "tokens_per_s": 2 * len(res) * (L_BLAT + 2) / max(dt - t_w - t_p, 1e-9),
             "what": f"config 4 model shape, BLAT-shaped assay ({len(full)} rows), both directions, inference-time retrieval on a synthetic {n_seq}-sequence "
                     "alignment (weights by the HIP pair-count kernel, prior fused on the device)"}

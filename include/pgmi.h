@@ -205,6 +205,12 @@ int pgmi_profile_get(pgmi_model* m, int kernel_class, double* ms, int64_t* launc
 int pgmi_profile_reset(pgmi_model* m);
 int pgmi_synchronize(pgmi_model* m);
 
+/* Test hooks of the GEMM launchers (bit-neutral: they only change how a launch is cut into work items / row chunks):
+ * "gemm_half_tail" (0: no half-height tail items; default 1), "gemm_max_rows" (> 0: cut every launch into row chunks of at most
+ * that many rows).  The library reads PGMI_GEMM_HALF_TAIL / PGMI_GEMM_MAX_ROWS when a model is created (and at the model-less
+ * pgmi_op_* / pgmi_bench_* entries); this call changes them for a live model.  Process-wide; returns PGMI_EINVAL for another name. */
+int pgmi_set_option(const char* name, int64_t value);
+
 /* ---- single ops (numerics tests compare each against the torch op it replaces) -------------
  * All pointers are host; each call uploads, runs the production kernel, downloads. */
 int pgmi_op_layernorm(int device, const float* x, const float* w, const float* b,
@@ -237,6 +243,20 @@ int pgmi_tr_token_logprobs(pgmi_model* m, const int32_t* tokens, int B, int T, f
 int pgmi_tr_sequence_loglik(pgmi_model* m, const int32_t* tokens, const int32_t* lens, int B, int T,
                             const float* log_prior, int P, const int32_t* prior_a0, const int32_t* prior_row0,
                             const int32_t* prior_n, const int32_t* prior_flip, float alpha, float* out);
+/* pgmi_tr_sequence_loglik_shared: the same quantity for B sequences of EXACTLY T tokens each (no padding), computed with the work
+ *   the reference's loop repeats shared: the reference forwards every mutated sequence in full, once per reading direction
+ *   (tranception/utils/scoring_utils.py:97-128 inside :77-150; model_pytorch.py:878-928), although the model is causal (attention
+ *   model_pytorch.py:155-183, depth-wise convolution :73-88) and a mutated sequence equals the wild type up to its first mutated token.
+ *   ref[b] names the sequence of this call whose prefix sequence b shares (its "root": the wild type cut to the same window); a root
+ *   has ref[b] == b and is forwarded in full.  For every other sequence only the rows from the 32-token tile of its first difference
+ *   from its root on are forwarded; keys, values, convolution history and log-probability rows before that are the root's.  Every row
+ *   goes through the same kernels with the same inputs in the same order as in pgmi_tr_sequence_loglik: out[b] has the same bits.
+ *   token_logprobs (optional, f32 [B,T,V]): the rows pgmi_tr_token_logprobs would return.  rows_forwarded (optional): token rows that
+ *   went through the network (B*T for the unshared call). */
+int pgmi_tr_sequence_loglik_shared(pgmi_model* m, const int32_t* tokens, const int32_t* ref, int B, int T,
+                                   const float* log_prior, int P, const int32_t* prior_a0, const int32_t* prior_row0,
+                                   const int32_t* prior_n, const int32_t* prior_flip, float alpha, float* out,
+                                   float* token_logprobs, int64_t* rows_forwarded);
 
 /* Tuning utility: times `iters` launches of the production GEMM (device-resident random operands,
  * HIP events) for one shape; variant selects the launch parameters (negative or below 1000 = library default;

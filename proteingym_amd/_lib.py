@@ -63,11 +63,14 @@ SIGNATURES = [
     ("pgmi_profile_get", C.c_int, [C.c_void_p, C.c_int, _f64p, _i64p, _f64p, _f64p]),
     ("pgmi_profile_reset", C.c_int, [C.c_void_p]),
     ("pgmi_synchronize", C.c_int, [C.c_void_p]),
+    ("pgmi_set_option", C.c_int, [C.c_char_p, C.c_int64]),
     ("pgmi_op_layernorm", C.c_int, [C.c_int, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_float, _f32p]),
     ("pgmi_op_gemm", C.c_int, [C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),
     ("pgmi_tr_token_logprobs", C.c_int, [C.c_void_p, _i32p, C.c_int, C.c_int, _f32p]),
     ("pgmi_tr_sequence_loglik", C.c_int, [C.c_void_p, _i32p, _i32p, C.c_int, C.c_int, _f32p, C.c_int,
                                           _i32p, _i32p, _i32p, _i32p, C.c_float, _f32p]),
+    ("pgmi_tr_sequence_loglik_shared", C.c_int, [C.c_void_p, _i32p, _i32p, C.c_int, C.c_int, _f32p, C.c_int,
+                                                 _i32p, _i32p, _i32p, _i32p, C.c_float, _f32p, _f32p, _i64p]),
     ("pgmi_bench_gemm", C.c_int, [C.c_int] * 9 + [_f64p]),
     ("pgmi_bench_gemm_ab", C.c_int, [C.c_int] * 7 + [_i32p, C.c_int, C.c_int, C.c_int, _f64p]),
     ("pgmi_op_attention", C.c_int, [C.c_int, C.c_int, _f32p, _i32p, C.c_int, C.c_int, C.c_int, C.c_int, _f32p]),

@@ -71,6 +71,8 @@ struct pgmi_model {
     float *tr_lm_head = nullptr, *tr_zero_bias = nullptr, *tr_slopes = nullptr;   // Tranception head / ALiBi slopes
     float* tr_prior = nullptr;                          // device copy of the retrieval log-prior [P,V]
     int tr_prior_rows = 0;
+    int32_t* tr_meta = nullptr;                         // prefix-shared scoring: the chunk's index arrays (TrChunk)
+    size_t tr_meta_cap = 0;
     // MSA Transformer
     float* msa_pe = nullptr;                            // msa_position_embedding [1024, D]
     float* xt = nullptr;                                // residual stream in column-major token order
@@ -783,6 +785,121 @@ int run_msa(pgmi_model* m, int R, int C, int keep_col = -1, bool* compacted = nu
     return PGMI_OK;
 }
 
+// ---- Tranception: prefix-shared scoring ------------------------------------------------------------
+// The reference forwards every mutated sequence in full, in both reading directions (scoring_utils.py:77-150, model_pytorch.py:878-928).
+// The model is causal (attention model_pytorch.py:155-183; depth-wise convolution :73-88): every hidden state of a sequence before its
+// first token that differs from the wild type IS the wild type's.  One chunk of work = ROOT sequences forwarded in full plus sequences
+// that own only the rows from seq_a on (seq_a = the 32-token tile of the first differing token): LayerNorm and the four GEMMs of a
+// layer run on the packed suffix rows (row-local), the convolution takes its six rows of history and the attention its earlier key
+// tiles from the root's rows of the same launch, and the per-sequence reduction reads the root's log-probability rows before seq_a.
+// Every row is computed by the same kernels from the same inputs in the same order as in a full forward: the same bits.
+struct TrChunk {
+    std::vector<int32_t> seq;                         // call-level index of every chunk-local sequence (a root may repeat over chunks)
+    std::vector<int32_t> off, a, root;                // packed row of token a; first owned token; chunk-local index of the root
+    std::vector<uint32_t> vt;                         // V^T block offset (halfs per plane)
+    std::vector<int32_t> tile_seq, tile_j, blk_seq, blk_j, tokens;
+    int rows = 0, padded = 0;
+    double att_flops = 0;
+    int add(int call_index, const int32_t* tok, int T, int a0, int root_local, int D) {
+        const int local = (int)seq.size(), n = T - a0;
+        seq.push_back(call_index);
+        off.push_back(rows);
+        a.push_back(a0);
+        root.push_back(root_local < 0 ? local : root_local);
+        vt.push_back((uint32_t)((size_t)padded * (size_t)D));
+        for (int j = 0; j < (n + 31) / 32; ++j) { tile_seq.push_back(local); tile_j.push_back(j); }
+        for (int j = 0; j < (n + 127) / 128; ++j) { blk_seq.push_back(local); blk_j.push_back(j); }
+        tokens.insert(tokens.end(), tok + a0, tok + T);
+        rows += n;
+        padded += (n + 31) / 32 * 32;
+        att_flops += 2.0 * D * ((double)T * T - (double)a0 * a0);         // 4 D per (query, visible key) pair
+        return local;
+    }
+};
+
+// Runs one chunk: tokens (packed), index arrays and the retrieval arguments are uploaded, the forward leaves the suffix rows'
+// log-probabilities in m->lp [rows, V] and the per-sequence reductions in m->denom [sequences].
+int run_tranception_shared(pgmi_model* m, TrChunk& ck, int T, const float* prior_dev, const int32_t* a0, const int32_t* r0,
+                           const int32_t* pn, const int32_t* fl, float alpha) {
+    const pgmi_config& c = m->cfg;
+    const int M = ck.rows, D = c.embed_dim, F = c.ffn_dim, H = c.heads, V = c.vocab, S = (int)ck.seq.size();
+    hipStream_t s = m->stream;
+    // attention blocks with the most key tiles first: the launch's tail is made of the short ones
+    {
+        std::vector<int> order(ck.blk_seq.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
+        auto keys = [&](int i) { return std::min(T, ck.a[ck.blk_seq[i]] + (ck.blk_j[i] + 1) * 128); };
+        std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return keys(x) > keys(y); });
+        std::vector<int32_t> bs(order.size()), bj(order.size());
+        for (size_t i = 0; i < order.size(); ++i) { bs[i] = ck.blk_seq[order[i]]; bj[i] = ck.blk_j[order[i]]; }
+        ck.blk_seq.swap(bs);
+        ck.blk_j.swap(bj);
+    }
+    const size_t nt = ck.tile_seq.size(), nb = ck.blk_seq.size();
+    const size_t need = (size_t)8 * S + 2 * nt + 2 * nb;
+    int rc = ensure_cap(m, &m->tr_meta, &m->tr_meta_cap, std::max(need, (size_t)1 << 16));
+    if (rc) return rc;
+    std::vector<int32_t> meta(need);
+    int32_t* p = meta.data();
+    auto put = [&](const void* src, size_t n) { memcpy(p, src, n * 4); p += n; return (int32_t*)(m->tr_meta + (p - n - meta.data())); };
+    std::vector<int32_t> pa(S, 0), pr(S, 0), pc(S, 0), pf(S, 0);
+    if (prior_dev)
+        for (int i = 0; i < S; ++i) { pa[i] = a0[ck.seq[i]]; pr[i] = r0[ck.seq[i]]; pc[i] = pn[ck.seq[i]]; pf[i] = fl[ck.seq[i]]; }
+    AttRagged rg{};
+    rg.seq_off = put(ck.off.data(), S);
+    rg.seq_a = put(ck.a.data(), S);
+    rg.seq_root = put(ck.root.data(), S);
+    rg.seq_vt = reinterpret_cast<const uint32_t*>(put(ck.vt.data(), S));
+    const int32_t* d_pa = put(pa.data(), S);
+    const int32_t* d_pr = put(pr.data(), S);
+    const int32_t* d_pc = put(pc.data(), S);
+    const int32_t* d_pf = put(pf.data(), S);
+    rg.tile_seq = put(ck.tile_seq.data(), nt);
+    rg.tile_j = put(ck.tile_j.data(), nt);
+    rg.blk_seq = put(ck.blk_seq.data(), nb);
+    rg.blk_j = put(ck.blk_j.data(), nb);
+    rg.n_tiles = (int)nt;
+    rg.n_blocks = (int)nb;
+    PGMI_HIP(hipMemcpyAsync(m->tr_meta, meta.data(), need * 4, hipMemcpyHostToDevice, s));
+    PGMI_HIP(hipMemcpyAsync(m->tokens, ck.tokens.data(), (size_t)M * 4, hipMemcpyHostToDevice, s));
+    PGMI_HIP(hipStreamSynchronize(s));                 // the host vectors go out of scope with the caller's chunk
+    m->last_B = m->last_T = 0;                          // the V^T planes now hold another layout: the dense path clears them again
+    { ProfScope ps(m, PGMI_K_EMBED, 0, (double)M * D * 4);
+      launch_gather_rows(m->embed_tokens, m->tokens, M, D, m->x, s); }
+    const double ln_bytes = 2.0 * M * D * 4;
+    for (int l = 0; l < c.layers; ++l) {
+        const Layer& L = m->layers[l];
+        { ProfScope ps(m, PGMI_K_LAYERNORM, 0, ln_bytes);
+          launch_layernorm16(m->x, L.ln1_w, L.ln1_b, M, D, m->ln_eps, m->h16, m->h16_plane, 1, s); }
+        { ProfScope ps(m, PGMI_K_GEMM_QKV, 2.0 * M * 3 * D * D, 0);
+          rc = linear(m, nullptr, m->h16, m->h16_plane, nullptr, L.wqkv16, L.bqkv, nullptr, m->qkv, nullptr, 0, M, 3 * D, D, EPI_NONE);
+          if (rc) return rc; }
+        { ProfScope ps(m, PGMI_K_ATTENTION, ck.att_flops, 0);
+          rc = launch_attention_tr_ragged(m->qkv, L.conv, m->tr_slopes, T, H, rg, m->qk16, m->qk16_plane, m->vt16, m->vt16_plane,
+                                          m->h16, m->h16_plane, s);
+          if (rc) return rc; }
+        { ProfScope ps(m, PGMI_K_GEMM_OUT, 2.0 * M * D * D, 0);
+          rc = linear(m, nullptr, m->h16, m->h16_plane, nullptr, L.wo16, L.bo, m->x, m->x, nullptr, 0, M, D, D, EPI_NONE);
+          if (rc) return rc; }
+        { ProfScope ps(m, PGMI_K_LAYERNORM, 0, ln_bytes);
+          launch_layernorm16(m->x, L.ln2_w, L.ln2_b, M, D, m->ln_eps, m->h16, m->h16_plane, 1, s); }
+        { ProfScope ps(m, PGMI_K_GEMM_FC1, 2.0 * M * F * D, 0);
+          rc = linear(m, nullptr, m->h16, m->h16_plane, nullptr, L.w116, L.b1, nullptr, nullptr, m->g16, m->g16_plane, M, F, D, EPI_SQRELU);
+          if (rc) return rc; }
+        { ProfScope ps(m, PGMI_K_GEMM_FC2, 2.0 * M * F * D, 0);
+          rc = linear(m, nullptr, m->g16, m->g16_plane, nullptr, L.w216, L.b2, m->x, m->x, nullptr, 0, M, D, F, EPI_NONE);
+          if (rc) return rc; }
+    }
+    { ProfScope ps(m, PGMI_K_HEAD, 2.0 * M * D * V, 0);
+      launch_layernorm(m->x, m->lna_w, m->lna_b, M, D, m->ln_eps, m->h, s);
+      launch_vocab_logsoftmax(m->h, m->tr_lm_head, m->tr_zero_bias, M, D, V, m->lp, m->nonfinite, s); }
+    { ProfScope ps(m, PGMI_K_SCORE, 0, (double)S * T * 8);
+      launch_seq_loglik_ragged(m->lp, m->tokens, rg.seq_off, rg.seq_a, rg.seq_root, S, T, V, prior_dev, d_pa, d_pr, d_pc, d_pf, alpha,
+                               m->denom, s); }
+    PGMI_HIP(hipGetLastError());
+    return PGMI_OK;
+}
+
 // fp16 range check for the 16-bit modes: the vocabulary kernel raises the flag when a computed
 // log-probability is NaN/inf (an activation exceeded fp16's 65504 upstream).
 int check_nonfinite(pgmi_model* m) {
@@ -965,6 +1082,7 @@ int pgmi_model_create(const pgmi_config* cfg, const float* w, int64_t n_weights,
         PGMI_HIP(hipMemset(m->vt16, 0, m->vt16_plane * 2 * sizeof(unsigned short)));
     }
     m->keep_rows = env_int("PGMI_KEEP_ROWS", 1);
+    gemm_options_from_env();                             // the GEMM launchers' test hooks: read here, not per launch
     m->gemm_variant = env_int("PGMI_GEMM_VARIANT", 0);   // tuning only (gemm_f16.hip set_tune); below 1000 = the product configuration
     if (cfg->arch == PGMI_ARCH_MSA) {
         TRY(dev_alloc(m->allocs, &m->xt, R * D));
@@ -1006,6 +1124,13 @@ void pgmi_model_destroy(pgmi_model* m) {
 }
 
 int pgmi_model_device(const pgmi_model* m) { return m ? m->device : -1; }
+
+int pgmi_set_option(const char* name, int64_t value) {
+    if (!name) { set_error("null option name"); return PGMI_EINVAL; }
+    const int rc = gemm_set_option(name, (long long)value);
+    if (rc) set_error("unknown option '%s' (gemm_half_tail, gemm_max_rows)", name);
+    return rc;
+}
 
 int pgmi_synchronize(pgmi_model* m) {
     if (!m) { set_error("null model"); return PGMI_EINVAL; }
@@ -1446,6 +1571,7 @@ int pgmi_op_gemm(int device, int precision, const float* A, const float* W, cons
     if (precision != PGMI_PREC_FP32 && precision != PGMI_PREC_F16X3 && precision != PGMI_PREC_BF16) { set_error("unknown precision %d", precision); return PGMI_EINVAL; }
     if (pgmi_device_count() <= 0) { set_error("no HIP device visible"); return PGMI_ENODEV; }
     PGMI_HIP(hipSetDevice(device));
+    gemm_options_from_env();                             // a model-less entry of the tests: the hooks are read per call here
     std::vector<void*> pool;
     float *dA, *dW = nullptr, *dB = nullptr, *dR = nullptr, *dC;
     int rc = 0;
@@ -1581,11 +1707,106 @@ int pgmi_tr_sequence_loglik(pgmi_model* m, const int32_t* tokens, const int32_t*
     return check_nonfinite(m);
 }
 
+int pgmi_tr_sequence_loglik_shared(pgmi_model* m, const int32_t* tokens, const int32_t* ref, int B, int T,
+                                   const float* log_prior, int P, const int32_t* prior_a0, const int32_t* prior_row0,
+                                   const int32_t* prior_n, const int32_t* prior_flip, float alpha, float* out, float* token_logprobs,
+                                   int64_t* rows_forwarded) {
+    if (!m || !tokens || !ref || !out || B <= 0 || T <= 0) { set_error("bad argument"); return PGMI_EINVAL; }
+    if (m->cfg.arch != PGMI_ARCH_TRANCEPTION) { set_error("not a Tranception model"); return PGMI_EINVAL; }
+    if (log_prior && (!prior_a0 || !prior_row0 || !prior_n || !prior_flip || P <= 0)) { set_error("incomplete retrieval arguments"); return PGMI_EINVAL; }
+    if (T > m->cfg.max_positions) { set_error("sequence of %d tokens exceeds the model context n_ctx=%d", T, m->cfg.max_positions); return PGMI_EINVAL; }
+    const int V = m->cfg.vocab, D = m->cfg.embed_dim;
+    const int Tpad = (T + 31) / 32 * 32;
+    if (2 * Tpad > m->max_rows) { set_error("T=%d exceeds workspace rows %d", T, m->max_rows); return PGMI_EINVAL; }
+    for (int b = 0; b < B; ++b) {
+        if (ref[b] < 0 || ref[b] >= B || ref[ref[b]] != ref[b]) { set_error("ref[%d]=%d is not a root (a sequence that is its own reference)", b, ref[b]); return PGMI_EINVAL; }
+        for (int t = 0; t < T; ++t) {
+            const int tk = tokens[(size_t)b * T + t];
+            if (tk < 0 || tk >= V) { set_error("token id %d out of range at [%d,%d]", tk, b, t); return PGMI_EINVAL; }
+        }
+        if (log_prior && prior_n[b] > 0 &&
+            (prior_a0[b] < 0 || prior_a0[b] + prior_n[b] > T - 1 || prior_row0[b] < 0 || prior_row0[b] + prior_n[b] > P)) {
+            set_error("retrieval slice of sequence %d out of range", b);
+            return PGMI_EINVAL;
+        }
+    }
+    PGMI_HIP(hipSetDevice(m->device));
+    hipStream_t s = m->stream;
+    if (log_prior) {
+        if (P > m->tr_prior_rows) {
+            float* np_ = nullptr;
+            int rc = dev_alloc(m->allocs, &np_, (size_t)P * V);
+            if (rc) return rc;
+            m->tr_prior = np_;
+            m->tr_prior_rows = P;
+        }
+        PGMI_HIP(hipMemcpyAsync(m->tr_prior, log_prior, (size_t)P * V * 4, hipMemcpyHostToDevice, s));
+    }
+    // first owned token of every sequence: the 32-token tile of its first difference from its root (a copy of the root: the last tile)
+    std::vector<int> a0(B, 0);
+    std::vector<std::vector<int>> members(B);
+    std::vector<int> roots;
+    for (int b = 0; b < B; ++b) {
+        if (ref[b] == b) { roots.push_back(b); continue; }
+        const int32_t *x = tokens + (size_t)b * T, *y = tokens + (size_t)ref[b] * T;
+        int p = 0;
+        while (p < T && x[p] == y[p]) ++p;
+        a0[b] = std::min(p, T - 1) / 32 * 32;
+        members[ref[b]].push_back(b);
+    }
+    const int cap = m->max_rows;
+    int64_t forwarded = 0;
+    std::vector<float> lp_host;
+    TrChunk ck;
+    auto flush = [&]() -> int {
+        if (ck.seq.empty()) return PGMI_OK;
+        int rc = run_tranception_shared(m, ck, T, log_prior ? m->tr_prior : nullptr, prior_a0, prior_row0, prior_n, prior_flip, alpha);
+        if (rc) return rc;
+        const int S = (int)ck.seq.size();
+        std::vector<float> res(S);
+        PGMI_HIP(hipMemcpyAsync(res.data(), m->denom, (size_t)S * 4, hipMemcpyDeviceToHost, s));
+        if (token_logprobs) {
+            lp_host.resize((size_t)ck.rows * V);
+            PGMI_HIP(hipMemcpyAsync(lp_host.data(), m->lp, lp_host.size() * 4, hipMemcpyDeviceToHost, s));
+        }
+        PGMI_HIP(hipStreamSynchronize(s));
+        for (int i = 0; i < S; ++i) out[ck.seq[i]] = res[i];
+        if (token_logprobs)
+            for (int i = 0; i < S; ++i) {
+                float* dst = token_logprobs + (size_t)ck.seq[i] * T * V;
+                const int a = ck.a[i], r = ck.root[i];
+                if (a > 0) memcpy(dst, lp_host.data() + (size_t)ck.off[r] * V, (size_t)a * V * 4);
+                memcpy(dst + (size_t)a * V, lp_host.data() + (size_t)ck.off[i] * V, (size_t)(T - a) * V * 4);
+            }
+        forwarded += ck.rows;
+        ck = TrChunk();
+        return PGMI_OK;
+    };
+    for (int r : roots) {
+        const int first = members[r].empty() ? 0 : (T - a0[members[r][0]] + 31) / 32 * 32;
+        if (!ck.seq.empty() && ck.padded + Tpad + first > cap) { int rc = flush(); if (rc) return rc; }
+        int rl = ck.add(r, tokens + (size_t)r * T, T, 0, -1, D);
+        for (int b : members[r]) {
+            if (ck.padded + (T - a0[b] + 31) / 32 * 32 > cap) {
+                int rc = flush();
+                if (rc) return rc;
+                rl = ck.add(r, tokens + (size_t)r * T, T, 0, -1, D);           // the root again: its rows serve the rest of the group
+            }
+            ck.add(b, tokens + (size_t)b * T, T, a0[b], rl, D);
+        }
+    }
+    int rc = flush();
+    if (rc) return rc;
+    if (rows_forwarded) *rows_forwarded = forwarded;
+    return check_nonfinite(m);
+}
+
 int pgmi_bench_gemm_ab(int device, int precision, int M, int N, int K, int epilogue, int split_out, const int* variants,
                        int n_variants, int rounds, int iters, double* ms_out) {
     if (M <= 0 || N <= 0 || K <= 0 || iters <= 0 || rounds <= 0 || n_variants <= 0 || !variants || !ms_out) { set_error("bad argument"); return PGMI_EINVAL; }
     if (pgmi_device_count() <= 0) { set_error("no HIP device visible"); return PGMI_ENODEV; }
     PGMI_HIP(hipSetDevice(device));
+    gemm_options_from_env();
     std::vector<void*> pool;
     auto cleanup = [&]() { for (void* p : pool) hipFree(p); };
     std::vector<float> hA((size_t)M * K), hW((size_t)N * K), hb(N);

@@ -116,14 +116,26 @@ __global__ __launch_bounds__(256) void qkv_prep_kernel(
 // needs (6 rows of causal history) are staged ONCE in LDS with coalesced float4 loads and the 7-tap
 // filters are read from an LDS copy, instead of 7 strided global loads per output and per-tap scalar weight
 // loads (computing the taps from global memory ran at 2.3 TB/s; this pass is HBM-bound: 4 B in + 4 B out per element).
+// RAG (see RagMap below): blockIdx.x walks a list of (sequence, 32-token tile of its suffix); the six rows of causal history before a
+// suffix's first tile are its ROOT's rows (same tokens up to there: the same pre-convolution q | k | v, bit for bit).
+template <bool RAG>
 __global__ __launch_bounds__(256) void qkv_prep_conv_kernel(
     const float* __restrict__ qkv, const float* __restrict__ conv, int T, int H, int Tp,
-    unsigned short* __restrict__ qk16, size_t qk_plane, unsigned short* __restrict__ vt16, size_t vt_plane) {
+    unsigned short* __restrict__ qk16, size_t qk_plane, unsigned short* __restrict__ vt16, size_t vt_plane,
+    const int32_t* __restrict__ seq_off, const int32_t* __restrict__ seq_a, const int32_t* __restrict__ seq_root,
+    const uint32_t* __restrict__ seq_vt, const int32_t* __restrict__ ent_seq, const int32_t* __restrict__ ent_j) {
     constexpr int RSTR = 196;                                 // 192 floats (q|k|v of one head) + pad
     constexpr int NLD = (38 * 48 + 255) / 256;                // float4 loads per thread: all issued before the first LDS store
     __shared__ __attribute__((aligned(16))) float raw[38 * RSTR];
     __shared__ __attribute__((aligned(16))) float cwl[3 * 8 * 64];   // [which][tap (7 = bias)][d]
-    const int b = blockIdx.z, h = blockIdx.y, t0 = blockIdx.x * 32;
+    const int b = RAG ? ent_seq[blockIdx.x] : blockIdx.z, h = blockIdx.y;
+    // t0: absolute position of the tile's first token; row(t) = packed row of the sequence's token t (its own rows from a0 on, its
+    // root's before)
+    const int a0 = RAG ? seq_a[b] : 0;
+    const int t0 = RAG ? a0 + ent_j[blockIdx.x] * 32 : blockIdx.x * 32;
+    const int own0 = RAG ? seq_off[b] - a0 : b * T, root0 = RAG ? seq_off[seq_root[b]] : b * T;
+    auto rowof = [&](int t) -> size_t { return (size_t)((RAG && t < a0) ? root0 + t : own0 + t); };
+    const int Tpo = RAG ? (T - a0 + 31) / 32 * 32 : Tp;
     const int tid = threadIdx.x;
     const int D = H * kHeadDim;
     const size_t RS = (size_t)3 * D;
@@ -134,7 +146,7 @@ __global__ __launch_bounds__(256) void qkv_prep_conv_kernel(
         const int i = min(tid + 256 * k, 38 * 48 - 1);        // from clamped (always valid) addresses, zeroed afterwards: a load inside
         const int row = i / 48, seg = (i % 48) >> 4, c4 = i & 15;   // a per-lane `if` makes hipcc branch around every load and wait for it
         const int t = min(max(t0 - 6 + row, 0), T - 1);       // before the next one (8 serial round trips: measured 33 % slower than the rolled loop)
-        ld[k] = *reinterpret_cast<const f32x4*>(qkv + ((size_t)b * T + t) * RS + (size_t)seg * D + h * kHeadDim + c4 * 4);
+        ld[k] = *reinterpret_cast<const f32x4*>(qkv + rowof(t) * RS + (size_t)seg * D + h * kHeadDim + c4 * 4);
     }
     float cw[6];                                              // the head group's filters: 3 x 64 x 8 floats = 6 per thread, in flight with the rows
 #pragma unroll                                                // (a rolled loop waited for every one of them in turn: 6 serial round trips per workgroup)
@@ -188,7 +200,7 @@ __global__ __launch_bounds__(256) void qkv_prep_conv_kernel(
                 split_act(v1, hh[e], ll[e]);
                 split_act(v2, hh[4 + e], ll[4 + e]);
             }
-            unsigned short* dst = qk16 + ((size_t)b * T + t) * (2 * D) + (size_t)which * D + h * kHeadDim + 8 * c;
+            unsigned short* dst = qk16 + rowof(t) * (2 * D) + (size_t)which * D + h * kHeadDim + 8 * c;
             *reinterpret_cast<u32x4*>(dst) = u32x4{pack_h2(hh[0], hh[1]), pack_h2(hh[2], hh[3]), pack_h2(hh[4], hh[5]), pack_h2(hh[6], hh[7])};
             *reinterpret_cast<u32x4*>(dst + qk_plane) = u32x4{pack_h2(ll[0], ll[1]), pack_h2(ll[2], ll[3]), pack_h2(ll[4], ll[5]), pack_h2(ll[6], ll[7])};
         }
@@ -211,7 +223,8 @@ __global__ __launch_bounds__(256) void qkv_prep_conv_kernel(
             if (t0 + key >= T) y = 0.0f;
             split_act(y, hh[e], ll[e]);
         }
-        unsigned short* row = vt16 + (((size_t)b * H + h) * kHeadDim + d) * Tp + t0 + 8 * p;
+        unsigned short* row = RAG ? vt16 + (size_t)seq_vt[b] + ((size_t)h * kHeadDim + d) * Tpo + (t0 - a0) + 8 * p
+                                  : vt16 + (((size_t)b * H + h) * kHeadDim + d) * Tp + t0 + 8 * p;
         *reinterpret_cast<u32x4*>(row) = u32x4{pack_h2(hh[0], hh[1]), pack_h2(hh[2], hh[3]), pack_h2(hh[4], hh[5]), pack_h2(hh[6], hh[7])};
         *reinterpret_cast<u32x4*>(row + vt_plane) = u32x4{pack_h2(ll[0], ll[1]), pack_h2(ll[2], ll[3]), pack_h2(ll[4], ll[5]), pack_h2(ll[6], ll[7])};
     }
@@ -223,11 +236,27 @@ __global__ __launch_bounds__(256) void qkv_prep_conv_kernel(
 // (K / V^T read once instead of once per query block; every query tile of T = 288 in one block) -4 % / -36 %; the score MFMAs of key
 // tile kt + 1 issued inside the softmax of tile kt (own accumulators, 4-stage ring, 235 VGPRs) -3 ... -5 % at every shape.  Two
 // waves share a SIMD's matrix pipe AND its VALU issue: work moved between them, or between a wave's own phases, does not net.
-template <int WPB, int OUT, int NSTG, int DH = 64>
+// RAG (Tranception prefix-shared scoring, api.hip run_tranception_shared): the launch holds SUFFIXES of sequences of T tokens.  Sequence
+// b owns the packed rows [seq_off[b], seq_off[b] + T - seq_a[b]) = its tokens seq_a[b] .. T-1 (seq_a a multiple of 32) and its own V^T
+// block at seq_vt[b] (row pitch roundup(T - seq_a[b], 32)); the keys before seq_a[b] are those of its ROOT sequence seq_root[b], which
+// is in the same launch with seq_a = 0 (the model is causal: a sequence that equals its root up to token seq_a - 1 has the root's K and V
+// there, bit for bit).  Key tiles keep their ABSOLUTE alignment -- tile kt = keys 32 kt .. 32 kt + 31 -- and every query tile holds
+// the same 32 queries as in a full forward, so each row goes through the same tiles in the same order: the same bits.
+// blockIdx.x indexes a list of (sequence, query block) entries.
+struct RagMap {
+    const int32_t* seq_off;
+    const int32_t* seq_a;
+    const int32_t* seq_root;
+    const uint32_t* seq_vt;        // halfs, per plane
+    const int32_t* ent_seq;        // per entry of the launch's list (query blocks here, 32-token tiles in the prep pass)
+    const int32_t* ent_j;
+};
+
+template <int WPB, int OUT, int NSTG, int DH = 64, bool RAG = false>
 __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
     const unsigned short* __restrict__ qk16, size_t qk_plane, const unsigned short* __restrict__ vt16,
     size_t vt_plane, const int32_t* __restrict__ kv_len, const float* __restrict__ slopes, int T, int H,
-    int Tp, float* __restrict__ ctx, unsigned short* __restrict__ ctx16, size_t plane) {
+    int Tp, float* __restrict__ ctx, unsigned short* __restrict__ ctx16, size_t plane, RagMap rag) {
     constexpr float defer_thr = kAttDefer;
     // slopes != nullptr selects the Tranception flavour (tranception/model_pytorch.py:155-183): causal
     // mask (key <= query) and the grouped-ALiBi bias slope[h] * key added to the scaled scores.
@@ -243,13 +272,18 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
     constexpr int NS = DH / 16, ND = DH / 32;
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];   // [NSTG][STG_CH]
 
-    const int b = blockIdx.z, h = blockIdx.y;
+    const int b = RAG ? rag.ent_seq[blockIdx.x] : blockIdx.z, h = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: scalar branches, SGPR DMA bases
     const int r = lane & 31, kh = lane >> 5;
     const int D = H * DH;
-    const int Tk = kv_len ? kv_len[b] : T;
-    const int q0 = (blockIdx.x * WPB + wave) * 32;
+    const int Tk = (!RAG && kv_len) ? kv_len[b] : T;
+    // RAG: a0 = first token the sequence owns, row0 / rrow0 = packed row of ITS token a0 / of its root's token 0, kt0 = first own key tile
+    const int a0 = RAG ? rag.seq_a[b] : 0, kt0 = a0 / AKT;
+    const int qblk = RAG ? rag.ent_j[blockIdx.x] : (int)blockIdx.x;
+    const int row0 = RAG ? rag.seq_off[b] : b * T, rrow0 = RAG ? rag.seq_off[rag.seq_root[b]] : 0;
+    const int Tpo = RAG ? (T - a0 + 31) / 32 * 32 : Tp;            // row pitch of the sequence's own V^T block
+    const int q0 = a0 + (qblk * WPB + wave) * 32;                  // absolute position of the wave's first query
     const bool active = q0 < T;
     // (Two workgroups share a CU, one wave of each per SIMD.  Measured and not kept, profiles/r3: a static priority for the wave in
     // the odd hardware slot, -3 %; the lane <-> lane + 32 max exchange through LDS instead of v_permlane32_swap, -1.3 %; 8-byte
@@ -264,7 +298,7 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
     u32x4 qh[NS], ql[NS];
     if (!q_lds) {
         const int qrow = min(q0 + r, T - 1);
-        const unsigned short* qp = qk16 + ((size_t)b * T + qrow) * (2 * D) + h * DH + kh * 8;
+        const unsigned short* qp = qk16 + ((size_t)row0 + (qrow - a0)) * (2 * D) + h * DH + kh * 8;
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             qh[s] = *reinterpret_cast<const u32x4*>(qp + s * 16);
@@ -285,15 +319,20 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
     const size_t seq_halfs = (size_t)T * (2 * D), vt_halfs = (size_t)DH * Tp;
     const unsigned long long qk_bytes = std::min<unsigned long long>(0xFFFFFFFFull, (unsigned long long)qk_plane * 2ull + seq_halfs * 2ull);
     const unsigned long long vt_bytes = std::min<unsigned long long>(0xFFFFFFFFull, (unsigned long long)vt_plane * 2ull + vt_halfs * 2ull);
-    const __amdgpu_buffer_rsrc_t rsQK = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(qk16) + (size_t)b * seq_halfs, 0, (int)(unsigned int)qk_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsVT = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(vt16) + ((size_t)b * H + h) * vt_halfs, 0, (int)(unsigned int)vt_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsQK = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(qk16) + (size_t)row0 * (2 * D), 0, (int)(unsigned int)qk_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsVT = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short*>(vt16) + (RAG ? (size_t)rag.seq_vt[b] + (size_t)h * DH * Tpo : ((size_t)b * H + h) * vt_halfs), 0, (int)(unsigned int)vt_bytes, 0x00020000);
+    // RAG: the root's planes for the key tiles before kt0 (the root owns all of its T tokens: V^T row pitch Tp)
+    const __amdgpu_buffer_rsrc_t rsQKr = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(qk16) + (size_t)rrow0 * (2 * D), 0, (int)(unsigned int)qk_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsVTr = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<unsigned short*>(vt16) + (RAG ? (size_t)rag.seq_vt[rag.seq_root[b]] + (size_t)h * DH * Tp : (size_t)0), 0, (int)(unsigned int)vt_bytes, 0x00020000);
     // causal: keys beyond the block's last query tile are never needed (uniform bound for the block)
     const bool causal = slopes != nullptr;
-    const int last_q = min(T, (int)(blockIdx.x * WPB + WPB) * 32);
+    const int last_q = min(T, a0 + (qblk * WPB + WPB) * 32);
     const int nkt = causal ? (min(Tk, last_q) + AKT - 1) / AKT : (Tk + AKT - 1) / AKT;
     // voff_last: the same offsets for the LAST key tile with its K rows clamped to the sequence's last row (finite, masked by Tk) --
     // the only tile that can reach past row T-1, i.e. into the next sequence or past the end of the operand
-    int voff[NDMA], voff_last[NDMA], sbase[NDMA], sstep[NDMA], slot0[NDMA];
+    int voff[NDMA], voff_last[NDMA], voff_root[NDMA], sbase[NDMA], sstep[NDMA], slot0[NDMA];
     bool is_k[NDMA];
 #pragma unroll
     for (int i = 0; i < NDMA; ++i) {
@@ -304,27 +343,29 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
         if (is_k[i]) {
             const int p = wi / (KCH / 64), key = ((wi % (KCH / 64)) * 64 + lane) / KCPR;
             const int c = (lane % KCPR) ^ (DH == 64 ? ((key >> 1) & 7) : (key & 15));
-            voff[i] = key * (2 * D) * 2 + c * 16;
+            voff[i] = voff_root[i] = key * (2 * D) * 2 + c * 16;
             voff_last[i] = min(key, T - 1 - (nkt - 1) * AKT) * (2 * D) * 2 + c * 16;
             sbase[i] = (int)((unsigned int)p * (unsigned int)qk_plane * 2u + (unsigned int)(D + h * DH) * 2u);
             sstep[i] = AKT * (2 * D) * 2;
         } else {
             const int wv = wi - 2 * KCH / 64, p = wv / (VCH / 64), g = (wv % (VCH / 64)) * 64 + lane;
             const int d = g >> 2, c = (g & 3) ^ ((d >> 2) & 3);
-            voff[i] = voff_last[i] = d * Tp * 2 + c * 16;
+            voff[i] = voff_last[i] = d * Tpo * 2 + c * 16;
+            voff_root[i] = d * Tp * 2 + c * 16;
             sbase[i] = (int)((unsigned int)p * (unsigned int)vt_plane * 2u);
             sstep[i] = (AKT / 8) * 16;
         }
     }
     auto issue_tile = [&](int kt, int buf) {
         u32x4* base = lds + buf * STG_CH;
+        const bool from_root = RAG && kt < kt0;               // wave-uniform: a scalar select of the descriptor
 #pragma unroll
         for (int i = 0; i < NDMA; ++i) {
-            const int vo = (kt == nkt - 1) ? voff_last[i] : voff[i];
-            const int so = sbase[i] + kt * sstep[i];
+            const int vo = from_root ? voff_root[i] : ((kt == nkt - 1) ? voff_last[i] : voff[i]);
+            const int so = sbase[i] + (from_root ? kt : kt - kt0) * sstep[i];
             // (soffset goes through a named local: with the array expression written in the call hipcc 7.2 silently drops the kernel's host stub)
-            if (is_k[i]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQK, (__attribute__((address_space(3))) void*)(base + slot0[i]), 16, vo, so, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsVT, (__attribute__((address_space(3))) void*)(base + slot0[i]), 16, vo, so, 0, 0);
+            if (is_k[i]) __builtin_amdgcn_raw_ptr_buffer_load_lds(from_root ? rsQKr : rsQK, (__attribute__((address_space(3))) void*)(base + slot0[i]), 16, vo, so, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(from_root ? rsVTr : rsVT, (__attribute__((address_space(3))) void*)(base + slot0[i]), 16, vo, so, 0, 0);
         }
     };
 
@@ -341,7 +382,7 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
             for (int i = 0; i < NQ; ++i) {
                 const int f = i * 64 + lane, pq = f / KCH, row = (f % KCH) / KCPR;
                 const int c = (f % KCPR) ^ (DH == 64 ? ((row >> 1) & 7) : (row & 15));
-                const int vo = (int)(((unsigned int)min(q0 + row, T - 1) * (unsigned int)(2 * D) + (unsigned int)(h * DH)) * 2u + (unsigned int)c * 16u);
+                const int vo = (int)(((unsigned int)(min(q0 + row, T - 1) - a0) * (unsigned int)(2 * D) + (unsigned int)(h * DH)) * 2u + (unsigned int)c * 16u);
                 const int so = (int)((unsigned int)pq * (unsigned int)qk_plane * 2u);
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQK, (__attribute__((address_space(3))) void*)(qbase + i * 64), 16, vo, so, 0, 0);
             }
@@ -449,14 +490,17 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
             // inside fp16's range -- and O and l carry the same factor, which cancels in O / l.  The O-wide rescale (36 packed
             // multiplies on 64 accumulator registers + their wait for the previous P V MFMAs) then runs on the first key tiles
             // only instead of on nearly every tile.  defer_thr = 0: rescale whenever any lane's maximum moved (exact running max).
+            // The branch is wave-wide (some row moved by more than defer_thr), the new reference is PER ROW: a row that moved by less keeps
+            // alpha == 1 and its reference, so its bits depend on its own scores only -- not on which rows share its wave.
             if (!__all(m_new <= m_run + defer_thr)) {
-                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+                const bool moved = m_new > m_run + defer_thr;
+                const float alpha = moved ? __builtin_amdgcn_exp2f(m_run - m_new) : 1.0f;
                 l_run *= alpha;
 #pragma unroll
                 for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
                     for (int v = 0; v < 16; ++v) { om[dt][v] *= alpha; oc[dt][v] *= alpha; }
-                m_run = m_new;
+                if (moved) m_run = m_new;
             }
             const float mb = m_run - 10.0f;
             typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -510,7 +554,7 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
             // by store issue, not by bytes).  All 64 lanes take part in the swaps; rows beyond T only skip the stores.
             const float inv = 1.0f / l_tot;
             const bool row_ok = q0 + r < T;
-            unsigned short* rowp = ctx16 + ((size_t)b * T + min(q0 + r, T - 1)) * (size_t)(2 * D) + (size_t)(ND * h) * 64;
+            unsigned short* rowp = ctx16 + ((size_t)row0 + (min(q0 + r, T - 1) - a0)) * (size_t)(2 * D) + (size_t)(ND * h) * 64;
 #pragma unroll
             for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
@@ -540,7 +584,7 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
                 }
         } else if (q0 + r < T) {
             const float inv = 1.0f / l_tot;
-            const size_t off = ((size_t)b * T + q0 + r) * D + (size_t)h * DH + 4 * kh;
+            const size_t off = ((size_t)row0 + (q0 + r - a0)) * D + (size_t)h * DH + 4 * kh;
 #pragma unroll
             for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
@@ -556,7 +600,7 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
 #pragma unroll
                         for (int e = 0; e < 4; ++e) split_act(val[e], hh[e], ll[e]);
                         // K-interleaved GEMM operand (common.h ki_off): column h*DH + dt*32 + 8g + 4kh of a row of D
-                        unsigned short* dst = ctx16 + ((size_t)b * T + q0 + r) * (size_t)(2 * D) + (size_t)(ND * h + dt) * 64 + 8 * g + 4 * kh;
+                        unsigned short* dst = ctx16 + ((size_t)row0 + (q0 + r - a0)) * (size_t)(2 * D) + (size_t)(ND * h + dt) * 64 + 8 * g + 4 * kh;
                         *reinterpret_cast<u32x2*>(dst) = u32x2{pack_h2(hh[0], hh[1]), pack_h2(hh[2], hh[3])};
                         *reinterpret_cast<u32x2*>(dst + 32) = u32x2{pack_h2(ll[0], ll[1]), pack_h2(ll[2], ll[3])};
                     }
@@ -565,17 +609,17 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
     }
 }
 
-template <int WPB, int OUT, int NSTG, int DH>
+template <int WPB, int OUT, int NSTG, int DH, bool RAG = false>
 static int launch_att16v2_one(dim3 grid, const unsigned short* qk16, size_t qk_plane, const unsigned short* vt16, size_t vt_plane,
                               const int32_t* kv_len, const float* slopes, int T, int H, int Tp, float* ctx, unsigned short* ctx16,
-                              size_t plane, hipStream_t s) {
+                              size_t plane, hipStream_t s, RagMap rag = RagMap{}) {
     constexpr size_t lds_bytes = (size_t)NSTG * (DH * 16) * 16;          // stage = DH * 16 chunks of 16 B
-    auto kfn = attention_f16x3_v2_kernel<WPB, OUT, NSTG, DH>;
+    auto kfn = attention_f16x3_v2_kernel<WPB, OUT, NSTG, DH, RAG>;
     if (lds_bytes > 65536) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) { set_error("hipFuncSetAttribute: %s", hipGetErrorString(e)); return PGMI_EHIP; }
     }
-    hipLaunchKernelGGL(kfn, grid, dim3(WPB * 64), lds_bytes, s, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane);
+    hipLaunchKernelGGL(kfn, grid, dim3(WPB * 64), lds_bytes, s, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane, rag);
     return PGMI_OK;
 }
 
@@ -632,7 +676,8 @@ int launch_attention_f16x3_v2(const float* qkv, const int32_t* kv_len, const flo
     }
     if (qkv && conv && rotary) { set_error("attention_f16x3_v2: depth-wise convolution and rotary together are not a model this library knows"); return PGMI_EINVAL; }
     if (qkv && conv)       // Tranception: LDS-staged depth-wise conv + split
-        hipLaunchKernelGGL(qkv_prep_conv_kernel, dim3(n32, H, B), dim3(256), 0, s, qkv, conv, T, H, Tp, qk16, qk_plane, vt16, vt_plane);
+        hipLaunchKernelGGL(qkv_prep_conv_kernel<false>, dim3(n32, H, B), dim3(256), 0, s, qkv, conv, T, H, Tp, qk16, qk_plane, vt16, vt_plane,
+                           nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     else if (qkv)          // operands not prepared by the fused QKV epilogue: run the prep pass
         hipLaunchKernelGGL(qkv_prep_kernel, dim3(n32, H, B), dim3(256), 0, s, qkv, cos_t, sin_t, rotary, T, H, Tp,
                            qk16, qk_plane, vt16, vt_plane);
@@ -642,6 +687,34 @@ int launch_attention_f16x3_v2(const float* qkv, const int32_t* kv_len, const flo
     const dim3 grid(nblk, H, B);
     if (out_mode == 0) rc = launch_att16v2_mode<0, 3>(wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane, s);
     else rc = launch_att16v2_mode<1, 3>(wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane, s);
+    if (rc) return rc;
+    PGMI_HIP(hipGetLastError());
+    return PGMI_OK;
+}
+
+// Tranception prefix-shared scoring (RagMap): depth-wise conv prep over a list of n_tiles (sequence, 32-token tile) entries, then causal
+// grouped-ALiBi attention over a list of n_blocks (sequence, block of four query tiles) entries; split-plane context rows out (packed rows).
+int launch_attention_tr_ragged(const float* qkv, const float* conv, const float* slopes, int T, int H, const AttRagged& rg,
+                               unsigned short* qk16, size_t qk_plane, unsigned short* vt16, size_t vt_plane, unsigned short* ctx16,
+                               size_t plane, hipStream_t s) {
+    if (T <= 0 || H <= 0 || !qkv || !conv || !slopes || rg.n_tiles <= 0 || rg.n_blocks <= 0) {
+        set_error("attention_tr_ragged: bad arguments T=%d H=%d tiles=%d blocks=%d", T, H, rg.n_tiles, rg.n_blocks);
+        return PGMI_EINVAL;
+    }
+    const int Tp = (T + 31) / 32 * 32;
+    {
+        const unsigned long long seq_bytes = (unsigned long long)T * 2ull * (unsigned long long)H * 64ull * 2ull;
+        const unsigned long long vt_bytes = 64ull * (unsigned long long)Tp * 2ull;
+        if ((unsigned long long)qk_plane * 2ull + seq_bytes >= (1ull << 32) || (unsigned long long)vt_plane * 2ull + vt_bytes >= (1ull << 32)) {
+            set_error("attention_tr_ragged: operand planes exceed the 32-bit offset range of the K / V^T DMA (create the model with a smaller max_rows)");
+            return PGMI_EINVAL;
+        }
+    }
+    hipLaunchKernelGGL(qkv_prep_conv_kernel<true>, dim3(rg.n_tiles, H, 1), dim3(256), 0, s, qkv, conv, T, H, Tp, qk16, qk_plane, vt16, vt_plane,
+                       rg.seq_off, rg.seq_a, rg.seq_root, rg.seq_vt, rg.tile_seq, rg.tile_j);
+    const RagMap rag{rg.seq_off, rg.seq_a, rg.seq_root, rg.seq_vt, rg.blk_seq, rg.blk_j};
+    int rc = launch_att16v2_one<4, 1, 3, 64, true>(dim3(rg.n_blocks, H, 1), qk16, qk_plane, vt16, vt_plane, nullptr, slopes, T, H, Tp, nullptr,
+                                                   ctx16, plane, s, rag);
     if (rc) return rc;
     PGMI_HIP(hipGetLastError());
     return PGMI_OK;

@@ -85,6 +85,9 @@ void launch_fill_f32(float* p, int64_t n, float v, hipStream_t s);
 void launch_seq_loglik(const float* lp, const int32_t* tokens, const int32_t* lens, int B, int T, int V,
                        const float* prior, const int32_t* a0, const int32_t* row0, const int32_t* n,
                        const int32_t* flip, float alpha, float* out, hipStream_t s);
+void launch_seq_loglik_ragged(const float* lp, const int32_t* tokens, const int32_t* seq_off, const int32_t* seq_a,
+                              const int32_t* seq_root, int B, int T, int V, const float* prior, const int32_t* a0,
+                              const int32_t* row0, const int32_t* n, const int32_t* flip, float alpha, float* out, hipStream_t s);
 void launch_score_mutants(const float* table, int V, const int32_t* sub_pos, const int32_t* sub_wt,
                           const int32_t* sub_mt, const int64_t* mut_off, int64_t n_mut,
                           double* scores, hipStream_t s);
@@ -113,6 +116,8 @@ int launch_gemm_f32(const float* A, const float* W, const float* bias, const flo
                     float* C, int M, int N, int K, int epilogue, hipStream_t s);
 
 // ---- gemm_f16.hip ------------------------------------------------------------------------
+void gemm_options_from_env();                      // PGMI_GEMM_HALF_TAIL / PGMI_GEMM_MAX_ROWS (test hooks): at model creation, never per launch
+int gemm_set_option(const char* name, long long value);
 // 16-bit-plane GEMM: C = epi(A W^T * out_scale + bias) (+ residual).  A/W: `planes` planes of
 // fp16 (hi, lo) or one bf16 plane, K-contiguous rows.  Exactly one of Cf (fp32) / Ch (planes).
 int launch_gemm16(const unsigned short* A, size_t a_plane, const unsigned short* W, size_t w_plane,
@@ -147,5 +152,21 @@ int launch_attention_f16x3_v2(const float* qkv, const int32_t* kv_len, const flo
                               unsigned short* vt16, size_t vt_plane, float* ctx, unsigned short* ctx16, size_t plane,
                               int out_mode, hipStream_t s, const float* conv = nullptr, const float* slopes = nullptr,
                               int head_dim = 64);     // 128: H heads of two 64-lane slot groups (ESM2-15B), fused-QKV operands only
+
+// Tranception prefix-shared scoring: device arrays that describe a launch over SUFFIXES of sequences (attention_f16.hip RagMap).
+struct AttRagged {
+    const int32_t* seq_off;        // [sequences] first packed row of the sequence (its token seq_a)
+    const int32_t* seq_a;          // [sequences] first token the sequence owns: a multiple of 32, 0 for a root
+    const int32_t* seq_root;       // [sequences] the sequence whose K / V / conv history stand for the tokens before seq_a
+    const uint32_t* seq_vt;        // [sequences] offset (halfs, per plane) of the sequence's V^T block [H][64][roundup(T - seq_a, 32)]
+    const int32_t* tile_seq;       // [n_tiles] 32-token tiles of the suffixes: sequence, tile index inside the suffix
+    const int32_t* tile_j;
+    const int32_t* blk_seq;        // [n_blocks] blocks of four query tiles: sequence, block index inside the suffix
+    const int32_t* blk_j;
+    int n_tiles, n_blocks;
+};
+int launch_attention_tr_ragged(const float* qkv, const float* conv, const float* slopes, int T, int H, const AttRagged& rg,
+                               unsigned short* qk16, size_t qk_plane, unsigned short* vt16, size_t vt_plane, unsigned short* ctx16,
+                               size_t plane, hipStream_t s);
 
 }  // namespace pgmi

@@ -23,6 +23,7 @@
 // Roofline: MFMA-bound; peak 2.5 PFLOP/s of 16-bit MFMA = 833 TFLOP/s of fp32-equivalent algorithmic FLOPs in f16x3.
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <algorithm>
 #include <mutex>
 #include <type_traits>
@@ -237,6 +238,23 @@ static int x_num_cus() {
 // FC1 (N = 5120: 20 column panels) runs at the same speed with 4 and with 8 but fetches less with 8 (3.26 vs 3.47 GB per launch: with
 // 20 column panels a group of 4 rows is 80 tiles = 2.5 rounds of an XCD, and the partial rounds straddle two groups): wide outputs keep 8.
 constexpr int kGroupM = 4, kGroupMWide = 8, kWideTilesN = 16;
+// Test hooks (bit-neutral: both only change how a launch is cut into items / row chunks).  Read from the environment when a model is
+// created and at the op-level entries (gemm_options_from_env), changed on a live model through pgmi_set_option -- never per launch.
+//   PGMI_GEMM_HALF_TAIL / "gemm_half_tail": 0 = no half-height tail items;  PGMI_GEMM_MAX_ROWS / "gemm_max_rows": force row chunks
+struct GemmOptions { int half_tail = 1; long long max_rows = 0; };
+static GemmOptions g_opt;
+void gemm_options_from_env() {
+    const char* h = getenv("PGMI_GEMM_HALF_TAIL");
+    const char* r = getenv("PGMI_GEMM_MAX_ROWS");
+    g_opt.half_tail = h ? atoi(h) : 1;
+    g_opt.max_rows = r ? atoll(r) : 0;
+}
+int gemm_set_option(const char* name, long long value) {
+    if (!strcmp(name, "gemm_half_tail")) { g_opt.half_tail = (int)value; return PGMI_OK; }
+    if (!strcmp(name, "gemm_max_rows")) { g_opt.max_rows = value; return PGMI_OK; }
+    return PGMI_EINVAL;
+}
+
 // Launch parameters: variants >= 1000 of launch_gemm16 override the row panels per group for the interleaved A/B of
 // scripts/gemm_ab.py (tile order does not touch a row's arithmetic: same bits).
 struct GemmTune { int group_m = 0; };
@@ -263,7 +281,7 @@ static int launch_gemm16x_one(const unsigned short* A, const unsigned short* W,
     // items on two CUs, each over the full K range in the same order, so every output element is computed exactly as in a
     // full tile (bit-identical: a row's bits must not depend on how many rows travel with it, tests/test_gpu_cli.py) -- when
     // all the halves still fit one round.
-    const int want_half = getenv("PGMI_GEMM_HALF_TAIL") ? atoi(getenv("PGMI_GEMM_HALF_TAIL")) : 1;   // read per launch: the tests toggle it
+    const int want_half = g_opt.half_tail;
     if (want_half && !qkv && rem > 0 && 2 * rem <= G) {
         tp.n_main = T - rem; tp.half = 1; tp.n_tail = 2 * rem;
     }
@@ -345,8 +363,7 @@ static int launch_gemm16x(const unsigned short* A, const unsigned short* W,
         set_error("gemm16x: weight of %d x %d split elements exceeds the 32-bit offset range", N, K);
         return PGMI_EINVAL;
     }
-    const char* tr = getenv("PGMI_GEMM_MAX_ROWS");                      // tests: force chunking at small shapes (read per launch)
-    const long long test_rows = tr ? atoll(tr) : 0;
+    const long long test_rows = g_opt.max_rows;                          // tests: force chunking at small shapes
     long long max_rows = (long long)(lim / ((unsigned long long)K * 4ull));
     if (Cf) max_rows = std::min(max_rows, (long long)(((1ull << 31) - 1) / ((unsigned long long)N * 4ull)));   // the fp32 epilogue's buffer offsets
     if (test_rows > 0) max_rows = std::min(max_rows, test_rows);

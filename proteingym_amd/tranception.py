@@ -105,6 +105,21 @@ def sequence_replace_single(sequence, char_to_replace, char_replacements):
     return codes.tobytes().decode("ascii")
 
 
+def wild_type_rows(slices, target_seq):
+    """For every row of ``get_sequence_slices``' frame the position of the wild-type row cut to the same window (the row the
+    reference subtracts, scoring_utils.py:142-148), its own position where there is none: what ``sequence_loglik`` shares prefixes with."""
+    n = len(slices)
+    own = np.arange(n, dtype=np.int64)
+    if target_seq is None or n == 0:
+        return own
+    wt = (slices['mutated_sequence'] == target_seq).to_numpy()
+    starts, ends = slices['window_start'].to_numpy(), slices['window_end'].to_numpy()
+    first = {}
+    for i in np.flatnonzero(wt):
+        first.setdefault((int(starts[i]), int(ends[i])), int(i))
+    return np.array([first.get((int(a), int(b)), int(i)) for i, (a, b) in enumerate(zip(starts, ends))], dtype=np.int64)
+
+
 def get_sequence_slices(df, target_seq, model_context_len, start_idx=1, scoring_window="optimal", indel_mode=False):
     """Behaviour of scoring_utils.py:152-203, written on plain lists: every input row yields a (mutated, window)
     row and a wild-type row cropped to the SAME window; rows identical in every column are merged; the 'mutant'
@@ -416,6 +431,10 @@ def load_checkpoint(checkpoint_dir: str):
 class TranceptionModel:
     """Device-resident Tranception.  ``score_mutants`` mirrors the reference method of the same name."""
 
+    share_prefix = True          # forward a mutated sequence from its first mutated token's tile on (sequence_loglik)
+    rows_forwarded = 0           # token rows that went through the network ...
+    rows_full = 0                # ... and the rows the reference's loop forwards for the same calls
+
     def __init__(self, cfg: dict, weights: np.ndarray, device: int = 0, scoring_window: str = "optimal",
                  retrieval: Optional[dict] = None, max_rows: int = 0):
         lib = _lib.load()
@@ -435,6 +454,7 @@ class TranceptionModel:
         self.scoring_window = scoring_window
         # retrieval: dict(log_prior [L,25] float32, MSA_start (0-based), MSA_end, weight)
         self.retrieval = retrieval
+        self.share_prefix = os.environ.get("PGMI_TR_SHARE_PREFIX", "1") != "0"
 
     def close(self):
         if getattr(self, "_h", None):
@@ -475,10 +495,17 @@ class TranceptionModel:
         _lib.check(_lib.load().pgmi_tr_token_logprobs(self._h, _lib.ptr(t, _lib._i32p), B, T, _lib.ptr(out, _lib._f32p)))
         return out
 
-    def sequence_loglik(self, sliced_sequences, window_start=None, window_end=None, reverse=False, mutated_sequences=None) -> np.ndarray:
+    def sequence_loglik(self, sliced_sequences, window_start=None, window_end=None, reverse=False, mutated_sequences=None,
+                        reference=None) -> np.ndarray:
         """sum_t log p(token_{t+1} | tokens_{<=t}) per sliced sequence (scoring_utils.py:97-128), fused
         with the retrieval prior (model_pytorch.py:806-830) when the model was built with one.  ``mutated_sequences`` (the full
-        sequences the slices were cut from) are what indel scoring with retrieval re-aligns (model_pytorch.py:794-799)."""
+        sequences the slices were cut from) are what indel scoring with retrieval re-aligns (model_pytorch.py:794-799).
+
+        ``reference`` (additive; int array, one entry per sequence): the position in ``sliced_sequences`` of the sequence whose
+        PREFIX this one shares -- the wild type cut to the same window -- or its own position.  The model is causal, so the rows of a
+        mutated sequence before its first mutated token are the wild type's: with ``reference`` only the rows from there on are
+        forwarded (``pgmi_tr_sequence_loglik_shared``; the reference forwards every sequence in full, scoring_utils.py:77-150).  The
+        values are bit-identical to the unshared call; ``self.share_prefix = False`` (or PGMI_TR_SHARE_PREFIX=0) ignores it."""
         lib = _lib.load()
         seqs = list(sliced_sequences)
         n = len(seqs)
@@ -486,8 +513,12 @@ class TranceptionModel:
             return np.array([self._realigned_loglik(seqs[i], int(window_start[i]), int(window_end[i]), reverse, mutated_sequences[i])
                              for i in range(n)], dtype=np.float32)
         out = np.empty(n, dtype=np.float32)
-        order = np.argsort([len(s) for s in seqs], kind="stable")
+        lengths = np.array([len(s) for s in seqs], dtype=np.int64)
+        order = np.argsort(lengths, kind="stable")
         r = self.retrieval
+        share = reference is not None and getattr(self, "share_prefix", True)
+        if share:
+            reference = np.asarray(reference, dtype=np.int64)
         # groups of equal length -> no padding waste; every group goes through one ABI call
         start = 0
         while start < n:
@@ -499,6 +530,7 @@ class TranceptionModel:
             ids, lens = self.encode_batch([seqs[i] for i in idx])
             B, T = ids.shape
             res = np.empty(B, dtype=np.float32)
+            prior = (None, 0, None, None, None, None, 0.0)
             if r is not None:
                 a0 = np.zeros(B, np.int32); row0 = np.zeros(B, np.int32); nn = np.zeros(B, np.int32)
                 flip = np.full(B, 1 if reverse else 0, np.int32)
@@ -512,16 +544,35 @@ class TranceptionModel:
                     row0[j] = lo
                     nn[j] = hi - lo
                 lp = _lib.as_f32(r["log_prior"])
-                _lib.check(lib.pgmi_tr_sequence_loglik(self._h, _lib.ptr(ids, _lib._i32p), _lib.ptr(lens, _lib._i32p), B, T,
-                                                       _lib.ptr(lp, _lib._f32p), lp.shape[0], _lib.ptr(a0, _lib._i32p),
-                                                       _lib.ptr(row0, _lib._i32p), _lib.ptr(nn, _lib._i32p),
-                                                       _lib.ptr(flip, _lib._i32p), float(r["weight"]), _lib.ptr(res, _lib._f32p)))
+                prior = (_lib.ptr(lp, _lib._f32p), lp.shape[0], _lib.ptr(a0, _lib._i32p), _lib.ptr(row0, _lib._i32p),
+                         _lib.ptr(nn, _lib._i32p), _lib.ptr(flip, _lib._i32p), float(r["weight"]))
+            ref_local = self._local_references(idx, reference, lengths, ids) if share else None
+            if ref_local is not None:
+                rows = np.zeros(1, dtype=np.int64)
+                _lib.check(lib.pgmi_tr_sequence_loglik_shared(self._h, _lib.ptr(ids, _lib._i32p), _lib.ptr(ref_local, _lib._i32p), B, T,
+                                                              *prior, _lib.ptr(res, _lib._f32p), None, _lib.ptr(rows, _lib._i64p)))
+                self.rows_forwarded += int(rows[0])
             else:
                 _lib.check(lib.pgmi_tr_sequence_loglik(self._h, _lib.ptr(ids, _lib._i32p), _lib.ptr(lens, _lib._i32p), B, T,
-                                                       None, 0, None, None, None, None, 0.0, _lib.ptr(res, _lib._f32p)))
+                                                       *prior, _lib.ptr(res, _lib._f32p)))
+                self.rows_forwarded += B * T
+            self.rows_full += B * T
             out[idx] = res
             start = end
         return out
+
+    @staticmethod
+    def _local_references(idx, reference, lengths, ids):
+        """``reference`` (positions in the caller's list) as positions inside one equal-length group, int32 [B]; a sequence whose
+        reference is not in the group (another length), that is its own reference's reference, or that shares no token with it
+        stands for itself.  None when nothing is shared (every sequence a root: the plain call does the same work)."""
+        where = {int(i): j for j, i in enumerate(idx)}
+        local = np.arange(len(idx), dtype=np.int32)
+        for j, i in enumerate(idx):
+            k = where.get(int(reference[i]), j)
+            if k != j and int(reference[idx[k]]) == int(idx[k]) and ids[j, 0] == ids[k, 0]:
+                local[j] = k
+        return local if (local != np.arange(len(idx))).any() else None
 
     def _realigned_loglik(self, sliced, start, end, reverse, mutated_sequence) -> float:
         """Indel scoring with retrieval, one sequence (model_pytorch.py:794-839): the family log-prior is re-indexed through the
@@ -571,7 +622,8 @@ class TranceptionModel:
         the wild type's value for the same window start (optimal) / the single wild-type total (sliding) subtracted."""
         realign = dict(mutated_sequences=list(slices['mutated_sequence'])) if (self.retrieval or {}).get("aligner") else {}
         loglik = self.sequence_loglik(slices['sliced_mutated_sequence'], slices['window_start'].to_numpy(),
-                                      slices['window_end'].to_numpy(), reverse=reverse, **realign)
+                                      slices['window_end'].to_numpy(), reverse=reverse,
+                                      reference=wild_type_rows(slices, target_seq), **realign)
         per = pd.DataFrame({'mutated_sequence': list(slices['mutated_sequence']),
                             'sliced_mutated_sequence': list(slices['sliced_mutated_sequence']),
                             'window_start': list(slices['window_start']), 'window_end': list(slices['window_end']),

@@ -30,3 +30,14 @@ def lib():
     from proteingym_amd import build_native, _lib
     build_native.build(verbose=False)
     return _lib.load()
+
+
+@pytest.fixture
+def gemm_option(lib):
+    """Sets a test hook of the GEMM launchers on the live library (pgmi_set_option) and restores the defaults afterwards."""
+    def set_(name, value):
+        from proteingym_amd import _lib
+        _lib.check(lib.pgmi_set_option(name.encode(), int(value)))
+    yield set_
+    lib.pgmi_set_option(b"gemm_half_tail", 1)
+    lib.pgmi_set_option(b"gemm_max_rows", 0)

@@ -110,7 +110,7 @@ def test_determinism_and_chunking(lib, golden, golden_dir):
 
 
 @pytest.mark.parametrize("name", ["esm1v_toy_1", "esm2_toy", "esm2_toy_h128"])
-def test_gemm_row_chunks_inside_a_model_bit_identical(lib, golden, golden_dir, name, monkeypatch):
+def test_gemm_row_chunks_inside_a_model_bit_identical(lib, golden, golden_dir, name, gemm_option):
     """Every GEMM of the forward cut into row chunks (the path activations beyond 4 GiB take: gemm_f16.hip launch_gemm16x;
     the fused QKV projection chunks at sequence boundaries and offsets its V^T scatter): same table, same scores."""
     import pandas as pd
@@ -120,7 +120,7 @@ def test_gemm_row_chunks_inside_a_model_bit_identical(lib, golden, golden_dir, n
     m = pesm.load_model_and_alphabet(path)[0]
     a = pesm.Assay(m, seq, muts)
     s0, t0 = a.run(want_table=True)
-    monkeypatch.setenv("PGMI_GEMM_MAX_ROWS", "300")            # a few sequences per chunk (T = len(seq) + 2 tokens each)
+    gemm_option("gemm_max_rows", 300)                          # a few sequences per chunk (T = len(seq) + 2 tokens each)
     s1, t1 = a.run(want_table=True)
     assert np.array_equal(s0, s1) and np.array_equal(t0, t1, equal_nan=True)
     a.close()
@@ -307,9 +307,9 @@ def test_real_small_esm2_shapes_load_and_match_oracle(lib):
 
 
 @pytest.mark.parametrize("arch", ["ESM1V_650M", "ESM2_650M"])
-def test_token_logprobs_do_not_depend_on_the_batch_or_on_the_gemm_item_kind(lib, monkeypatch, arch):
+def test_token_logprobs_do_not_depend_on_the_batch_or_on_the_gemm_item_kind(lib, gemm_option, arch):
     """The first sequences of a batch of 4 / 60 / 230 (4 layers at the 650M width: 1280 x 20 heads x 5120, T = 72): the small launches
-    run every GEMM tile as two half-height items, the larger ones as full-height items (+ a half-height tail), PGMI_GEMM_HALF_TAIL=0
+    run every GEMM tile as two half-height items, the larger ones as full-height items (+ a half-height tail), the option gemm_half_tail = 0
     forces full-height items everywhere -- the same bits in all of them, through the fused QKV (rotary for ESM2), the split-plane
     (FC1 + GELU) and the fp32 + residual epilogues."""
     cfg = dict(getattr(synthetic, arch), layers=4)
@@ -317,10 +317,10 @@ def test_token_logprobs_do_not_depend_on_the_batch_or_on_the_gemm_item_kind(lib,
     rng = np.random.default_rng(1)
     tok = rng.integers(4, 24, size=(230, 72)).astype(np.int32)
     tok[:, 0], tok[:, -1] = 0, 2
-    monkeypatch.setenv("PGMI_GEMM_HALF_TAIL", "1")
+    gemm_option("gemm_half_tail", 1)
     base = m.token_logprobs(tok[:4])
-    for half in ("0", "1"):
-        monkeypatch.setenv("PGMI_GEMM_HALF_TAIL", half)
+    for half in (0, 1):
+        gemm_option("gemm_half_tail", half)
         for B in (4, 60, 230):
             assert np.array_equal(m.token_logprobs(tok[:B])[:4], base), (half, B)
     m.close()

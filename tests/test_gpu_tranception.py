@@ -175,9 +175,9 @@ def test_run_sharded_mutant_chunks_equal_the_cli(lib, gold, golden_dir, tmp_path
         assert open(tmp_path / "sharded" / f"{name}.csv").read() == open(tmp_path / "single" / f"{name}.csv").read()
 
 
-def test_token_logprobs_do_not_depend_on_the_batch_or_on_the_gemm_item_kind(lib, golden_dir, monkeypatch):
+def test_token_logprobs_do_not_depend_on_the_batch_or_on_the_gemm_item_kind(lib, golden_dir, gemm_option):
     """The first sequences of a batch of 7 / 100 / 200: the small launches run every GEMM tile as two half-height items, the
-    200-sequence one as full-height items (2 x 228 tiles do not fit one round of CUs), PGMI_GEMM_HALF_TAIL=0 forces full-height
+    200-sequence one as full-height items (2 x 228 tiles do not fit one round of CUs), the option gemm_half_tail = 0 forces full-height
     items at every size -- the same bits in all of them, through the split-plane (c_fc, squared ReLU) and the fp32 epilogues.
     (Round 4: a rewrite of the split-plane epilogue passed every op-level comparison on random data and differed here, on rows
     holding values below fp16's normal range.)"""
@@ -185,10 +185,10 @@ def test_token_logprobs_do_not_depend_on_the_batch_or_on_the_gemm_item_kind(lib,
     rng = np.random.default_rng(0)
     seqs = ["".join(rng.choice(list("ACDEFGHIKLMNPQRSTVWY"), size=70)) for _ in range(200)]
     ids, _ = m.encode_batch(seqs)
-    monkeypatch.setenv("PGMI_GEMM_HALF_TAIL", "1")
+    gemm_option("gemm_half_tail", 1)
     base = m.token_logprobs(ids[:7])
-    for half in ("0", "1"):
-        monkeypatch.setenv("PGMI_GEMM_HALF_TAIL", half)
+    for half in (0, 1):
+        gemm_option("gemm_half_tail", half)
         for B in (7, 100, 200):
             assert np.array_equal(m.token_logprobs(ids[:B])[:7], base), (half, B)
     m.close()
@@ -255,3 +255,145 @@ def test_indels_with_retrieval_vs_reference(lib, golden_dir, tmp_path):
     with pytest.raises(IndexError):
         cli.main(cli.create_parser().parse_args(common + ["--MSA_filename", "TOY_MSA.a2m", "--MSA_start", "11", "--MSA_end", "60",
                                                           "--output_scores_folder", str(tmp_path / "out2")]))
+
+
+# ---- prefix-shared scoring (pgmi_tr_sequence_loglik_shared): the bits of the full forward ---------------------------------
+def _shared_vs_full(model, wt, mutants, reverse=False, retrieval=None, token_level=True):
+    """out / token log-probs of the shared entry against the unshared entries on [wild type] + mutants (all of one length)."""
+    import ctypes as C
+    from proteingym_amd import _lib
+    lib = _lib.load()
+    seqs = [wt] + list(mutants)
+    if reverse:
+        seqs = [s[::-1] for s in seqs]
+    ids, lens = model.encode_batch(seqs)
+    B, T = ids.shape
+    ref = np.zeros(B, dtype=np.int32)
+    prior = (None, 0, None, None, None, None, 0.0)
+    if retrieval is not None:
+        lp = _lib.as_f32(retrieval["log_prior"])
+        a0 = np.full(B, retrieval["a0"], np.int32); r0 = np.full(B, retrieval["row0"], np.int32)
+        nn = np.full(B, retrieval["n"], np.int32); fl = np.full(B, 1 if reverse else 0, np.int32)
+        prior = (_lib.ptr(lp, _lib._f32p), lp.shape[0], _lib.ptr(a0, _lib._i32p), _lib.ptr(r0, _lib._i32p), _lib.ptr(nn, _lib._i32p),
+                 _lib.ptr(fl, _lib._i32p), 0.6)
+    full = np.empty(B, np.float32)
+    _lib.check(lib.pgmi_tr_sequence_loglik(model._h, _lib.ptr(ids, _lib._i32p), _lib.ptr(lens, _lib._i32p), B, T, *prior, _lib.ptr(full, _lib._f32p)))
+    shared = np.empty(B, np.float32)
+    tok = np.empty((B, T, 25), np.float32) if token_level else None
+    rows = np.zeros(1, np.int64)
+    _lib.check(lib.pgmi_tr_sequence_loglik_shared(model._h, _lib.ptr(ids, _lib._i32p), _lib.ptr(ref, _lib._i32p), B, T, *prior,
+                                                  _lib.ptr(shared, _lib._f32p), _lib.ptr(tok, _lib._f32p) if token_level else None,
+                                                  _lib.ptr(rows, _lib._i64p)))
+    assert np.array_equal(shared, full), np.abs(shared - full).max()
+    if token_level:
+        assert np.array_equal(tok, model.token_logprobs(ids))
+    return int(rows[0]), B * T
+
+
+def _mutants_everywhere(wt, rng, n_multi=12):
+    aa = "ACDEFGHIKLMNPQRSTVWY"
+    L = len(wt)
+
+    def sub(s, p):
+        return s[:p] + rng.choice([c for c in aa if c != s[p]]) + s[p + 1:]
+    out = [sub(wt, p) for p in list(range(0, L, 3)) + [L - 1, L - 2, 30, 31, 32, 63, 64]if p < L]
+    for _ in range(n_multi):
+        s = wt
+        for p in rng.choice(L, size=int(rng.integers(2, 6)), replace=False):
+            s = sub(s, int(p))
+        out.append(s)
+    out.append(wt)                                                    # a copy of the root
+    return out
+
+
+@pytest.mark.parametrize("L", [40, 94, 126, 200])
+def test_prefix_shared_scoring_has_the_bits_of_the_full_forward(model, L):
+    """Sequence log-likelihoods and every token log-prob row of the shared entry == the unshared entries: mutants at every third
+    position (first residue, last residue, both sides of the 32-token tile edges), multi-mutants, a copy of the wild type; T = L + 2 on
+    and off multiples of 32; both reading directions; with a retrieval prior fused."""
+    rng = np.random.default_rng(L)
+    wt = "".join(rng.choice(list("ACDEFGHIKLMNPQRSTVWY"), size=L))
+    muts = _mutants_everywhere(wt, rng)
+    done, full = _shared_vs_full(model, wt, muts)
+    assert done < full and (L < 64 or done < 0.75 * full)
+    _shared_vs_full(model, wt, muts, reverse=True)
+    prior = np.log(rng.dirichlet(np.ones(25), size=L + 10)).astype(np.float32)
+    _shared_vs_full(model, wt, muts, retrieval=dict(log_prior=prior, a0=3, row0=5, n=L - 8), token_level=False)
+    _shared_vs_full(model, wt, muts, reverse=True, retrieval=dict(log_prior=prior, a0=2, row0=4, n=L - 8), token_level=False)
+
+
+def test_prefix_shared_scoring_in_chunks_and_groups(lib, golden_dir):
+    """A workspace of 2 048 rows: the groups are cut into chunks, every chunk carries its root again; several roots (windows) in one
+    call, a root without members, members listed before their root."""
+    import ctypes as C
+    from proteingym_amd import _lib
+    m = ptr.from_pretrained(os.path.join(golden_dir, "Tranception_toy"), max_rows=2048)
+    rng = np.random.default_rng(7)
+    L = 150
+    roots = ["".join(rng.choice(list("ACDEFGHIKLMNPQRSTVWY"), size=L)) for _ in range(3)]
+    seqs, ref = [], []
+    for k, wt in enumerate(roots[:2]):
+        mut = _mutants_everywhere(wt, rng, n_multi=4)
+        base = len(seqs)
+        seqs += mut[:5] + [wt] + mut[5:]                              # the root in the middle of its group
+        ref += [base + 5] * (len(mut) + 1)
+    seqs.append(roots[2]); ref.append(len(seqs) - 1)                  # a root on its own
+    ids, lens = m.encode_batch(seqs)
+    B, T = ids.shape
+    full = np.empty(B, np.float32)
+    _lib.check(_lib.load().pgmi_tr_sequence_loglik(m._h, _lib.ptr(ids, _lib._i32p), _lib.ptr(lens, _lib._i32p), B, T,
+                                                   None, 0, None, None, None, None, 0.0, _lib.ptr(full, _lib._f32p)))
+    shared = np.empty(B, np.float32)
+    rows = np.zeros(1, np.int64)
+    r = np.asarray(ref, dtype=np.int32)
+    _lib.check(_lib.load().pgmi_tr_sequence_loglik_shared(m._h, _lib.ptr(ids, _lib._i32p), _lib.ptr(r, _lib._i32p), B, T, None, 0, None, None,
+                                                          None, None, 0.0, _lib.ptr(shared, _lib._f32p), None, _lib.ptr(rows, _lib._i64p)))
+    assert np.array_equal(shared, full)
+    assert rows[0] > 2048                                             # more than one chunk ran
+    bad = r.copy(); bad[0] = 1                                        # sequence 1 is not a root
+    with pytest.raises(_lib.PgmiError, match="not a root"):
+        _lib.check(_lib.load().pgmi_tr_sequence_loglik_shared(m._h, _lib.ptr(ids, _lib._i32p), _lib.ptr(bad, _lib._i32p), B, T, None, 0, None,
+                                                              None, None, None, 0.0, _lib.ptr(shared, _lib._f32p), None, None))
+    m.close()
+
+
+def test_score_mutants_is_the_same_frame_with_and_without_prefix_sharing(model, gold, golden_dir):
+    """TranceptionModel.score_mutants (slices, wild-type delta, mirror average) with share_prefix on and off: the same bits in every
+    column, for the short protein, the 1 100-residue protein (a window per mutated position) and the 'sliding' window."""
+    for csv, key in (("TOY_TRANCEPTION_DMS.csv", "seq"), ("TOY_TRANCEPTION_LONG_DMS.csv", "seq_long")):
+        df = pd.read_csv(os.path.join(golden_dir, csv))
+        for window in ("optimal", "sliding"):
+            model.scoring_window = window
+            try:
+                model.share_prefix = True
+                model.rows_forwarded = model.rows_full = 0
+                a = model.score_mutants(DMS_data=df, target_seq=str(gold[key]), scoring_mirror=True)
+                saved = (model.rows_forwarded, model.rows_full)
+                model.share_prefix = False
+                b = model.score_mutants(DMS_data=df, target_seq=str(gold[key]), scoring_mirror=True)
+            finally:
+                model.share_prefix, model.scoring_window = True, "optimal"
+            assert list(a["mutated_sequence"]) == list(b["mutated_sequence"])
+            for c in ("avg_score_L_to_R", "avg_score_R_to_L", "avg_score"):
+                assert np.array_equal(a[c].to_numpy(), b[c].to_numpy()), (csv, window, c)
+            assert saved[0] < saved[1]
+
+
+def test_prefix_shared_scoring_at_the_large_width(lib):
+    """Tranception-L's layer shape (1280 wide, 20 heads: five ALiBi slopes, FFN 5120; 4 layers), a 286-residue protein and a
+    1 022-residue one (32 key tiles): shared == full, bit for bit, in both directions; the rows forwarded are counted."""
+    from proteingym_amd import synthetic
+    cfg = dict(synthetic.TRANCEPTION_L, layers=4)
+    m = ptr.TranceptionModel(cfg, synthetic.random_tranception_weights(cfg, seed=5), device=0)
+    rng = np.random.default_rng(1)
+    for L, n in ((286, 60), (1022, 12)):
+        wt = "".join(rng.choice(list("ACDEFGHIKLMNPQRSTVWY"), size=L))
+        muts = []
+        for p in rng.choice(L, size=n, replace=False):
+            p = int(p)
+            muts.append(wt[:p] + ("A" if wt[p] != "A" else "C") + wt[p + 1:])
+        done, full = _shared_vs_full(m, wt, muts, token_level=False)
+        done_r, _ = _shared_vs_full(m, wt, muts, reverse=True, token_level=False)
+        print(f"L = {L}: rows forwarded {done} + {done_r} of 2 x {full}")
+        assert done + done_r < 1.35 * full                             # uniform positions: ~0.56 of the rows per direction, + the root
+    m.close()

@@ -4,6 +4,7 @@
   reference by tests/golden/make_golden.py -- runs everywhere (also on the GPU box).
 * test_oracle_vs_live_reference: runs the reference itself (only where /root/reference exists).
 """
+import ctypes as C
 import os
 
 import numpy as np
@@ -348,7 +349,7 @@ class _OracleBackedTranception:
         obj.scoring_window = scoring_window
         obj.retrieval = retrieval
 
-        def sequence_loglik(seqs, window_start=None, window_end=None, reverse=False):
+        def sequence_loglik(seqs, window_start=None, window_end=None, reverse=False, **kw):
             return np.asarray(to.sequence_scores(cfg, W, list(seqs), list(window_start), list(window_end), reverse=reverse,
                                                  retrieval=retrieval), dtype=np.float32)
         obj.sequence_loglik = sequence_loglik
@@ -1042,6 +1043,23 @@ class _OracleBackedDevice:
         res[:] = (ll * torch.as_tensor(mask[:, 1:]).to(ll.dtype)).sum(1).numpy()
         return 0
 
+    def pgmi_tr_sequence_loglik_shared(self, handle, tokens, ref, B, T, log_prior, P, a0, row0, count, flip, alpha, out, token_lp, rows):
+        """The shared-prefix entry's CONTRACT (include/pgmi.h): every sequence has T tokens, ref[b] is a root of this call whose
+        prefix b shares -- checked here -- and the values are those of the unshared call (the oracle forwards in full)."""
+        ids = np.ctypeslib.as_array(tokens, shape=(B, T))
+        r = np.ctypeslib.as_array(ref, shape=(B,))
+        assert ((r >= 0) & (r < B)).all() and (r[r] == r).all()
+        assert (ids[np.arange(B), 0] == ids[r, 0]).all() and (ids != 3).all()            # the [CLS] is shared; no [PAD]
+        first_diff = np.array([T if (ids[b] == ids[r[b]]).all() else int(np.argmax(ids[b] != ids[r[b]])) for b in range(B)])
+        self.shared.append((B, int((r != np.arange(B)).sum()), first_diff[r != np.arange(B)].tolist()))
+        lens = (C.c_int32 * B)(*([T] * B))
+        rc = self.pgmi_tr_sequence_loglik(handle, tokens, lens, B, T, log_prior, P, a0, row0, count, flip, alpha, out)
+        if rows:
+            rows[0] = int(sum(T - (min(p, T - 1) // 32) * 32 for p in first_diff[r != np.arange(B)])) + T * int((r == np.arange(B)).sum())
+        return rc
+
+    shared = []
+
 
 def test_tranception_product_indels_with_retrieval_host_logic_on_cpu(golden_dir, tmp_path, monkeypatch):
     """The product's side of indel scoring with retrieval (tranception.SequenceAligner, realigned_prior_rows,
@@ -1218,3 +1236,52 @@ def test_msa_prior_ragged_alignment_like_the_live_reference(tmp_path):
                                 filter_MSA=False, verbose=False)
     with pytest.raises(IndexError):
         ptr.get_msa_prior(str(a2m), None, 0, 8, 14, filter_MSA=False)
+
+
+def test_tranception_product_prefix_sharing_host_logic_on_cpu(golden_dir, monkeypatch):
+    """The host side of prefix-shared scoring (tranception.wild_type_rows, TranceptionModel.sequence_loglik / _local_references) through
+    the product's own score_mutants with the device served by the oracle: every mutated slice names the wild type cut to ITS window as
+    its root (short protein: one window; 1 100 residues: a window per mutated position; 'sliding': per chunk), roots stand for
+    themselves, and the reference's goldens come out.  With share_prefix off the plain entry is used."""
+    from oracle import tranception_oracle as to
+    from proteingym_amd import tranception as ptr, _lib
+    g = np.load(os.path.join(golden_dir, "golden_tranception.npz"))
+    gm = np.load(os.path.join(golden_dir, "golden_tranception_modes.npz"))
+    seq, seql = str(g["seq"]), str(g["seq_long"])
+    cfg, W = to.load_checkpoint(os.path.join(golden_dir, "Tranception_toy"))
+    device = _OracleBackedDevice(cfg, W)
+    device.shared = []
+    monkeypatch.setattr(_lib, "load", lambda: device)
+
+    def model(window="optimal", share=True):
+        m = object.__new__(ptr.TranceptionModel)
+        m._h, m.n_ctx, m.scoring_window, m.retrieval, m.cfg, m.share_prefix = None, cfg["n_ctx"], window, None, cfg, share
+        return m
+
+    def check(m, df, target, gold, prefix):
+        r = m.score_mutants(DMS_data=df, target_seq=target, scoring_mirror=True)
+        r = pd.merge(pd.DataFrame({"mutated_sequence": [to.get_mutated_sequence(target, x) for x in df["mutant"]]}), r, on="mutated_sequence", how="left")
+        for c in ("avg_score_L_to_R", "avg_score_R_to_L", "avg_score"):
+            assert np.abs(r[c].to_numpy() - gold[f"{prefix}/{c}"]).max() < 2e-5, (prefix, c)
+    dms = pd.read_csv(os.path.join(golden_dir, "TOY_TRANCEPTION_DMS.csv"))
+    dml = pd.read_csv(os.path.join(golden_dir, "TOY_TRANCEPTION_LONG_DMS.csv"))
+    m = model()
+    check(m, dms, seq, g, "scores")
+    assert len(device.shared) == 2                                         # one call per reading direction: one length, one window
+    for B, n_shared, first in device.shared:
+        assert n_shared == B - 1 and min(first) >= 1                       # everything but the wild type shares; [CLS] is never the difference
+    assert 0 < m.rows_forwarded < m.rows_full
+    device.shared = []
+    check(model(), dml, seql, g, "scores_long")                            # longer than the context: the root of a slice is the wild type of ITS window
+    assert sum(n for _, n, _ in device.shared) > 0
+    device.shared = []
+    check(model("sliding"), dml, seql, gm, "sliding")
+    assert sum(n for _, n, _ in device.shared) > 0
+    device.shared = []
+    m = model(share=False)
+    check(m, dms, seq, g, "scores")
+    assert device.shared == [] and m.rows_forwarded == m.rows_full > 0
+    # no reference sequence: raw log-likelihoods, nothing to share
+    device.shared = []
+    r = model().score_mutants(DMS_data=pd.DataFrame({"mutated_sequence": [seq, to.get_mutated_sequence(seq, dms["mutant"][0])]}), target_seq=None)
+    assert device.shared == [] and len(r) == 2
