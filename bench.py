@@ -10,14 +10,13 @@ masked windows -> 33-layer forward over every masked position -> LM head on the 
 -> log-softmax table -> per-mutant score (label_row).  Synthetic sequence, synthetic
 random-init weights (no network), deterministic seeds.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU): STRONG scaling on the north-star's own
-workload -- one pass over the 217-assay-shaped substitution benchmark (2 465 767 mutants), assays
-sharded over the ranks by the product planner (run_benchmark.plan_assays), inputs resident, no
-data-path collective until the ONE RCCL all_gather of the per-mutant score vectors at the end
-(scripts/bench_scale.py).  value = all mutants / max-over-ranks time; the K "steps" are K consecutive
-slices of that one pass.  The one-GPU point of this curve is the N = 1 line's
-`secondary.benchmark_217_end_to_end.rank0_wall_clock.assay_run_s`.  The weak-scaling figure (one
-BLAT-shaped assay per rank) stays in the line as `weak_scaling`.
+N > 1 (launched by torch.distributed.run, one rank per GPU): the SAME step on every rank -- one BLAT-shaped assay per rank per
+step (its own synthetic assay), then the path's one exchange: an RCCL all_gather of the per-mutant score vectors.  Per-GPU work
+is fixed ("scaling": "weak"), value = N x 4 996 x K mutants / max-over-ranks seconds, so value(N) / (N x value(1)) is the scaling
+efficiency of the step the N = 1 line measures.  After that timed region the line gains `strong_scaling_217`: ONE pass over the
+217-assay-shaped substitution benchmark (2 465 767 mutants, the north star's workload) with the assays sharded over the ranks by
+the product planner (run_benchmark.plan_assays), inputs resident, timed with its own barriers (scripts/bench_scale.py); its
+one-GPU point is the N = 1 line's `one_gpu_same_workload_mutants_per_s`.
 
 Extra objects on the JSON line: `roofline` (dominant kernel = the FFN GEMMs, HIP-event timed
 inside the timed region, against the MFMA peak of the dtype) and `cpu_baseline` (the oracle's
@@ -36,24 +35,30 @@ sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "f16x3": 2500.0}   # MI355X_MICROARCH.md, dense
 L_BLAT, N_MUT_BLAT = 286, 4996
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r4", "pmc_traffic.json")
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r5", "pmc_traffic.json")
 
 
-def ffn_traffic(precision, M, D, F):
-    """HBM-side bytes per FFN GEMM launch from the committed rocprofv3 --pmc passes of this same command
-    (scripts/pmc_profile.sh: FETCH_SIZE and WRITE_SIZE in separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md).
-    Counters cannot be read from inside the run, so the summary is a committed file -- and it is only used when it was
-    taken on THIS build: pmc_profile.sh stamps it with build_native._digest() (sha256 over the kernel sources, headers
-    and compiler flags); any other digest, precision or shape gives traffic = null and says why."""
+def ffn_traffic(precision, M, D, F, live=None):
+    """HBM-side bytes per FFN GEMM launch from rocprofv3 --pmc passes of this same command (FETCH_SIZE and WRITE_SIZE in separate
+    runs, FETCH_SIZE doubled per MI355X_MICROARCH.md).  ``live``: the passes `live_traffic` collected on THIS box after the timed
+    region (preferred); otherwise the committed file of scripts/pmc_profile.sh -- only when it was taken on THIS build: it is
+    stamped with build_native._digest() (sha256 over the kernel sources, headers and compiler flags); any other digest, precision
+    or shape gives traffic = null and says why."""
     if precision != "f16x3":
         return None, {"unavailable": "PMC passes were taken on the f16x3 kernels only"}
-    if not os.path.exists(PMC_TRAFFIC):
-        return None, {"unavailable": f"{os.path.relpath(PMC_TRAFFIC, ROOT)} not found"}
     from proteingym_amd import build_native
-    doc = json.load(open(PMC_TRAFFIC))
-    if doc.get("lib_digest") != build_native._digest():
-        return None, {"unavailable": f"{os.path.relpath(PMC_TRAFFIC, ROOT)} was collected on another build of the kernels "
-                                     f"(digest {str(doc.get('lib_digest'))[:12]} != {build_native._digest()[:12]}): re-run scripts/pmc_profile.sh"}
+    if live is not None and live.get("kernels"):
+        doc, where = live, "rocprofv3 --pmc passes run by bench.py itself on this box, after the timed region"
+    else:
+        why_not_live = (live or {}).get("unavailable", "not attempted")
+        if not os.path.exists(PMC_TRAFFIC):
+            return None, {"unavailable": f"{os.path.relpath(PMC_TRAFFIC, ROOT)} not found", "in_run_passes": why_not_live}
+        doc = json.load(open(PMC_TRAFFIC))
+        where = f"{os.path.relpath(PMC_TRAFFIC, ROOT)} (committed passes of scripts/pmc_profile.sh; in-run passes: {why_not_live})"
+        if doc.get("lib_digest") != build_native._digest():
+            return None, {"unavailable": f"{os.path.relpath(PMC_TRAFFIC, ROOT)} was collected on another build of the kernels "
+                                         f"(digest {str(doc.get('lib_digest'))[:12]} != {build_native._digest()[:12]}): re-run scripts/pmc_profile.sh",
+                          "in_run_passes": why_not_live}
     if doc.get("rows_per_launch") not in (None, M):
         return None, {"unavailable": f"PMC passes cover launches of {doc.get('rows_per_launch')} rows, this run has {M}"}
     k = doc["kernels"]
@@ -64,15 +69,81 @@ def ffn_traffic(precision, M, D, F):
     algo = {"fc1": {"read": 4.0 * (M * D + F * D), "write": 4.0 * M * F}, "fc2_and_out_mean": {"read": 4.0 * (M * (F + D) / 2 + (D * F + D * D) / 2) + 4.0 * M * D, "write": 4.0 * M * D}}
     detail = {"fc1": {"fetch_bytes": fc1["fetch_bytes"], "write_bytes": fc1["write_bytes"], "algorithmic_read": algo["fc1"]["read"],
                       "algorithmic_write": algo["fc1"]["write"], "fetch_over_algorithmic": fc1["fetch_bytes"] / algo["fc1"]["read"],
-                      "l2_hit_rate": fc1["l2_hit_rate"]},
+                      "l2_hit_rate": fc1.get("l2_hit_rate")},
               "fc2_and_out_projection_mean": {"fetch_bytes": fc2["fetch_bytes"], "write_bytes": fc2["write_bytes"],
                                               "algorithmic_read": algo["fc2_and_out_mean"]["read"], "algorithmic_write": algo["fc2_and_out_mean"]["write"],
                                               "fetch_over_algorithmic": fc2["fetch_bytes"] / algo["fc2_and_out_mean"]["read"],
-                                              "l2_hit_rate": fc2["l2_hit_rate"]},
-              "lib_digest": doc["lib_digest"][:16], "git_head": doc.get("git_head"),
-              "source": f"{os.path.relpath(PMC_TRAFFIC, ROOT)} (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes of `bench.py --layers 4` on "
-                        "this build; bytes at the L2<->fabric boundary: requests served by the 256 MB Infinity Cache are counted)"}
+                                              "l2_hit_rate": fc2.get("l2_hit_rate")},
+              "lib_digest": str(doc.get("lib_digest"))[:16], "git_head": doc.get("git_head"),
+              "source": where + "; separate FETCH_SIZE / WRITE_SIZE passes of `bench.py --layers 2..4` (every dispatch at the full row "
+                                "count); bytes at the L2<->fabric boundary: requests served by the 256 MB Infinity Cache are counted"}
     return fc1["fetch_bytes"] + fc1["write_bytes"], detail
+
+
+def live_traffic(precision, timeout_s=150):
+    """FETCH_SIZE / WRITE_SIZE of the GEMM launches collected NOW, on this box: two `rocprofv3 --kernel-trace --pmc <counter>` child
+    runs of this script (2 layers, one step, every dispatch at the full row count), parsed like scripts/pmc_summarize.py.  Counters
+    cannot be read from inside a run, so the children run after the timed region.  Never raises: {"unavailable": reason}."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    from collections import defaultdict
+    try:
+        exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+        if precision != "f16x3":
+            return {"unavailable": "f16x3 only"}
+        if exe is None:
+            return {"unavailable": "rocprofv3 not on this box"}
+        from proteingym_amd import build_native
+        agg = defaultdict(lambda: defaultdict(lambda: [0.0, 0]))
+        with tempfile.TemporaryDirectory(dir="/tmp") as d:
+            env = dict(os.environ, PGMI_KEEP_ROWS="0", TMPDIR="/tmp")
+            for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+                env.pop(k, None)
+            for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+                cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", os.path.join(d, counter), "-o", "p", "--",
+                       sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "0", "--cpu-seconds", "0", "--layers", "2",
+                       "--no-box-state", "--no-secondary", "--no-live-traffic", "--precision", precision]
+                done = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env, cwd="/tmp")
+                if done.returncode != 0:
+                    return {"unavailable": f"rocprofv3 --pmc {counter} exited {done.returncode}: {done.stderr.strip()[-200:]}"}
+                for f in glob.glob(os.path.join(d, counter, "**", "*counter_collection.csv"), recursive=True):
+                    for r in csv.DictReader(open(f)):
+                        a = agg[r["Kernel_Name"].split("(")[0][:60]][r["Counter_Name"]]
+                        a[0] += float(r["Counter_Value"])
+                        a[1] += 1
+        kernels = {}
+        for name, c in agg.items():
+            if "gemm16x_kernel" not in name or "FETCH_SIZE" not in c or "WRITE_SIZE" not in c:
+                continue
+            kernels[name] = {"dispatches": c["FETCH_SIZE"][1], "fetch_bytes": c["FETCH_SIZE"][0] / c["FETCH_SIZE"][1] * 1024 * 2,
+                             "write_bytes": c["WRITE_SIZE"][0] / c["WRITE_SIZE"][1] * 1024}
+        if not kernels:
+            return {"unavailable": "no gemm16x_kernel dispatch in the counter files"}
+        return {"lib_digest": build_native._digest(), "git_head": os.environ.get("PGMI_GIT_HEAD"), "rows_per_launch": None, "kernels": kernels}
+    except Exception as e:                                             # noqa: BLE001 -- a profiler hiccup must never take the line down
+        return {"unavailable": repr(e)}
+
+
+def end_to_end_fields(e2e, b217):
+    """Top-level keys that carry the metric SURVEY 8d defines (weights resident -> CSV written) beside the device-only `value`:
+    e2e = {"mutants", "seconds", ...} of the BLAT-shaped assay through parse + upload + run + D2H + CSV; b217 = the
+    benchmark_217_end_to_end leg (or None)."""
+    out = {}
+    if e2e and e2e.get("seconds"):
+        out["value_end_to_end"] = e2e["mutants"] / e2e["seconds"]
+        out["value_end_to_end_detail"] = e2e
+    if b217 and b217.get("seconds"):
+        out["benchmark_217_end_to_end_mutants_per_s"] = b217["mutants"] / b217["seconds"]
+        if b217.get("rank0_wall_clock", {}).get("assay_run_s"):
+            # the one-GPU point of the N > 1 line's strong_scaling_217 (same workload, same timed region: mutants / seconds inside the scorer)
+            out["one_gpu_same_workload_mutants_per_s"] = b217["mutants"] / b217["rank0_wall_clock"]["assay_run_s"]
+            out["one_gpu_same_workload"] = ("the 217-assay-shaped table of the N > 1 lines' strong_scaling_217 on one GPU (secondary."
+                                            "benchmark_217_end_to_end: mutants / rank0_wall_clock.assay_run_s); its scaling efficiency at N GPUs = "
+                                            "strong_scaling_217.mutants_per_s / (N * this number)")
+    return out
 
 
 def box_state(step, seconds=2.0):
@@ -379,6 +450,38 @@ def secondary(precision, budget_note="bounded: every leg is a few seconds of GPU
     return out
 
 
+def end_to_end_blat(model, seq, muts, reps=3):
+    """The BLAT-shaped assay from mutant STRINGS to a CSV on disk with the weights resident ("weights resident" to "all
+    CSVs written"): parse + upload (Assay), run, scores to the host, the assay's frame with its score column written like the CLI
+    writes it.  Mean of `reps` runs after one untimed run."""
+    import tempfile
+    import pandas as pd
+    from proteingym_amd import compute_fitness as cf, esm as pesm
+    rng = np.random.default_rng(0)
+    frame = pd.DataFrame({"mutant": muts, "DMS_score": rng.standard_normal(len(muts))})
+    frame["DMS_score_bin"] = (frame["DMS_score"] > 0).astype(int)
+    parts = {"assay_create_s": 0.0, "run_s": 0.0, "csv_s": 0.0}
+    with tempfile.TemporaryDirectory() as d:
+        for r in range(reps + 1):
+            t0 = time.perf_counter()
+            a = pesm.Assay(model, seq, muts, offset_idx=1)
+            t1 = time.perf_counter()
+            scores = a.run()
+            t2 = time.perf_counter()
+            df = frame.copy()
+            df["esm1v_t33_650M_UR90S_1"] = scores
+            cf.write_atomically(df, os.path.join(d, f"BLAT_{r}.csv"))
+            t3 = time.perf_counter()
+            a.close()
+            if r:
+                parts["assay_create_s"] += (t1 - t0) / reps
+                parts["run_s"] += (t2 - t1) / reps
+                parts["csv_s"] += (t3 - t2) / reps
+    return {"mutants": len(muts), "seconds": sum(parts.values()), **{k: round(v, 4) for k, v in parts.items()},
+            "what": "one BLAT-shaped assay, weights resident: mutant strings parsed + uploaded (pgmi_assay_create), masked-marginals, scores "
+                    f"copied to the host, CSV written (all input columns + the score column); mean of {reps} runs"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -392,6 +495,7 @@ def main():
                     help="score with N checkpoints per step and average (ESM-1v ensemble rate; the headline is 1)")
     ap.add_argument("--variant", type=int, default=None, help="debug: PGMI_GEMM_VARIANT tile configuration")
     ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` object (other configs; ~1 min after the headline)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not run the rocprofv3 --pmc child passes for roofline.traffic (the committed file is used)")
     ap.add_argument("--no-box-state", action="store_true", help="skip the `box` object (shader clock / socket power during ~2 s of untimed extra steps)")
     args = ap.parse_args()
 
@@ -453,9 +557,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # N > 1: the BLAT-per-rank loop is the secondary weak-scaling figure (3 steps); the headline is the strong-scaling pass below
-    blat_steps = args.steps if world == 1 else min(args.steps, 3)
-    for _ in range(args.warmup if world == 1 else 1):
+    # every N: W untimed steps, then exactly K timed steps between two fences; N > 1 adds the 217-assay pass AFTER this region
+    blat_steps = args.steps
+    for _ in range(args.warmup):
         step()
     model.profile_reset()
     model.profile_enable(True)
@@ -472,14 +576,19 @@ def main():
         dt = float(tmax.item())
 
     if world > 1:
-        weak = {"value": world * n_mut * blat_steps / dt, "unit": "mutants/s", "ms_per_step": dt / blat_steps * 1e3, "steps": blat_steps,
-                "what": "one BLAT-shaped assay (L=286, 4 996 mutants) per rank per step + all_gather of the score vectors: per-GPU work fixed"}
+        prof = model.profile()
         assay.close()
         sys.path.insert(0, os.path.join(ROOT, "scripts"))
         import bench_scale
-        st = bench_scale.run(model, rank, world, args.steps, args.warmup, torch, dist,
+        strong_steps = max(1, min(args.steps, 4))
+        st = bench_scale.run(model, rank, world, strong_steps, min(args.warmup, 1), torch, dist,
                              max_assays=int(os.environ.get("PGMI_BENCH_217_ASSAYS", "0")))
-        prof = model.profile()
+        st["mutants_per_s"] = st["mutants"] / st["seconds"]
+        st["what"] = (f"ONE pass over the {st['assays']}-assay-shaped DMS substitution benchmark ({st['mutants']} mutants; real seq_len / mutant counts "
+                      "of reference_files/DMS_substitutions.csv, optimal 1024 windows), 1 checkpoint, assays sharded over the ranks by "
+                      "run_benchmark.plan_assays, inputs resident in HBM, one all_gather of the per-mutant score vectors; total work fixed; "
+                      f"timed between its own barriers as {strong_steps} consecutive slices of each rank's work list, max over ranks")
+        st["scaling_efficiency"] = "mutants_per_s / (N * one_gpu_same_workload_mutants_per_s of the N = 1 line)"
         from proteingym_amd import dist as pdist
         rccl = pdist.collective_identity(local_rank)                  # a collective: every rank calls it
         if rank == 0:
@@ -491,34 +600,29 @@ def main():
             passes = 3 if args.precision == "f16x3" else 1
             out = {
                 "metric": "mutants scored/sec (ESM-1v 650M masked-marginal)",
-                "value": st["mutants"] / st["seconds"], "unit": "mutants/s",
+                "value": world * n_mut * blat_steps / dt, "unit": "mutants/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": st["seconds"] / args.steps * 1e3,
-                "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                "ms_per_step": dt / blat_steps * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": {"fp32": "f32", "bf16": "bf16",
                           "f16x3": "f16x3 (fp32 operands split into 2 fp16 planes, 3 fp16 MFMAs per product, fp32 accumulate)"}[args.precision],
                 "data": "synthetic",
-                "config": {"workload": f"ESM-1v 650M masked-marginals, ONE pass over the {st['assays']}-assay-shaped DMS substitution benchmark "
-                                       f"({st['mutants']} mutants; real seq_len / mutant counts of reference_files/DMS_substitutions.csv, optimal 1024 windows), "
-                                       f"1 checkpoint, assays sharded over {world} ranks by run_benchmark.plan_assays, inputs resident in HBM, one RCCL "
-                                       "all_gather of the per-mutant score vectors; total work fixed",
-                           "steps_are": f"{args.steps} consecutive slices of each rank's work list (the timed region is exactly one pass); "
-                                        f"warm-up = the first {min(args.warmup, args.steps)} slices, untimed, then repeated inside the pass",
-                           "one_gpu_point_of_this_curve": "the N = 1 line's secondary.benchmark_217_end_to_end: mutants / rank0_wall_clock.assay_run_s",
+                "config": {"workload": "ESM-1v 650M (33x1280, 20 heads, FFN 5120) masked-marginals, the N = 1 line's step on every rank: one "
+                                       f"BLAT_ECOLX_Stiffler_2015-shaped assay per rank per step (BASELINE.json configs[1]: L=286, T=288, {n_mut} single "
+                                       f"mutants, inputs resident in HBM, a different synthetic assay per rank), then ONE all_gather of the {world} score vectors "
+                                       "(RCCL over xGMI); per-GPU work fixed",
+                           "value_is": "all ranks' mutants / max-over-ranks seconds of the K steps; value(N) / (N * value(1)) = scaling efficiency",
+                           "north_star_workload": "strong_scaling_217 (the whole 217-assay table sharded over the ranks), timed after this region",
                            "precision": args.precision, "layers": args.layers},
                 "rccl": rccl,
-                "scaling_efficiency_formula": "value(N) / (N * one_gpu_same_workload_mutants_per_s of the N = 1 line) -- NOT value(N) / (N * value(1)): "
-                                              "value(1) is BASELINE configs[1] (one BLAT-shaped assay), this line is the 217-assay table",
-                "strong_scaling": st,
-                "weak_scaling": weak,
+                "strong_scaling_217": st,
                 **({"REHEARSAL": "PGMI_BENCH_SHARE_GPU=1: ranks share a GPU and use gloo -- not a measurement"} if share else {}),
-                "roofline": {"bound": "mfma", "kernel": "gemm (fc1+GELU, fc2+residual), rank 0, all shapes of its share of the benchmark",
-                             "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                             "avg_launch_ms": ffn_ms / max(ffn_n, 1), "traffic": None,
-                             "traffic_detail": {"unavailable": "PMC passes cover the N = 1 workload's launch shape only"},
+                "roofline": {"bound": "mfma", "kernel": "gemm (fc1+GELU, fc2+residual), rank 0", "achieved": achieved, "peak": peak,
+                             "unit": "TFLOP/s", "frac": achieved / peak, "avg_launch_ms": ffn_ms / max(ffn_n, 1), "traffic": None,
+                             "traffic_detail": {"unavailable": "PMC passes are collected on the N = 1 line"},
                              "mfma_passes": passes, "mfma_util": passes * achieved / peak,
-                             "note": "achieved = algorithmic FLOPs (2*M*N*K per GEMM) / HIP-event time of rank 0's FFN GEMM launches in the timed pass"},
-                "kernels": {k: {"ms": round(v["ms"], 2), "launches": v["launches"],
+                             "note": "achieved = algorithmic FLOPs (2*M*N*K per GEMM) / HIP-event time of rank 0's FFN GEMM launches in the timed steps"},
+                "kernels": {k: {"ms_per_step": round(v["ms"] / blat_steps, 3), "launches_per_step": v["launches"] // blat_steps,
                                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 and v["flops"] > 0 else None}
                             for k, v in prof.items()},
             }
@@ -538,7 +642,8 @@ def main():
         peak = PEAK_TFLOPS[args.precision]
         passes = 3 if args.precision == "f16x3" else 1          # MFMA FLOPs executed per algorithmic FLOP
         total_fl = sum(v["flops"] for v in prof.values())
-        traffic, traffic_detail = ffn_traffic(args.precision, len(assay.positions) * assay.T, cfg["embed_dim"], cfg["ffn_dim"])
+        live = None if (args.no_live_traffic or args.layers != 33) else live_traffic(args.precision)
+        traffic, traffic_detail = ffn_traffic(args.precision, len(assay.positions) * assay.T, cfg["embed_dim"], cfg["ffn_dim"], live=live)
         kern = {k: {"ms_per_step": round(v["ms"] / args.steps, 3), "launches_per_step": v["launches"] // args.steps,
                     "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 and v["flops"] > 0 else None,
                     "gbps": round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1) if v["ms"] > 0 and v["bytes"] > 0 else None}
@@ -557,7 +662,11 @@ def main():
                                    "BLAT_ECOLX_Stiffler_2015-shaped assay per step (BASELINE.json configs[1]: L=286, T=288, "
                                    f"{len(assay.positions)} masked positions run, {n_mut} single mutants), "
                                    f"{args.checkpoints} checkpoint{'s averaged (ensemble rate)' if args.checkpoints > 1 else ''}; "
-                                   "N > 1 runs the 217-assay-shaped benchmark sharded over the ranks (strong scaling)",
+                                   "N > 1 runs the same step on every rank + one all_gather (weak scaling) and adds strong_scaling_217",
+                       "value_is": "DEVICE-ONLY rate of the hot path: inputs resident in HBM when the timed region starts, scores left in HBM "
+                                   "(mutants / seconds of the K timed steps).  The metric as SURVEY 8d words it -- weights resident to CSV written -- is "
+                                   "value_end_to_end (this assay: mutant strings parsed, uploaded, scored, copied back, CSV written) and, for the whole "
+                                   "217-assay table, benchmark_217_end_to_end_mutants_per_s",
                        "precision": args.precision, "layers": args.layers,
                        "last_layer": ("after its attention the last layer runs on the masked row of every sequence only -- the one row "
                                       "masked-marginals reads (class kept_rows); scores bit-identical to the full evaluation"
@@ -576,6 +685,13 @@ def main():
         }
         if box is not None:
             out["box"] = box
+        e2e = None
+        if world == 1 and args.layers == 33:                          # SURVEY 8d's wording of the metric on this assay (after the timed region)
+            try:
+                e2e = end_to_end_blat(model, seq, muts)
+            except Exception as e:                                    # noqa: BLE001
+                e2e = {"error": repr(e)}
+            out.update(end_to_end_fields(e2e, None))
         if world == 1 and args.cpu_seconds > 0:
             _, gpu_table = assay.run(want_table=True)                 # outside the timed region
             for m2, a2, _ in extra:
@@ -596,11 +712,7 @@ def main():
                 except Exception as e:                               # a secondary leg must never take the headline line down
                     out["secondary"] = {"error": repr(e)}
                 b217 = out["secondary"].get("benchmark_217_end_to_end") if isinstance(out["secondary"], dict) else None
-                if b217 and b217.get("rank0_wall_clock", {}).get("assay_run_s"):
-                    # the one-GPU point of the N > 1 strong-scaling curve (same workload, same timed region: mutants / seconds inside the scorer)
-                    out["one_gpu_same_workload_mutants_per_s"] = b217["mutants"] / b217["rank0_wall_clock"]["assay_run_s"]
-                    out["one_gpu_same_workload"] = ("the 217-assay-shaped table of the N > 1 lines on one GPU (secondary.benchmark_217_end_to_end: mutants / "
-                                                    "rank0_wall_clock.assay_run_s); scaling efficiency at N GPUs = value(N) / (N * this number)")
+                out.update(end_to_end_fields(e2e, b217))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -801,6 +801,7 @@ struct TrChunk {
     int rows = 0, padded = 0;
     double att_flops = 0;
     int add(int call_index, const int32_t* tok, int T, int a0, int root_local, int D) {
+        const int qrows = 32 * att16_waves_per_block(T);  // queries per attention block
         const int local = (int)seq.size(), n = T - a0;
         seq.push_back(call_index);
         off.push_back(rows);
@@ -808,7 +809,7 @@ struct TrChunk {
         root.push_back(root_local < 0 ? local : root_local);
         vt.push_back((uint32_t)((size_t)padded * (size_t)D));
         for (int j = 0; j < (n + 31) / 32; ++j) { tile_seq.push_back(local); tile_j.push_back(j); }
-        for (int j = 0; j < (n + 127) / 128; ++j) { blk_seq.push_back(local); blk_j.push_back(j); }
+        for (int j = 0; j < (n + qrows - 1) / qrows; ++j) { blk_seq.push_back(local); blk_j.push_back(j); }
         tokens.insert(tokens.end(), tok + a0, tok + T);
         rows += n;
         padded += (n + 31) / 32 * 32;
@@ -828,7 +829,8 @@ int run_tranception_shared(pgmi_model* m, TrChunk& ck, int T, const float* prior
     {
         std::vector<int> order(ck.blk_seq.size());
         for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
-        auto keys = [&](int i) { return std::min(T, ck.a[ck.blk_seq[i]] + (ck.blk_j[i] + 1) * 128); };
+        const int qrows = 32 * att16_waves_per_block(T);
+        auto keys = [&](int i) { return std::min(T, ck.a[ck.blk_seq[i]] + (ck.blk_j[i] + 1) * qrows); };
         std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return keys(x) > keys(y); });
         std::vector<int32_t> bs(order.size()), bj(order.size());
         for (size_t i = 0; i < order.size(); ++i) { bs[i] = ck.blk_seq[order[i]]; bj[i] = ck.blk_j[order[i]]; }

@@ -636,6 +636,13 @@ static int launch_att16v2_mode(int wpb, dim3 grid, const unsigned short* qk16, s
     }
 }
 
+// Query tiles (waves) per workgroup for sequences of T tokens, head_dim 64: the tiles are spread evenly over ceil(n / 4) blocks
+int att16_waves_per_block(int T) {
+    const int n32 = (T + 31) / 32, nblk = (n32 + 3) / 4;
+    const int wpb = (n32 + nblk - 1) / nblk;
+    return wpb == 3 ? 4 : wpb;                    // measured: a 4th (idle) wave that only helps loading beats 3-wave blocks
+}
+
 // qkv fp32 [B*T, 3D] -> (rotary) -> split planes -> attention.  Scratch: qk16 2 planes of B*T*2D
 // halfs (plane stride qk_plane), vt16 2 planes of B*H*64*Tp halfs (plane stride vt_plane), Tp = T
 // rounded up to 32.
@@ -681,9 +688,7 @@ int launch_attention_f16x3_v2(const float* qkv, const int32_t* kv_len, const flo
     else if (qkv)          // operands not prepared by the fused QKV epilogue: run the prep pass
         hipLaunchKernelGGL(qkv_prep_kernel, dim3(n32, H, B), dim3(256), 0, s, qkv, cos_t, sin_t, rotary, T, H, Tp,
                            qk16, qk_plane, vt16, vt_plane);
-    const int nblk = (n32 + 3) / 4;
-    int wpb = (n32 + nblk - 1) / nblk;
-    if (wpb == 3) wpb = 4;                        // measured: a 4th (idle) wave that only helps loading beats 3-wave blocks
+    const int wpb = att16_waves_per_block(T), nblk = (n32 + wpb - 1) / wpb;
     const dim3 grid(nblk, H, B);
     if (out_mode == 0) rc = launch_att16v2_mode<0, 3>(wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane, s);
     else rc = launch_att16v2_mode<1, 3>(wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane, s);
@@ -693,7 +698,7 @@ int launch_attention_f16x3_v2(const float* qkv, const int32_t* kv_len, const flo
 }
 
 // Tranception prefix-shared scoring (RagMap): depth-wise conv prep over a list of n_tiles (sequence, 32-token tile) entries, then causal
-// grouped-ALiBi attention over a list of n_blocks (sequence, block of four query tiles) entries; split-plane context rows out (packed rows).
+// grouped-ALiBi attention over a list of n_blocks (sequence, block of att16_waves_per_block(T) query tiles) entries; split-plane context rows out (packed rows).
 int launch_attention_tr_ragged(const float* qkv, const float* conv, const float* slopes, int T, int H, const AttRagged& rg,
                                unsigned short* qk16, size_t qk_plane, unsigned short* vt16, size_t vt_plane, unsigned short* ctx16,
                                size_t plane, hipStream_t s) {
@@ -712,9 +717,15 @@ int launch_attention_tr_ragged(const float* qkv, const float* conv, const float*
     }
     hipLaunchKernelGGL(qkv_prep_conv_kernel<true>, dim3(rg.n_tiles, H, 1), dim3(256), 0, s, qkv, conv, T, H, Tp, qk16, qk_plane, vt16, vt_plane,
                        rg.seq_off, rg.seq_a, rg.seq_root, rg.seq_vt, rg.tile_seq, rg.tile_j);
+    // the same instantiation (waves per block) as the dense launch of T tokens: a row is computed by the same code
     const RagMap rag{rg.seq_off, rg.seq_a, rg.seq_root, rg.seq_vt, rg.blk_seq, rg.blk_j};
-    int rc = launch_att16v2_one<4, 1, 3, 64, true>(dim3(rg.n_blocks, H, 1), qk16, qk_plane, vt16, vt_plane, nullptr, slopes, T, H, Tp, nullptr,
-                                                   ctx16, plane, s, rag);
+    const dim3 grid(rg.n_blocks, H, 1);
+    int rc;
+    switch (att16_waves_per_block(T)) {
+        case 1: rc = launch_att16v2_one<1, 1, 3, 64, true>(grid, qk16, qk_plane, vt16, vt_plane, nullptr, slopes, T, H, Tp, nullptr, ctx16, plane, s, rag); break;
+        case 2: rc = launch_att16v2_one<2, 1, 3, 64, true>(grid, qk16, qk_plane, vt16, vt_plane, nullptr, slopes, T, H, Tp, nullptr, ctx16, plane, s, rag); break;
+        default: rc = launch_att16v2_one<4, 1, 3, 64, true>(grid, qk16, qk_plane, vt16, vt_plane, nullptr, slopes, T, H, Tp, nullptr, ctx16, plane, s, rag); break;
+    }
     if (rc) return rc;
     PGMI_HIP(hipGetLastError());
     return PGMI_OK;

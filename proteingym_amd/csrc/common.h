@@ -161,10 +161,11 @@ struct AttRagged {
     const uint32_t* seq_vt;        // [sequences] offset (halfs, per plane) of the sequence's V^T block [H][64][roundup(T - seq_a, 32)]
     const int32_t* tile_seq;       // [n_tiles] 32-token tiles of the suffixes: sequence, tile index inside the suffix
     const int32_t* tile_j;
-    const int32_t* blk_seq;        // [n_blocks] blocks of four query tiles: sequence, block index inside the suffix
+    const int32_t* blk_seq;        // [n_blocks] blocks of att16_waves_per_block(T) query tiles: sequence, block index inside the suffix
     const int32_t* blk_j;
     int n_tiles, n_blocks;
 };
+int att16_waves_per_block(int T);
 int launch_attention_tr_ragged(const float* qkv, const float* conv, const float* slopes, int T, int H, const AttRagged& rg,
                                unsigned short* qk16, size_t qk_plane, unsigned short* vt16, size_t vt_plane, unsigned short* ctx16,
                                size_t plane, hipStream_t s);

@@ -1,4 +1,4 @@
-"""Strong-scaling leg of bench.py (N > 1): ONE pass over the 217-assay-shaped substitution benchmark, sharded over the
+"""Strong-scaling leg of bench.py (N > 1; the line's `strong_scaling_217` object, timed after the headline's K steps): ONE pass over the 217-assay-shaped substitution benchmark, sharded over the
 ranks exactly as the product runner shards it (run_benchmark.plan_assays: LPT on planned seconds), inputs resident.
 
 north_star: "mutants/sec on synthetic 217-assay-shaped input reported at 1/2/4/8 GPUs".  The table is

@@ -16,6 +16,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# PGMI_TEST_WORLD=8: the same tests as EIGHT ranks on the one GPU -- the rehearsal of the driver's 8-GPU launch (scripts/gpu/r5_world8.sh)
+WORLD = int(os.environ.get("PGMI_TEST_WORLD", "2"))
 
 
 def _free_port():
@@ -76,8 +78,8 @@ def test_run_benchmark_two_ranks_write_the_one_process_files(lib, golden, golden
     common = ["--model-location", os.path.join(golden_dir, "esm1v_toy_1.pt"), os.path.join(golden_dir, "esm1v_toy_2.pt"),
               "--model_type", "ESM1v", "--dms_mapping", str(tmp_path / "map.csv"), "--dms-input", golden_dir, "--backend", "gloo", *extra]
     _launch("proteingym_amd.run_benchmark", common + ["--dms-output", str(tmp_path / "w1")], 1)
-    outs = _launch("proteingym_amd.run_benchmark", common + ["--dms-output", str(tmp_path / "w2")], 2)
-    assert "on 2 GPU(s)" in outs[0]
+    outs = _launch("proteingym_amd.run_benchmark", common + ["--dms-output", str(tmp_path / "w2")], WORLD)
+    assert f"on {WORLD} GPU(s)" in outs[0]
     _same_files(tmp_path / "w1", tmp_path / "w2", names)
     df = pd.read_csv(tmp_path / "w2" / "TOY_A.csv")
     assert np.abs(df["esm1v_toy_1"].to_numpy() - golden["cli/esm1v_toy_1"]).max() < 1e-4       # and they are the reference's numbers
@@ -89,7 +91,7 @@ def test_run_benchmark_wt_marginals_two_ranks(lib, golden, golden_dir, tmp_path)
     common = ["--model-location", os.path.join(golden_dir, "esm1v_toy_1.pt"), "--model_type", "ESM1b", "--dms_mapping", str(tmp_path / "map.csv"),
               "--dms-input", golden_dir, "--backend", "gloo", "--scoring-strategy", "wt-marginals", "--scoring-window", "overlapping"]
     _launch("proteingym_amd.run_benchmark", common + ["--dms-output", str(tmp_path / "w1")], 1)
-    _launch("proteingym_amd.run_benchmark", common + ["--dms-output", str(tmp_path / "w2")], 2)
+    _launch("proteingym_amd.run_benchmark", common + ["--dms-output", str(tmp_path / "w2")], WORLD)
     _same_files(tmp_path / "w1", tmp_path / "w2", names)
 
 
@@ -103,8 +105,8 @@ def test_run_indels_two_ranks_pool_the_sequences(lib, golden_dir, tmp_path):
     common = ["--model-location", os.path.join(golden_dir, "esm2_toy.pt"), "--model_type", "ESM2", "--dms_mapping", str(tmp_path / "map.csv"),
               "--dms-input", str(tmp_path), "--backend", "gloo"]
     _launch("proteingym_amd.run_indels", common + ["--dms-output", str(tmp_path / "w1")], 1)
-    outs = _launch("proteingym_amd.run_indels", common + ["--dms-output", str(tmp_path / "w2")], 2)
-    assert "on 2 GPU(s)" in outs[0]
+    outs = _launch("proteingym_amd.run_indels", common + ["--dms-output", str(tmp_path / "w2")], WORLD)
+    assert f"on {WORLD} GPU(s)" in outs[0]
     _same_files(tmp_path / "w1", tmp_path / "w2", ["I0.csv", "I1.csv"])
 
 
@@ -126,7 +128,7 @@ def test_run_sharded_tranception_two_ranks_mutant_chunks(lib, golden_dir, tmp_pa
               "--DMS_data_folder", str(dms), "--inference_time_retrieval", "--MSA_folder", golden_dir]
     head = ["tranception", "--max-chunk-rows", "7", "--backend", "gloo", "--"]
     _launch("proteingym_amd.run_sharded", head + common + ["--output_scores_folder", str(tmp_path / "w1")], 1)
-    _launch("proteingym_amd.run_sharded", head + common + ["--output_scores_folder", str(tmp_path / "w2")], 2)
+    _launch("proteingym_amd.run_sharded", head + common + ["--output_scores_folder", str(tmp_path / "w2")], WORLD)
     _same_files(tmp_path / "w1", tmp_path / "w2", ["A.csv", "B.csv"])
 
 
@@ -138,5 +140,5 @@ def test_run_sharded_msa_transformer_two_ranks_seed_position_pairs(lib, golden_d
               "--msa-samples", "12", "--seeds", "1", "2"]
     head = ["msa_transformer", "--shard", "positions", "--backend", "gloo", "--"]
     _launch("proteingym_amd.run_sharded", head + common + ["--dms-output", str(tmp_path / "w1")], 1)
-    _launch("proteingym_amd.run_sharded", head + common + ["--dms-output", str(tmp_path / "w2")], 2)
+    _launch("proteingym_amd.run_sharded", head + common + ["--dms-output", str(tmp_path / "w2")], WORLD)
     _same_files(tmp_path / "w1", tmp_path / "w2", ["TOY_MSA_DMS.csv"])

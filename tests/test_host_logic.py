@@ -484,3 +484,34 @@ def test_bench_box_state_never_raises(monkeypatch):
     assert calls[0] > 0 and ("unavailable" in out or {"sclk_mhz", "socket_power_w", "samples"} <= set(out))
     monkeypatch.setenv("PATH", "/nonexistent")                       # no rocm-smi at all
     assert "unavailable" in bench.box_state(step, seconds=0.1)
+
+
+def test_bench_line_carries_the_metric_as_survey_8d_words_it():
+    """bench.end_to_end_fields: the top-level keys beside the device-only `value` -- value_end_to_end (the BLAT-shaped assay from mutant
+    strings to a CSV, weights resident), the whole table's end-to-end rate and the one-GPU point of the N > 1 line's strong pass;
+    bench.ffn_traffic prefers counters collected in the run and says where its numbers come from; the N > 1 line is the same step."""
+    import importlib.util
+    root = os.path.join(os.path.dirname(__file__), "..")
+    spec = importlib.util.spec_from_file_location("bench_mod_fields", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    e2e = {"mutants": 4996, "seconds": 0.32, "assay_create_s": 0.01, "run_s": 0.29, "csv_s": 0.02}
+    b217 = {"mutants": 2465767, "seconds": 165.0, "rank0_wall_clock": {"assay_run_s": 160.0}}
+    f = bench.end_to_end_fields(e2e, b217)
+    assert abs(f["value_end_to_end"] - 4996 / 0.32) < 1e-9 and f["value_end_to_end_detail"] is e2e
+    assert abs(f["benchmark_217_end_to_end_mutants_per_s"] - 2465767 / 165.0) < 1e-9
+    assert abs(f["one_gpu_same_workload_mutants_per_s"] - 2465767 / 160.0) < 1e-9 and "strong_scaling_217" in f["one_gpu_same_workload"]
+    assert bench.end_to_end_fields(None, None) == {} and "value_end_to_end" not in bench.end_to_end_fields({"error": "x"}, None)
+    assert bench.live_traffic("fp32") == {"unavailable": "f16x3 only"}
+    M, D, F = 82368, 1280, 5120
+    live = {"lib_digest": "abc", "git_head": None, "rows_per_launch": None,
+            "kernels": {"void pgmi::gemm16x_kernel<1, 1, false>": {"dispatches": 2, "fetch_bytes": 3.3e9, "write_bytes": 1.69e9},
+                        "void pgmi::gemm16x_kernel<0, 0, false>": {"dispatches": 4, "fetch_bytes": 2.0e9, "write_bytes": 0.42e9}}}
+    traffic, detail = bench.ffn_traffic("f16x3", M, D, F, live=live)
+    assert traffic == 3.3e9 + 1.69e9 and "bench.py itself" in detail["source"] and detail["fc1"]["fetch_over_algorithmic"] > 7
+    none, why = bench.ffn_traffic("f16x3", M, D, F, live={"unavailable": "rocprofv3 not on this box"})
+    assert none is None or "committed" in why["source"]              # falls back to the committed file (or says why it cannot)
+    src = open(os.path.join(root, "bench.py")).read()
+    for key in ('"value_is"', '"strong_scaling_217"', '"scaling": "weak"', "value_end_to_end"):
+        assert key in src
+    assert '"scaling": "strong"' not in src                           # the N > 1 headline is the N = 1 step on every rank

@@ -1285,3 +1285,75 @@ def test_tranception_product_prefix_sharing_host_logic_on_cpu(golden_dir, monkey
     device.shared = []
     r = model().score_mutants(DMS_data=pd.DataFrame({"mutated_sequence": [seq, to.get_mutated_sequence(seq, dms["mutant"][0])]}), target_seq=None)
     assert device.shared == [] and len(r) == 2
+
+
+@pytest.mark.skipif(not rh.reference_available(), reason="/root/reference not present (GPU box)")
+def test_accept_real_weights_script_on_the_toy_goldens(tmp_path, monkeypatch, golden_dir, capsys):
+    """scripts/accept_real_weights.py end to end on a stand-in ProteinGym checkout (the reference's own merge.py, performance script,
+    constants and registry, linked, around a four-assay reference file of the toy goldens): run_benchmark writes the CSVs (the device
+    served by the reference CLI's golden scores), the reference's scripts turn them into the per-assay Spearman table, and the script
+    compares it with a 'published' table -- exit 0 when that table holds the golden CLI scores' Spearman at 3 decimals, 1 when one
+    published value is moved by 0.01, 2 (nothing scored, every absent input named) without checkpoints or DMS files."""
+    import importlib.util
+    import json
+    import shutil
+    from scipy.stats import spearmanr
+    spec = importlib.util.spec_from_file_location("accept_real_weights", os.path.join(os.path.dirname(__file__), "..", "scripts", "accept_real_weights.py"))
+    accept = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(accept)
+    g = np.load(os.path.join(golden_dir, "golden_esm.npz"), allow_pickle=True)
+    _GoldenCliScorer.golden = g
+    pg = tmp_path / "ProteinGym"
+    (pg / "proteingym").mkdir(parents=True)
+    (pg / "reference_files").mkdir()
+    for f in ("merge.py", "performance_DMS_benchmarks.py", "constants.json"):
+        os.symlink(os.path.join("/root/reference/proteingym", f), pg / "proteingym" / f)
+    registry = json.load(open("/root/reference/config.json"))
+    registry["model_list_zero_shot_substitutions_DMS"]["ESM2_650M"]["input_score_name"] = "esm2_toy"     # the toy checkpoint's stem
+    json.dump(registry, open(pg / "config.json", "w"))
+    dms = tmp_path / "dms"
+    dms.mkdir()
+    layout = [("TOY_A", "TOY_DMS.csv", "seq", "Activity", "medium", "Human"), ("TOY_B", "TOY_DMS.csv", "seq", "Stability", "low", "Virus"),
+              ("TOY_C", "TOY_DMS.csv", "seq", "Binding", "high", "Eukaryote"), ("TOY_D", "TOY_DMS.csv", "seq", "Expression", "medium", "Prokaryote")]
+    rows = []
+    for dms_id, src, seq_key, sel, neff, taxon in layout:
+        shutil.copy(os.path.join(golden_dir, src), dms / f"{dms_id}.csv")
+        rows.append(dict(DMS_id=dms_id, DMS_filename=f"{dms_id}.csv", target_seq=str(g[seq_key]), DMS_total_number_mutants=len(pd.read_csv(dms / f"{dms_id}.csv")),
+                         UniProt_ID=dms_id + "_X", coarse_selection_type=sel, MSA_Neff_L_category=neff, taxon=taxon, MSA_start=1, MSA_end=len(str(g[seq_key]))))
+    pd.DataFrame(rows).to_csv(pg / "reference_files" / "DMS_substitutions.csv", index=False)
+    clean = json.load(open("/root/reference/proteingym/constants.json"))["clean_names"]
+    pub = {}
+    for dms_id, src, *_ in layout:
+        y = pd.read_csv(dms / f"{dms_id}.csv")["DMS_score"]
+        pre = "cli_long/" if "LONG" in src else "cli/"
+        one = round(float(spearmanr(y, g[pre + "esm1v_toy_1"])[0]), 3)
+        two = np.mean([g[pre + "esm1v_toy_1"], g[pre + "esm1v_toy_2"]], axis=0)
+        pub[dms_id] = {clean["ESM1v_single"]: one, clean["ESM1v_ensemble"]: round(float(spearmanr(y, two)[0]), 3),
+                       clean["ESM2_650M"]: round(float(spearmanr(y, g[pre + "esm2_toy"])[0]), 3)}
+    published = tmp_path / "published.csv"
+    pd.DataFrame.from_dict(pub, orient="index").to_csv(published, index_label="DMS ID")
+
+    def fewer_resamples(perf):
+        slow = perf.compute_bootstrap_standard_error_functional_categories
+        perf.compute_bootstrap_standard_error_functional_categories = lambda df, number_assay_reshuffle=20: slow(df, 20)
+    ck = tmp_path / "ckpt"
+    ck.mkdir()
+    for n in ("esm1v_toy_1.pt", "esm1v_toy_2.pt", "esm2_toy.pt"):
+        (ck / n).write_bytes(b"stand-in: the scorer is served by the golden CLI scores")
+    argv = ["--proteingym", str(pg), "--dms-folder", str(dms), "--esm1v", str(ck / "esm1v_toy_1.pt"), str(ck / "esm1v_toy_2.pt"), "--esm2", str(ck / "esm2_toy.pt"),
+            "--assays", "TOY_A", "TOY_B", "TOY_C", "TOY_D", "--published", str(published)]
+    assert accept.main(argv + ["--out", str(tmp_path / "run1")], make_model=_GoldenCliScorer, patch_performance=fewer_resamples) == 0
+    report = pd.read_csv(tmp_path / "run1" / "acceptance_report.csv")
+    assert len(report) == 12 and (report["verdict"] == "ok").all() and report["abs_difference"].max() <= 0.001 + 1e-12
+    assert (np.abs(report["scipy_on_our_scores"] - report["reference_script_on_our_scores"]) <= 0.0005 + 1e-9).all()
+    moved = pd.read_csv(published, index_col="DMS ID")
+    moved.iloc[1, 0] += 0.01
+    moved.to_csv(tmp_path / "moved.csv", index_label="DMS ID")
+    argv_moved = argv[:-1] + [str(tmp_path / "moved.csv")]
+    assert accept.main(argv_moved + ["--out", str(tmp_path / "run2"), "--assays", "TOY_A", "TOY_B"], make_model=_GoldenCliScorer, patch_performance=fewer_resamples) == 1
+    capsys.readouterr()
+    assert accept.main(["--proteingym", str(pg), "--dms-folder", str(tmp_path / "no_such_folder"), "--esm1v", str(ck / "absent.pt"), "--assays", "TOY_A", "NOT_AN_ASSAY",
+                        "--out", str(tmp_path / "run3")]) == 2
+    err = capsys.readouterr().err
+    assert "absent.pt" in err and "NOT_AN_ASSAY" in err and "no_such_folder" in err and not os.path.exists(tmp_path / "run3")
+    assert accept.main(["--proteingym", str(tmp_path / "nowhere"), "--dms-folder", str(dms), "--esm1v", str(ck / "esm1v_toy_1.pt")]) == 2
