@@ -15,6 +15,8 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+#include <math.h>
 #include <algorithm>
 #include <vector>
 
@@ -55,10 +57,56 @@ __device__ __forceinline__ void step24(f32x16 (&acc)[2][4], u32x4 (&af)[2][4], u
     __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
 }
 
+// f16 / f64 denormal mode of THIS wave = flush (MODE.FP_DENORM[3:2] = 0): v_cvt_pk_f16_f32 then returns +-0 for results below fp16's
+// normal range, which is what split_act's compare + select does by hand
+__device__ __forceinline__ void f16_denorm_flush() { __builtin_amdgcn_s_setreg(1 | (6 << 6) | (1 << 11), 0); }
+
+// split_act for a pair, without the compare + select (needs f16_denorm_flush): hi = fp16(x) packed, lo = fp16((x - hi) 2^11) through one
+// packed multiply and a mixed-precision fma per value (x 2^11 and the fma are exact)
+__device__ __forceinline__ void split_pair(float x0, float x1, hh2& hi, hh2& lo) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    hi = hh2{(_Float16)x0, (_Float16)x1};
+    const f2 xs = f2{x0, x1} * f2{2048.0f, 2048.0f};
+    const float l0 = fmaf((float)hi[0], -2048.0f, xs[0]), l1 = fmaf((float)hi[1], -2048.0f, xs[1]);
+    lo = hh2{(_Float16)l0, (_Float16)l1};
+}
+
+__global__ void split_selftest(const float* x, int n, unsigned short* hi_out, unsigned short* lo_out, unsigned short* hi_ref, unsigned short* lo_ref) {
+    f16_denorm_flush();
+    const int i = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
+    if (i + 1 >= n) return;
+    hh2 h, l;
+    split_pair(x[i], x[i + 1], h, l);
+    hi_out[i] = __builtin_bit_cast(unsigned short, h[0]); hi_out[i + 1] = __builtin_bit_cast(unsigned short, h[1]);
+    lo_out[i] = __builtin_bit_cast(unsigned short, l[0]); lo_out[i + 1] = __builtin_bit_cast(unsigned short, l[1]);
+    _Float16 a, b;
+    split_act(x[i], a, b); hi_ref[i] = __builtin_bit_cast(unsigned short, a); lo_ref[i] = __builtin_bit_cast(unsigned short, b);
+    split_act(x[i + 1], a, b); hi_ref[i + 1] = __builtin_bit_cast(unsigned short, a); lo_ref[i + 1] = __builtin_bit_cast(unsigned short, b);
+}
+
 // FC1-like epilogue of one wave: 128 values per lane through scale + bias, GELU, split; 32 dwordx4 stores per wave (lane-contiguous:
 // every store instruction writes 1 KB), accumulators cleared.
-__device__ __forceinline__ void epilogue(f32x16 (&acc)[2][4], unsigned short* out, int lane, float scale) {
+// FAST 0: split_act; 1: packed split; 3: the arithmetic only (stores behind a flag that is never set); 4: the stores only (raw accumulators)
+template <int FAST>
+__device__ __forceinline__ void epilogue(f32x16 (&acc)[2][4], unsigned short* out, int lane, float scale, bool do_store = true) {
     u32x4* dst = reinterpret_cast<u32x4*>(out) + lane;
+    if (FAST == 4) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    dst[((i * 2 + j) * 4 + g) * 64] = u32x4{__builtin_bit_cast(unsigned, acc[j][i][4 * g]), __builtin_bit_cast(unsigned, acc[j][i][4 * g + 1]),
+                                                             __builtin_bit_cast(unsigned, acc[j][i][4 * g + 2]), __builtin_bit_cast(unsigned, acc[j][i][4 * g + 3])};
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) acc[j][i][v] = 0.f;
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -68,13 +116,35 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[2][4], unsigned short* ou
                 f32x4 v;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = fmaf(acc[j][i][4 * g + e], scale, 0.01f * e);
-                v = gelu_erf16(v);
-                _Float16 h[4], l[4];
+                if (FAST != 5 && FAST != 7) v = gelu_erf16(v);
+                if (FAST == 7) {                                               // gelu_erf16 with its four v_exp_f32 replaced by fmas (wrong values, same shape)
+                    auto all = [](float t) { return f32x4{t, t, t, t}; };
+                    const f32x4 bq = __builtin_elementwise_max(-__builtin_elementwise_abs(v), all(-6.0f));
+                    f32x4 q = __builtin_elementwise_fma(v, all(0.0f), all(3.309269596e-05f));
+                    q = __builtin_elementwise_fma(q, bq, all(7.692188374e-04f));
+                    q = __builtin_elementwise_fma(q, bq, all(8.080714382e-03f));
+                    q = __builtin_elementwise_fma(q, bq, all(5.341210216e-02f));
+                    q = __builtin_elementwise_fma(q, bq, all(-4.587709904e-01f));
+                    q = __builtin_elementwise_fma(q, bq, all(1.151201725e+00f));
+                    q = __builtin_elementwise_fma(q, bq, all(-9.999930859e-01f));
+                    q = __builtin_elementwise_fma(q, bq, all(0.25f));
+                    v = __builtin_elementwise_fma(bq, q, __builtin_elementwise_max(v, all(0.0f)));
+                }
+                hh2 a, b, c, d;
+                if (FAST == 6) {
+                    a = hh2{(_Float16)v[0], (_Float16)v[1]}; b = hh2{(_Float16)v[2], (_Float16)v[3]}; c = a; d = b;
+                } else if (FAST == 1) {
+                    split_pair(v[0], v[1], a, c);
+                    split_pair(v[2], v[3], b, d);
+                } else {
+                    _Float16 h[4], l[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) split_act(v[e], h[e], l[e]);
-                const hh2 a = {h[0], h[1]}, b = {h[2], h[3]}, c = {l[0], l[1]}, d = {l[2], l[3]};
-                dst[((i * 2 + j) * 4 + g) * 64] = u32x4{__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, c),
-                                                         __builtin_bit_cast(unsigned, d)};
+                    for (int e = 0; e < 4; ++e) split_act(v[e], h[e], l[e]);
+                    a = hh2{h[0], h[1]}; b = hh2{h[2], h[3]}; c = hh2{l[0], l[1]}; d = hh2{l[2], l[3]};
+                }
+                const u32x4 pk = u32x4{__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), __builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d)};
+                if (FAST == 3 || FAST >= 5) { asm volatile("" :: "v"(pk)); if (do_store) dst[((i * 2 + j) * 4 + g) * 64] = pk; }
+                else dst[((i * 2 + j) * 4 + g) * 64] = pk;
             }
 #pragma unroll
     for (int j = 0; j < 2; ++j)
@@ -96,10 +166,14 @@ __device__ __forceinline__ void item_coords(int item, int n_items, int tiles_m, 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // CW = 1: the item's first wait is COUNTED -- vmcnt(32): the eight DMAs of its first K tile were issued before the previous epilogue's 32
 // stores, so they have landed once at most 32 operations are outstanding -- instead of the product's vmcnt(0), which waits for the stores
+// VAR 2 / 3: the CU slots of an XCD start 1 / 3 us apart (slot = blockIdx.x / 8 mod 32): do the epilogues' store bursts cost less when the 32 CUs behind
+// one L2-fabric port do not burst together?   VAR 4: the next item's first TWO K tiles are in flight before the epilogue's stores (the probe has no LDS
+// patches, both stages are free), with counted waits across the stores: the stores get two K tiles of time to drain before anybody waits for them.
 template <int EPI, int CW>
 __global__ __launch_bounds__(512, 2) void pingpong8(const unsigned short* __restrict__ A, const unsigned short* __restrict__ W, unsigned short* out,
                                                     int n_items, float* sink) {
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];                  // [2][4096]
+    if (EPI == 2) f16_denorm_flush();
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool late = wave >= 4;
     const int wm = wave >> 2, wn = wave & 3, r = lane & 31, kh = lane >> 5, fsw = (r >> 1) & 7;
@@ -150,12 +224,21 @@ __global__ __launch_bounds__(512, 2) void pingpong8(const unsigned short* __rest
     };
     int item = blockIdx.x;
     if (item >= n_items) return;
+    if (CW == 2 || CW == 3) {                                                    // 100 MHz wall clock
+        const unsigned long long t_end = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(((blockIdx.x >> 3) & 31) * (CW == 2 ? 100 : 300));
+        while (__builtin_amdgcn_s_memrealtime() < t_end) __builtin_amdgcn_s_sleep(8);
+    }
     decode(item);
     issue(0, 0);
     float keep = 0.f;
     bool first = true;
     while (true) {
-        if (CW && EPI && !first) {
+        if (CW == 4 && EPI && !first) {
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0x8078);                                   // vmcnt(40) lgkmcnt(0): tile 0 landed; tile 1's eight DMAs and the 32 stores may be out
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+        } else if (CW == 1 && EPI && !first) {
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_waitcnt(0x8070);                                   // vmcnt(32) lgkmcnt(0)
             __builtin_amdgcn_s_barrier();
@@ -163,14 +246,16 @@ __global__ __launch_bounds__(512, 2) void pingpong8(const unsigned short* __rest
         } else {
             phase(true);
         }
+        const bool was_first = first;
         first = false;
         int cur = 0;
         if (late) phase(false);
         for (int kt = 0; kt < NKT; ++kt) {
             const u32x4* Ab = lds + cur * 4096;
             const u32x4* Wb = Ab + 2048;
+            const bool ahead = CW == 4 && EPI && !was_first && kt == 0;          // tile 1 of this item is already in flight, behind it the stores
             __builtin_amdgcn_s_setprio(0);
-            if (kt + 1 < NKT) issue(kt + 1, cur ^ 1);
+            if (kt + 1 < NKT && !ahead) issue(kt + 1, cur ^ 1);
             frags(Ab, Wb, 0);
             phase(false);
             __builtin_amdgcn_s_setprio(1);
@@ -178,10 +263,20 @@ __global__ __launch_bounds__(512, 2) void pingpong8(const unsigned short* __rest
             phase(false);
             __builtin_amdgcn_s_setprio(0);
             frags(Ab, Wb, 1);
-            phase(late);
+            auto close = [&](bool vm) {                                           // the wave group's last barrier of the K tile
+                if (vm && ahead) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_waitcnt(0x8070);                           // vmcnt(32): tile 1 landed, the stores may still be out
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    phase(vm);
+                }
+            };
+            close(late);
             __builtin_amdgcn_s_setprio(1);
             step24(acc, af, wf);
-            phase(!late);
+            close(!late);
             cur ^= 1;
         }
         __builtin_amdgcn_s_setprio(0);
@@ -189,8 +284,8 @@ __global__ __launch_bounds__(512, 2) void pingpong8(const unsigned short* __rest
         const int done = item;
         item += gridDim.x;
         const bool more = item < n_items;
-        if (more) { decode(item); issue(0, 0); }
-        if (EPI) epilogue(acc, out + ((size_t)done * 8 + wave) * 16384, lane, 1e-4f);
+        if (more) { decode(item); issue(0, 0); if (CW == 4 && EPI) issue(1, 1); }
+        if (EPI) epilogue<(EPI == 2 ? 1 : EPI == 1 ? 0 : EPI)>(acc, out + ((size_t)done * 8 + wave) * 16384, lane, 1e-4f, n_items < 0);
         else { keep += acc[0][0][0]; }
         if (!more) break;
     }
@@ -298,7 +393,7 @@ __global__ __launch_bounds__(256, 2) void duo4(const unsigned short* __restrict_
         const bool more = item < n_items;
         __builtin_amdgcn_s_barrier();                                             // every wave is through its last fragment reads: the ring restarts at slot 0
         if (more) { decode(item); issue(0, 0); issue(1, 1); }
-        if (EPI) epilogue(acc, out + ((size_t)done * 4 + wave) * 16384, lane, 1e-4f);
+        if (EPI) epilogue<(EPI == 2 ? 1 : 0)>(acc, out + ((size_t)done * 4 + wave) * 16384, lane, 1e-4f);
         else { keep += acc[0][0][0]; }
         if (!more) break;
     }
@@ -338,39 +433,49 @@ int main(int argc, char** argv) {
     for (size_t o = 0; o < w_bytes; o += h.size() * 2) hipMemcpy((char*)W + o, h.data(), std::min(h.size() * 2, w_bytes - o), hipMemcpyHostToDevice);
     hipDeviceProp_t prop; hipGetDeviceProperties(&prop, 0);
     const int cus = prop.multiProcessorCount - prop.multiProcessorCount % 8;
-    auto pp0 = pingpong8<0, 0>; auto pp1 = pingpong8<1, 0>; auto pp2 = pingpong8<1, 1>;
-    auto d00 = duo4<0, 0>; auto d01 = duo4<0, 1>; auto d10 = duo4<1, 0>; auto d11 = duo4<1, 1>;
-    hipFuncSetAttribute(reinterpret_cast<const void*>(pp0), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(pp1), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(pp2), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
-    for (auto f : {reinterpret_cast<const void*>(d00), reinterpret_cast<const void*>(d01), reinterpret_cast<const void*>(d10), reinterpret_cast<const void*>(d11)})
+    auto d00 = duo4<0, 0>; auto d10 = duo4<1, 0>; auto d11 = duo4<1, 1>;
+    for (auto f : {reinterpret_cast<const void*>(d00), reinterpret_cast<const void*>(d10), reinterpret_cast<const void*>(d11)})
         hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+    typedef void (*Kfn)(const unsigned short*, const unsigned short*, unsigned short*, int, float*);
+    struct Variant { const char* name; Kfn fn; bool duo; };
+    const Variant vs[] = {
+        {"pingpong8 no epilogue", pingpong8<0, 0>, false},
+        {"pingpong8 + FC1-like epilogue", pingpong8<1, 0>, false},
+        {"pingpong8 + epilogue, arithmetic only (no stores)", pingpong8<3, 0>, false},
+        {"pingpong8 + epilogue, stores only (raw accumulators)", pingpong8<4, 0>, false},
+        {"pingpong8 arithmetic only: scale + bias + split, no GELU", pingpong8<5, 0>, false},
+        {"pingpong8 arithmetic only: GELU, plain conversion (no split)", pingpong8<6, 0>, false},
+        {"pingpong8 arithmetic only: GELU without v_exp_f32, split", pingpong8<7, 0>, false},
+        {"pingpong8 + epilogue, counted first wait", pingpong8<1, 1>, false},
+        {"pingpong8 + epilogue, packed split (no compare)", pingpong8<2, 0>, false},
+        {"pingpong8 + epilogue, CU slots 1 us apart", pingpong8<1, 2>, false},
+        {"pingpong8 + epilogue, two K tiles in flight before the stores", pingpong8<1, 4>, false},
+        {"duo4 contiguous no epilogue", d00, true},
+        {"duo4 contiguous + epilogue", d10, true},
+        {"duo4 split-32B + epilogue", d11, true},
+    };
+    constexpr int NV = sizeof(vs) / sizeof(vs[0]);
+    for (const Variant& v : vs)
+        if (!v.duo) hipFuncSetAttribute(reinterpret_cast<const void*>(v.fn), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
     const double flops = 2.0 * M_ROWS * (double)N_ROWS * K_ELEMS;             // algorithmic (one product per element pair)
-    constexpr int NV = 7;
-    const char* names[NV] = {"pingpong8 no epilogue", "duo4 contiguous no epilogue", "duo4 split-32B no epilogue", "pingpong8 + FC1-like epilogue",
-                             "pingpong8 + epilogue, counted wait", "duo4 contiguous + epilogue", "duo4 split-32B + epilogue"};
     printf("FC1 shape %d x %d x %d: %d tiles of 256 x 256 / %d tiles of 128 x 256, %d CUs\n", M_ROWS, N_ROWS, K_ELEMS, items8, items4, cus);
     std::vector<std::vector<float>> ms(NV);
     for (int r = 0; r <= rounds; ++r) {
         float t[NV];
-        t[0] = time_one(pp0, dim3(cus), dim3(512), 136 * 1024, A, W, out, items8, sink);
-        t[1] = time_one(d00, dim3(2 * cus), dim3(256), 80 * 1024, A, W, out, items4, sink);
-        t[2] = time_one(d01, dim3(2 * cus), dim3(256), 80 * 1024, A, W, out, items4, sink);
-        t[3] = time_one(pp1, dim3(cus), dim3(512), 136 * 1024, A, W, out, items8, sink);
-        t[4] = time_one(pp2, dim3(cus), dim3(512), 136 * 1024, A, W, out, items8, sink);
-        t[5] = time_one(d10, dim3(2 * cus), dim3(256), 80 * 1024, A, W, out, items4, sink);
-        t[6] = time_one(d11, dim3(2 * cus), dim3(256), 80 * 1024, A, W, out, items4, sink);
+        for (int k = 0; k < NV; ++k)
+            t[k] = vs[k].duo ? time_one(vs[k].fn, dim3(2 * cus), dim3(256), 80 * 1024, A, W, out, items4, sink)
+                             : time_one(vs[k].fn, dim3(cus), dim3(512), 136 * 1024, A, W, out, items8, sink);
         if (r == 0) continue;                                                  // warm-up round
         for (int k = 0; k < NV; ++k) ms[k].push_back(t[k]);
         printf("round %d:", r);
-        for (int k = 0; k < NV; ++k) printf("  %.3f ms = %.1f", t[k], flops / t[k] / 1e9);
+        for (int k = 0; k < NV; ++k) printf(" %.1f", flops / t[k] / 1e9);
         printf("  TFLOP/s\n");
         fflush(stdout);
     }
     for (int k = 0; k < NV; ++k) {
         std::sort(ms[k].begin(), ms[k].end());
         const float med = ms[k][ms[k].size() / 2];
-        printf("%-34s median %.3f ms = %.1f TFLOP/s algorithmic\n", names[k], med, flops / med / 1e9);
+        printf("%-64s median %.3f ms = %.1f TFLOP/s algorithmic\n", vs[k].name, med, flops / med / 1e9);
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { printf("HIP error: %s\n", hipGetErrorString(e)); return 1; }
