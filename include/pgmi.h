@@ -248,8 +248,10 @@ int pgmi_tr_sequence_loglik(pgmi_model* m, const int32_t* tokens, const int32_t*
  *   (tranception/utils/scoring_utils.py:97-128 inside :77-150; model_pytorch.py:878-928), although the model is causal (attention
  *   model_pytorch.py:155-183, depth-wise convolution :73-88) and a mutated sequence equals the wild type up to its first mutated token.
  *   ref[b] names the sequence of this call whose prefix sequence b shares (its "root": the wild type cut to the same window); a root
- *   has ref[b] == b and is forwarded in full.  For every other sequence only the rows from the 32-token tile of its first difference
- *   from its root on are forwarded; keys, values, convolution history and log-probability rows before that are the root's.  Every row
+ *   has ref[b] == b and is forwarded in full.  For every other sequence only the rows from its first difference from its root on go
+ *   through LayerNorm, the GEMMs and the head (the depth-wise convolution and the attention also recompute the head of that token's
+ *   32-token tile from the root's rows, so that tiles stay whole); keys, values, convolution history and log-probability rows before
+ *   that are the root's.  Every row
  *   goes through the same kernels with the same inputs in the same order as in pgmi_tr_sequence_loglik: out[b] has the same bits.
  *   token_logprobs (optional, f32 [B,T,V]): the rows pgmi_tr_token_logprobs would return.  rows_forwarded (optional): token rows that
  *   went through the network (B*T for the unshared call). */

@@ -789,31 +789,33 @@ int run_msa(pgmi_model* m, int R, int C, int keep_col = -1, bool* compacted = nu
 // The reference forwards every mutated sequence in full, in both reading directions (scoring_utils.py:77-150, model_pytorch.py:878-928).
 // The model is causal (attention model_pytorch.py:155-183; depth-wise convolution :73-88): every hidden state of a sequence before its
 // first token that differs from the wild type IS the wild type's.  One chunk of work = ROOT sequences forwarded in full plus sequences
-// that own only the rows from seq_a on (seq_a = the 32-token tile of the first differing token): LayerNorm and the four GEMMs of a
-// layer run on the packed suffix rows (row-local), the convolution takes its six rows of history and the attention its earlier key
-// tiles from the root's rows of the same launch, and the per-sequence reduction reads the root's log-probability rows before seq_a.
+// that own only the rows from seq_p on (seq_p = the first token that differs from the root): LayerNorm, the four GEMMs of a layer and
+// the head run on the packed suffix rows (row-local); the convolution takes its history -- and the head of seq_p's 32-token tile, which
+// the attention wants whole -- from the root's input rows of the same launch, the attention its earlier key tiles from the root's
+// operand planes, and the per-sequence reduction reads the root's log-probability rows before seq_p.
 // Every row is computed by the same kernels from the same inputs in the same order as in a full forward: the same bits.
 struct TrChunk {
     std::vector<int32_t> seq;                         // call-level index of every chunk-local sequence (a root may repeat over chunks)
-    std::vector<int32_t> off, a, root;                // packed row of token a; first owned token; chunk-local index of the root
+    std::vector<int32_t> off, p, q, root;             // packed row of token p; first own token; operand row of its tile's first token; chunk-local root
     std::vector<uint32_t> vt;                         // V^T block offset (halfs per plane)
     std::vector<int32_t> tile_seq, tile_j, blk_seq, blk_j, tokens;
-    int rows = 0, padded = 0;
+    int rows = 0, padded = 0;                         // packed rows; operand rows (every sequence from its tile on, rounded up to whole tiles)
     double att_flops = 0;
-    int add(int call_index, const int32_t* tok, int T, int a0, int root_local, int D) {
+    int add(int call_index, const int32_t* tok, int T, int p0, int root_local, int D) {
         const int qrows = 32 * att16_waves_per_block(T);  // queries per attention block
-        const int local = (int)seq.size(), n = T - a0;
+        const int local = (int)seq.size(), a0 = p0 / 32 * 32, n = T - a0;
         seq.push_back(call_index);
         off.push_back(rows);
-        a.push_back(a0);
+        p.push_back(p0);
+        q.push_back(padded);
         root.push_back(root_local < 0 ? local : root_local);
         vt.push_back((uint32_t)((size_t)padded * (size_t)D));
         for (int j = 0; j < (n + 31) / 32; ++j) { tile_seq.push_back(local); tile_j.push_back(j); }
         for (int j = 0; j < (n + qrows - 1) / qrows; ++j) { blk_seq.push_back(local); blk_j.push_back(j); }
-        tokens.insert(tokens.end(), tok + a0, tok + T);
-        rows += n;
+        tokens.insert(tokens.end(), tok + p0, tok + T);
+        rows += T - p0;
         padded += (n + 31) / 32 * 32;
-        att_flops += 2.0 * D * ((double)T * T - (double)a0 * a0);         // 4 D per (query, visible key) pair
+        att_flops += 2.0 * D * ((double)T * T - (double)p0 * p0);         // 4 D per (query, visible key) pair
         return local;
     }
 };
@@ -830,7 +832,7 @@ int run_tranception_shared(pgmi_model* m, TrChunk& ck, int T, const float* prior
         std::vector<int> order(ck.blk_seq.size());
         for (size_t i = 0; i < order.size(); ++i) order[i] = (int)i;
         const int qrows = 32 * att16_waves_per_block(T);
-        auto keys = [&](int i) { return std::min(T, ck.a[ck.blk_seq[i]] + (ck.blk_j[i] + 1) * qrows); };
+        auto keys = [&](int i) { return std::min(T, ck.p[ck.blk_seq[i]] / 32 * 32 + (ck.blk_j[i] + 1) * qrows); };
         std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return keys(x) > keys(y); });
         std::vector<int32_t> bs(order.size()), bj(order.size());
         for (size_t i = 0; i < order.size(); ++i) { bs[i] = ck.blk_seq[order[i]]; bj[i] = ck.blk_j[order[i]]; }
@@ -838,7 +840,7 @@ int run_tranception_shared(pgmi_model* m, TrChunk& ck, int T, const float* prior
         ck.blk_j.swap(bj);
     }
     const size_t nt = ck.tile_seq.size(), nb = ck.blk_seq.size();
-    const size_t need = (size_t)8 * S + 2 * nt + 2 * nb;
+    const size_t need = (size_t)9 * S + 2 * nt + 2 * nb;
     int rc = ensure_cap(m, &m->tr_meta, &m->tr_meta_cap, std::max(need, (size_t)1 << 16));
     if (rc) return rc;
     std::vector<int32_t> meta(need);
@@ -849,7 +851,8 @@ int run_tranception_shared(pgmi_model* m, TrChunk& ck, int T, const float* prior
         for (int i = 0; i < S; ++i) { pa[i] = a0[ck.seq[i]]; pr[i] = r0[ck.seq[i]]; pc[i] = pn[ck.seq[i]]; pf[i] = fl[ck.seq[i]]; }
     AttRagged rg{};
     rg.seq_off = put(ck.off.data(), S);
-    rg.seq_a = put(ck.a.data(), S);
+    rg.seq_p = put(ck.p.data(), S);
+    rg.seq_q = put(ck.q.data(), S);
     rg.seq_root = put(ck.root.data(), S);
     rg.seq_vt = reinterpret_cast<const uint32_t*>(put(ck.vt.data(), S));
     const int32_t* d_pa = put(pa.data(), S);
@@ -896,7 +899,7 @@ int run_tranception_shared(pgmi_model* m, TrChunk& ck, int T, const float* prior
       launch_layernorm(m->x, m->lna_w, m->lna_b, M, D, m->ln_eps, m->h, s);
       launch_vocab_logsoftmax(m->h, m->tr_lm_head, m->tr_zero_bias, M, D, V, m->lp, m->nonfinite, s); }
     { ProfScope ps(m, PGMI_K_SCORE, 0, (double)S * T * 8);
-      launch_seq_loglik_ragged(m->lp, m->tokens, rg.seq_off, rg.seq_a, rg.seq_root, S, T, V, prior_dev, d_pa, d_pr, d_pc, d_pf, alpha,
+      launch_seq_loglik_ragged(m->lp, m->tokens, rg.seq_off, rg.seq_p, rg.seq_root, S, T, V, prior_dev, d_pa, d_pr, d_pc, d_pf, alpha,
                                m->denom, s); }
     PGMI_HIP(hipGetLastError());
     return PGMI_OK;
@@ -1744,7 +1747,7 @@ int pgmi_tr_sequence_loglik_shared(pgmi_model* m, const int32_t* tokens, const i
         }
         PGMI_HIP(hipMemcpyAsync(m->tr_prior, log_prior, (size_t)P * V * 4, hipMemcpyHostToDevice, s));
     }
-    // first owned token of every sequence: the 32-token tile of its first difference from its root (a copy of the root: the last tile)
+    // first own token of every sequence: its first difference from its root (a copy of the root: the last token)
     std::vector<int> a0(B, 0);
     std::vector<std::vector<int>> members(B);
     std::vector<int> roots;
@@ -1753,7 +1756,7 @@ int pgmi_tr_sequence_loglik_shared(pgmi_model* m, const int32_t* tokens, const i
         const int32_t *x = tokens + (size_t)b * T, *y = tokens + (size_t)ref[b] * T;
         int p = 0;
         while (p < T && x[p] == y[p]) ++p;
-        a0[b] = std::min(p, T - 1) / 32 * 32;
+        a0[b] = std::min(p, T - 1);
         members[ref[b]].push_back(b);
     }
     const int cap = m->max_rows;
@@ -1776,7 +1779,7 @@ int pgmi_tr_sequence_loglik_shared(pgmi_model* m, const int32_t* tokens, const i
         if (token_logprobs)
             for (int i = 0; i < S; ++i) {
                 float* dst = token_logprobs + (size_t)ck.seq[i] * T * V;
-                const int a = ck.a[i], r = ck.root[i];
+                const int a = ck.p[i], r = ck.root[i];
                 if (a > 0) memcpy(dst, lp_host.data() + (size_t)ck.off[r] * V, (size_t)a * V * 4);
                 memcpy(dst + (size_t)a * V, lp_host.data() + (size_t)ck.off[i] * V, (size_t)(T - a) * V * 4);
             }
@@ -1785,11 +1788,12 @@ int pgmi_tr_sequence_loglik_shared(pgmi_model* m, const int32_t* tokens, const i
         return PGMI_OK;
     };
     for (int r : roots) {
-        const int first = members[r].empty() ? 0 : (T - a0[members[r][0]] + 31) / 32 * 32;
+        auto padded_rows = [&](int b) { return (T - a0[b] / 32 * 32 + 31) / 32 * 32; };
+        const int first = members[r].empty() ? 0 : padded_rows(members[r][0]);
         if (!ck.seq.empty() && ck.padded + Tpad + first > cap) { int rc = flush(); if (rc) return rc; }
         int rl = ck.add(r, tokens + (size_t)r * T, T, 0, -1, D);
         for (int b : members[r]) {
-            if (ck.padded + (T - a0[b] + 31) / 32 * 32 > cap) {
+            if (ck.padded + padded_rows(b) > cap) {
                 int rc = flush();
                 if (rc) return rc;
                 rl = ck.add(r, tokens + (size_t)r * T, T, 0, -1, D);           // the root again: its rows serve the rest of the group

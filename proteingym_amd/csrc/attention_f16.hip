@@ -116,25 +116,28 @@ __global__ __launch_bounds__(256) void qkv_prep_kernel(
 // needs (6 rows of causal history) are staged ONCE in LDS with coalesced float4 loads and the 7-tap
 // filters are read from an LDS copy, instead of 7 strided global loads per output and per-tap scalar weight
 // loads (computing the taps from global memory ran at 2.3 TB/s; this pass is HBM-bound: 4 B in + 4 B out per element).
-// RAG (see RagMap below): blockIdx.x walks a list of (sequence, 32-token tile of its suffix); the six rows of causal history before a
-// suffix's first tile are its ROOT's rows (same tokens up to there: the same pre-convolution q | k | v, bit for bit).
+// RAG (see RagMap below): blockIdx.x walks a list of (sequence, 32-token tile from the tile of its first own token on); the input rows
+// of tokens before the sequence's first own token -- the causal history, and the head of that first tile -- are its ROOT's rows (same
+// tokens up to there: the same pre-convolution q | k | v, bit for bit), so the tile's operand rows come out whole.
 template <bool RAG>
 __global__ __launch_bounds__(256) void qkv_prep_conv_kernel(
     const float* __restrict__ qkv, const float* __restrict__ conv, int T, int H, int Tp,
     unsigned short* __restrict__ qk16, size_t qk_plane, unsigned short* __restrict__ vt16, size_t vt_plane,
-    const int32_t* __restrict__ seq_off, const int32_t* __restrict__ seq_a, const int32_t* __restrict__ seq_root,
+    const int32_t* __restrict__ seq_off, const int32_t* __restrict__ seq_p, const int32_t* __restrict__ seq_q, const int32_t* __restrict__ seq_root,
     const uint32_t* __restrict__ seq_vt, const int32_t* __restrict__ ent_seq, const int32_t* __restrict__ ent_j) {
     constexpr int RSTR = 196;                                 // 192 floats (q|k|v of one head) + pad
     constexpr int NLD = (38 * 48 + 255) / 256;                // float4 loads per thread: all issued before the first LDS store
     __shared__ __attribute__((aligned(16))) float raw[38 * RSTR];
     __shared__ __attribute__((aligned(16))) float cwl[3 * 8 * 64];   // [which][tap (7 = bias)][d]
     const int b = RAG ? ent_seq[blockIdx.x] : blockIdx.z, h = blockIdx.y;
-    // t0: absolute position of the tile's first token; row(t) = packed row of the sequence's token t (its own rows from a0 on, its
-    // root's before)
-    const int a0 = RAG ? seq_a[b] : 0;
+    // p0: the sequence's first own token, a0: the 32-token tile it lies in, t0: absolute position of this tile's first token;
+    // rowof(t) = packed INPUT row of token t (own rows from p0 on, the root's before); orow(t) = row of the q | k operand planes
+    const int p0 = RAG ? seq_p[b] : 0, a0 = p0 & ~31;
     const int t0 = RAG ? a0 + ent_j[blockIdx.x] * 32 : blockIdx.x * 32;
-    const int own0 = RAG ? seq_off[b] - a0 : b * T, root0 = RAG ? seq_off[seq_root[b]] : b * T;
-    auto rowof = [&](int t) -> size_t { return (size_t)((RAG && t < a0) ? root0 + t : own0 + t); };
+    const int own0 = RAG ? seq_off[b] - p0 : b * T, root0 = RAG ? seq_off[seq_root[b]] : b * T;
+    const int oq0 = RAG ? seq_q[b] - a0 : b * T;
+    auto rowof = [&](int t) -> size_t { return (size_t)((RAG && t < p0) ? root0 + t : own0 + t); };
+    auto orow = [&](int t) -> size_t { return (size_t)(oq0 + t); };
     const int Tpo = RAG ? (T - a0 + 31) / 32 * 32 : Tp;
     const int tid = threadIdx.x;
     const int D = H * kHeadDim;
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(256) void qkv_prep_conv_kernel(
                 split_act(v1, hh[e], ll[e]);
                 split_act(v2, hh[4 + e], ll[4 + e]);
             }
-            unsigned short* dst = qk16 + rowof(t) * (2 * D) + (size_t)which * D + h * kHeadDim + 8 * c;
+            unsigned short* dst = qk16 + orow(t) * (2 * D) + (size_t)which * D + h * kHeadDim + 8 * c;
             *reinterpret_cast<u32x4*>(dst) = u32x4{pack_h2(hh[0], hh[1]), pack_h2(hh[2], hh[3]), pack_h2(hh[4], hh[5]), pack_h2(hh[6], hh[7])};
             *reinterpret_cast<u32x4*>(dst + qk_plane) = u32x4{pack_h2(ll[0], ll[1]), pack_h2(ll[2], ll[3]), pack_h2(ll[4], ll[5]), pack_h2(ll[6], ll[7])};
         }
@@ -237,15 +240,18 @@ __global__ __launch_bounds__(256) void qkv_prep_conv_kernel(
 // tile kt + 1 issued inside the softmax of tile kt (own accumulators, 4-stage ring, 235 VGPRs) -3 ... -5 % at every shape.  Two
 // waves share a SIMD's matrix pipe AND its VALU issue: work moved between them, or between a wave's own phases, does not net.
 // RAG (Tranception prefix-shared scoring, api.hip run_tranception_shared): the launch holds SUFFIXES of sequences of T tokens.  Sequence
-// b owns the packed rows [seq_off[b], seq_off[b] + T - seq_a[b]) = its tokens seq_a[b] .. T-1 (seq_a a multiple of 32) and its own V^T
-// block at seq_vt[b] (row pitch roundup(T - seq_a[b], 32)); the keys before seq_a[b] are those of its ROOT sequence seq_root[b], which
-// is in the same launch with seq_a = 0 (the model is causal: a sequence that equals its root up to token seq_a - 1 has the root's K and V
-// there, bit for bit).  Key tiles keep their ABSOLUTE alignment -- tile kt = keys 32 kt .. 32 kt + 31 -- and every query tile holds
-// the same 32 queries as in a full forward, so each row goes through the same tiles in the same order: the same bits.
+// b owns the packed rows [seq_off[b], seq_off[b] + T - seq_p[b]) of the residual stream / context = its tokens seq_p[b] .. T-1, and in
+// the attention operand planes the rows [seq_q[b], seq_q[b] + T - a) and the V^T block seq_vt[b] (row pitch roundup(T - a, 32)) for the
+// tokens from a = seq_p[b] rounded down to a multiple of 32 (the prep pass fills the head of that tile from the root's inputs).  The keys
+// before a are those of its ROOT sequence seq_root[b], which is in the same launch with seq_p = 0 (the model is causal: a sequence that
+// equals its root up to token seq_p - 1 has the root's K and V there, bit for bit).  Key tiles keep their ABSOLUTE alignment -- tile
+// kt = keys 32 kt .. 32 kt + 31 -- and every query tile holds the same 32 queries as in a full forward, so each row goes through the
+// same tiles in the same order: the same bits.  Context rows of the tokens before seq_p are not written.
 // blockIdx.x indexes a list of (sequence, query block) entries.
 struct RagMap {
     const int32_t* seq_off;
-    const int32_t* seq_a;
+    const int32_t* seq_p;
+    const int32_t* seq_q;
     const int32_t* seq_root;
     const uint32_t* seq_vt;        // halfs, per plane
     const int32_t* ent_seq;        // per entry of the launch's list (query blocks here, 32-token tiles in the prep pass)
@@ -278,10 +284,12 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
     const int r = lane & 31, kh = lane >> 5;
     const int D = H * DH;
     const int Tk = (!RAG && kv_len) ? kv_len[b] : T;
-    // RAG: a0 = first token the sequence owns, row0 / rrow0 = packed row of ITS token a0 / of its root's token 0, kt0 = first own key tile
-    const int a0 = RAG ? rag.seq_a[b] : 0, kt0 = a0 / AKT;
+    // RAG: p0 = first token the sequence owns, a0 = its tile; row0 / rrow0 = operand row of ITS token a0 / of its root's token 0; kt0 = first
+    // own key tile; orow0 + t = context (output) row of token t >= p0
+    const int p0 = RAG ? rag.seq_p[b] : 0, a0 = p0 & ~(AKT - 1), kt0 = a0 / AKT;
     const int qblk = RAG ? rag.ent_j[blockIdx.x] : (int)blockIdx.x;
-    const int row0 = RAG ? rag.seq_off[b] : b * T, rrow0 = RAG ? rag.seq_off[rag.seq_root[b]] : 0;
+    const int row0 = RAG ? rag.seq_q[b] : b * T, rrow0 = RAG ? rag.seq_q[rag.seq_root[b]] : 0;
+    const int orow0 = RAG ? rag.seq_off[b] - p0 : b * T;
     const int Tpo = RAG ? (T - a0 + 31) / 32 * 32 : Tp;            // row pitch of the sequence's own V^T block
     const int q0 = a0 + (qblk * WPB + wave) * 32;                  // absolute position of the wave's first query
     const bool active = q0 < T;
@@ -553,8 +561,8 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
             // lane instead of 16 of half the width (a row-per-lane store touches 32-64 lines per instruction: the epilogue is bound
             // by store issue, not by bytes).  All 64 lanes take part in the swaps; rows beyond T only skip the stores.
             const float inv = 1.0f / l_tot;
-            const bool row_ok = q0 + r < T;
-            unsigned short* rowp = ctx16 + ((size_t)row0 + (min(q0 + r, T - 1) - a0)) * (size_t)(2 * D) + (size_t)(ND * h) * 64;
+            const bool row_ok = q0 + r < T && q0 + r >= p0;
+            unsigned short* rowp = ctx16 + (size_t)(orow0 + max(min(q0 + r, T - 1), p0)) * (size_t)(2 * D) + (size_t)(ND * h) * 64;
 #pragma unroll
             for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
@@ -582,9 +590,9 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
                         *reinterpret_cast<u32x4*>(dst + 32) = u32x4{first[2], first[3], second[2], second[3]};
                     }
                 }
-        } else if (q0 + r < T) {
+        } else if (q0 + r < T && q0 + r >= p0) {
             const float inv = 1.0f / l_tot;
-            const size_t off = ((size_t)row0 + (q0 + r - a0)) * D + (size_t)h * DH + 4 * kh;
+            const size_t off = (size_t)(orow0 + q0 + r) * D + (size_t)h * DH + 4 * kh;
 #pragma unroll
             for (int dt = 0; dt < ND; ++dt)
 #pragma unroll
@@ -600,7 +608,7 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
 #pragma unroll
                         for (int e = 0; e < 4; ++e) split_act(val[e], hh[e], ll[e]);
                         // K-interleaved GEMM operand (common.h ki_off): column h*DH + dt*32 + 8g + 4kh of a row of D
-                        unsigned short* dst = ctx16 + ((size_t)row0 + (q0 + r - a0)) * (size_t)(2 * D) + (size_t)(ND * h + dt) * 64 + 8 * g + 4 * kh;
+                        unsigned short* dst = ctx16 + (size_t)(orow0 + q0 + r) * (size_t)(2 * D) + (size_t)(ND * h + dt) * 64 + 8 * g + 4 * kh;
                         *reinterpret_cast<u32x2*>(dst) = u32x2{pack_h2(hh[0], hh[1]), pack_h2(hh[2], hh[3])};
                         *reinterpret_cast<u32x2*>(dst + 32) = u32x2{pack_h2(ll[0], ll[1]), pack_h2(ll[2], ll[3])};
                     }
@@ -684,7 +692,7 @@ int launch_attention_f16x3_v2(const float* qkv, const int32_t* kv_len, const flo
     if (qkv && conv && rotary) { set_error("attention_f16x3_v2: depth-wise convolution and rotary together are not a model this library knows"); return PGMI_EINVAL; }
     if (qkv && conv)       // Tranception: LDS-staged depth-wise conv + split
         hipLaunchKernelGGL(qkv_prep_conv_kernel<false>, dim3(n32, H, B), dim3(256), 0, s, qkv, conv, T, H, Tp, qk16, qk_plane, vt16, vt_plane,
-                           nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+                           nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
     else if (qkv)          // operands not prepared by the fused QKV epilogue: run the prep pass
         hipLaunchKernelGGL(qkv_prep_kernel, dim3(n32, H, B), dim3(256), 0, s, qkv, cos_t, sin_t, rotary, T, H, Tp,
                            qk16, qk_plane, vt16, vt_plane);
@@ -716,9 +724,9 @@ int launch_attention_tr_ragged(const float* qkv, const float* conv, const float*
         }
     }
     hipLaunchKernelGGL(qkv_prep_conv_kernel<true>, dim3(rg.n_tiles, H, 1), dim3(256), 0, s, qkv, conv, T, H, Tp, qk16, qk_plane, vt16, vt_plane,
-                       rg.seq_off, rg.seq_a, rg.seq_root, rg.seq_vt, rg.tile_seq, rg.tile_j);
+                       rg.seq_off, rg.seq_p, rg.seq_q, rg.seq_root, rg.seq_vt, rg.tile_seq, rg.tile_j);
     // the same instantiation (waves per block) as the dense launch of T tokens: a row is computed by the same code
-    const RagMap rag{rg.seq_off, rg.seq_a, rg.seq_root, rg.seq_vt, rg.blk_seq, rg.blk_j};
+    const RagMap rag{rg.seq_off, rg.seq_p, rg.seq_q, rg.seq_root, rg.seq_vt, rg.blk_seq, rg.blk_j};
     const dim3 grid(rg.n_blocks, H, 1);
     int rc;
     switch (att16_waves_per_block(T)) {

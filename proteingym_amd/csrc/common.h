@@ -85,7 +85,7 @@ void launch_fill_f32(float* p, int64_t n, float v, hipStream_t s);
 void launch_seq_loglik(const float* lp, const int32_t* tokens, const int32_t* lens, int B, int T, int V,
                        const float* prior, const int32_t* a0, const int32_t* row0, const int32_t* n,
                        const int32_t* flip, float alpha, float* out, hipStream_t s);
-void launch_seq_loglik_ragged(const float* lp, const int32_t* tokens, const int32_t* seq_off, const int32_t* seq_a,
+void launch_seq_loglik_ragged(const float* lp, const int32_t* tokens, const int32_t* seq_off, const int32_t* seq_p,
                               const int32_t* seq_root, int B, int T, int V, const float* prior, const int32_t* a0,
                               const int32_t* row0, const int32_t* n, const int32_t* flip, float alpha, float* out, hipStream_t s);
 void launch_score_mutants(const float* table, int V, const int32_t* sub_pos, const int32_t* sub_wt,
@@ -155,11 +155,12 @@ int launch_attention_f16x3_v2(const float* qkv, const int32_t* kv_len, const flo
 
 // Tranception prefix-shared scoring: device arrays that describe a launch over SUFFIXES of sequences (attention_f16.hip RagMap).
 struct AttRagged {
-    const int32_t* seq_off;        // [sequences] first packed row of the sequence (its token seq_a)
-    const int32_t* seq_a;          // [sequences] first token the sequence owns: a multiple of 32, 0 for a root
-    const int32_t* seq_root;       // [sequences] the sequence whose K / V / conv history stand for the tokens before seq_a
-    const uint32_t* seq_vt;        // [sequences] offset (halfs, per plane) of the sequence's V^T block [H][64][roundup(T - seq_a, 32)]
-    const int32_t* tile_seq;       // [n_tiles] 32-token tiles of the suffixes: sequence, tile index inside the suffix
+    const int32_t* seq_off;        // [sequences] first packed row of the sequence (its token seq_p): residual stream, q | k | v inputs, context
+    const int32_t* seq_p;          // [sequences] first token the sequence owns (0 for a root); a = seq_p rounded down to a multiple of 32
+    const int32_t* seq_q;          // [sequences] row of the q | k operand planes of the sequence's token a
+    const int32_t* seq_root;       // [sequences] the sequence whose rows stand for the tokens before seq_p
+    const uint32_t* seq_vt;        // [sequences] offset (halfs, per plane) of the sequence's V^T block [H][64][roundup(T - a, 32)]
+    const int32_t* tile_seq;       // [n_tiles] 32-token tiles from token a on: sequence, tile index
     const int32_t* tile_j;
     const int32_t* blk_seq;        // [n_blocks] blocks of att16_waves_per_block(T) query tiles: sequence, block index inside the suffix
     const int32_t* blk_j;

@@ -391,11 +391,11 @@ __global__ __launch_bounds__(256) void seq_loglik_kernel(const float* __restrict
     if (lane == 0) out[b] = acc;
 }
 // The same reduction over SUFFIX rows (Tranception prefix-shared scoring, common.h AttRagged): sequence b owns the packed rows of its
-// tokens seq_a[b] .. T-1 (log-probabilities in lp, ids in tokens, both packed); the rows before seq_a[b] are its root's (the model is
+// tokens seq_p[b] .. T-1 (log-probabilities in lp, ids in tokens, both packed); the rows before seq_p[b] are its root's (the model is
 // causal: the same tokens give the same rows).  Same lane partition, same order, same arithmetic as seq_loglik_kernel: with the same
 // row values the sum has the same bits.
 __global__ __launch_bounds__(256) void seq_loglik_ragged_kernel(const float* __restrict__ lp, const int32_t* __restrict__ tokens,
-                                                                const int32_t* __restrict__ seq_off, const int32_t* __restrict__ seq_a,
+                                                                const int32_t* __restrict__ seq_off, const int32_t* __restrict__ seq_p,
                                                                 const int32_t* __restrict__ seq_root, int B, int T, int V,
                                                                 const float* __restrict__ prior, const int32_t* __restrict__ a0,
                                                                 const int32_t* __restrict__ row0, const int32_t* __restrict__ n,
@@ -404,7 +404,7 @@ __global__ __launch_bounds__(256) void seq_loglik_ragged_kernel(const float* __r
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (b >= B) return;
-    const int a = seq_a[b], own0 = seq_off[b] - a, root0 = seq_off[seq_root[b]];
+    const int a = seq_p[b], own0 = seq_off[b] - a, root0 = seq_off[seq_root[b]];
     float acc = 0.f;
     for (int t = lane; t < T - 1; t += 64) {
         const int tgt = tokens[(t + 1 < a) ? root0 + t + 1 : own0 + t + 1];
@@ -419,10 +419,10 @@ __global__ __launch_bounds__(256) void seq_loglik_ragged_kernel(const float* __r
     acc = wave_sum(acc);
     if (lane == 0) out[b] = acc;
 }
-void launch_seq_loglik_ragged(const float* lp, const int32_t* tokens, const int32_t* seq_off, const int32_t* seq_a,
+void launch_seq_loglik_ragged(const float* lp, const int32_t* tokens, const int32_t* seq_off, const int32_t* seq_p,
                               const int32_t* seq_root, int B, int T, int V, const float* prior, const int32_t* a0,
                               const int32_t* row0, const int32_t* n, const int32_t* flip, float alpha, float* out, hipStream_t s) {
-    hipLaunchKernelGGL(seq_loglik_ragged_kernel, dim3((B + 3) / 4), dim3(256), 0, s, lp, tokens, seq_off, seq_a, seq_root, B, T, V,
+    hipLaunchKernelGGL(seq_loglik_ragged_kernel, dim3((B + 3) / 4), dim3(256), 0, s, lp, tokens, seq_off, seq_p, seq_root, B, T, V,
                        prior, a0, row0, n, flip, alpha, out);
 }
 void launch_seq_loglik(const float* lp, const int32_t* tokens, const int32_t* lens, int B, int T, int V,

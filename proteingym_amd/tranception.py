@@ -431,7 +431,7 @@ def load_checkpoint(checkpoint_dir: str):
 class TranceptionModel:
     """Device-resident Tranception.  ``score_mutants`` mirrors the reference method of the same name."""
 
-    share_prefix = True          # forward a mutated sequence from its first mutated token's tile on (sequence_loglik)
+    share_prefix = True          # forward a mutated sequence from its first mutated token on (sequence_loglik)
     rows_forwarded = 0           # token rows that went through the network ...
     rows_full = 0                # ... and the rows the reference's loop forwards for the same calls
 

@@ -315,7 +315,7 @@ def test_prefix_shared_scoring_has_the_bits_of_the_full_forward(model, L):
     wt = "".join(rng.choice(list("ACDEFGHIKLMNPQRSTVWY"), size=L))
     muts = _mutants_everywhere(wt, rng)
     done, full = _shared_vs_full(model, wt, muts)
-    assert done < full and (L < 64 or done < 0.75 * full)
+    assert done < full and (L < 64 or done < 0.7 * full)
     _shared_vs_full(model, wt, muts, reverse=True)
     prior = np.log(rng.dirichlet(np.ones(25), size=L + 10)).astype(np.float32)
     _shared_vs_full(model, wt, muts, retrieval=dict(log_prior=prior, a0=3, row0=5, n=L - 8), token_level=False)
@@ -395,5 +395,5 @@ def test_prefix_shared_scoring_at_the_large_width(lib):
         done, full = _shared_vs_full(m, wt, muts, token_level=False)
         done_r, _ = _shared_vs_full(m, wt, muts, reverse=True, token_level=False)
         print(f"L = {L}: rows forwarded {done} + {done_r} of 2 x {full}")
-        assert done + done_r < 1.35 * full                             # uniform positions: ~0.56 of the rows per direction, + the root
+        assert done + done_r < 1.15 * full                             # uniform positions: ~half of the rows per direction, + the root
     m.close()

@@ -1055,7 +1055,7 @@ class _OracleBackedDevice:
         lens = (C.c_int32 * B)(*([T] * B))
         rc = self.pgmi_tr_sequence_loglik(handle, tokens, lens, B, T, log_prior, P, a0, row0, count, flip, alpha, out)
         if rows:
-            rows[0] = int(sum(T - (min(p, T - 1) // 32) * 32 for p in first_diff[r != np.arange(B)])) + T * int((r == np.arange(B)).sum())
+            rows[0] = int(sum(T - min(p, T - 1) for p in first_diff[r != np.arange(B)])) + T * int((r == np.arange(B)).sum())
         return rc
 
     shared = []
