@@ -254,6 +254,54 @@ def test_esm2_15b_width_8_layers_vs_oracle(lib):
     assert err32 < TOL + noise
 
 
+@pytest.mark.skipif(os.environ.get("PGMI_TEST_15B_FULL") != "1", reason="ESM2-15B at full depth: 60 GB of weights, ~3 minutes; set PGMI_TEST_15B_FULL=1")
+def test_esm2_15b_full_depth_equals_its_8_layer_prefix(lib):
+    """ESM2-15B as released (48 x 5120, 40 heads of 128, FFN 20480: 15.1 G parameters, 60 GB of split weight planes resident; launcher:
+    scripts/scoring_DMS_zero_shot/scoring_ESM2_substitutions.sh) instantiated ONCE at full depth.  Layers 0 - 7 are the 8-layer model of
+    test_esm2_15b_width_8_layers_vs_oracle (4.2e-5 against the fp64 oracle); layers 8 - 47 carry layer 7's LayerNorms, q / k / v and
+    FC1 (the same compute as any layer) and ZERO out-projection and FC2, so each of them adds exactly 0 to the residual stream: the
+    48-layer table must equal the 8-layer table bit for bit -- through 40 more layers of kernels at the 15B shape, the last layer's
+    kept-rows path included -- while the memory plan (weights + workspace) and the launch sequence are those of the real model."""
+    import time
+    if _avail_gb() < 200:
+        pytest.skip("needs ~130 GB of host memory for the 60 GB blob and its source")
+    cfg8, blob8 = _blob("ESM2_15B", 15, 0.075, layers=8)
+    seq, muts, _ = synthetic.random_assay(seed=8, L=150, n_single=40, n_multi=10)
+    m = pesm.EsmModel(cfg8, blob8, device=0, max_rows=16384)
+    a = pesm.Assay(m, seq, muts)
+    s8, t8 = a.run(want_table=True)
+    a.close()
+    m.close()
+    cfg = dict(synthetic.ESM2_15B)
+    shapes = synthetic.key_shapes(cfg)
+    blob = np.zeros(sum(int(np.prod(sh)) for _, sh in shapes), dtype=np.float32)
+    src, dst = synthetic.blob_to_arrays(cfg8, blob8), synthetic.blob_to_arrays(cfg, blob)
+    for k, v in dst.items():
+        if k == "lm_head.weight":
+            continue
+        if not k.startswith("layers."):
+            v[...] = src[k]
+            continue
+        layer, leaf = int(k.split(".")[1]), k.split(".", 2)[2]
+        if layer < 8:
+            v[...] = src[k]
+        elif not (leaf.startswith("self_attn.out_proj") or leaf.startswith("fc2")):
+            v[...] = src[f"layers.7.{leaf}"]
+    t0 = time.time()
+    m = pesm.EsmModel(cfg, blob, device=0, max_rows=16384)
+    t_create = time.time() - t0
+    a = pesm.Assay(m, seq, muts)
+    t0 = time.time()
+    s48, t48 = a.run(want_table=True)
+    t_run = time.time() - t0
+    a.close()
+    m.close()
+    print(f"ESM2-15B, 48 layers ({blob.size / 1e9:.1f} G parameters): model created in {t_create:.0f} s, {len(a.positions)} masked forwards of {a.T} tokens in "
+          f"{t_run:.2f} s; table and scores equal the 8-layer prefix bit for bit")
+    assert np.isfinite(s48).all()
+    assert np.array_equal(t48, t8, equal_nan=True) and np.array_equal(s48, s8)
+
+
 def test_esm1v_650m_short_assays_grouped_equal_one_at_a_time(lib):
     """run_benchmark's short-assay groups at the REAL width (33 x 1280 x 20): three proteins of 40 / 57 / 95 residues, their masked
     copies in one padded launch sequence, against one Assay.run() per protein -- every score bit for bit."""
