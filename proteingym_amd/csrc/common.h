@@ -167,6 +167,7 @@ struct AttRagged {
     int n_tiles, n_blocks;
 };
 int att16_waves_per_block(int T);
+int att_set_option(const char* name, long long value);      // "att_xcd_local": block order of the dense attention launches (A/B only)
 int launch_attention_tr_ragged(const float* qkv, const float* conv, const float* slopes, int T, int H, const AttRagged& rg,
                                unsigned short* qk16, size_t qk_plane, unsigned short* vt16, size_t vt_plane, unsigned short* ctx16,
                                size_t plane, hipStream_t s);

@@ -1,8 +1,8 @@
 """Attention-kernel timing: ms per launch and algorithmic TFLOP/s of the attention class at several (sequences, tokens) shapes of the
 ESM-1v 650M layer (median over rounds, measured by the library's own per-class HIP events).  Two builds of the kernel are compared with
-scripts/lib_ab.sh, not from here.
+scripts/lib_ab.sh; launch options of ONE build (pgmi_set_option) are compared here, interleaved round by round.
 
-    python scripts/att_bench.py [--rounds 5]
+    python scripts/att_bench.py [--rounds 5] [--ab att_xcd_local=0,att_xcd_local=1]
 """
 import argparse
 import json
@@ -12,7 +12,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from proteingym_amd import esm as pesm, synthetic  # noqa: E402
+from proteingym_amd import _lib, esm as pesm, synthetic  # noqa: E402
 
 
 def main():
@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--layers", type=int, default=4)
     ap.add_argument("--shapes", default="286x286,90x1100,150x150,600x120")      # positions x residues
+    ap.add_argument("--ab", default="", help="comma-separated option=value settings, timed alternately in every round (pgmi_set_option)")
     a = ap.parse_args()
     cfg = dict(synthetic.ESM1V_650M, layers=a.layers)
     model = pesm.EsmModel(cfg, synthetic.random_weights(cfg, seed=1), device=0)
@@ -34,17 +35,23 @@ def main():
             muts = muts * (P // L + 1)
         assay = pesm.Assay(model, seq, muts)
         assay.run_device_only()
-        res = []
+        settings = [v for v in a.ab.split(",") if v] or [""]
+        res = {v: [] for v in settings}
         for _ in range(a.rounds):
-            model.profile_reset()
-            model.profile_enable(True)
-            assay.run_device_only()
-            model.profile_enable(False)
-            pr = model.profile()["attention"]
-            res.append((pr["ms"] / pr["launches"], pr["flops"] / (pr["ms"] * 1e-3) / 1e12))
-        ms, tf = float(np.median([r[0] for r in res])), float(np.median([r[1] for r in res]))
-        out[shp] = {"T": assay.T, "sequences": len(assay.positions), "ms_per_launch": round(ms, 4), "tflops": round(tf, 1)}
-        print(f"{shp:>10s} T={assay.T:4d} seqs={len(assay.positions):4d}: {ms:.4f} ms/launch  {tf:6.1f} TFLOP/s", flush=True)
+            for v in settings:
+                if v:
+                    name, val = v.split("=")
+                    _lib.check(_lib.load().pgmi_set_option(name.encode(), int(val)))
+                model.profile_reset()
+                model.profile_enable(True)
+                assay.run_device_only()
+                model.profile_enable(False)
+                pr = model.profile()["attention"]
+                res[v].append((pr["ms"] / pr["launches"], pr["flops"] / (pr["ms"] * 1e-3) / 1e12))
+        for v in settings:
+            ms, tf = float(np.median([r[0] for r in res[v]])), float(np.median([r[1] for r in res[v]]))
+            out[shp + (" " + v if v else "")] = {"T": assay.T, "sequences": len(assay.positions), "ms_per_launch": round(ms, 4), "tflops": round(tf, 1)}
+            print(f"{shp:>10s} T={assay.T:4d} seqs={len(assay.positions):4d} {v:>18s}: {ms:.4f} ms/launch  {tf:6.1f} TFLOP/s", flush=True)
         assay.close()
     print(json.dumps(out))
     model.close()

@@ -283,3 +283,34 @@ def test_gemm16x_operand_beyond_4_gib(lib):
     ref = A[rows].astype(np.float64) @ W.astype(np.float64).T + bias.astype(np.float64)
     err = np.abs(Cc[rows] - ref).max()
     assert err < 2e-5, err
+
+
+@pytest.mark.parametrize("B,T,H,kv", [(3, 288, 4, None), (2, 1000, 2, None), (5, 130, 2, [130, 97, 128, 1, 66]), (70, 160, 20, None)])
+def test_attention_launch_options_keep_the_bits(lib, B, T, H, kv):
+    """The launch options of the dense attention (pgmi_set_option): the XCD-local block order and the experimental persistent kernel walk the same
+    (sequence, head, query block) items through the same tiles in the same order -- the context rows must be those of the default launch, bit
+    for bit (fp32 output through the op entry; the split-plane output through a model: tests/test_gpu_esm.py)."""
+    rng = np.random.default_rng(T)
+    D = H * 64
+    qkv = rng.standard_normal((B, T, 3 * D)).astype(np.float32)
+    qkv[..., :D] *= 0.4
+    qkv[0, 0, :D] *= 6.0
+    kvl = np.asarray(kv, np.int32) if kv is not None else None
+
+    def run():
+        ctx = np.full((B, T, D), np.nan, np.float32)
+        _lib.check(lib.pgmi_op_attention(0, _lib.PREC_F16X3, _p(qkv), _p(kvl, _lib._i32p) if kvl is not None else None, B, T, H, 0, _p(ctx)))
+        if kv is not None:
+            for b in range(B):
+                ctx[b, kv[b]:] = 0
+        return ctx
+    try:
+        _lib.check(lib.pgmi_set_option(b"att_xcd_local", 0))
+        base = run()
+        assert np.isfinite(base).all()
+        for name, value in ((b"att_xcd_local", 1), (b"att_persist", 1), (b"att_persist", 2)):
+            _lib.check(lib.pgmi_set_option(name, value))
+            assert np.array_equal(run(), base), (name, value)
+    finally:
+        lib.pgmi_set_option(b"att_xcd_local", -1)
+        lib.pgmi_set_option(b"att_persist", 0)
