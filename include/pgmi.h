@@ -207,8 +207,8 @@ int pgmi_synchronize(pgmi_model* m);
 
 /* Test hooks of the GEMM launchers (bit-neutral: they only change how a launch is cut into work items / row chunks):
  * "gemm_half_tail" (0: no half-height tail items; default 1), "gemm_max_rows" (> 0: cut every launch into row chunks of at most
- * that many rows), "att_xcd_local" (1, default: the dense attention launches walk their blocks in the XCD-local order; 0: the
- * (query block, head, sequence) grid -- same bits, for interleaved timing).  The library reads PGMI_GEMM_HALF_TAIL / PGMI_GEMM_MAX_ROWS
+ * that many rows), "att_xcd_local" (1: the dense attention launches walk their blocks in the XCD-local order; 0: the (query block,
+ * head, sequence) grid; -1, default: by shape -- same bits, for interleaved timing).  The library reads PGMI_GEMM_HALF_TAIL / PGMI_GEMM_MAX_ROWS
  * when a model is created (and at the model-less pgmi_op_* / pgmi_bench_* entries); this call changes them for a live model.
  * Process-wide; returns PGMI_EINVAL for another name. */
 int pgmi_set_option(const char* name, int64_t value);

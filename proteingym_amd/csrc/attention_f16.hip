@@ -639,324 +639,13 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
     }
 }
 
-// Experiment of round 5 (option "att_persist", off by default): the PERSISTENT form of the dense head_dim-64 kernel above.
-// A workgroup walks a contiguous run of (sequence, head, query block) items -- the query blocks of one (sequence, head) one after the
-// other, so their K / V^T tiles are L2-hot -- and the NEXT item's first K / V^T tile and Q tile are in flight (DMA) while the current item's
-// epilogue arithmetic runs; that item's stores are issued after the next Q tile has been read.  Per row the arithmetic is the statement
-// sequence of the kernel above (same tiles, same order): the same bits.  4 waves, 3-stage ring, OUT 0 / 1; key padding, causal + ALiBi.
-template <int OUT>
-__global__ __launch_bounds__(256) void attention_f16x3_persist_kernel(
-    const unsigned short* __restrict__ qk16, size_t qk_plane, const unsigned short* __restrict__ vt16, size_t vt_plane,
-    const int32_t* __restrict__ kv_len, const float* __restrict__ slopes, int T, int H, int Tp, float* __restrict__ ctx,
-    unsigned short* __restrict__ ctx16, size_t plane, int nblk, int nseq, int items_per_wg) {
-    constexpr float defer_thr = kAttDefer;
-    constexpr int WPB = 4, NSTG = 3, DH = 64;
-    constexpr int KCPR = DH / 8, KCH = AKT * KCPR, VCH = DH * 4, STG_CH = 2 * KCH + 2 * VCH, NWI = STG_CH / 64, NDMA = NWI / WPB;
-    constexpr int NS = DH / 16, ND = DH / 32;
-    extern __shared__ __attribute__((aligned(16))) u32x4 lds[];   // [NSTG][STG_CH]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r = lane & 31, kh = lane >> 5;
-    const int D = H * DH;
-    const int n_items = nseq * H * nblk;
-    int item = blockIdx.x * items_per_wg;
-    const int item_end = min(n_items, item + items_per_wg);
-    if (item >= item_end) return;
-    const bool causal = slopes != nullptr;
-    const size_t seq_halfs = (size_t)T * (2 * D), vt_halfs = (size_t)DH * Tp;
-    const unsigned long long qk_bytes = std::min<unsigned long long>(0xFFFFFFFFull, (unsigned long long)qk_plane * 2ull + seq_halfs * 2ull);
-    const unsigned long long vt_bytes = std::min<unsigned long long>(0xFFFFFFFFull, (unsigned long long)vt_plane * 2ull + vt_halfs * 2ull);
-    // item-independent parts of the DMA map (see the kernel above); the head's column offset lives in the descriptors here
-    int voff[NDMA], sbase[NDMA], sstep[NDMA], slot0[NDMA], keyrow[NDMA];
-    bool is_k[NDMA];
-#pragma unroll
-    for (int i = 0; i < NDMA; ++i) {
-        const int wi = wave + WPB * i;
-        slot0[i] = wi * 64;
-        is_k[i] = wi < 2 * KCH / 64;
-        if (is_k[i]) {
-            const int p = wi / (KCH / 64), key = ((wi % (KCH / 64)) * 64 + lane) / KCPR;
-            const int c = (lane % KCPR) ^ ((key >> 1) & 7);
-            keyrow[i] = key;
-            voff[i] = c * 16;
-            sbase[i] = (int)((unsigned int)p * (unsigned int)qk_plane * 2u);
-            sstep[i] = AKT * (2 * D) * 2;
-        } else {
-            const int wv = wi - 2 * KCH / 64, p = wv / (VCH / 64), g = (wv % (VCH / 64)) * 64 + lane;
-            const int d = g >> 2, c = (g & 3) ^ ((d >> 2) & 3);
-            keyrow[i] = 0;
-            voff[i] = d * Tp * 2 + c * 16;
-            sbase[i] = (int)((unsigned int)p * (unsigned int)vt_plane * 2u);
-            sstep[i] = (AKT / 8) * 16;
-        }
-    }
-    // ---- per-item state ----
-    int b = 0, h = 0, q0 = 0, nkt = 0, Tk = T, last_rows = 31;
-    bool active = false;
-    float slope2 = 0.0f;
-    __amdgpu_buffer_rsrc_t rsK, rsQ, rsVT;
-    auto setup = [&](int it) {
-        const int pair = it / nblk, qblk = it - pair * nblk;
-        b = pair / H;
-        h = pair - b * H;
-        Tk = kv_len ? kv_len[b] : T;
-        q0 = (qblk * WPB + wave) * 32;
-        active = q0 < T;
-        const int last_q = min(T, (qblk * WPB + WPB) * 32);
-        nkt = causal ? (min(Tk, last_q) + AKT - 1) / AKT : (Tk + AKT - 1) / AKT;
-        last_rows = T - 1 - (nkt - 1) * AKT;                    // the last key tile's K rows are clamped to the sequence's last row
-        constexpr float kLog2e = 1.4426950408889634f;
-        slope2 = causal ? slopes[h] * kLog2e : 0.0f;
-        unsigned short* seq = const_cast<unsigned short*>(qk16) + (size_t)b * seq_halfs;
-        rsQ = __builtin_amdgcn_make_buffer_rsrc(seq + h * DH, 0, (int)(unsigned int)qk_bytes, 0x00020000);
-        rsK = __builtin_amdgcn_make_buffer_rsrc(seq + D + h * DH, 0, (int)(unsigned int)qk_bytes, 0x00020000);
-        rsVT = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(vt16) + ((size_t)b * H + h) * vt_halfs, 0, (int)(unsigned int)vt_bytes, 0x00020000);
-    };
-    auto issue_tile = [&](int kt, int buf) {
-        u32x4* base = lds + buf * STG_CH;
-#pragma unroll
-        for (int i = 0; i < NDMA; ++i) {
-            const int so = sbase[i] + kt * sstep[i];
-            if (is_k[i]) {
-                const int vo = ((kt == nkt - 1) ? min(keyrow[i], last_rows) : keyrow[i]) * (2 * D) * 2 + voff[i];
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsK, (__attribute__((address_space(3))) void*)(base + slot0[i]), 16, vo, so, 0, 0);
-            } else {
-                const int vo = voff[i];
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsVT, (__attribute__((address_space(3))) void*)(base + slot0[i]), 16, vo, so, 0, 0);
-            }
-        }
-    };
-    u32x4* const qbase = lds + STG_CH + wave * (2 * KCH);           // this wave's half of stages 1 .. 2
-    auto issue_q = [&]() {
-        if (!active) return;
-        constexpr int NQ = 2 * KCH / 64;
-#pragma unroll
-        for (int i = 0; i < NQ; ++i) {
-            const int f = i * 64 + lane, pq = f / KCH, row = (f % KCH) / KCPR;
-            const int c = (f % KCPR) ^ ((row >> 1) & 7);
-            const int vo = (int)((unsigned int)min(q0 + row, T - 1) * (unsigned int)(2 * D) * 2u + (unsigned int)c * 16u);
-            const int so = (int)((unsigned int)pq * (unsigned int)qk_plane * 2u);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQ, (__attribute__((address_space(3))) void*)(qbase + i * 64), 16, vo, so, 0, 0);
-        }
-    };
-    constexpr float kInvLo = 1.0f / kLoScale;
-    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    u32x4 qh[NS], ql[NS];
-    auto scores = [&](int buf, f32x16& sm, f32x16& sc) {
-        const u32x4* Kb = lds + buf * STG_CH;
-#pragma unroll
-        for (int s = 0; s < NS; ++s) {
-            const int ci = r * KCPR + ((2 * s + kh) ^ ((r >> 1) & 7));
-            const u32x4 kfh = Kb[ci], kfl = Kb[KCH + ci];
-            sc = mfma_h(kfh, ql[s], s == 0 ? zero16 : sc);
-            sc = mfma_h(kfl, qh[s], sc);
-            sm = mfma_h(kfh, qh[s], s == 0 ? zero16 : sm);
-        }
-    };
-    auto wait_tile = [&](int younger) {
-        if (younger >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMA) : "memory");
-        else if (younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    };
-    // the previous item's finished output: 8 stores of 16 bytes per lane, issued after the next item's Q tile has been read
-    u32x4 pend[8];
-    unsigned short* pend16 = nullptr;
-    float* pend32 = nullptr;
-    bool pend_ok = false;
-    auto flush_pending = [&]() {
-        if (!pend_ok) return;
-        if constexpr (OUT == 1) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {                       // k = dt * 2 + gp
-                unsigned short* dst = pend16 + (k >> 1) * 64 + 8 * (2 * (k & 1) + kh);
-                *reinterpret_cast<u32x4*>(dst) = pend[2 * k];
-                *reinterpret_cast<u32x4*>(dst + 32) = pend[2 * k + 1];
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 8; ++k)                         // k = dt * 4 + g
-                *reinterpret_cast<u32x4*>(pend32 + (k >> 2) * 32 + 8 * (k & 3)) = pend[k];
-        }
-        pend_ok = false;
-    };
-
-    setup(item);
-    issue_tile(0, 0);
-    issue_q();
-    while (true) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's share of tile 0 and its own Q tile have landed
-        if (active) {
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                const int ci = r * KCPR + ((2 * s + kh) ^ ((r >> 1) & 7));
-                qh[s] = qbase[ci];
-                ql[s] = qbase[KCH + ci];
-            }
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                               // every wave holds its Q in registers: stages 1 and 2 are free again
-        asm volatile("" ::: "memory");
-        flush_pending();                                            // stores first, DMAs after them: the counted waits below stay valid
-        if (1 < nkt) issue_tile(1, 1);
-
-        f32x16 om[ND], oc[ND];
-#pragma unroll
-        for (int dt = 0; dt < ND; ++dt)
-#pragma unroll
-            for (int v = 0; v < 16; ++v) { om[dt][v] = 0.f; oc[dt][v] = 0.f; }
-        float m_run = -INFINITY, l_run = 0.f;
-        int cur = 0;
-        for (int kt = 0; kt < nkt; ++kt) {
-            wait_tile(min(NSTG - 2, nkt - 1 - kt));
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (kt + NSTG - 1 < nkt) issue_tile(kt + NSTG - 1, (cur == 0) ? NSTG - 1 : cur - 1);
-            if (active && !(causal && kt * AKT > q0 + 31)) {
-                const u32x4* Vb = lds + cur * STG_CH + 2 * KCH;
-                f32x16 sm, sc;
-                scores(cur, sm, sc);
-                float st[16];
-                if (causal) {
-                    const float kb = (float)(kt * AKT + 4 * kh);
-#pragma unroll
-                    for (int v = 0; v < 16; ++v)
-                        st[v] = fmaf(slope2, kb + (float)((v & 3) + 8 * (v >> 2)), fmaf(sc[v], kInvLo, sm[v]));
-                    if (kt * AKT + AKT - 1 > q0) {
-#pragma unroll
-                        for (int v = 0; v < 16; ++v) {
-                            const int key = kt * AKT + (v & 3) + 8 * (v >> 2) + 4 * kh;
-                            if (key > q0 + r) st[v] = -INFINITY;
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int v = 0; v < 16; ++v) st[v] = fmaf(sc[v], kInvLo, sm[v]);
-                }
-                if (kt * AKT + AKT > Tk) {
-#pragma unroll
-                    for (int v = 0; v < 16; ++v) {
-                        const int key = kt * AKT + (v & 3) + 8 * (v >> 2) + 4 * kh;
-                        if (key >= Tk) st[v] = -INFINITY;
-                    }
-                }
-                float mloc = st[0];
-#pragma unroll
-                for (int v = 1; v < 16; ++v) mloc = fmaxf(mloc, st[v]);
-                {
-                    const unsigned int mu = __builtin_bit_cast(unsigned int, mloc);
-                    const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
-                    const unsigned int s0 = sw[0], s1 = sw[1];
-                    mloc = fmaxf(__builtin_bit_cast(float, s0), __builtin_bit_cast(float, s1));
-                }
-                const float m_new = fmaxf(m_run, mloc);
-                if (!__all(m_new <= m_run + defer_thr)) {
-                    const bool moved = m_new > m_run + defer_thr;
-                    const float alpha = moved ? __builtin_amdgcn_exp2f(m_run - m_new) : 1.0f;
-                    l_run *= alpha;
-#pragma unroll
-                    for (int dt = 0; dt < ND; ++dt)
-#pragma unroll
-                        for (int v = 0; v < 16; ++v) { om[dt][v] *= alpha; oc[dt][v] *= alpha; }
-                    if (moved) m_run = m_new;
-                }
-                const float mb = m_run - 10.0f;
-                typedef float f32x2 __attribute__((ext_vector_type(2)));
-#pragma unroll
-                for (int v = 0; v < 16; v += 2) {
-                    const f32x2 dlt = f32x2{st[v], st[v + 1]} - f32x2{mb, mb};
-                    st[v] = __builtin_amdgcn_exp2f(dlt[0]);
-                    st[v + 1] = __builtin_amdgcn_exp2f(dlt[1]);
-                }
-                l_run += ((st[0] + st[1]) + (st[2] + st[3])) + ((st[4] + st[5]) + (st[6] + st[7])) +
-                         (((st[8] + st[9]) + (st[10] + st[11])) + ((st[12] + st[13]) + (st[14] + st[15])));
-#pragma unroll
-                for (int m = 0; m < 2; ++m) {
-                    u32x4 ph, pl;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float p0 = st[8 * m + 2 * e], p1 = st[8 * m + 2 * e + 1];
-                        typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
-                        const fp16x2 hi2 = __builtin_amdgcn_cvt_pkrtz(p0, p1);
-                        const f32x2 ps = f32x2{p0, p1} * f32x2{kLoScale, kLoScale};
-                        const float l0 = fmaf((float)hi2[0], -kLoScale, ps[0]), l1 = fmaf((float)hi2[1], -kLoScale, ps[1]);
-                        const fp16x2 lo2 = __builtin_amdgcn_cvt_pkrtz(l0, l1);
-                        ph[e] = __builtin_bit_cast(unsigned int, hi2);
-                        pl[e] = __builtin_bit_cast(unsigned int, lo2);
-                    }
-#pragma unroll
-                    for (int dt = 0; dt < ND; ++dt) {
-                        const int d = dt * 32 + r;
-                        const int ci = d * 4 + ((2 * m + kh) ^ ((d >> 2) & 3));
-                        const u32x4 vfh = Vb[ci], vfl = Vb[VCH + ci];
-                        oc[dt] = mfma_h(vfh, pl, oc[dt]);
-                        oc[dt] = mfma_h(vfl, ph, oc[dt]);
-                        om[dt] = mfma_h(vfh, ph, om[dt]);
-                    }
-                }
-            }
-            cur = (cur == NSTG - 1) ? 0 : cur + 1;
-        }
-        // ---- the item's LDS reads are over for every wave after this barrier: the ring takes the next item's first tile and Q tiles ----
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        const bool was_active = active;
-        const int ob = b, oh = h, oq0 = q0;
-        ++item;
-        const bool more = item < item_end;
-        if (more) {
-            setup(item);
-            issue_tile(0, 0);
-            issue_q();
-        }
-        // ---- epilogue arithmetic of the finished item under the DMAs just issued; its stores wait for flush_pending ----
-        if (was_active) {
-            const float l_tot = l_run + __shfl_xor(l_run, 32);
-            const float inv = 1.0f / l_tot;
-            pend_ok = oq0 + r < T;
-            if constexpr (OUT == 1) {
-                pend16 = ctx16 + ((size_t)ob * T + min(oq0 + r, T - 1)) * (size_t)(2 * D) + (size_t)(ND * oh) * 64;
-#pragma unroll
-                for (int dt = 0; dt < ND; ++dt)
-#pragma unroll
-                    for (int gp = 0; gp < 2; ++gp) {
-                        unsigned int w[2][4];
-#pragma unroll
-                        for (int gi = 0; gi < 2; ++gi) {
-                            const int g = 2 * gp + gi;
-                            _Float16 hh[4], ll[4];
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) split_act(fmaf(oc[dt][4 * g + e], kInvLo, om[dt][4 * g + e]) * inv, hh[e], ll[e]);
-                            w[gi][0] = pack_h2(hh[0], hh[1]); w[gi][1] = pack_h2(hh[2], hh[3]);
-                            w[gi][2] = pack_h2(ll[0], ll[1]); w[gi][3] = pack_h2(ll[2], ll[3]);
-                        }
-                        unsigned int first[4], second[4];
-#pragma unroll
-                        for (int k = 0; k < 4; ++k) {
-                            const auto sw = __builtin_amdgcn_permlane32_swap(w[0][k], w[1][k], false, false);
-                            first[k] = sw[0];
-                            second[k] = sw[1];
-                        }
-                        pend[2 * (dt * 2 + gp)] = u32x4{first[0], first[1], second[0], second[1]};
-                        pend[2 * (dt * 2 + gp) + 1] = u32x4{first[2], first[3], second[2], second[3]};
-                    }
-            } else {
-                pend32 = ctx + ((size_t)ob * T + min(oq0 + r, T - 1)) * D + (size_t)oh * DH + 4 * kh;
-#pragma unroll
-                for (int dt = 0; dt < ND; ++dt)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) {
-                        f32x4 val;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) val[e] = fmaf(oc[dt][4 * g + e], kInvLo, om[dt][4 * g + e]) * inv;
-                        pend[dt * 4 + g] = __builtin_bit_cast(u32x4, val);
-                    }
-            }
-        }
-        if (!more) break;
-    }
-    flush_pending();
-}
+// Measured and NOT kept (round 5, profiles/r5/att_ab_2_persistent_kernel_with_prefetch.log; the code is in git history, commit "experiment:
+// persistent attention kernel"): the PERSISTENT form of the dense head_dim-64 kernel -- a workgroup walks a contiguous run of (sequence, head,
+// query block) items, the next item's first K / V^T tile and Q tile in flight (DMA) under the current item's epilogue arithmetic, its stores
+// issued after the next Q tile is read; bits equal to this kernel's -- is 9 % slower at T = 288, 13 % at T = 1024, 5 % at T = 152: the per-item
+// state (descriptors, bounds) becomes mutable and leaves the SGPRs (54 spilled), 225 VGPRs instead of 188, one more barrier per item, and what the
+// prefetch hides is small beside that.  The XCD-local block ORDER alone (the query blocks of one (sequence, head) on one XCD, K / V^T fetched
+// into its L2 once) is +2.5 % at T = 1024 and -2 % at T = 288 (att_ab_1_xcd_local_order.log): fetch traffic is not what bounds this kernel.
 
 template <int WPB, int OUT, int NSTG, int DH, bool RAG = false>
 static int launch_att16v2_one(dim3 grid, const unsigned short* qk16, size_t qk_plane, const unsigned short* vt16, size_t vt_plane,
@@ -990,10 +679,8 @@ static int launch_att16v2_mode(int wpb, dim3 grid, const unsigned short* qk16, s
 // (query block, head, sequence) grid of rounds 1-4 (kept for the interleaved A/B of scripts/att_bench.py: block order does not touch a
 // row's arithmetic, same bits).
 static int g_att_xcd_local = -1;     // -1: by shape (XCD-local from eight query blocks per sequence on: +2.5 % at T = 1024, -2 % at T = 288)
-static int g_att_persist = 0;        // experiment: the persistent kernel for the dense head_dim-64 launches with four waves per block
 int att_set_option(const char* name, long long value) {
     if (!strcmp(name, "att_xcd_local")) { g_att_xcd_local = (int)value; return PGMI_OK; }
-    if (!strcmp(name, "att_persist")) { g_att_persist = (int)value; return PGMI_OK; }
     return PGMI_EINVAL;
 }
 // grid of a dense launch of nblk query blocks x H heads x B sequences, and the dense_nblk argument that goes with it
@@ -1058,23 +745,6 @@ int launch_attention_f16x3_v2(const float* qkv, const int32_t* kv_len, const flo
         hipLaunchKernelGGL(qkv_prep_kernel, dim3(n32, H, B), dim3(256), 0, s, qkv, cos_t, sin_t, rotary, T, H, Tp,
                            qk16, qk_plane, vt16, vt_plane);
     const int wpb = att16_waves_per_block(T), nblk = (n32 + wpb - 1) / wpb;
-    if (g_att_persist && wpb == 4) {
-        // persistent experiment: g_att_persist workgroups per CU-slot pair (two co-resident workgroups per CU), contiguous item runs
-        int dev = 0, cus = 256;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-        const long long n_items = (long long)B * H * nblk;
-        const long long wgs = std::min<long long>(n_items, (long long)cus * 2 * g_att_persist);
-        const int per = (int)((n_items + wgs - 1) / wgs);
-        const dim3 pgrid((unsigned)((n_items + per - 1) / per), 1, 1);
-        constexpr size_t lds_bytes = (size_t)3 * (64 * 16) * 16;
-        if (out_mode == 0)
-            hipLaunchKernelGGL(attention_f16x3_persist_kernel<0>, pgrid, dim3(256), lds_bytes, s, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane, nblk, B, per);
-        else
-            hipLaunchKernelGGL(attention_f16x3_persist_kernel<1>, pgrid, dim3(256), lds_bytes, s, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane, nblk, B, per);
-        PGMI_HIP(hipGetLastError());
-        return PGMI_OK;
-    }
     int dn = 0;
     const dim3 grid = dense_grid(nblk, H, B, &dn);
     if (out_mode == 0) rc = launch_att16v2_mode<0, 3>(wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane, s, dn, B);

@@ -424,8 +424,9 @@ def test_esm2_beyond_1024_tokens_vs_oracle(lib):
 
 @pytest.mark.parametrize("arch", ["ESM1V_650M", "ESM2_650M"])
 def test_attention_launch_options_keep_the_bits_of_a_model(lib, arch):
-    """Split-plane attention output (the model path) under the XCD-local block order and the experimental persistent kernel: 4 layers at the
-    650M width, T = 288 and a padded batch (key masks): the same token log-probs, bit for bit."""
+    """Split-plane attention output (the model path) under the XCD-local block order: 4 layers at the 650M width, T = 288 and a padded batch
+    (key masks): the same token log-probs, bit for bit."""
+    from proteingym_amd import _lib
     cfg = dict(getattr(synthetic, arch), layers=4)
     m = pesm.EsmModel(cfg, synthetic.random_weights(cfg, seed=3, embed_std=0.15), device=0)
     rng = np.random.default_rng(2)
@@ -438,12 +439,11 @@ def test_attention_launch_options_keep_the_bits_of_a_model(lib, arch):
     try:
         _lib.check(lib.pgmi_set_option(b"att_xcd_local", 0))
         base = m.token_logprobs(tok)
-        for name, value in ((b"att_xcd_local", 1), (b"att_persist", 1), (b"att_persist", 3)):
+        for name, value in ((b"att_xcd_local", 1), (b"att_xcd_local", -1)):
             _lib.check(lib.pgmi_set_option(name, value))
             got = m.token_logprobs(tok)
             keep = tok != 1
             assert np.array_equal(got[keep], base[keep]), (name, value)
     finally:
         lib.pgmi_set_option(b"att_xcd_local", -1)
-        lib.pgmi_set_option(b"att_persist", 0)
         m.close()

@@ -287,8 +287,8 @@ def test_gemm16x_operand_beyond_4_gib(lib):
 
 @pytest.mark.parametrize("B,T,H,kv", [(3, 288, 4, None), (2, 1000, 2, None), (5, 130, 2, [130, 97, 128, 1, 66]), (70, 160, 20, None)])
 def test_attention_launch_options_keep_the_bits(lib, B, T, H, kv):
-    """The launch options of the dense attention (pgmi_set_option): the XCD-local block order and the experimental persistent kernel walk the same
-    (sequence, head, query block) items through the same tiles in the same order -- the context rows must be those of the default launch, bit
+    """The launch option of the dense attention (pgmi_set_option "att_xcd_local"): the XCD-local block order walks the same (sequence, head,
+    query block) items through the same tiles in the same order -- the context rows must be those of the (query block, head, sequence) grid, bit
     for bit (fp32 output through the op entry; the split-plane output through a model: tests/test_gpu_esm.py)."""
     rng = np.random.default_rng(T)
     D = H * 64
@@ -308,9 +308,8 @@ def test_attention_launch_options_keep_the_bits(lib, B, T, H, kv):
         _lib.check(lib.pgmi_set_option(b"att_xcd_local", 0))
         base = run()
         assert np.isfinite(base).all()
-        for name, value in ((b"att_xcd_local", 1), (b"att_persist", 1), (b"att_persist", 2)):
+        for name, value in ((b"att_xcd_local", 1), (b"att_xcd_local", -1)):
             _lib.check(lib.pgmi_set_option(name, value))
             assert np.array_equal(run(), base), (name, value)
     finally:
         lib.pgmi_set_option(b"att_xcd_local", -1)
-        lib.pgmi_set_option(b"att_persist", 0)
