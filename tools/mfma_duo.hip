@@ -33,7 +33,8 @@ __device__ __forceinline__ f32x16 mf(u32x4 a, u32x4 b, f32x16 c) {
 }
 
 // the wave's 24 MFMAs of one k16 step (gemm16x_kernel.h mfmas()): w_lo a_hi, (w_hi 2^-11) a_lo, w_hi a_hi
-__device__ __forceinline__ void step24(f32x16 (&acc)[2][4], u32x4 (&af)[2][4], u32x4 (&wf)[2][2]) {
+template <int TM>
+__device__ __forceinline__ void step24(f32x16 (&acc)[2][TM], u32x4 (&af)[2][TM], u32x4 (&wf)[2][2]) {
     u32x4 whs[2];
     const hh2 sc = {(_Float16)(1.0f / 2048.0f), (_Float16)(1.0f / 2048.0f)};
 #pragma unroll
@@ -43,18 +44,18 @@ __device__ __forceinline__ void step24(f32x16 (&acc)[2][4], u32x4 (&af)[2][4], u
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[j][i] = mf(wf[1][j], af[0][i], acc[j][i]);
+        for (int i = 0; i < TM; ++i) acc[j][i] = mf(wf[1][j], af[0][i], acc[j][i]);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[j][i] = mf(whs[j], af[1][i], acc[j][i]);
+        for (int i = 0; i < TM; ++i) acc[j][i] = mf(whs[j], af[1][i], acc[j][i]);
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) acc[j][i] = mf(wf[0][j], af[0][i], acc[j][i]);
+        for (int i = 0; i < TM; ++i) acc[j][i] = mf(wf[0][j], af[0][i], acc[j][i]);
 #pragma unroll
     for (int k = 0; k < 8; ++k) { __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); __builtin_amdgcn_sched_group_barrier(0x002, 1, 0); }
-    __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 6 * TM - 8, 0);
 }
 
 // f16 / f64 denormal mode of THIS wave = flush (MODE.FP_DENORM[3:2] = 0): v_cvt_pk_f16_f32 then returns +-0 for results below fp16's
@@ -87,12 +88,12 @@ __global__ void split_selftest(const float* x, int n, unsigned short* hi_out, un
 // FC1-like epilogue of one wave: 128 values per lane through scale + bias, GELU, split; 32 dwordx4 stores per wave (lane-contiguous:
 // every store instruction writes 1 KB), accumulators cleared.
 // FAST 0: split_act; 1: packed split; 3: the arithmetic only (stores behind a flag that is never set); 4: the stores only (raw accumulators)
-template <int FAST>
-__device__ __forceinline__ void epilogue(f32x16 (&acc)[2][4], unsigned short* out, int lane, float scale, bool do_store = true) {
+template <int FAST, int TM = 4>
+__device__ __forceinline__ void epilogue(f32x16 (&acc)[2][TM], unsigned short* out, int lane, float scale, bool do_store = true) {
     u32x4* dst = reinterpret_cast<u32x4*>(out) + lane;
     if (FAST == 4) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -102,13 +103,13 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[2][4], unsigned short* ou
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int v = 0; v < 16; ++v) acc[j][i][v] = 0.f;
         return;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -149,7 +150,7 @@ __device__ __forceinline__ void epilogue(f32x16 (&acc)[2][4], unsigned short* ou
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int v = 0; v < 16; ++v) acc[j][i][v] = 0.f;
 }
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(512, 2) void pingpong8(const unsigned short* __rest
             frags(Ab, Wb, 0);
             phase(false);
             __builtin_amdgcn_s_setprio(1);
-            step24(acc, af, wf);
+            step24<4>(acc, af, wf);
             phase(false);
             __builtin_amdgcn_s_setprio(0);
             frags(Ab, Wb, 1);
@@ -275,7 +276,7 @@ __global__ __launch_bounds__(512, 2) void pingpong8(const unsigned short* __rest
             };
             close(late);
             __builtin_amdgcn_s_setprio(1);
-            step24(acc, af, wf);
+            step24<4>(acc, af, wf);
             close(!late);
             cur ^= 1;
         }
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void duo4(const unsigned short* __restrict_
             __builtin_amdgcn_sched_barrier(0);
             __builtin_amdgcn_s_waitcnt(0xC07F);                                   // lgkmcnt(0)
             __builtin_amdgcn_s_setprio(1);
-            step24(acc, af, wf);
+            step24<4>(acc, af, wf);
             __builtin_amdgcn_s_setprio(0);
             slot = slot == 2 ? 0 : slot + 1;
         }
@@ -405,6 +406,129 @@ __global__ __launch_bounds__(256, 2) void duo4(const unsigned short* __restrict_
 #pragma unroll
                 for (int v = 0; v < 16; ++v) keep += acc[j][i][v];
         sink[blockIdx.x * 256 + tid] = keep;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// duo8: TWO 8-wave ping-pong workgroups per CU -- 128 x 256 tiles, wave tile 64 x 64 (TM 2 x TN 2: 64 accumulator registers, 128 VGPRs:
+// four waves per SIMD, two of each workgroup), each workgroup with the product's own ping-pong inside (waves 4-7 one phase behind waves 0-3,
+// 12 MFMAs per compute phase, K16 half-stages in a 3-slot ring = 72 KB).  A workgroup ALONE can keep the matrix pipe busy (unlike duo4's lone
+// wave per SIMD): while one is in its epilogue the other has the pipe to itself.  Price: twice the fragment reads per MFMA, half-length phases.
+template <int EPI>
+__global__ __launch_bounds__(512, 4) void duo8(const unsigned short* __restrict__ A, const unsigned short* __restrict__ W, unsigned short* out,
+                                               int n_items, float* sink) {
+    extern __shared__ __attribute__((aligned(16))) u32x4 lds[];                  // [3][1536] chunks
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool late = wave >= 4;
+    const int wm = (wave >> 1) & 1, wn = (wave & 1) | ((wave >> 2) << 1);       // early waves 0-3 and late waves 4-7 each cover 2 x 2 of the 2 (M) x 4 (N) wave tiles
+    const int r = lane & 31, kh = lane >> 5, fsw = (r >> 2) & 3;
+    const int tiles_m = (M_ROWS + 127) / 128, tiles_n = N_ROWS / 256;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(A), 0, (int)((unsigned)M_ROWS * ROW_BYTES), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(W), 0, (int)((unsigned)N_ROWS * ROW_BYTES), 0x00020000);
+    // staging: the half-stage's 24 wave-instructions (8 for A's 128 rows, 16 for W's 256 rows; 16 rows x 4 chunks each); wave w issues w, w + 8, w + 16
+    const int row_in = lane >> 2, c4 = lane & 3;
+    unsigned off[3];
+    auto decode = [&](int item) {
+        int tm, tn;
+        item_coords(item, n_items, tiles_m, tiles_n, tm, tn);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int q = wave + 8 * i;
+            const bool isA = q < 8;
+            const int row = 16 * (isA ? q : q - 8) + row_in;
+            const int hc = c4 ^ ((row >> 2) & 3);
+            const unsigned within = (unsigned)((hc >> 1) * 64 + (hc & 1) * 16);
+            off[i] = isA ? (unsigned)min(tm * 128 + row, M_ROWS - 1) * ROW_BYTES + within : (unsigned)min(tn * 256 + row, N_ROWS - 1) * ROW_BYTES + within;
+        }
+    };
+    auto issue = [&](int h, int slot) {
+        u32x4* base = lds + slot * 1536 + wave * 64;
+        const int so = (h >> 1) * 128 + (h & 1) * 32;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (__attribute__((address_space(3))) void*)(base), 16, (int)off[0], so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(base + 512), 16, (int)off[1], so, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (__attribute__((address_space(3))) void*)(base + 1024), 16, (int)off[2], so, 0, 0);
+    };
+    f32x16 acc[2][2];
+    u32x4 af[2][2], wf[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) acc[j][i][v] = 0.f;
+    auto frags = [&](int slot) {
+        const u32x4* Ab = lds + slot * 1536;
+        const u32x4* Wb = Ab + 512;
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int c = (p * 2 + kh) ^ fsw;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[p][i] = Ab[((wm * 2 + i) * 32 + r) * 4 + c];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) wf[p][j] = Wb[((wn * 2 + j) * 32 + r) * 4 + c];
+        }
+    };
+    // phase ends: every wave's LDS traffic has landed; at the end of ODD global phases also this wave's share of the NEXT half-stage (at most
+    // `allow` younger operations may still be out: the three DMAs of the half-stage after it, and behind an epilogue its 16 stores)
+    auto bar_lgkm = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto bar_vm = [&](int allow) {
+        __builtin_amdgcn_sched_barrier(0);
+        if (allow >= 19) __builtin_amdgcn_s_waitcnt(0x4073);                     // vmcnt(19) lgkmcnt(0)
+        else if (allow >= 3) __builtin_amdgcn_s_waitcnt(0x0073);                 // vmcnt(3) lgkmcnt(0)
+        else __builtin_amdgcn_s_waitcnt(0x0070);                                 // vmcnt(0) lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int item = blockIdx.x;
+    if (item >= n_items) return;
+    decode(item);
+    issue(0, 0);
+    issue(1, 1);
+    float keep = 0.f;
+    constexpr int NH = 2 * NKT;
+    bool first = true;
+    while (true) {
+        // half-stage 0 landed everywhere (half-stage 1 and, behind an epilogue, its 16 stores may be out)
+        bar_vm((EPI && !first) ? 19 : 3);
+        if (late) bar_lgkm();                                                     // late waves run one phase behind
+        int slot = 0;
+        for (int h = 0; h < NH; ++h) {
+            const int behind = (EPI && !first && h == 0) ? 19 : (h + 2 < NH ? 3 : 0);   // what may be out when half-stage h + 1 must have landed
+            // -- memory phase: this wave's share of half-stage h + 2 into the slot half-stage h - 1 left, then the fragments of h --
+            __builtin_amdgcn_s_setprio(0);
+            if (h + 2 < NH) issue(h + 2, slot == 0 ? 2 : slot - 1);
+            frags(slot);
+            if (late) bar_vm(behind); else bar_lgkm();                            // late: an odd global phase ends here
+            // -- compute phase --
+            __builtin_amdgcn_s_setprio(1);
+            step24<2>(acc, af, wf);
+            if (late) bar_lgkm(); else bar_vm(behind);                            // early: an odd global phase ends here
+            slot = slot == 2 ? 0 : slot + 1;
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (!late) bar_lgkm();                                                    // realign: every wave is through its last fragment reads
+        first = false;
+        const int done = item;
+        item += gridDim.x;
+        const bool more = item < n_items;
+        if (more) { decode(item); issue(0, 0); issue(1, 1); }
+        if (EPI) epilogue<0, 2>(acc, out + ((size_t)done * 8 + wave) * 8192, lane, 1e-4f);
+        else { keep += acc[0][0][0]; }
+        if (!more) break;
+    }
+    if (!EPI) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) keep += acc[j][i][v];
+        sink[blockIdx.x * 512 + tid] = keep;
     }
 }
 
@@ -437,33 +561,35 @@ int main(int argc, char** argv) {
     for (auto f : {reinterpret_cast<const void*>(d00), reinterpret_cast<const void*>(d10), reinterpret_cast<const void*>(d11)})
         hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
     typedef void (*Kfn)(const unsigned short*, const unsigned short*, unsigned short*, int, float*);
-    struct Variant { const char* name; Kfn fn; bool duo; };
+    struct Variant { const char* name; Kfn fn; int duo; };
     const Variant vs[] = {
-        {"pingpong8 no epilogue", pingpong8<0, 0>, false},
-        {"pingpong8 + FC1-like epilogue", pingpong8<1, 0>, false},
-        {"pingpong8 + epilogue, arithmetic only (no stores)", pingpong8<3, 0>, false},
-        {"pingpong8 + epilogue, stores only (raw accumulators)", pingpong8<4, 0>, false},
-        {"pingpong8 arithmetic only: scale + bias + split, no GELU", pingpong8<5, 0>, false},
-        {"pingpong8 arithmetic only: GELU, plain conversion (no split)", pingpong8<6, 0>, false},
-        {"pingpong8 arithmetic only: GELU without v_exp_f32, split", pingpong8<7, 0>, false},
-        {"pingpong8 + epilogue, counted first wait", pingpong8<1, 1>, false},
-        {"pingpong8 + epilogue, packed split (no compare)", pingpong8<2, 0>, false},
-        {"pingpong8 + epilogue, CU slots 1 us apart", pingpong8<1, 2>, false},
-        {"pingpong8 + epilogue, two K tiles in flight before the stores", pingpong8<1, 4>, false},
-        {"duo4 contiguous no epilogue", d00, true},
-        {"duo4 contiguous + epilogue", d10, true},
-        {"duo4 split-32B + epilogue", d11, true},
+        {"pingpong8 no epilogue", pingpong8<0, 0>, 0},
+        {"pingpong8 + FC1-like epilogue", pingpong8<1, 0>, 0},
+        {"pingpong8 + epilogue, arithmetic only (no stores)", pingpong8<3, 0>, 0},
+        {"pingpong8 + epilogue, stores only (raw accumulators)", pingpong8<4, 0>, 0},
+        {"pingpong8 arithmetic only: scale + bias + split, no GELU", pingpong8<5, 0>, 0},
+        {"pingpong8 arithmetic only: GELU, plain conversion (no split)", pingpong8<6, 0>, 0},
+        {"pingpong8 arithmetic only: GELU without v_exp_f32, split", pingpong8<7, 0>, 0},
+        {"pingpong8 + epilogue, counted first wait", pingpong8<1, 1>, 0},
+        {"pingpong8 + epilogue, packed split (no compare)", pingpong8<2, 0>, 0},
+        {"pingpong8 + epilogue, CU slots 1 us apart", pingpong8<1, 2>, 0},
+        {"pingpong8 + epilogue, two K tiles in flight before the stores", pingpong8<1, 4>, 0},
+        {"duo4 contiguous no epilogue", d00, 1},
+        {"duo4 contiguous + epilogue", d10, 1},
+        {"duo4 split-32B + epilogue", d11, 1},
+        {"duo8 (two 8-wave ping-pong workgroups per CU, 64 x 64 wave tiles) no epilogue", duo8<0>, 2},
+        {"duo8 + FC1-like epilogue", duo8<1>, 2},
     };
     constexpr int NV = sizeof(vs) / sizeof(vs[0]);
     for (const Variant& v : vs)
-        if (!v.duo) hipFuncSetAttribute(reinterpret_cast<const void*>(v.fn), hipFuncAttributeMaxDynamicSharedMemorySize, 136 * 1024);
+        hipFuncSetAttribute(reinterpret_cast<const void*>(v.fn), hipFuncAttributeMaxDynamicSharedMemorySize, (v.duo ? 80 : 136) * 1024);
     const double flops = 2.0 * M_ROWS * (double)N_ROWS * K_ELEMS;             // algorithmic (one product per element pair)
     printf("FC1 shape %d x %d x %d: %d tiles of 256 x 256 / %d tiles of 128 x 256, %d CUs\n", M_ROWS, N_ROWS, K_ELEMS, items8, items4, cus);
     std::vector<std::vector<float>> ms(NV);
     for (int r = 0; r <= rounds; ++r) {
         float t[NV];
         for (int k = 0; k < NV; ++k)
-            t[k] = vs[k].duo ? time_one(vs[k].fn, dim3(2 * cus), dim3(256), 80 * 1024, A, W, out, items4, sink)
+            t[k] = vs[k].duo ? time_one(vs[k].fn, dim3(2 * cus), dim3(vs[k].duo == 1 ? 256 : 512), 80 * 1024, A, W, out, items4, sink)
                              : time_one(vs[k].fn, dim3(cus), dim3(512), 136 * 1024, A, W, out, items8, sink);
         if (r == 0) continue;                                                  // warm-up round
         for (int k = 0; k < NV; ++k) ms[k].push_back(t[k]);
