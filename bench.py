@@ -80,7 +80,7 @@ def ffn_traffic(precision, M, D, F, live=None):
     return fc1["fetch_bytes"] + fc1["write_bytes"], detail
 
 
-def live_traffic(precision, timeout_s=150):
+def live_traffic(precision, timeout_s=90):
     """FETCH_SIZE / WRITE_SIZE of the GEMM launches collected NOW, on this box: two `rocprofv3 --kernel-trace --pmc <counter>` child
     runs of this script (2 layers, one step, every dispatch at the full row count), parsed like scripts/pmc_summarize.py.  Counters
     cannot be read from inside a run, so the children run after the timed region.  Never raises: {"unavailable": reason}."""
