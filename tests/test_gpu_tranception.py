@@ -306,7 +306,7 @@ def _mutants_everywhere(wt, rng, n_multi=12):
     return out
 
 
-@pytest.mark.parametrize("L", [40, 94, 126, 200])
+@pytest.mark.parametrize("L", [12, 30, 40, 62, 94, 126, 200])
 def test_prefix_shared_scoring_has_the_bits_of_the_full_forward(model, L):
     """Sequence log-likelihoods and every token log-prob row of the shared entry == the unshared entries: mutants at every third
     position (first residue, last residue, both sides of the 32-token tile edges), multi-mutants, a copy of the wild type; T = L + 2 on
@@ -320,6 +320,16 @@ def test_prefix_shared_scoring_has_the_bits_of_the_full_forward(model, L):
     prior = np.log(rng.dirichlet(np.ones(25), size=L + 10)).astype(np.float32)
     _shared_vs_full(model, wt, muts, retrieval=dict(log_prior=prior, a0=3, row0=5, n=L - 8), token_level=False)
     _shared_vs_full(model, wt, muts, reverse=True, retrieval=dict(log_prior=prior, a0=2, row0=4, n=L - 8), token_level=False)
+
+
+def test_prefix_shared_scoring_one_two_and_three_query_tiles(model):
+    """T = 14 ... 96 tokens: one, two and three 32-token tiles per sequence, i.e. the one-, two- and four-wave instantiations of the attention
+    kernel (the ragged launch uses the instantiation the dense launch of that T uses), T exactly 32 and 64 included."""
+    rng = np.random.default_rng(3)
+    for L in (12, 30, 31, 62, 63, 94):
+        wt = "".join(rng.choice(list("ACDEFGHIKLMNPQRSTVWY"), size=L))
+        _shared_vs_full(model, wt, _mutants_everywhere(wt, rng, n_multi=3))
+        _shared_vs_full(model, wt, _mutants_everywhere(wt, rng, n_multi=3), reverse=True)
 
 
 def test_prefix_shared_scoring_in_chunks_and_groups(lib, golden_dir):
