@@ -432,6 +432,7 @@ class TranceptionModel:
     """Device-resident Tranception.  ``score_mutants`` mirrors the reference method of the same name."""
 
     share_prefix = True          # forward a mutated sequence from its first mutated token on (sequence_loglik)
+    share_intermediate = True    # ... and multi-mutants from their SECOND mutated token on where an intermediate root pays (intermediate_roots)
     rows_forwarded = 0           # token rows that went through the network ...
     rows_full = 0                # ... and the rows the reference's loop forwards for the same calls
 
@@ -548,9 +549,24 @@ class TranceptionModel:
                          _lib.ptr(nn, _lib._i32p), _lib.ptr(flip, _lib._i32p), float(r["weight"]))
             ref_local = self._local_references(idx, reference, lengths, ids) if share else None
             if ref_local is not None:
+                # multi-mutants: a sequence shares MORE with "the wild type + its first mutation" than with the wild type; where that pays, such
+                # intermediate sequences are added to the call as roots of their own (forwarded in full, their scores dropped)
+                ids_c, ref_c, extra = self.intermediate_roots(ids, ref_local) if getattr(self, "share_intermediate", True) else (ids, ref_local, 0)
+                Bc = B + extra
+                res_c = np.empty(Bc, dtype=np.float32)
+                prior_c = prior
+                if r is not None and extra:                       # an added root is scored like the wild-type row it was made from (same window)
+                    src = np.concatenate([np.arange(B), ref_c[B:]])
+                    a0c, r0c, nnc, flc = (np.ascontiguousarray(v[src]) for v in (a0, row0, nn, flip))
+                    prior_c = (prior[0], prior[1], _lib.ptr(a0c, _lib._i32p), _lib.ptr(r0c, _lib._i32p), _lib.ptr(nnc, _lib._i32p),
+                               _lib.ptr(flc, _lib._i32p), prior[6])
+                if extra:
+                    ref_c = ref_c.copy()
+                    ref_c[B:] = np.arange(B, Bc)                  # (ref_c[B:] held the wild-type row each new root was made from)
                 rows = np.zeros(1, dtype=np.int64)
-                _lib.check(lib.pgmi_tr_sequence_loglik_shared(self._h, _lib.ptr(ids, _lib._i32p), _lib.ptr(ref_local, _lib._i32p), B, T,
-                                                              *prior, _lib.ptr(res, _lib._f32p), None, _lib.ptr(rows, _lib._i64p)))
+                _lib.check(lib.pgmi_tr_sequence_loglik_shared(self._h, _lib.ptr(ids_c, _lib._i32p), _lib.ptr(ref_c, _lib._i32p), Bc, T,
+                                                              *prior_c, _lib.ptr(res_c, _lib._f32p), None, _lib.ptr(rows, _lib._i64p)))
+                res = res_c[:B]
                 self.rows_forwarded += int(rows[0])
             else:
                 _lib.check(lib.pgmi_tr_sequence_loglik(self._h, _lib.ptr(ids, _lib._i32p), _lib.ptr(lens, _lib._i32p), B, T,
@@ -573,6 +589,67 @@ class TranceptionModel:
             if k != j and int(reference[idx[k]]) == int(idx[k]) and ids[j, 0] == ids[k, 0]:
                 local[j] = k
         return local if (local != np.arange(len(idx))).any() else None
+
+    @staticmethod
+    def intermediate_roots(ids, ref_local):
+        """Roots between the wild type and the multi-mutants of one equal-length group (additive; the reference has nothing like it).
+        A sequence that differs from its wild-type row at tokens f < g < ... is forwarded from f on when it shares the wild type's prefix,
+        but only from g on when it shares the prefix of "wild type + the substitution at f".  For every such (wild-type row, f, token) the
+        members are counted: if the rows they save, sum (g - f), exceed what forwarding the intermediate sequence in full costs -- T rows for
+        a new sequence, f rows when it is itself a row of the group (it then stops sharing with the wild type) -- it becomes a root.
+        Returns (ids with the new root rows appended, reference positions, number of rows appended); for an appended root the reference entry
+        holds the wild-type row it was made from (the caller copies that row's retrieval arguments, then makes the root its own reference).
+        A sequence's bits do not depend on which root serves its prefix (any root holds the same tokens there)."""
+        B, T = ids.shape
+        ref = np.asarray(ref_local, dtype=np.int64)
+        member = ref != np.arange(B)
+        if not member.any():
+            return ids, ref_local, 0
+        diff = ids != ids[ref]
+        count = diff.sum(axis=1)
+        multi = np.flatnonzero(member & (count >= 2))
+        if not multi.size:
+            return ids, ref_local, 0
+        first = diff[multi].argmax(axis=1)
+        rest = diff[multi].copy()
+        rest[np.arange(multi.size), first] = False
+        second = rest.argmax(axis=1)
+        token = ids[multi, first]
+        key = (ref[multi] * T + first) * 64 + token                    # (wild-type row, position, token): vocabulary of 25
+        uniq, inverse = np.unique(key, return_inverse=True)
+        saved = np.bincount(inverse, weights=(second - first).astype(np.float64), minlength=uniq.size)
+        # is the intermediate sequence already a row of the group?  (a single mutant listed in the assay)
+        single = np.flatnonzero(member & (count == 1))
+        where = {}
+        if single.size:
+            f1 = diff[single].argmax(axis=1)
+            for row, k in zip(single, (ref[single] * T + f1) * 64 + ids[single, f1]):
+                where.setdefault(int(k), int(row))
+        out_ref = ref.copy()
+        new_rows, new_src = [], []
+        for u, k in enumerate(uniq):
+            k = int(k)
+            f = (k // 64) % T
+            cost = f if k in where else T
+            if saved[u] <= cost:
+                continue
+            rows = multi[inverse == u]
+            if k in where:
+                root = where[k]
+                out_ref[root] = root                                    # forwarded in full from now on
+            else:
+                root = B + len(new_rows)
+                wt_row = k // 64 // T
+                seq = ids[wt_row].copy()
+                seq[f] = k % 64
+                new_rows.append(seq)
+                new_src.append(wt_row)
+            out_ref[rows] = root
+        if not new_rows and (out_ref == ref).all():
+            return ids, ref_local, 0
+        ids_c = np.ascontiguousarray(np.concatenate([ids, np.stack(new_rows)]) if new_rows else ids, dtype=np.int32)
+        ref_c = np.ascontiguousarray(np.concatenate([out_ref, np.asarray(new_src, dtype=np.int64)]), dtype=np.int32)
+        return ids_c, ref_c, len(new_rows)
 
     def _realigned_loglik(self, sliced, start, end, reverse, mutated_sequence) -> float:
         """Indel scoring with retrieval, one sequence (model_pytorch.py:794-839): the family log-prior is re-indexed through the

@@ -407,3 +407,44 @@ def test_prefix_shared_scoring_at_the_large_width(lib):
         print(f"L = {L}: rows forwarded {done} + {done_r} of 2 x {full}")
         assert done + done_r < 1.15 * full                             # uniform positions: ~half of the rows per direction, + the root
     m.close()
+
+
+def test_multi_mutants_share_intermediate_roots_same_bits(model):
+    """A pairwise library (3 x 4 first substitutions, each with 5 x 3 second ones) and random triples: with intermediate roots ("wild type +
+    first substitution", tranception.intermediate_roots) the same frame as with the wild type as the only root and as with every sequence in
+    full -- bit for bit, both directions -- and fewer rows forwarded."""
+    rng = np.random.default_rng(11)
+    L = 120
+    aa = "ACDEFGHIKLMNPQRSTVWY"
+    wt = "".join(rng.choice(list(aa), size=L))
+
+    def name(p, c):
+        c = c if wt[p] != c else ("A" if c != "A" else "C")
+        return f"{wt[p]}{p + 1}{c}"
+    muts = []
+    for i in (5, 40, 70):
+        for a in "DEKR":
+            for j in (80, 90, 100, 110, 118):
+                for b in "GPW":
+                    muts.append(name(i, a) + ":" + name(j, b))
+    for _ in range(40):
+        pos = sorted(int(p) for p in rng.choice(L, size=3, replace=False))
+        muts.append(":".join(name(p, str(rng.choice(list(aa)))) for p in pos))
+    muts.append(name(5, "D"))
+    muts = list(dict.fromkeys(muts))
+    df = pd.DataFrame({"mutant": muts, "mutated_sequence": ptr.mutated_sequences(wt, muts)}).drop_duplicates("mutated_sequence")
+    frames, rows = {}, {}
+    for name, (share, inter) in {"full": (False, False), "wild type": (True, False), "intermediate": (True, True)}.items():
+        model.share_prefix, model.share_intermediate = share, inter
+        model.rows_forwarded = model.rows_full = 0
+        try:
+            frames[name] = model.score_mutants(DMS_data=df, target_seq=wt, scoring_mirror=True)
+        finally:
+            model.share_prefix, model.share_intermediate = True, True
+        rows[name] = model.rows_forwarded
+    for name in ("wild type", "intermediate"):
+        assert list(frames[name]["mutated_sequence"]) == list(frames["full"]["mutated_sequence"])
+        for c in ("avg_score_L_to_R", "avg_score_R_to_L", "avg_score"):
+            assert np.array_equal(frames[name][c].to_numpy(), frames["full"][c].to_numpy()), (name, c)
+    print("rows forwarded:", rows)
+    assert rows["intermediate"] < 0.8 * rows["wild type"] < 0.8 * rows["full"]

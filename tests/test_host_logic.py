@@ -515,3 +515,50 @@ def test_bench_line_carries_the_metric_as_survey_8d_words_it():
     for key in ('"value_is"', '"strong_scaling_217"', '"scaling": "weak"', "value_end_to_end"):
         assert key in src
     assert '"scaling": "strong"' not in src                           # the N > 1 headline is the N = 1 step on every rank
+
+
+def test_tranception_intermediate_roots_for_multi_mutants():
+    """tranception.TranceptionModel.intermediate_roots: in a pairwise library the double mutants are served by "wild type + first substitution"
+    roots (appended to the call unless that single mutant is a row already), every reference is a root, every sequence equals its root before
+    its first difference from it, and fewer rows are forwarded; a library of singles, or groups too small to pay for a root, stay as they are."""
+    from proteingym_amd import tranception as ptr
+    rng = np.random.default_rng(0)
+    T = 60
+    wt = rng.integers(5, 25, size=T).astype(np.int32)
+    wt[0], wt[-1] = 1, 2
+
+    def sub(s, p, tok):
+        s = s.copy()
+        s[p] = tok if s[p] != tok else (tok - 5 + 1) % 20 + 5
+        return s
+    rows = [wt.copy()]
+    for i in (3, 10, 20):
+        for a in (5, 6):
+            for j in (30, 40, 50):
+                for b in (7, 8, 9):
+                    rows.append(sub(sub(wt, i, a), j, b))
+    rows.append(sub(wt, 3, 5))                                        # one of the intermediates is a row of the library
+    ids = np.stack(rows).astype(np.int32)
+    B = len(ids)
+    ref = np.zeros(B, dtype=np.int32)
+    ids_c, ref_c, extra = ptr.TranceptionModel.intermediate_roots(ids, ref)
+    assert extra == 5 and ids_c.shape == (B + 5, T) and np.array_equal(ids_c[:B], ids)
+    full = ref_c.copy()
+    assert (full[B:] == 0).all()                                       # made from the wild-type row (the caller copies its retrieval arguments)
+    full[B:] = np.arange(B, B + extra)
+    assert (full[full] == full).all()
+    assert full[B - 1] == B - 1                                        # the listed single mutant serves its doubles: forwarded in full now
+
+    def first_diff(b):
+        d = np.flatnonzero(ids_c[b] != ids_c[full[b]])
+        return int(d[0]) if d.size else T - 1
+    before = T + sum(T - int(np.flatnonzero(ids[b] != wt)[0]) for b in range(1, B))
+    after = sum(T if full[b] == b else T - first_diff(b) for b in range(B + extra))
+    assert after < 0.6 * before
+    for b in range(1, B - 1):                                          # every double starts at its SECOND substitution
+        assert first_diff(b) == int(np.flatnonzero(ids[b] != wt)[1])
+    singles = np.stack([wt] + [sub(wt, p, 7) for p in range(1, 40)]).astype(np.int32)
+    same = ptr.TranceptionModel.intermediate_roots(singles, np.zeros(len(singles), dtype=np.int32))
+    assert same[2] == 0 and same[0] is singles
+    few = np.stack([wt, sub(sub(wt, 50, 5), 55, 6), sub(sub(wt, 50, 5), 57, 6)]).astype(np.int32)     # two members save 5 + 7 rows: less than a root costs
+    assert ptr.TranceptionModel.intermediate_roots(few, np.zeros(3, dtype=np.int32))[2] == 0
