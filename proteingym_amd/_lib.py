@@ -19,8 +19,15 @@ K_NAMES = ["embed", "layernorm", "gemm_qkv", "attention", "gemm_out", "gemm_fc1"
            "head", "score", "kept_rows"]
 
 
+EINVAL, ENOMEM, EHIP, ENODEV, EPARSE, EOVERFLOW = -1, -2, -3, -4, -5, -6          # include/pgmi.h PGMI_E*
+
+
 class PgmiError(RuntimeError):
-    pass
+    """A failing C call; ``code`` is its PGMI_E* return value (None when the failure is the binding's own)."""
+
+    def __init__(self, message, code=None):
+        super().__init__(message)
+        self.code = code
 
 
 class Config(C.Structure):
@@ -101,7 +108,7 @@ def load():
 
 def check(rc: int):
     if rc != 0:
-        raise PgmiError(f"libpgmi error {rc}: {load().pgmi_last_error().decode(errors='replace')}")
+        raise PgmiError(f"libpgmi error {rc}: {load().pgmi_last_error().decode(errors='replace')}", code=int(rc))
 
 
 def ptr(a: np.ndarray, ty):

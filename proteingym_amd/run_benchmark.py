@@ -133,11 +133,13 @@ class _DeviceScorer:
         assay = pesm.Assay(self.model, seq, mutants, offset_idx=int(offset), alphabet=self.alphabet,
                            all_positions=self.all_positions)
         t1 = time.time()
-        out = assay.run()
+        try:
+            out = assay.run()
+        finally:
+            assay.close()
         t2 = time.time()
         self.log.append(dict(seq_len=len(seq), rows=len(mutants), positions_run=int(len(assay.positions)), T=int(assay.T),
                              create_s=t1 - t0, run_s=t2 - t1))
-        assay.close()
         self.create_s += t1 - t0
         self.run_s += t2 - t1
         return out
@@ -236,6 +238,86 @@ def _write_csv(df, path):
     os.replace(path + ".tmp", path)
 
 
+# ---- failure isolation ------------------------------------------------------------------------------------------------------
+# The reference isolates failures for free: one process per --dms_index (scripts/scoring_DMS_zero_shot/
+# scoring_ESM1v_substitutions.sh:21-31), so a wild-type mismatch in one DMS file (the assertion of compute_fitness.py:243)
+# loses that assay only.  Here many assays share a process AND a collective: a unit that fails fills NaN, every rank still
+# reaches every collective, the failed assay's CSV is not written (a re-run picks it up), the others are written as in a clean
+# run, and the job exits non-zero with a summary.  PGMI_EOVERFLOW (a 16-bit mode met an activation beyond fp16's range) is not
+# a failure: that (assay, checkpoint) is re-scored on an fp32 model of the same checkpoint, built once per rank when first
+# needed, and scores_summary.csv says so (precision_<checkpoint> = fp32).
+def is_overflow(e) -> bool:
+    return isinstance(e, pesm.PgmiError) and getattr(e, "code", None) == pesm._lib.EOVERFLOW
+
+
+def _describe(e) -> str:
+    return f"{type(e).__name__}: {e}"
+
+
+def _seam(make_model, loc, precision=None):
+    """The test seam: ``make_model(location)``; one that also takes ``precision=`` can serve the fp32 retry."""
+    if precision is None:
+        return make_model(loc)
+    import inspect
+    try:
+        takes = "precision" in inspect.signature(make_model).parameters
+    except (TypeError, ValueError):
+        takes = False
+    return make_model(loc, precision=precision) if takes else None
+
+
+class _Fp32Retry:
+    """The fp32 model of one checkpoint on this rank, built when the first unit overflows and closed with the checkpoint."""
+
+    def __init__(self, build, requested: str):
+        self.build, self.requested, self.model = build, requested, None
+
+    def wanted(self, e) -> bool:
+        return is_overflow(e) and self.requested != "fp32"
+
+    def get(self):
+        if self.model is None:
+            self.model = self.build()
+            if self.model is None:
+                raise pesm.PgmiError("no fp32 model available for the retry")
+        return self.model
+
+    def close(self):
+        if self.model is not None and hasattr(self.model, "close"):
+            self.model.close()
+        self.model = None
+
+
+def _exchange_reports(world, *dicts):
+    """Union of per-rank {key -> value} reports (failed assays, fp32 retries) on every rank; the lower rank's value wins."""
+    if world == 1:
+        return [dict(d) for d in dicts]
+    import torch.distributed as tdist
+    got = [None] * world
+    tdist.all_gather_object(got, [dict(d) for d in dicts])
+    out = [{} for _ in dicts]
+    for per_rank in got:
+        for o, d in zip(out, per_rank):
+            for k, v in d.items():
+                o.setdefault(k, v)
+    return out
+
+
+def _summary_rows(mapping, todo, cols, vectors, failed, used):
+    """scores_summary.csv: one row per assay of the job -- rows, mean per checkpoint column, status, the precision every
+    (assay, checkpoint) was scored in, and the message of a failed one."""
+    rows = []
+    for k, i in enumerate(todo):
+        v = vectors[k]
+        ok = i not in failed
+        rows.append({"DMS_id": str(mapping.iloc[i]["DMS_id"]), "mutants": int(v.shape[1]),
+                     **{f"mean_{name}": float(np.mean(v[c])) if v.shape[1] and ok else float("nan") for c, name in enumerate(cols)},
+                     "status": "ok" if ok else "failed",
+                     **{f"precision_{name}": used.get((i, c), "") for c, name in enumerate(cols)},
+                     "error": failed.get(i, "")})
+    return rows
+
+
 def main(args, make_model=None):
     """``make_model`` is a test seam: (location) -> object with score(seq, mutants, offset) and close()."""
     rank, local_rank, world = pdist.init_from_env(args.backend)
@@ -310,50 +392,117 @@ def main(args, make_model=None):
     writer = ThreadPoolExecutor(max_workers=2) if owner_writes else None
     pending = []
     assay_log = []
+    failed, used = {}, {}                           # assay -> message;  (assay, checkpoint index) -> precision of a retry
+    unread = {}
+
+    def frame_or_none(i):                           # an unreadable DMS file fails that assay (once), not the rank
+        if i in unread:
+            return None
+        try:
+            return frame(i)
+        except BaseException as e:                  # noqa: BLE001 -- isolation: see the note above _Fp32Retry
+            if isinstance(e, KeyboardInterrupt):
+                raise
+            reads.pop(i, None)
+            unread[i] = _describe(e)
+            failed.setdefault(i, unread[i])
+            print(f"[rank {rank}] assay {mapping.iloc[i]['DMS_id']} FAILED: {unread[i]}", flush=True)
+            return None
+
+    def blank(i):
+        return np.full(len(frames[i][0]), np.nan) if i in frames else np.zeros(0)
+
+    def real_model(loc, precision):
+        return (_DeviceWtMarginals(loc, local_rank, precision, args.scoring_window) if wt_marginals
+                else _DeviceScorer(loc, local_rank, precision, args.all_positions))
+
     for ci, loc in enumerate(args.model_location):
         t = time.time()
-        model = make_model(loc) if make_model is not None else \
-            (_DeviceWtMarginals(loc, local_rank, args.precision, args.scoring_window) if wt_marginals
-             else _DeviceScorer(loc, local_rank, args.precision, args.all_positions))
+        try:
+            model = _seam(make_model, loc) if make_model is not None else real_model(loc, args.precision)
+        except BaseException as e:                  # noqa: BLE001 -- a checkpoint this rank cannot load fails this rank's assays
+            if isinstance(e, KeyboardInterrupt):
+                raise
+            print(f"[rank {rank}] checkpoint {loc} FAILED to load: {_describe(e)}", flush=True)
+            for i in mine:
+                frame_or_none(i)
+                failed.setdefault(i, f"checkpoint {loc}: {_describe(e)}")
+                local.setdefault(i, []).append(blank(i))
+            continue
+        retry = _Fp32Retry((lambda loc=loc: _seam(make_model, loc, "fp32")) if make_model is not None
+                           else (lambda loc=loc: real_model(loc, "fp32")), args.precision)
         clock["checkpoint_load_s"] = clock.get("checkpoint_load_s", 0.0) + time.time() - t
         last = ci == len(args.model_location) - 1
         grouped = hasattr(model, "score_group") and bool(groups)
         logged = []
+
+        def score_one(i, fr):
+            """One assay on this checkpoint -> its vector (NaN when it failed, now or on an earlier checkpoint)."""
+            if i in failed:
+                return blank(i)
+            df, mutant_col, seq, offset = fr
+            try:
+                muts = [str(m) for m in df[mutant_col]]
+                try:
+                    return np.asarray(model.score(seq, muts, offset), dtype=np.float64)
+                except pesm.PgmiError as e:
+                    if not retry.wanted(e):
+                        raise
+                    print(f"[rank {rank}] assay {mapping.iloc[i]['DMS_id']} x {cols[ci]}: {args.precision} left the fp16 range, "
+                          "re-scoring this assay in fp32", flush=True)
+                    v = np.asarray(retry.get().score(seq, muts, offset), dtype=np.float64)
+                    used[(i, ci)] = "fp32"
+                    return v
+            except BaseException as e:              # noqa: BLE001
+                if isinstance(e, KeyboardInterrupt):
+                    raise
+                failed[i] = _describe(e)
+                print(f"[rank {rank}] assay {mapping.iloc[i]['DMS_id']} x {cols[ci]} FAILED: {failed[i]}", flush=True)
+                return blank(i)
+
         for unit in ([[i] for i in order if i not in in_group] + groups) if grouped else [[i] for i in order]:
-            fr = [frame(i) for i in unit]
+            fr = [frame_or_none(i) for i in unit]
             t = time.time()
-            if len(unit) == 1:
-                df, mutant_col, seq, offset = fr[0]
-                got = [model.score(seq, [str(m) for m in df[mutant_col]], offset)]
-            else:
-                got = model.score_group([(seq, [str(m) for m in df[mutant_col]], offset) for df, mutant_col, seq, offset in fr])
+            got = None
+            if len(unit) > 1 and not any(i in failed for i in unit):
+                try:
+                    got = [np.asarray(v, dtype=np.float64) for v in
+                           model.score_group([(seq, [str(m) for m in df[mutant_col]], offset) for df, mutant_col, seq, offset in fr])]
+                except BaseException as e:          # noqa: BLE001 -- which member it was shows one at a time
+                    if isinstance(e, KeyboardInterrupt):
+                        raise
+                    got = None
+            if got is None:
+                got = [score_one(i, f) for i, f in zip(unit, fr)]
             clock["score_s"] += time.time() - t
-            logged += unit
-            for i, v, (df, _, _, _) in zip(unit, got, fr):
-                local.setdefault(i, []).append(np.asarray(v, dtype=np.float64))
-                if last and writer is not None:
-                    pending.append(writer.submit(_write_csv, _finish_frame(df, cols, ens_cols, local[i]),
-                                                 os.path.join(args.dms_output, str(mapping.iloc[i]["DMS_id"]) + ".csv")))
+            logged += [i for i in unit if i not in failed and (i, ci) not in used]
+            for i, v in zip(unit, got):
+                local.setdefault(i, []).append(v)
+                if last and writer is not None and i not in failed:
+                    pending.append((i, writer.submit(_write_csv, _finish_frame(frames[i][0], cols, ens_cols, local[i]),
+                                                     os.path.join(args.dms_output, str(mapping.iloc[i]["DMS_id"]) + ".csv"))))
         for k in ("create_s", "run_s"):
             if hasattr(model, k):
                 clock["assay_" + k] = clock.get("assay_" + k, 0.0) + getattr(model, k)
-        assay_log += [dict(e, checkpoint=ci, DMS_id=str(mapping.iloc[i]["DMS_id"])) for e, i in zip(getattr(model, "log", []), logged)]
+        if len(getattr(model, "log", [])) == len(logged):
+            assay_log += [dict(e, checkpoint=ci, DMS_id=str(mapping.iloc[i]["DMS_id"])) for e, i in zip(model.log, logged)]
         model.close()
+        retry.close()
     t = time.time()
-    for f in pending:
-        f.result()                                 # re-raises a writer's exception
+    for i, f in pending:
+        try:
+            f.result()
+        except BaseException as e:                  # noqa: BLE001 -- a CSV that could not be written is a failed assay
+            if isinstance(e, KeyboardInterrupt):
+                raise
+            failed[i] = "writing the CSV: " + _describe(e)
+            print(f"[rank {rank}] assay {mapping.iloc[i]['DMS_id']} FAILED: {failed[i]}", flush=True)
     if writer is not None:
         writer.shutdown()
     reader.shutdown()
     clock["wait_write_s"] = time.time() - t
     # exchange: per item a [n_checkpoints * n_mut] vector
-    sizes = []
-    n_rows = {}
-    for k, i in enumerate(todo):
-        row = mapping.iloc[i]
-        n = int(row["DMS_total_number_mutants"]) if "DMS_total_number_mutants" in mapping.columns and i not in frames \
-            else (len(frames[i][0]) if i in frames else None)
-        n_rows[i] = n
+    n_rows = {i: (len(frames[i][0]) if i in frames else 0) for i in todo}
     if world > 1:
         import torch
         import torch.distributed as tdist
@@ -364,8 +513,9 @@ def main(args, make_model=None):
         tdist.all_reduce(cnt)                       # exact row counts (files may differ from the mapping)
         for k, i in enumerate(todo):
             n_rows[i] = int(cnt[k])
+    failed, used = _exchange_reports(world, failed, used)
     sizes = [n_rows[i] * len(cols) for i in todo]
-    payload = {assignment[rank][j]: np.concatenate(local[i]) for j, i in enumerate(mine)}
+    payload = {assignment[rank][j]: np.concatenate(local[i]) if local.get(i) else np.zeros(0) for j, i in enumerate(mine)}
     dev = None
     if world > 1:
         import torch.distributed as tdist
@@ -374,50 +524,88 @@ def main(args, make_model=None):
 
     if rank == 0:
         n_mut = 0
-        summary = []
+        vectors = []
         for k, i in enumerate(todo):
             row = mapping.iloc[i].replace(np.nan, "")
             v = allv[k].reshape(len(cols), -1)
+            vectors.append(v)
+            if i in failed:
+                continue
             if not owner_writes:
-                df = frames[i][0] if i in frames else pd.read_csv(os.path.join(args.dms_input, row["DMS_filename"]))
-                _write_csv(_finish_frame(df, cols, ens_cols, v), os.path.join(args.dms_output, str(row["DMS_id"]) + ".csv"))
+                try:
+                    df = frames[i][0] if i in frames else pd.read_csv(os.path.join(args.dms_input, row["DMS_filename"]))
+                    _write_csv(_finish_frame(df, cols, ens_cols, v), os.path.join(args.dms_output, str(row["DMS_id"]) + ".csv"))
+                except BaseException as e:          # noqa: BLE001
+                    if isinstance(e, KeyboardInterrupt):
+                        raise
+                    failed[i] = "writing the CSV: " + _describe(e)
+                    continue
             n_mut += v.shape[1]
-            summary.append({"DMS_id": str(row["DMS_id"]), "mutants": v.shape[1],
-                            **{f"mean_{name}": float(np.mean(v[c])) if v.shape[1] else float("nan") for c, name in enumerate(cols)}})
-        if world > 1:                              # what the gathered vectors are for when the owners write the CSVs
-            _write_csv(pd.DataFrame(summary), os.path.join(args.dms_output, "scores_summary.csv"))
+        if world > 1 or failed or used:            # what the gathered vectors are for when the owners write the CSVs
+            _write_csv(pd.DataFrame(_summary_rows(mapping, todo, cols, vectors, failed, used)),
+                       os.path.join(args.dms_output, "scores_summary.csv"))
         dt = time.time() - t0
-        print(f"scored {len(todo)} assays / {n_mut} mutants x {len(cols)} checkpoint(s) on {world} GPU(s) "
+        print(f"scored {len(todo) - len(failed)} assays / {n_mut} mutants x {len(cols)} checkpoint(s) on {world} GPU(s) "
               f"in {dt:.1f}s = {n_mut / max(dt, 1e-9):.1f} mutants/s (ensemble rate)")
         print("rank 0 wall clock: " + ", ".join(f"{k} {v:.1f}" for k, v in clock.items())
               + " (score_s = mutant parse + upload + GPU; checkpoint load and the rest are the difference)")
-        stats = dict(seconds=dt, mutants=n_mut, assays=len(todo), checkpoints=len(cols), world=world, rank0_wall_clock=dict(clock),
-                     rank0_assays=assay_log)
+        stats = dict(seconds=dt, mutants=n_mut, assays=len(todo) - len(failed), checkpoints=len(cols), world=world,
+                     rank0_wall_clock=dict(clock), rank0_assays=assay_log, failed=dict(failed),
+                     precision_used={f"{mapping.iloc[i]['DMS_id']}:{cols[c]}": p for (i, c), p in used.items()})
     else:
         stats = None
     if world > 1:
         import torch.distributed as tdist
         tdist.barrier()
         tdist.destroy_process_group()
+    _exit_on_failures(mapping, failed, rank)
     return stats
+
+
+def _exit_on_failures(mapping, failed, rank, who="run_benchmark"):
+    if not failed:
+        return
+    if rank == 0:
+        import sys
+        for i, why in sorted(failed.items()):
+            print(f"{who}: assay {mapping.iloc[i]['DMS_id']} failed: {why}", file=sys.stderr, flush=True)
+    raise SystemExit(f"{who}: {len(failed)} assay(s) failed (scores_summary.csv lists them); their CSVs were not written")
 
 
 def main_position_shards(args, mapping, todo, cols, ens_cols, rank, local_rank, world, make_model=None):
     """--shard positions: every assay's masked positions are cut into chunks, chunks are LPT-balanced over the ranks,
     each rank fills the table rows of its chunks, ONE all_gather moves the partial tables (NaN = not mine), every
     rank merges them and rank 0 scores the mutants from the complete tables (bit-identical to Assay.run()) and
-    writes the CSVs.  ``make_model`` is a test seam: (location) -> object with table_rows(seq, positions, offset)."""
+    writes the CSVs.  ``make_model`` is a test seam: (location) -> object with table_rows(seq, positions, offset).
+
+    Failures (see the note above ``_Fp32Retry``): an assay whose file or mutant column is bad anywhere is dropped on every
+    rank BEFORE the plan (the plan must be the same everywhere); a chunk that fails on one rank fails its assay; a chunk
+    that leaves the fp16 range sends the WHOLE assay (every rank's chunks of it) through fp32 models for that checkpoint,
+    so a table never mixes precisions and the scores do not depend on the number of ranks.  The reports travel as
+    objects between the passes; every rank takes part in every exchange."""
     t0 = time.time()
-    frames = []
-    for i in todo:
+    frames, failed, used = [], {}, {}
+    for a, i in enumerate(todo):
         row = mapping.iloc[i].replace(np.nan, "")
-        mutant_col = row["DMS_mutant_column"] if "DMS_mutant_column" in mapping.columns else args.mutation_col
-        df = pd.read_csv(os.path.join(args.dms_input, row["DMS_filename"]))
         seq = str(row["target_seq"]).upper()
-        offset = int(row["start_idx"]) if "start_idx" in mapping.columns and row["start_idx"] != "" else 1
-        muts = [str(m) for m in df[mutant_col]]
-        pos = np.arange(len(seq) + 2, dtype=np.int32) if args.all_positions else pesm.positions_read(muts, seq, offset)
-        frames.append(dict(df=df, seq=seq, offset=offset, mutants=muts, positions=pos, dms_id=str(row["DMS_id"])))
+        f = dict(df=None, seq=seq, offset=1, mutants=[], positions=np.zeros(0, np.int32), dms_id=str(row["DMS_id"]))
+        try:
+            mutant_col = row["DMS_mutant_column"] if "DMS_mutant_column" in mapping.columns else args.mutation_col
+            f["df"] = pd.read_csv(os.path.join(args.dms_input, row["DMS_filename"]))
+            f["offset"] = int(row["start_idx"]) if "start_idx" in mapping.columns and row["start_idx"] != "" else 1
+            f["mutants"] = [str(m) for m in f["df"][mutant_col]]
+            f["positions"] = np.arange(len(seq) + 2, dtype=np.int32) if args.all_positions else \
+                pesm.positions_read(f["mutants"], seq, f["offset"])
+        except BaseException as e:                  # noqa: BLE001
+            if isinstance(e, KeyboardInterrupt):
+                raise
+            failed[a] = _describe(e)
+        frames.append(f)
+    failed, = _exchange_reports(world, failed)
+    for a in failed:
+        frames[a]["positions"] = np.zeros(0, np.int32)
+        if rank == 0:
+            print(f"assay {frames[a]['dms_id']} FAILED: {failed[a]}", flush=True)
     items, assignment = pdist.plan_position_chunks([len(f["seq"]) for f in frames], [f["positions"] for f in frames],
                                                    world, chunk_forwards=args.chunk_forwards)
     n_toks = [len(f["seq"]) + 2 for f in frames]
@@ -425,39 +613,103 @@ def main_position_shards(args, mapping, todo, cols, ens_cols, rank, local_rank, 
     if world > 1:
         import torch.distributed as tdist
         dev = "cuda" if tdist.get_backend() == "nccl" else "cpu"
-    for ci, loc in enumerate(args.model_location):
-        if make_model is not None:
-            model = make_model(loc)
-        else:
-            model = _DeviceTables(loc, local_rank, args.precision)
-        local = {a: np.full((n_toks[a], 33), np.nan, dtype=np.float32) for a in range(len(frames))}
+
+    def fill(model, local, which, report_overflow):
+        """This rank's chunks of the assays in ``which`` -> rows of ``local``; returns ({assay: message}, {assays that overflowed})."""
+        bad, over = {}, set()
         for k in assignment[rank]:
             a, chunk = items[k]
-            rows = model.table_rows(frames[a]["seq"], chunk, frames[a]["offset"])
-            local[a][chunk] = rows
-        tables = pdist.gather_tables(local, n_toks, device=dev)
-        if hasattr(model, "close"):
+            if a not in which or a in bad or a in over:
+                continue
+            try:
+                local[a][chunk] = model.table_rows(frames[a]["seq"], chunk, frames[a]["offset"])
+            except BaseException as e:              # noqa: BLE001
+                if isinstance(e, KeyboardInterrupt):
+                    raise
+                if report_overflow and is_overflow(e):
+                    over.add(a)
+                else:
+                    bad[a] = _describe(e)
+                    print(f"[rank {rank}] assay {frames[a]['dms_id']} FAILED: {bad[a]}", flush=True)
+        return bad, over
+
+    for ci, loc in enumerate(args.model_location):
+        live = {a for a in range(len(frames)) if a not in failed}
+        local = {a: np.full((n_toks[a], 33), np.nan, dtype=np.float32) for a in range(len(frames))}
+        model, bad, over = None, {}, set()
+        try:
+            model = _seam(make_model, loc) if make_model is not None else _DeviceTables(loc, local_rank, args.precision)
+            bad, over = fill(model, local, live, args.precision != "fp32")
+        except BaseException as e:                  # noqa: BLE001 -- a checkpoint this rank cannot load fails the assays it holds chunks of
+            if isinstance(e, KeyboardInterrupt):
+                raise
+            bad = {items[k][0]: f"checkpoint {loc}: {_describe(e)}" for k in assignment[rank] if items[k][0] in live}
+        if model is not None and hasattr(model, "close"):
             model.close()
+        bad, over = _exchange_reports(world, bad, {a: 1 for a in over})
+        failed.update({a: m for a, m in bad.items() if a not in failed})
+        redo = {a for a in over if a not in failed}
+        if redo:                                    # the same set on every rank
+            if rank == 0:
+                print(f"{cols[ci]}: {args.precision} left the fp16 range in {sorted(frames[a]['dms_id'] for a in redo)}: "
+                      "those assays are re-scored in fp32 on every rank", flush=True)
+            for a in redo:
+                local[a][:] = np.nan
+                used[(a, ci)] = "fp32"
+            bad = {}
+            try:
+                model32 = _seam(make_model, loc, "fp32") if make_model is not None else _DeviceTables(loc, local_rank, "fp32")
+                if model32 is None:
+                    raise pesm.PgmiError("no fp32 model available for the retry")
+                bad, _ = fill(model32, local, redo, False)
+                if hasattr(model32, "close"):
+                    model32.close()
+            except BaseException as e:              # noqa: BLE001
+                if isinstance(e, KeyboardInterrupt):
+                    raise
+                bad = {items[k][0]: f"fp32 retry of {loc}: {_describe(e)}" for k in assignment[rank] if items[k][0] in redo}
+            bad, = _exchange_reports(world, bad)
+            failed.update({a: m for a, m in bad.items() if a not in failed})
+        tables = pdist.gather_tables(local, n_toks, device=dev)
         if rank == 0:
             for a, f in enumerate(frames):
-                f["df"][cols[ci]] = pesm.score_from_table(tables[a], f["mutants"], f["seq"], f["offset"])
+                if a in failed:
+                    continue
+                try:
+                    f["df"][cols[ci]] = pesm.score_from_table(tables[a], f["mutants"], f["seq"], f["offset"])
+                except BaseException as e:          # noqa: BLE001
+                    if isinstance(e, KeyboardInterrupt):
+                        raise
+                    failed[a] = _describe(e)
+    failed, = _exchange_reports(world, failed if rank == 0 else {})            # rank 0's view decides the exit code everywhere
     if rank == 0:
         n_mut = 0
-        for f in frames:
+        vectors = []
+        for a, f in enumerate(frames):
             df = f["df"]
+            if a in failed:
+                vectors.append(np.zeros((len(cols), 0 if df is None else len(df))))
+                continue
             if ens_cols:
                 df["Ensemble_ESM1v"] = sum(df[c] for c in cols) / len(cols)
             out = os.path.join(args.dms_output, f["dms_id"] + ".csv")
             df.to_csv(out + ".tmp", index=False)
             os.replace(out + ".tmp", out)
             n_mut += len(df)
+            vectors.append(np.stack([df[c].to_numpy(dtype=np.float64) for c in cols]))
+        by_index = {todo[a]: m for a, m in failed.items()}
+        if world > 1 or failed or used:
+            _write_csv(pd.DataFrame(_summary_rows(mapping, todo, cols, vectors, by_index,
+                                                  {(todo[a], c): p for (a, c), p in used.items()})),
+                       os.path.join(args.dms_output, "scores_summary.csv"))
         dt = time.time() - t0
-        print(f"scored {len(frames)} assays / {n_mut} mutants x {len(cols)} checkpoint(s) on {world} GPU(s), "
+        print(f"scored {len(frames) - len(failed)} assays / {n_mut} mutants x {len(cols)} checkpoint(s) on {world} GPU(s), "
               f"{len(items)} position chunks, in {dt:.1f}s = {n_mut / max(dt, 1e-9):.1f} mutants/s (ensemble rate)")
     if world > 1:
         import torch.distributed as tdist
         tdist.barrier()
         tdist.destroy_process_group()
+    _exit_on_failures(mapping, {todo[a]: m for a, m in failed.items()}, rank)
 
 
 class _DeviceTables:
@@ -470,8 +722,10 @@ class _DeviceTables:
     def table_rows(self, seq, positions, offset):
         first = seq[0] + str(offset) + ("A" if seq[0] != "A" else "C")          # any valid mutant: only the table is read
         a = pesm.Assay(self.model, seq, [first], offset_idx=offset, alphabet=self.alphabet, positions=positions)
-        _, table = a.run(want_table=True)
-        a.close()
+        try:
+            _, table = a.run(want_table=True)
+        finally:
+            a.close()
         return table[np.asarray(positions)]
 
     def close(self):

@@ -26,7 +26,8 @@ import pandas as pd
 
 from . import dist as pdist
 from . import esm as pesm
-from .run_benchmark import column_names, _finish_frame, _write_csv
+from .run_benchmark import (column_names, _finish_frame, _write_csv, _describe, _exchange_reports, is_overflow, _seam,
+                            _summary_rows, _exit_on_failures)
 
 
 def create_parser():
@@ -81,22 +82,44 @@ class _DevicePppl:
 
 
 def main(args, make_model=None):
-    """``make_model`` is a test seam: (location) -> object with score(sequences) -> float64 array, and close()."""
+    """``make_model`` is a test seam: (location) -> object with score(sequences) -> float64 array, and close().
+
+    Failures (run_benchmark, note above ``_Fp32Retry``): an assay whose file cannot be read or lacks the sequence column is
+    dropped on every rank before the pool is built; when a rank's share does not score in one piece, it is scored assay by
+    assay -- the assay that fails fills NaN; an assay that leaves the fp16 range anywhere is re-scored on fp32 models of the
+    same checkpoint on EVERY rank that holds rows of it, so a library never mixes precisions and the scores do not depend on
+    the number of ranks (pseudo-ppl is batch-invariant: the other assays' bits do not change) -- and every rank still reaches
+    every exchange; failed assays' CSVs are not written and the job exits non-zero."""
     rank, local_rank, world = pdist.init_from_env(args.backend)
     mapping = pd.read_csv(args.dms_mapping)
     indices = list(range(len(mapping))) if args.dms_indices is None else list(args.dms_indices)
     cols, ens_cols = column_names(args.model_location, args.model_type)
     os.makedirs(args.dms_output, exist_ok=True)
     t0 = time.time()
-    frames, pool, spans = [], [], []
+    read, failed, used = {}, {}, {}
     for i in indices:                                           # every rank reads the (small) input files: the pool
         row = mapping.iloc[i]                                   # and its partition must be identical everywhere
-        df = pd.read_csv(os.path.join(args.dms_input, row["DMS_filename"]))
-        if args.sequence_col not in df:
-            raise ValueError(f"{row['DMS_filename']}: no '{args.sequence_col}' column (indel assays carry the full mutated sequence)")
-        frames.append((str(row["DMS_id"]), df))
+        try:
+            df = pd.read_csv(os.path.join(args.dms_input, row["DMS_filename"]))
+            if args.sequence_col not in df:
+                raise ValueError(f"{row['DMS_filename']}: no '{args.sequence_col}' column (indel assays carry the full mutated sequence)")
+            read[i] = df
+        except BaseException as e:                              # noqa: BLE001
+            if isinstance(e, KeyboardInterrupt):
+                raise
+            failed[i] = _describe(e)
+    failed, = _exchange_reports(world, failed)                  # an assay unreadable anywhere is out of the pool everywhere
+    frames, pool, spans, owner = [], [], [], []
+    for i in indices:
+        if i in failed:
+            if rank == 0:
+                print(f"assay {mapping.iloc[i]['DMS_id']} FAILED: {failed[i]}", flush=True)
+            continue
+        df = read[i]
+        frames.append((i, str(mapping.iloc[i]["DMS_id"]), df))
         spans.append((len(pool), len(pool) + len(df)))
         pool.extend(str(s) for s in df[args.sequence_col])
+        owner += [i] * len(df)
     lengths = [len(s) for s in pool]
     assignment, loads = partition_pool(lengths, world)
     mine = assignment[rank]
@@ -104,11 +127,73 @@ def main(args, make_model=None):
     if world > 1:
         import torch.distributed as tdist
         dev = "cuda" if tdist.get_backend() == "nccl" else "cpu"
+
+    by_assay = {}
+    for j, k in enumerate(mine):
+        by_assay.setdefault(owner[k], []).append(j)
+
+    def score_by_assay(model, local, which, report_overflow):
+        """This rank's share of the assays in ``which``, one assay per call -> ({assay: message}, {assays that overflowed})."""
+        bad, over = {}, set()
+        for i in which:
+            js = by_assay.get(i, [])
+            if not js:
+                continue
+            try:
+                local[js] = np.asarray(model.score([pool[mine[j]] for j in js]), dtype=np.float64)
+            except BaseException as e:                          # noqa: BLE001
+                if isinstance(e, KeyboardInterrupt):
+                    raise
+                if report_overflow and is_overflow(e):
+                    over.add(i)
+                else:
+                    bad[i] = _describe(e)
+                    print(f"[rank {rank}] assay {mapping.iloc[i]['DMS_id']} x {cols[ci]} FAILED: {bad[i]}", flush=True)
+        return bad, over
+
     vectors = []
-    for loc in args.model_location:
-        model = make_model(loc) if make_model is not None else _DevicePppl(loc, local_rank, args.precision)
-        local = np.asarray(model.score([pool[k] for k in mine]), dtype=np.float64)
-        model.close()
+    for ci, loc in enumerate(args.model_location):
+        local = np.full(len(mine), np.nan, dtype=np.float64)
+        live = [i for i, _, _ in frames if i not in failed]
+        bad, over = {}, set()
+        model = None
+        try:
+            model = _seam(make_model, loc) if make_model is not None else _DevicePppl(loc, local_rank, args.precision)
+            try:
+                if len(live) < len(frames):
+                    raise RuntimeError("an assay of the pool failed on an earlier checkpoint")
+                local[:] = np.asarray(model.score([pool[k] for k in mine]), dtype=np.float64)
+            except BaseException as e:                          # noqa: BLE001 -- which assay it was shows one at a time
+                if isinstance(e, KeyboardInterrupt):
+                    raise
+                bad, over = score_by_assay(model, local, live, args.precision != "fp32")
+        except BaseException as e:                              # noqa: BLE001 -- a checkpoint this rank cannot load
+            if isinstance(e, KeyboardInterrupt):
+                raise
+            bad = {i: f"checkpoint {loc}: {_describe(e)}" for i in by_assay if i in live}
+        if model is not None:
+            model.close()
+        bad, over = _exchange_reports(world, bad, {i: 1 for i in over})
+        failed.update({i: m for i, m in bad.items() if i not in failed})
+        redo = [i for i in live if i in over and i not in failed]
+        if redo:                                                # the same list on every rank: a library never mixes precisions
+            if rank == 0:
+                print(f"{cols[ci]}: {args.precision} left the fp16 range in {[str(mapping.iloc[i]['DMS_id']) for i in redo]}: "
+                      "those assays are re-scored in fp32 on every rank", flush=True)
+            bad = {}
+            try:
+                model32 = _seam(make_model, loc, "fp32") if make_model is not None else _DevicePppl(loc, local_rank, "fp32")
+                if model32 is None:
+                    raise pesm.PgmiError("no fp32 model available for the retry")
+                bad, _ = score_by_assay(model32, local, redo, False)
+                model32.close()
+            except BaseException as e:                          # noqa: BLE001
+                if isinstance(e, KeyboardInterrupt):
+                    raise
+                bad = {i: f"fp32 retry of {loc}: {_describe(e)}" for i in redo if i in by_assay}
+            bad, = _exchange_reports(world, bad)
+            failed.update({i: m for i, m in bad.items() if i not in failed})
+            used.update({(i, ci): "fp32" for i in redo})
         if world > 1:                                           # one item per rank: its share of the pool
             got = pdist.gather_score_vectors({rank: local}, [len(a) for a in assignment], [[r] for r in range(world)], device=dev)
             full = np.empty(len(pool), dtype=np.float64)
@@ -119,8 +204,13 @@ def main(args, make_model=None):
             full[mine] = local
         vectors.append(full)
     if rank == 0:
-        for (dms_id, df), (a, b) in zip(frames, spans):
-            _write_csv(_finish_frame(df, cols, ens_cols, [v[a:b] for v in vectors]), os.path.join(args.dms_output, dms_id + ".csv"))
+        for (i, dms_id, df), (a, b) in zip(frames, spans):
+            if i not in failed:
+                _write_csv(_finish_frame(df, cols, ens_cols, [v[a:b] for v in vectors]), os.path.join(args.dms_output, dms_id + ".csv"))
+        if failed or used:
+            span_of = {i: ab for (i, _, _), ab in zip(frames, spans)}
+            per = [np.stack([v[slice(*span_of[i])] for v in vectors]) if i in span_of else np.zeros((len(cols), 0)) for i in indices]
+            _write_csv(pd.DataFrame(_summary_rows(mapping, indices, cols, per, failed, used)), os.path.join(args.dms_output, "scores_summary.csv"))
         dt = time.time() - t0
         rows = sum(max(0, L - 2) for L in lengths)
         print(f"pseudo-ppl: {len(frames)} assays / {len(pool)} sequences / {rows} masked forwards x {len(cols)} checkpoint(s) on "
@@ -130,6 +220,7 @@ def main(args, make_model=None):
         import torch.distributed as tdist
         tdist.barrier()
         tdist.destroy_process_group()
+    _exit_on_failures(mapping, failed, rank, who="run_indels")
     return vectors
 
 

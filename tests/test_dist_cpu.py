@@ -778,3 +778,247 @@ def test_bench_strong_scaling_pass_covers_the_table_once_on_two_ranks():
     for _, _, st in res:
         assert st["mutants"] == want and st["assays"] == 24 and st["seconds"] >= st["fastest_rank_seconds"] > 0
         assert st["positions_run"] > 0 and st["executed_algorithmic_flops"] > 0
+
+
+# ---- failure isolation: a bad assay / an fp16 overflow must neither lose the job nor hang the other ranks ----------------
+class _FlakyScorer(_FakeScorer):
+    """_FakeScorer with real-data trouble: the 55-residue assay's file has a wild-type mismatch (the assertion of
+    compute_fitness.py:243), the 41-residue assay leaves the fp16 range on checkpoint ckA unless the model is fp32."""
+
+    def __init__(self, location, precision=None):
+        super().__init__(location)
+        self.location, self.precision = location, precision
+
+    def score(self, seq, mutants, offset):
+        if len(seq) == 55:
+            raise AssertionError("The listed wildtype does not match the provided sequence")
+        if len(seq) == 41 and self.location == "ckA.pt" and self.precision != "fp32":
+            from proteingym_amd import _lib
+            raise _lib.PgmiError("libpgmi error -6: non-finite log-probabilities", code=_lib.EOVERFLOW)
+        v = super().score(seq, mutants, offset)
+        return v + 0.5 if self.precision == "fp32" else v
+
+
+def _flaky_assay_worker(rank, world, port, workdir, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    from proteingym_amd import run_benchmark as rb
+    args = rb.create_parser().parse_args([
+        "--model-location", "ckA.pt", "ckB.pt", "--model_type", "ESM1v", "--dms_mapping", os.path.join(workdir, "map.csv"),
+        "--dms-input", workdir, "--dms-output", os.path.join(workdir, "out_flaky"), "--backend", "gloo"])
+    try:
+        rb.main(args, make_model=_FlakyScorer)
+    except SystemExit as e:
+        q.put((rank, str(e)))
+        raise
+    q.put((rank, "clean exit"))
+
+
+def _write_five_assays(tmp_path):
+    import pandas as pd
+    from proteingym_amd import synthetic
+    rows, assays = [], {}
+    for k, L in enumerate((30, 90, 55, 41, 120)):
+        seq, muts, score = synthetic.random_assay(seed=10 + k, L=L, n_single=20 + k, n_multi=5)
+        pd.DataFrame({"mutant": muts, "DMS_score": score}).to_csv(tmp_path / f"B{k}.csv", index=False)
+        rows.append({"DMS_id": f"B{k}", "DMS_filename": f"B{k}.csv", "target_seq": seq})
+        assays[f"B{k}"] = (seq, muts)
+    pd.DataFrame(rows).to_csv(tmp_path / "map.csv", index=False)
+    return assays
+
+
+def test_assay_shards_world2_survive_a_bad_assay_and_retry_an_overflow_in_fp32(tmp_path):
+    """One assay raises the reference's wild-type assertion, one leaves the fp16 range on one checkpoint: both gloo ranks
+    reach every collective (no hang), the other assays' CSVs are byte-identical to a clean one-process run, the overflowing
+    (assay, checkpoint) carries the fp32 model's scores and scores_summary.csv says so, the bad assay has no CSV, and both
+    ranks exit non-zero."""
+    import pandas as pd
+    from proteingym_amd import run_benchmark as rb
+    assays = _write_five_assays(tmp_path)
+    clean = rb.create_parser().parse_args([
+        "--model-location", "ckA.pt", "ckB.pt", "--model_type", "ESM1v", "--dms_mapping", str(tmp_path / "map.csv"),
+        "--dms-input", str(tmp_path), "--dms-output", str(tmp_path / "out_clean")])
+    rb.main(clean, make_model=_FakeScorer)
+    assert not (tmp_path / "out_clean" / "scores_summary.csv").exists()          # one process, nothing to report
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_flaky_assay_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    said = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode not in (0, None)
+    assert all("1 assay(s) failed" in v for v in said.values()), said
+    out = tmp_path / "out_flaky"
+    for name in ("B0", "B1", "B4"):
+        assert (out / f"{name}.csv").read_bytes() == (tmp_path / "out_clean" / f"{name}.csv").read_bytes()
+    assert not (out / "B2.csv").exists()
+    seq, muts = assays["B3"]
+    got = pd.read_csv(out / "B3.csv", float_precision="round_trip")
+    a, b = _FakeScorer("ckA.pt").score(seq, muts, 1) + 0.5, _FakeScorer("ckB.pt").score(seq, muts, 1)
+    assert np.array_equal(got["ckA"].to_numpy(), a) and np.array_equal(got["ckB"].to_numpy(), b)
+    assert np.array_equal(got["Ensemble_ESM1v"].to_numpy(), (a + b) / 2)
+    summary = pd.read_csv(out / "scores_summary.csv", keep_default_na=False).set_index("DMS_id")
+    assert list(summary["status"]) == ["ok", "ok", "failed", "ok", "ok"]
+    assert "wildtype does not match" in summary.loc["B2", "error"]
+    assert summary.loc["B3", "precision_ckA"] == "fp32" and summary.loc["B3", "precision_ckB"] == ""
+    assert set(summary["precision_ckA"]) == {"", "fp32"}
+    # a re-run takes up exactly the assay that has no CSV
+    os.environ.pop("WORLD_SIZE", None)
+    again = rb.create_parser().parse_args([
+        "--model-location", "ckA.pt", "ckB.pt", "--model_type", "ESM1v", "--dms_mapping", str(tmp_path / "map.csv"),
+        "--dms-input", str(tmp_path), "--dms-output", str(out)])
+    stats = rb.main(again, make_model=_FakeScorer)
+    assert stats["assays"] == 1 and (out / "B2.csv").read_bytes() == (tmp_path / "out_clean" / "B2.csv").read_bytes()
+
+
+class _FlakyTables(_FakeTables):
+    """Position chunks: the 61-residue assay leaves the fp16 range in ONE of its chunks on ckA (position 40); a table must not
+    mix precisions, so every rank redoes its chunks of that assay on an fp32 model (rows + 1 here)."""
+
+    def __init__(self, location, precision=None):
+        super().__init__(location)
+        self.location, self.precision = location, precision
+
+    def table_rows(self, seq, positions, offset):
+        if len(seq) == 61 and self.location == "ckA.pt" and self.precision != "fp32" and 40 in [int(p) for p in positions]:
+            from proteingym_amd import _lib
+            raise _lib.PgmiError("libpgmi error -6: non-finite log-probabilities", code=_lib.EOVERFLOW)
+        rows = super().table_rows(seq, positions, offset)
+        return rows + np.float32(1.0) * (np.arange(33, dtype=np.float32) % 2) if self.precision == "fp32" else rows
+
+
+def _flaky_position_worker(rank, world, port, workdir, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    from proteingym_amd import run_benchmark as rb
+    args = rb.create_parser().parse_args([
+        "--model-location", "ckA.pt", "ckB.pt", "--model_type", "ESM1v", "--dms_mapping", os.path.join(workdir, "map.csv"),
+        "--dms-input", workdir, "--dms-output", os.path.join(workdir, "out"), "--backend", "gloo", "--shard", "positions",
+        "--chunk-forwards", "5"])
+    try:
+        rb.main(args, make_model=_FlakyTables)
+    except SystemExit as e:
+        q.put((rank, str(e)))
+        raise
+    q.put((rank, "clean exit"))
+
+
+def test_position_shards_world2_bad_file_and_whole_assay_fp32_retry(tmp_path):
+    """--shard positions with trouble: one assay's file lists a wrong wild type (dropped on every rank before the plan), one
+    overflows in a single chunk (the whole assay, on both ranks, goes through fp32).  No hang, the clean assay's CSV equals
+    the scores from the complete f16x3 tables, the retried one equals the scores from complete fp32 tables, exit code != 0."""
+    import pandas as pd
+    from proteingym_amd import esm as pesm, synthetic
+    rows, assays = [], {}
+    for k, L in enumerate((23, 61, 40)):
+        seq, muts, score = synthetic.random_assay(seed=k, L=L, n_single=30, n_multi=12)
+        if k == 2:
+            muts[3] = ("A" if seq[4] != "A" else "C") + "5" + "W"          # wild-type letter that is not in the sequence
+        pd.DataFrame({"mutant": muts, "DMS_score": score}).to_csv(tmp_path / f"A{k}.csv", index=False)
+        rows.append({"DMS_id": f"A{k}", "DMS_filename": f"A{k}.csv", "target_seq": seq})
+        assays[f"A{k}"] = (seq, muts)
+    pd.DataFrame(rows).to_csv(tmp_path / "map.csv", index=False)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_flaky_position_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    said = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode not in (0, None)
+    assert all("1 assay(s) failed" in v for v in said.values()), said
+    assert not (tmp_path / "out" / "A2.csv").exists()
+    for name, fp32_on in (("A0", ()), ("A1", ("ckA",))):
+        seq, muts = assays[name]
+        got = pd.read_csv(tmp_path / "out" / f"{name}.csv", float_precision="round_trip")
+        for ck in ("ckA", "ckB"):
+            fake = _FlakyTables(ck + ".pt", precision="fp32" if ck in fp32_on else None)
+            table = np.full((len(seq) + 2, 33), np.nan, dtype=np.float32)
+            for p in pesm.positions_read(muts, seq, 1):
+                table[p] = fake.table_rows(seq, [int(p)], 1)[0]
+            assert np.array_equal(got[ck].to_numpy(), pesm.score_from_table(table, muts, seq, 1))
+    summary = pd.read_csv(tmp_path / "out" / "scores_summary.csv", keep_default_na=False).set_index("DMS_id")
+    assert list(summary["status"]) == ["ok", "ok", "failed"] and summary.loc["A1", "precision_ckA"] == "fp32"
+    assert summary.loc["A0", "precision_ckA"] == "" and "does not match" in summary.loc["A2", "error"]
+
+
+class _FlakyPppl(_FakePppl):
+    """Pooled indel libraries: sequences of the 60-residue assay hold a character the tokenizer rejects; the 220-residue
+    assay leaves the fp16 range on esm2_a unless the model is fp32 (scores - 1 there)."""
+
+    def __init__(self, location, precision=None):
+        super().__init__(location)
+        self.location, self.precision = location, precision
+
+    def score(self, sequences):
+        if any("?" in s for s in sequences):
+            raise KeyError("?")
+        if self.location == "esm2_a.pt" and self.precision != "fp32" and any(200 < len(s) < 240 for s in sequences):
+            from proteingym_amd import _lib
+            raise _lib.PgmiError("libpgmi error -6: non-finite log-probabilities", code=_lib.EOVERFLOW)
+        v = super().score(sequences)
+        return v - 1.0 if self.precision == "fp32" else v
+
+
+def _flaky_indel_worker(rank, world, port, workdir, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    from proteingym_amd import run_indels as ri
+    args = ri.create_parser().parse_args([
+        "--model-location", "esm2_a.pt", "esm2_b.pt", "--model_type", "ESM2", "--dms_mapping", os.path.join(workdir, "map.csv"),
+        "--dms-input", workdir, "--dms-output", os.path.join(workdir, "out"), "--backend", "gloo"])
+    try:
+        ri.main(args, make_model=_FlakyPppl)
+    except SystemExit as e:
+        q.put((rank, str(e)))
+        raise
+    q.put((rank, "clean exit"))
+
+
+def test_run_indels_world2_isolates_a_bad_library_and_retries_an_overflow(tmp_path):
+    """The pooled pseudo-ppl runner with trouble in two of four assays (one of them unreadable): the pool is built without the
+    unreadable one on both ranks, the rank shares are re-scored assay by assay, the overflowing assay goes through fp32 on
+    both ranks, the clean assay's CSV holds the clean scores, exit code != 0, no hang."""
+    import pandas as pd
+    from proteingym_amd import synthetic
+    rng = np.random.default_rng(5)
+    rows, truth = [], {}
+    for k, (L, n) in enumerate(((60, 25), (400, 60), (220, 40))):
+        wt = synthetic.random_sequence(rng, L)
+        seqs = []
+        for _ in range(n):
+            p, d = int(rng.integers(1, L - 4)), int(rng.integers(-3, 4))
+            seqs.append(wt[:p] + (synthetic.random_sequence(rng, d) if d > 0 else "") + wt[p - min(d, 0):])
+        if k == 0:
+            seqs[7] = seqs[7][:5] + "?" + seqs[7][6:]
+        pd.DataFrame({"mutant": seqs, "mutated_sequence": seqs, "DMS_score": rng.standard_normal(n)}).to_csv(tmp_path / f"I{k}.csv", index=False)
+        rows.append({"DMS_id": f"I{k}", "DMS_filename": f"I{k}.csv", "target_seq": wt})
+        truth[f"I{k}"] = seqs
+    rows.append({"DMS_id": "I3", "DMS_filename": "I3_is_missing.csv", "target_seq": "MKV"})
+    pd.DataFrame(rows).to_csv(tmp_path / "map.csv", index=False)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_flaky_indel_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    said = dict(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode not in (0, None)
+    assert all("2 assay(s) failed" in v for v in said.values()), said
+    assert not (tmp_path / "out" / "I0.csv").exists() and not (tmp_path / "out" / "I3.csv").exists()
+    got = pd.read_csv(tmp_path / "out" / "I1.csv", float_precision="round_trip")
+    for ck in ("esm2_a", "esm2_b"):
+        assert np.array_equal(got[ck].to_numpy(), _FakePppl(ck + ".pt").score(truth["I1"]))
+    got = pd.read_csv(tmp_path / "out" / "I2.csv", float_precision="round_trip")
+    assert np.array_equal(got["esm2_a"].to_numpy(), _FakePppl("esm2_a.pt").score(truth["I2"]) - 1.0)
+    assert np.array_equal(got["esm2_b"].to_numpy(), _FakePppl("esm2_b.pt").score(truth["I2"]))
+    summary = pd.read_csv(tmp_path / "out" / "scores_summary.csv", keep_default_na=False).set_index("DMS_id")
+    assert list(summary["status"]) == ["failed", "ok", "ok", "failed"]
+    assert summary.loc["I2", "precision_esm2_a"] == "fp32" and summary.loc["I2", "precision_esm2_b"] == ""

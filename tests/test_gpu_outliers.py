@@ -89,3 +89,60 @@ def test_fp16_range_guard_raises_and_fp32_scores_the_assay(lib):
     print(f"overflow case, fp32 re-run: rows {err_t:.2e}, scores {err_s:.2e}")
     assert err_t < 5 * TOL and err_s < 5 * TOL            # a 1e5 activation: fp32's own resolution at that size is 8e-3 per add
     m16.close()
+
+
+def test_run_benchmark_retries_an_overflowing_checkpoint_in_fp32_and_survives_a_bad_assay(lib, tmp_path):
+    """The north-star runner on first contact with real data: two checkpoints, one of them with a
+    feed-forward unit at 1e5 (PGMI_EOVERFLOW in f16x3), three assays, one of them with a wild-type mismatch in its file (the
+    assertion of compute_fitness.py:243).  The runner must re-score the overflowing (assay, checkpoint) pairs on an fp32
+    model it builds itself -- scores equal to an fp32 model's, bit for bit, and at fp32 parity against the oracle --, keep
+    f16x3 for the clean checkpoint, write scores_summary.csv with precision_<checkpoint> = fp32, skip the bad assay's CSV and
+    exit non-zero; both kinds of shard (whole assays incl. a short-assay group, position chunks)."""
+    import pandas as pd
+    from oracle import esm_oracle as eo
+    from proteingym_amd import run_benchmark as rb
+    cfg = dict(synthetic.ESM1V_650M, layers=4)
+    clean = synthetic.random_weights(cfg, seed=9, embed_std=0.15)
+    hot = clean.copy()
+    synthetic.blob_to_arrays(cfg, hot)["layers.2.fc1.bias"][77] = 1.0e5
+    synthetic.save_fair_esm_checkpoint(str(tmp_path / "clean_ck.pt"), cfg, clean)
+    synthetic.save_fair_esm_checkpoint(str(tmp_path / "hot_ck.pt"), cfg, hot)
+    rows, assays = [], {}
+    for k, Ls in enumerate((40, 33, 52)):
+        seq, muts, score = synthetic.random_assay(seed=40 + k, L=Ls, n_single=60, n_multi=15)
+        if k == 2:
+            muts[5] = ("A" if seq[2] != "A" else "C") + "3" + "W"
+        pd.DataFrame({"mutant": muts, "DMS_score": score}).to_csv(tmp_path / f"R{k}.csv", index=False)
+        rows.append({"DMS_id": f"R{k}", "DMS_filename": f"R{k}.csv", "target_seq": seq, "DMS_total_number_mutants": len(muts)})
+        assays[f"R{k}"] = (seq, muts)
+    pd.DataFrame(rows).to_csv(tmp_path / "map.csv", index=False)
+    common = ["--model-location", str(tmp_path / "clean_ck.pt"), str(tmp_path / "hot_ck.pt"), "--model_type", "ESM1v",
+              "--dms_mapping", str(tmp_path / "map.csv"), "--dms-input", str(tmp_path)]
+    m16, _ = pesm.load_model_and_alphabet(str(tmp_path / "clean_ck.pt"), precision="f16x3")      # (the loader zeroes the <mask> row)
+    m32, _ = pesm.load_model_and_alphabet(str(tmp_path / "hot_ck.pt"), precision="fp32")
+    for mode, extra in (("assay", []), ("positions", ["--shard", "positions", "--chunk-forwards", "16"])):
+        out = tmp_path / ("out_" + mode)
+        with pytest.raises(SystemExit, match="1 assay.s. failed"):
+            rb.main(rb.create_parser().parse_args(common + ["--dms-output", str(out)] + extra))
+        assert not (out / "R2.csv").exists()
+        summary = pd.read_csv(out / "scores_summary.csv", keep_default_na=False).set_index("DMS_id")
+        assert list(summary["status"]) == ["ok", "ok", "failed"] and "does not match" in summary.loc["R2", "error"]
+        for name in ("R0", "R1"):
+            seq, muts = assays[name]
+            got = pd.read_csv(out / f"{name}.csv", float_precision="round_trip")
+            assert summary.loc[name, "precision_hot_ck"] == "fp32" and summary.loc[name, "precision_clean_ck"] == ""
+            assert np.array_equal(got["clean_ck"].to_numpy(), pesm.Assay(m16, seq, muts).run())
+            want32 = pesm.Assay(m32, seq, muts).run()
+            assert np.array_equal(got["hot_ck"].to_numpy(), want32)
+            assert np.array_equal(got["Ensemble_ESM1v"].to_numpy(), (got["clean_ck"].to_numpy() + want32) / 2)
+    seq, muts = assays["R0"]
+    positions = sorted({int(one[1:-1]) for m in muts for one in m.split(":")})
+    hot_loaded = hot.copy()
+    synthetic.blob_to_arrays(cfg, hot_loaded)["embed_tokens.weight"][32] = 0.0                  # pretrained.py:97
+    ref = _oracle(cfg, hot_loaded, seq, positions)
+    ref_s = np.array([eo.label_row(m, seq, ref, 1) for m in muts])
+    err = float(np.abs(pd.read_csv(tmp_path / "out_assay" / "R0.csv")["hot_ck"].to_numpy() - ref_s).max())
+    print(f"run_benchmark fp32 retry on the overflowing checkpoint: scores {err:.2e} from the fp32 oracle")
+    assert err < 5 * TOL                                   # the bar of the fp32 re-run above (a 1e5 activation)
+    m16.close()
+    m32.close()
