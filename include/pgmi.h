@@ -180,6 +180,15 @@ int pgmi_parse_mutants(const char* text, const int64_t* str_off, int64_t n_mut,
                        int32_t* sub_pos, int32_t* sub_wt, int32_t* sub_mt,
                        int64_t* mut_off, int64_t* n_sub);
 
+/* ---- host-side scoring from a log-prob table (label_row's arithmetic, compute_fitness.py:240-250) -----
+ * table: float32 [n_rows][vocab] log-probabilities (row = token position, <cls> = 0), e.g. a table merged from position shards
+ * or returned by pgmi_assay_run; sub_* / mut_off as pgmi_parse_mutants returns them.  scores[i] = sum over the substitutions of
+ * mutant i, in the order of its string, of the float32 difference table[pos][mt] - table[pos][wt], accumulated in double -- the
+ * reference's `.item()` sum and the device's score_mutants_kernel, bit for bit.  Host code, no GPU needed; rows that were never
+ * computed (NaN) give NaN scores.  PGMI_EINVAL on a position or token outside the table. */
+int pgmi_score_mutants(const float* table, int n_rows, int vocab, const int32_t* sub_pos, const int32_t* sub_wt,
+                       const int32_t* sub_mt, const int64_t* mut_off, int64_t n_mut, double* scores);
+
 /* get_optimal_window (proteingym/utils/scoring_utils.py:43-52) */
 void pgmi_optimal_window(int position, int seq_len_with_special, int model_window,
                          int* start, int* end);

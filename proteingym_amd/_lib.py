@@ -65,6 +65,7 @@ SIGNATURES = [
     ("pgmi_pppl_destroy", None, [C.c_void_p]),
     ("pgmi_parse_mutants", C.c_int, [C.c_char_p, _i64p, C.c_int64, C.c_char_p, C.c_int, C.c_int,
                                      _i32p, _i32p, _i32p, _i64p, _i64p]),
+    ("pgmi_score_mutants", C.c_int, [_f32p, C.c_int, C.c_int, _i32p, _i32p, _i32p, _i64p, C.c_int64, _f64p]),
     ("pgmi_optimal_window", None, [C.c_int, C.c_int, C.c_int, _i32p, _i32p]),
     ("pgmi_profile_enable", C.c_int, [C.c_void_p, C.c_int]),
     ("pgmi_profile_get", C.c_int, [C.c_void_p, C.c_int, _f64p, _i64p, _f64p, _f64p]),

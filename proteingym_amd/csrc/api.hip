@@ -1134,7 +1134,7 @@ int pgmi_set_option(const char* name, int64_t value) {
     if (!name) { set_error("null option name"); return PGMI_EINVAL; }
     int rc = gemm_set_option(name, (long long)value);
     if (rc) rc = att_set_option(name, (long long)value);
-    if (rc) set_error("unknown option '%s' (gemm_half_tail, gemm_max_rows, att_xcd_local)", name);
+    if (rc) set_error("unknown option '%s' (gemm_half_tail, gemm_max_rows, att_xcd_local, att_pp)", name);
     return rc;
 }
 
@@ -1243,6 +1243,29 @@ int pgmi_msa_masked_logprobs(pgmi_model* m, const int32_t* tokens, int R, int T,
         PGMI_HIP(hipStreamSynchronize(m->stream));
     }
     return check_nonfinite(m);
+}
+
+int pgmi_score_mutants(const float* table, int n_rows, int vocab, const int32_t* sub_pos, const int32_t* sub_wt, const int32_t* sub_mt,
+                       const int64_t* mut_off, int64_t n_mut, double* scores) {
+    // compute_fitness.py:240-250 on the host: the arithmetic of score_mutants_kernel (elementwise.hip)
+    if (!table || !mut_off || !scores || n_rows <= 0 || vocab <= 0 || n_mut < 0) { set_error("bad argument"); return PGMI_EINVAL; }
+    const int64_t n_sub = mut_off[n_mut];
+    if (n_sub > 0 && (!sub_pos || !sub_wt || !sub_mt)) { set_error("bad argument"); return PGMI_EINVAL; }
+    for (int64_t k = 0; k < n_sub; ++k)
+        if (sub_pos[k] < 0 || sub_pos[k] >= n_rows || sub_wt[k] < 0 || sub_wt[k] >= vocab || sub_mt[k] < 0 || sub_mt[k] >= vocab) {
+            set_error("substitution %lld reads table[%d][%d / %d] of a [%d][%d] table", (long long)k, sub_pos[k], sub_wt[k], sub_mt[k], n_rows, vocab);
+            return PGMI_EINVAL;
+        }
+    for (int64_t i = 0; i < n_mut; ++i) {
+        double sc = 0.0;
+        for (int64_t k = mut_off[i]; k < mut_off[i + 1]; ++k) {
+            const float* rowp = table + (size_t)sub_pos[k] * vocab;
+            const float d = rowp[sub_mt[k]] - rowp[sub_wt[k]];
+            sc += (double)d;
+        }
+        scores[i] = sc;
+    }
+    return PGMI_OK;
 }
 
 void pgmi_optimal_window(int position, int n, int window, int* start, int* end) {

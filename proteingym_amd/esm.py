@@ -529,15 +529,17 @@ def score_from_table(table: np.ndarray, mutants: Sequence[str], sequence: str, o
 
 
 def score_parsed(table: np.ndarray, sub_pos, sub_wt, sub_mt, mut_off) -> np.ndarray:
-    """score_from_table on the arrays parse_mutants returns (callers that need the parse for something else as well)."""
-    t = np.asarray(table, dtype=np.float32)
-    diff = (t[sub_pos, sub_mt] - t[sub_pos, sub_wt]).astype(np.float64)
-    out = np.zeros(len(mut_off) - 1, dtype=np.float64)
-    start = np.asarray(mut_off[:-1], dtype=np.int64)
-    depth = np.asarray(mut_off[1:], dtype=np.int64) - start
-    for j in range(int(depth.max()) if len(depth) else 0):  # j-th substitution of every mutant that has one:
-        sel = depth > j                                     # left-to-right accumulation, as the reference sums
-        out[sel] += diff[start[sel] + j]
+    """score_from_table on the arrays parse_mutants returns (callers that need the parse for something else as well):
+    ``pgmi_score_mutants``, host-side C with the arithmetic of ``score_mutants_kernel``."""
+    t = np.ascontiguousarray(table, dtype=np.float32)
+    if t.ndim != 2:
+        raise ValueError("table must be [positions, vocabulary]")
+    sub_pos, sub_wt, sub_mt = _lib.as_i32(sub_pos), _lib.as_i32(sub_wt), _lib.as_i32(sub_mt)
+    mut_off = np.ascontiguousarray(mut_off, dtype=np.int64)
+    out = np.empty(len(mut_off) - 1, dtype=np.float64)
+    _lib.check(_lib.load().pgmi_score_mutants(_lib.ptr(t, _lib._f32p), t.shape[0], t.shape[1], _lib.ptr(sub_pos, _lib._i32p),
+                                              _lib.ptr(sub_wt, _lib._i32p), _lib.ptr(sub_mt, _lib._i32p), _lib.ptr(mut_off, _lib._i64p),
+                                              len(mut_off) - 1, _lib.ptr(out, _lib._f64p)))
     return out
 
 

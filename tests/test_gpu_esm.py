@@ -80,6 +80,8 @@ def test_all_positions_equals_subset(models, golden, golden_dir):
     sa, ta = a.run(want_table=True)
     sb = b.run()
     assert np.array_equal(sa, sb)            # bit-identical: per-position results do not depend on batch
+    # pgmi_score_mutants (host C, the table -> scores export) gives the device's score_mutants_kernel bits
+    assert np.array_equal(pesm.score_from_table(ta, list(df["mutant"]), seq, 1), sa)
     assert not np.isnan(ta).any()
     assert np.abs(ta - golden["esm1v_toy_1/mm_table"]).max() < TOL
 
@@ -424,8 +426,8 @@ def test_esm2_beyond_1024_tokens_vs_oracle(lib):
 
 @pytest.mark.parametrize("arch", ["ESM1V_650M", "ESM2_650M"])
 def test_attention_launch_options_keep_the_bits_of_a_model(lib, arch):
-    """Split-plane attention output (the model path) under the XCD-local block order: 4 layers at the 650M width, T = 288 and a padded batch
-    (key masks): the same token log-probs, bit for bit."""
+    """Split-plane attention output (the model path) under the XCD-local block order and under the two-role 8-wave kernel (att_pp) against the
+    4-wave kernel: 4 layers at the 650M width, T = 288 and a padded batch (key masks): the same token log-probs, bit for bit."""
     from proteingym_amd import _lib
     cfg = dict(getattr(synthetic, arch), layers=4)
     m = pesm.EsmModel(cfg, synthetic.random_weights(cfg, seed=3, embed_std=0.15), device=0)
@@ -438,12 +440,14 @@ def test_attention_launch_options_keep_the_bits_of_a_model(lib, arch):
     tok[21, 30] = 2
     try:
         _lib.check(lib.pgmi_set_option(b"att_xcd_local", 0))
+        _lib.check(lib.pgmi_set_option(b"att_pp", 0))
         base = m.token_logprobs(tok)
-        for name, value in ((b"att_xcd_local", 1), (b"att_xcd_local", -1)):
+        for name, value in ((b"att_xcd_local", 1), (b"att_xcd_local", -1), (b"att_pp", 1), (b"att_pp", -1)):
             _lib.check(lib.pgmi_set_option(name, value))
             got = m.token_logprobs(tok)
             keep = tok != 1
             assert np.array_equal(got[keep], base[keep]), (name, value)
     finally:
         lib.pgmi_set_option(b"att_xcd_local", -1)
+        lib.pgmi_set_option(b"att_pp", -1)
         m.close()

@@ -313,3 +313,36 @@ def test_attention_launch_options_keep_the_bits(lib, B, T, H, kv):
             assert np.array_equal(run(), base), (name, value)
     finally:
         lib.pgmi_set_option(b"att_xcd_local", -1)
+
+
+@pytest.mark.parametrize("B,T,H,kv", [(3, 288, 4, None), (2, 1000, 2, None), (1, 1024, 3, None), (5, 230, 2, [230, 197, 228, 1, 66]),
+                                      (7, 224, 1, None), (33, 290, 20, None), (2, 737, 20, [737, 700])])
+def test_attention_pp_bits_equal_v2(lib, B, T, H, kv):
+    """The barrier-locked two-role attention kernel (attention_f16x3_pp_kernel: one 8-wave workgroup per eight consecutive query tiles,
+    up to two (sequence, head) streams per workgroup, X / Y segments alternating between the two waves of a SIMD) walks every query row
+    through the 4-wave kernel's arithmetic tile by tile: context rows equal bit for bit, with and without key padding, workgroups that
+    straddle two heads / two sequences, a last workgroup with idle waves, T on and off multiples of 32."""
+    rng = np.random.default_rng(T + H)
+    D = H * 64
+    qkv = rng.standard_normal((B, T, 3 * D)).astype(np.float32)
+    qkv[..., :D] *= 0.4
+    qkv[0, 0, :D] *= 6.0
+    qkv[..., 2 * D:] += rng.choice([0.0, 1e-3, 5.0], size=(B, T, 1)).astype(np.float32)
+    kvl = np.asarray(kv, np.int32) if kv is not None else None
+
+    def run():
+        ctx = np.full((B, T, D), np.nan, np.float32)
+        _lib.check(lib.pgmi_op_attention(0, _lib.PREC_F16X3, _p(qkv), _p(kvl, _lib._i32p) if kvl is not None else None, B, T, H, 0, _p(ctx)))
+        if kv is not None:
+            for b in range(B):
+                ctx[b, kv[b]:] = 0
+        return ctx
+    try:
+        _lib.check(lib.pgmi_set_option(b"att_pp", 0))
+        base = run()
+        assert np.isfinite(base).all()
+        _lib.check(lib.pgmi_set_option(b"att_pp", 1))
+        got = run()
+        assert np.array_equal(got, base), float(np.nanmax(np.abs(got - base)))
+    finally:
+        lib.pgmi_set_option(b"att_pp", -1)

@@ -562,3 +562,29 @@ def test_tranception_intermediate_roots_for_multi_mutants():
     assert same[2] == 0 and same[0] is singles
     few = np.stack([wt, sub(sub(wt, 50, 5), 55, 6), sub(sub(wt, 50, 5), 57, 6)]).astype(np.int32)     # two members save 5 + 7 rows: less than a root costs
     assert ptr.TranceptionModel.intermediate_roots(few, np.zeros(3, dtype=np.int32))[2] == 0
+
+
+def test_pgmi_score_mutants_is_label_rows_arithmetic_on_the_host():
+    """pgmi_score_mutants (host C, no GPU): per substitution an f32 difference table[pos, mt] - table[pos, wt], accumulated in
+    double in the order of the mutation string (compute_fitness.py:245-250) -- checked against a plain python loop of that
+    arithmetic, bit for bit, incl. depth-5 multi-mutants, an empty column and NaN (never computed) rows; indices outside the
+    table are refused."""
+    from proteingym_amd import esm as pesm, synthetic, _lib
+    seq, muts, _ = synthetic.random_assay(seed=4, L=57, n_single=200, n_multi=120)
+    rng = np.random.default_rng(0)
+    table = (rng.standard_normal((len(seq) + 2, 33)) * 7).astype(np.float32)
+    table[5] = np.nan
+    sub_pos, sub_wt, sub_mt, mut_off = pesm.parse_mutants(muts, seq, 1)
+    got = pesm.score_from_table(table, muts, seq, 1)
+    want = np.zeros(len(muts))
+    for i in range(len(muts)):
+        acc = 0.0
+        for k in range(mut_off[i], mut_off[i + 1]):
+            acc += float(np.float32(table[sub_pos[k], sub_mt[k]] - table[sub_pos[k], sub_wt[k]]))
+        want[i] = acc
+    assert np.array_equal(got, want, equal_nan=True) and np.isnan(got).any() and np.isfinite(got).sum() > 200
+    assert pesm.score_parsed(table, sub_pos[:0], sub_wt[:0], sub_mt[:0], np.zeros(1, np.int64)).shape == (0,)
+    bad = sub_pos.copy()
+    bad[3] = len(seq) + 2
+    with pytest.raises(_lib.PgmiError, match="reads table"):
+        pesm.score_parsed(table, bad, sub_wt, sub_mt, mut_off)
