@@ -219,7 +219,8 @@ int check_cfg(const pgmi_config* c) {
         if (c->precision != PGMI_PREC_F16X3) { set_error("MSA Transformer is available in precision f16x3 only"); return PGMI_EINVAL; }
     }
     if (c->precision != PGMI_PREC_FP32 && c->precision != PGMI_PREC_F16X3 && c->precision != PGMI_PREC_BF16) { set_error("unknown precision %d", c->precision); return PGMI_EINVAL; }
-    if (c->precision != PGMI_PREC_FP32 && (c->embed_dim % 64 || c->ffn_dim % 64)) { set_error("16-bit modes need embed_dim and ffn_dim to be multiples of 64"); return PGMI_EINVAL; }
+    // f16x3: K tiles of 32 (checked above); the bf16 GEMM's K tile is 64
+    if (c->precision == PGMI_PREC_BF16 && (c->embed_dim % 64 || c->ffn_dim % 64)) { set_error("precision bf16 needs embed_dim and ffn_dim to be multiples of 64"); return PGMI_EINVAL; }
     return PGMI_OK;
 }
 

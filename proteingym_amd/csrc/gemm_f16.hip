@@ -404,8 +404,11 @@ int launch_gemm16(const unsigned short* A, size_t a_plane, const unsigned short*
                   int M, int N, int K, int epilogue, float out_scale, int planes, bool bf, int variant,
                   hipStream_t s) {
     (void)a_plane; (void)w_plane;                 // f16x3 operands are K-interleaved (no plane stride); bf16 has one plane
-    if (M <= 0 || N <= 0 || K <= 0 || (K % 64) != 0 || (N % 4) != 0 || (!Cf && !Ch) || (Cf && Ch)) {
-        set_error("gemm16: unsupported shape/args M=%d N=%d K=%d (K %% 64 == 0, N %% 4 == 0 required)", M, N, K);
+    // K: whole 32-deep K tiles for the f16x3 kernel (one 128-byte line per row and tile; an odd tile count is fine: ESM2-35M has
+    // K = 480 = 15 tiles), 64 for the bf16 kernel's K tile
+    const int k_step = (planes == 2 && !bf) ? 32 : 64;
+    if (M <= 0 || N <= 0 || K <= 0 || (K % k_step) != 0 || (N % 4) != 0 || (!Cf && !Ch) || (Cf && Ch)) {
+        set_error("gemm16: unsupported shape/args M=%d N=%d K=%d (K %% %d == 0, N %% 4 == 0 required)", M, N, K, k_step);
         return PGMI_EINVAL;
     }
     if (planes == 2 && !bf) {
@@ -431,7 +434,7 @@ int launch_gemm16_qkv(const unsigned short* A, size_t a_plane, const unsigned sh
                       unsigned short* vt16, size_t vt_plane, const float* cos_t, const float* sin_t, int rotary,
                       int T, int H, int variant, hipStream_t s, int rot_halves) {
     (void)a_plane; (void)w_plane;
-    if (M <= 0 || D <= 0 || (K % 64) || (D % 64) || M % T || rot_halves < 1) {
+    if (M <= 0 || D <= 0 || (K % 32) || (D % 64) || M % T || rot_halves < 1) {
         set_error("gemm16_qkv: unsupported shape M=%d D=%d K=%d T=%d", M, D, K, T);
         return PGMI_EINVAL;
     }

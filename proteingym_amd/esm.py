@@ -257,9 +257,9 @@ class EsmModel:
                  max_rows: int = 0):
         lib = _lib.load()
         self.cfg = dict(cfg)
-        if precision != "fp32" and (cfg["embed_dim"] % 64 or cfg["ffn_dim"] % 64):
-            # the 16-bit GEMM tiles need K % 64 == 0 (e.g. ESM2-35M has embed_dim 480): such models run in
-            # the (also parity-gated) fp32 mode -- said out loud, never a silent switch
+        if precision == "bf16" and (cfg["embed_dim"] % 64 or cfg["ffn_dim"] % 64):
+            # the bf16 GEMM's K tile is 64 deep (ESM2-35M has embed_dim 480): that (un-gated, throughput) mode hands such a
+            # model to fp32 -- said out loud, never a silent switch.  f16x3 takes any multiple of 32.
             import sys
             print(f"[proteingym_amd] embed_dim={cfg['embed_dim']} / ffn_dim={cfg['ffn_dim']} is not a multiple of 64: "
                   f"using precision fp32 instead of {precision}", file=sys.stderr)

@@ -27,6 +27,8 @@ ESM2_650M = dict(arch=_lib.ARCH_ESM2, layers=33, embed_dim=1280, heads=20, ffn_d
                  max_positions=0, token_dropout=1, emb_layer_norm_before=0)
 ESM2_3B = dict(arch=_lib.ARCH_ESM2, layers=36, embed_dim=2560, heads=40, ffn_dim=10240,
                max_positions=0, token_dropout=1, emb_layer_norm_before=0)
+ESM2_35M = dict(arch=_lib.ARCH_ESM2, layers=12, embed_dim=480, heads=20, ffn_dim=1920,        # head_dim 24, embed_dim not a multiple of 64
+                max_positions=0, token_dropout=1, emb_layer_norm_before=0)                       # (pretrained.py:355-360; /root/reference/config.json:18)
 ESM2_15B = dict(arch=_lib.ARCH_ESM2, layers=48, embed_dim=5120, heads=40, ffn_dim=20480,      # head_dim 128 (pretrained.py:387-394)
                 max_positions=0, token_dropout=1, emb_layer_norm_before=0)
 
@@ -144,7 +146,8 @@ def save_fair_esm_checkpoint(path: str, cfg, blob: np.ndarray):
     stem = os.path.basename(path).split(".")[0]
     if cfg["arch"] == _lib.ARCH_ESM2:
         assert stem.startswith("esm2"), "ESM2 checkpoints are dispatched by file stem (pretrained.py:187)"
-        inv = 1.0 / (10000 ** (np.arange(0, 64, 2, dtype=np.float32) / 64))
+        dh = cfg["embed_dim"] // cfg["heads"]                                          # rotary_embedding.py:39-41: one frequency per pair of head dims
+        inv = (1.0 / (10000 ** (np.arange(0, dh, 2, dtype=np.float32) / dh))).astype(np.float32)
         for i in range(cfg["layers"]):
             model[f"encoder.sentence_encoder.layers.{i}.self_attn.rot_emb.inv_freq"] = torch.from_numpy(inv.copy())
         c = argparse.Namespace(encoder_layers=cfg["layers"], encoder_embed_dim=cfg["embed_dim"],

@@ -213,8 +213,7 @@ def test_small_head_dims_vs_reference(lib, golden_dir, name, precision):
     g = np.load(os.path.join(golden_dir, "golden_esm_small_heads.npz"))
     seq = str(np.load(os.path.join(golden_dir, "golden_esm.npz"))["seq"])
     m, _ = pesm.load_model_and_alphabet(os.path.join(golden_dir, name + ".pt"), precision=precision)
-    if name == "esm2_toy_h24":
-        assert m.precision == "fp32"                       # embed_dim 96 is not a multiple of 64
+    assert m.precision == precision                        # embed_dim 96 (h24: three K tiles of 32) runs in f16x3 too since round 6
     _, _, toks = pesm.Alphabet().get_batch_converter()([("p", seq)])
     assert np.abs(m(toks)["logits"][0] - g[f"{name}/wt_logprobs"]).max() < TOL
     n = toks.shape[1]
@@ -231,6 +230,39 @@ def test_small_head_dims_vs_reference(lib, golden_dir, name, precision):
 
 
 # ---- ESM2 with head_dim 128 (ESM2-15B: 48 x 5120, 40 heads), run as two 64-lane slot groups per head ----
+@pytest.mark.parametrize("precision", ["f16x3", "fp32"])
+def test_esm2_35m_width_f16x3_vs_reference(lib, golden_dir, tmp_path, precision):
+    """ESM2-35M's width -- embed_dim 480 (15 K tiles of 32: not a multiple of 64, an ODD tile count for the ping-pong GEMM's two
+    buffers), 20 heads of 24 (zero-padded to 64 slots), ffn 1920 -- in the parity-gated default mode against the UNMODIFIED
+    reference's outputs (tests/golden/make_golden_esm2_35m_width.py; the checkpoint is rebuilt from its seed and must hash to the
+    blob the reference ran on): wild-type log-probs, the whole masked-marginals table, a padded batch, the CLI's score column; flat
+    1e-4.  Rounds 2-5 sent this registry row (/root/reference/config.json:18, esm/pretrained.py:355-360) to the 3x slower fp32 mode."""
+    import hashlib
+    import pandas as pd
+    g = np.load(os.path.join(golden_dir, "golden_esm2_35m_width.npz"))
+    seq = str(np.load(os.path.join(golden_dir, "golden_esm.npz"))["seq"])
+    cfg = dict(synthetic.ESM2_35M, layers=3)
+    blob = synthetic.random_weights(cfg, seed=35, embed_std=0.15)
+    assert hashlib.sha256(blob.tobytes()).digest() == g["weights_sha256"].tobytes()
+    path = synthetic.save_fair_esm_checkpoint(str(tmp_path / "esm2_toy_35m_width.pt"), cfg, blob)
+    m, _ = pesm.load_model_and_alphabet(path, precision=precision)
+    assert m.precision == precision
+    _, _, toks = pesm.Alphabet().get_batch_converter()([("p", seq)])
+    e_wt = float(np.abs(m(toks)["logits"][0] - g["wt_logprobs"]).max())
+    n = toks.shape[1]
+    e_mm = float(np.abs(m.masked_logprobs(np.repeat(toks, n, axis=0), np.arange(n)) - g["mm_table"]).max())
+    pt = g["pad_tokens"]
+    valid = pt != 1
+    e_pad = float(np.abs(m.token_logprobs(pt)[valid] - g["pad_logprobs"][valid]).max())
+    df = pd.read_csv(os.path.join(golden_dir, "TOY_DMS.csv"))
+    a = pesm.Assay(m, seq, list(df["mutant"]), offset_idx=1)
+    e_cli = float(np.abs(a.run() - g["cli"]).max())
+    a.close()
+    m.close()
+    print(f"[{precision}] ESM2-35M width (480 x 20 heads of 24, 3 layers) vs the reference: wt {e_wt:.2e}, table {e_mm:.2e}, padded {e_pad:.2e}, CLI scores {e_cli:.2e}")
+    assert max(e_wt, e_mm, e_pad, e_cli) < TOL
+
+
 @pytest.mark.parametrize("precision", ["f16x3", "fp32"])
 def test_head_dim_128_vs_reference(lib, golden_dir, precision):
     """Reference-generated goldens (tests/golden/make_golden_h128.py: unmodified reference model and CLI on a 2-layer

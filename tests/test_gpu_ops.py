@@ -107,7 +107,10 @@ GEMM_VARIANTS = [0,                  # the product's launch parameters
                                             (2300, 1280, 1280, 0, True),      # 45 tiles: every one as two half-height items
                                             (4200, 5120, 128, 1, False),      # 340 tiles on 256 CUs: a second item per workgroup
                                             (15100, 1280, 256, 0, True),      # 300 tiles: 256 full + 44 x 2 halves
-                                            (15100, 1284, 256, 0, True)])     # the same with a ragged last column tile (N % 256 = 4)
+                                            (15100, 1284, 256, 0, True),      # the same with a ragged last column tile (N % 256 = 4)
+                                            (700, 1440, 480, 0, False),       # K = 480: 15 K tiles, an ODD count (ESM2-35M's embed_dim)
+                                            (2300, 1920, 480, 1, False),      # its FC1 (GELU), half-height tail items with an odd tile count
+                                            (300, 480, 96, 0, True)])         # three K tiles, residual
 def test_gemm_f16x3(lib, monkeypatch, variant, M, N, K, epi, res):
     """Split-fp16 3-pass GEMM: fp32-class accuracy (same bound as the fp32 kernel)."""
     monkeypatch.setenv("PGMI_GEMM_VARIANT", str(variant))

@@ -234,6 +234,25 @@ def test_oracle_reproduces_small_head_goldens(golden_dir, name):
     assert np.abs(scores - g[f"cli/{name}"]).max() < 2e-5
 
 
+def test_oracle_reproduces_the_esm2_35m_width_golden(golden_dir, tmp_path):
+    """ESM2-35M's width (embed_dim 480 = 15 K tiles of 32, 20 heads of 24): the checkpoint is rebuilt from its seed (the fixture
+    carries the sha256 of the weight blob the reference ran on), the oracle reproduces the reference's table and CLI column."""
+    import hashlib
+    from proteingym_amd import synthetic
+    g = np.load(os.path.join(golden_dir, "golden_esm2_35m_width.npz"))
+    seq = str(np.load(os.path.join(golden_dir, "golden_esm.npz"))["seq"])
+    cfg = dict(synthetic.ESM2_35M, layers=3)
+    blob = synthetic.random_weights(cfg, seed=35, embed_std=0.15)
+    assert hashlib.sha256(blob.tobytes()).digest() == g["weights_sha256"].tobytes()
+    path = synthetic.save_fair_esm_checkpoint(str(tmp_path / "esm2_toy_35m_width.pt"), cfg, blob)
+    ocfg, W = eo.load_checkpoint(path)
+    table = eo.masked_marginals_table(ocfg, W, seq, batch=16)
+    assert np.abs(table - g["mm_table"]).max() < 2e-5
+    df = pd.read_csv(os.path.join(golden_dir, "TOY_DMS.csv"))
+    scores = np.array([eo.label_row(m, seq, table, 1) for m in df["mutant"]])
+    assert np.abs(scores - g["cli"]).max() < 5e-5          # sums of up to five fp32-noise terms (the table rows hold 2e-5; the CLI ran batch 1)
+
+
 # ---- MSA Transformer ---------------------------------------------------------------------------------
 def test_msa_transformer_oracle_reproduces_golden(golden_dir):
     from oracle import msa_transformer_oracle as mo
