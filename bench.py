@@ -527,7 +527,25 @@ def end_to_end_blat(model, seq, muts, reps=3):
                     f"copied to the host, CSV written (all input columns + the score column); mean of {reps} runs"}
 
 
-def main():
+def only_json_on_stdout():
+    """From here on file descriptor 1 of this process IS its stderr: whatever a library prints on stdout (backend chatter such as
+    '[Gloo] Rank 0 is connected ...', the runners' progress lines, rocm-smi) lands there, and the ONE JSON line goes out through
+    the returned function on the real stdout -- a driver that parses the stream, not only its last line, reads exactly one line."""
+    sys.stdout.flush()
+    real = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line: str):
+        sys.stdout.flush()
+        os.write(real, (line + "\n").encode())
+    return emit
+
+
+def main(argv=None, make_model=None, make_assay=None):
+    """``make_model`` / ``make_assay`` are test seams (the N > 1 branch on two gloo ranks without a GPU, tests/test_dist_cpu.py):
+    (cfg, blob, device, precision) -> model with profile_reset / profile_enable / profile / close, and (model, seq, mutants) ->
+    assay with run_device_only(ptr), positions, T, close()."""
+    emit = only_json_on_stdout()
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
@@ -542,7 +560,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the `secondary` object (other configs; ~1 min after the headline)")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not run the rocprofv3 --pmc child passes for roofline.traffic (the committed file is used)")
     ap.add_argument("--no-box-state", action="store_true", help="skip the `box` object (shader clock / socket power during ~2 s of untimed extra steps)")
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    seam = make_model is not None
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -556,14 +575,17 @@ def main():
         os.environ["PGMI_GEMM_VARIANT"] = str(args.variant)
     import torch
     from proteingym_amd import build_native, esm as pesm, synthetic
-    build_native.build(verbose=False)
+    if not seam:
+        build_native.build(verbose=False)
     # PGMI_BENCH_SHARE_GPU=1 (rehearsal only, never a measurement): the ranks share the GPUs that exist (local_rank modulo the device
     # count) and talk over gloo through host memory -- RCCL refuses two ranks on one device -- so that the N > 1 code path can run
     # end to end on a one-GPU box
-    share = os.environ.get("PGMI_BENCH_SHARE_GPU") == "1"
-    if share:
+    share = os.environ.get("PGMI_BENCH_SHARE_GPU") == "1" or seam
+    if share and not seam:
         local_rank = local_rank % max(torch.cuda.device_count(), 1)
-    torch.cuda.set_device(local_rank)
+    if not seam:
+        torch.cuda.set_device(local_rank)
+    gdev = "cpu" if seam else "cuda"                                  # where the score vectors live
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -577,11 +599,11 @@ def main():
 
     cfg = dict(synthetic.ESM1V_650M, layers=args.layers)
     blob = synthetic.random_weights(cfg, seed=1)                      # same "checkpoint" on every rank
-    model = pesm.EsmModel(cfg, blob, device=local_rank, precision=args.precision)
+    model = make_model(cfg, blob, local_rank, args.precision) if seam else pesm.EsmModel(cfg, blob, device=local_rank, precision=args.precision)
     seq, muts, _ = synthetic.random_assay(seed=23 + rank, L=L_BLAT, n_single=N_MUT_BLAT, n_multi=0)
-    assay = pesm.Assay(model, seq, muts, offset_idx=1)                # uploads: inputs resident in HBM
+    assay = make_assay(model, seq, muts) if seam else pesm.Assay(model, seq, muts, offset_idx=1)    # uploads: inputs resident in HBM
     n_mut = len(muts)
-    scores_dev = torch.zeros(n_mut, dtype=torch.float64, device="cuda")
+    scores_dev = torch.zeros(n_mut, dtype=torch.float64, device=gdev)
     gathered = torch.zeros(world * n_mut, dtype=torch.float64, device=cdev) if world > 1 else None
     extra = []                                                        # checkpoints 2..N of an ensemble step
     for c in range(1, args.checkpoints):
@@ -600,7 +622,8 @@ def main():
     def fence():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not seam:
+            torch.cuda.synchronize()
 
     # every N: W untimed steps, then exactly K timed steps between two fences; N > 1 adds the 217-assay pass AFTER this region
     blat_steps = args.steps
@@ -627,7 +650,7 @@ def main():
         import bench_scale
         strong_steps = max(1, min(args.steps, 4))
         st = bench_scale.run(model, rank, world, strong_steps, min(args.warmup, 1), torch, dist,
-                             max_assays=int(os.environ.get("PGMI_BENCH_217_ASSAYS", "0")))
+                             max_assays=int(os.environ.get("PGMI_BENCH_217_ASSAYS", "0")), make_assay=make_assay)
         st["mutants_per_s"] = st["mutants"] / st["seconds"]
         st["what"] = (f"ONE pass over the {st['assays']}-assay-shaped DMS substitution benchmark ({st['mutants']} mutants; real seq_len / mutant counts "
                       "of reference_files/DMS_substitutions.csv, optimal 1024 windows), 1 checkpoint, assays sharded over the ranks by "
@@ -671,7 +694,7 @@ def main():
                                 "tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2) if v["ms"] > 0 and v["flops"] > 0 else None}
                             for k, v in prof.items()},
             }
-            print(json.dumps(out), flush=True)
+            emit(json.dumps(out))
         model.close()
         dist.barrier()
         dist.destroy_process_group()
@@ -758,7 +781,7 @@ def main():
                     out["secondary"] = {"error": repr(e)}
                 b217 = out["secondary"].get("benchmark_217_end_to_end") if isinstance(out["secondary"], dict) else None
                 out.update(end_to_end_fields(e2e, b217))
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -1022,3 +1022,58 @@ def test_run_indels_world2_isolates_a_bad_library_and_retries_an_overflow(tmp_pa
     summary = pd.read_csv(tmp_path / "out" / "scores_summary.csv", keep_default_na=False).set_index("DMS_id")
     assert list(summary["status"]) == ["failed", "ok", "ok", "failed"]
     assert summary.loc["I2", "precision_esm2_a"] == "fp32" and summary.loc["I2", "precision_esm2_b"] == ""
+
+
+# ---- bench.py --gpus N: the JSON line is the ONLY thing on stdout (backend chatter goes to stderr) ------------------------------
+class _FakeBenchModel(list):
+    """Stands in for EsmModel in bench.main's N > 1 branch: the per-class profile with plausible numbers, nothing else."""
+
+    def profile_reset(self):
+        pass
+
+    def profile_enable(self, on=True):
+        pass
+
+    def profile(self):
+        from proteingym_amd import _lib
+        return {k: dict(ms=1.0, launches=66, flops=1.0e12, bytes=0.0) for k in _lib.K_NAMES}
+
+    def close(self):
+        pass
+
+
+def _bench_main_entry():
+    """Runs in a child process (see the test below): bench.main's N > 1 branch over gloo with the seams."""
+    import bench
+    print("[Gloo] Rank chatter that a backend might print on stdout")            # must end up on stderr
+    bench.main(["--gpus", "2", "--steps", "2", "--warmup", "1"], make_model=lambda cfg, blob, dev, prec: _FakeBenchModel(),
+               make_assay=_FakeBenchAssay)
+
+
+def test_bench_n_gt_1_prints_exactly_one_json_line_on_stdout():
+    """The driver launches `bench.py --gpus N` under torch.distributed.run and reads stdout: two gloo ranks through bench.main
+    (model and assay seams, 24 assays of the table) -- rank 0's stdout is ONE line and it is the JSON object with the contract's
+    keys, rank 1's stdout is empty; everything any library printed is on stderr."""
+    import json
+    import subprocess
+    import sys
+    port = _free_port()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2",
+                   PGMI_BENCH_217_ASSAYS="24", OMP_NUM_THREADS="1")
+        code = f"import sys; sys.path[:0] = [{root!r}, {os.path.join(root, 'tests')!r}]; import test_dist_cpu as t; t._bench_main_entry()"
+        procs.append(subprocess.Popen([sys.executable, "-c", code], env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=600) for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], outs
+    lines = outs[0][0].splitlines()
+    assert len(lines) == 1, outs[0][0]
+    line = json.loads(lines[0])
+    assert outs[1][0] == ""
+    assert "Rank chatter" in outs[0][1] and "Rank chatter" in outs[1][1]
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+                "data", "config", "roofline", "strong_scaling_217", "rccl"):
+        assert key in line, key
+    assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 2 and line["rccl"]["world_size"] == 2
+    assert line["strong_scaling_217"]["assays"] == 24 and line["value"] > 0
