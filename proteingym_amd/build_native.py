@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libpgmi.so")
 BUILD = os.path.join(HERE, "csrc", "_build")
-SOURCES = ["api.hip", "elementwise.hip", "gemm_f32.hip", "gemm_f16.hip", "attention_f32.hip", "attention_f16.hip", "attention_f16_pp.hip", "msa_weights.hip", "msa_transformer.hip"]
+SOURCES = ["api.hip", "elementwise.hip", "gemm_f32.hip", "gemm_f16.hip", "attention_f32.hip", "attention_f16.hip", "msa_weights.hip", "msa_transformer.hip"]
 # attention_f16.hip: keep the MFMA accumulators in ArchVGPRs.  hipcc put the running O / S accumulators into AGPRs and then
 # paid 64 v_accvgpr_read + 64 v_accvgpr_write around every online-softmax rescale and around the S -> P conversion (VALU work
 # on accumulator data); the kernel fits 184 VGPRs at the same occupancy without them.

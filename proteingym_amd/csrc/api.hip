@@ -1135,7 +1135,7 @@ int pgmi_set_option(const char* name, int64_t value) {
     if (!name) { set_error("null option name"); return PGMI_EINVAL; }
     int rc = gemm_set_option(name, (long long)value);
     if (rc) rc = att_set_option(name, (long long)value);
-    if (rc) set_error("unknown option '%s' (gemm_half_tail, gemm_max_rows, att_xcd_local, att_pp)", name);
+    if (rc) set_error("unknown option '%s' (gemm_half_tail, gemm_max_rows, att_xcd_local, att_v3)", name);
     return rc;
 }
 

@@ -643,11 +643,362 @@ static int launch_att16v2_one(dim3 grid, const unsigned short* qk16, size_t qk_p
 }
 
 
-// the two-role 8-wave kernel of round 6 lives in attention_f16_pp.hip (compiled with its own flags)
-bool att_pp_serves(int T, const float* conv, const float* slopes, int head_dim);
-int att_pp_set_option(long long value);
-int launch_att16_pp(const unsigned short* qk16, size_t qk_plane, const unsigned short* vt16, size_t vt_plane, const int32_t* kv_len,
-                    int B, int T, int H, int Tp, float* ctx, unsigned short* ctx16, int out_mode, hipStream_t s);
+// ---- Round 6: the software-pipelined form of the dense head_dim-64 kernel -----------------------------------------------------------
+// What bounds attention_f16x3_v2_kernel (measured, profiles/r6): per key tile a wave issues 12 S MFMAs, then ~150 VALU instructions of
+// online softmax, then 12 P V MFMAs -- a dependent chain -- and the two waves of a SIMD (one from each of the CU's two workgroups) do NOT
+// hide each other's phases: on gfx950 an MFMA stream of one wave and a VALU stream of its SIMD partner take at least the SUM of their
+// times (tools/mfma_valu_pair.hip: 0.46 us + 0.40 us alone, 0.82 - 1.02 us side by side), whatever the priorities; a barrier-locked
+// two-role workgroup built on that overlap was bit-identical and 12 - 23 % slower (git history, profiles/r6/att_ab_1_*).  What does
+// overlap is VALU work in the shadow of THE SAME wave's MFMAs (0.59 us per MFMA + VALU unit with both waves of a SIMD running such a
+// stream).  So this kernel gives every wave independent matrix and vector work in the same stretch of its instruction stream:
+//     step kt:   P V of key tile kt - 1   (12 MFMAs: P was finished in step kt - 1)
+//                softmax of key tile kt   (VALU: its scores were finished in step kt - 1)
+//                S = K Q^T of tile kt + 1 (12 MFMAs, after the softmax has read the previous scores out of the accumulators)
+// The arithmetic of a row is the v2 kernel's, operation for operation in the same order (the deferred rescale of O by alpha(kt) still
+// sits between P V (kt - 1) and P V (kt)): bit-identical (tests/test_gpu_ops.py::test_attention_v3_bits_equal_v2), so which kernel serves
+// a shape is a launch option ("att_v3").  LDS: the v2 ring, but a stage holds the pair the step needs TOGETHER: bundle m = {K tile m,
+// V^T tile m - 2}, needed in step m - 1, issued two steps ahead.
+template <int WPB, int OUT>
+__global__ __launch_bounds__(WPB * 64, 2) void attention_f16x3_v3_kernel(
+    const unsigned short* __restrict__ qk16, size_t qk_plane, const unsigned short* __restrict__ vt16, size_t vt_plane,
+    const int32_t* __restrict__ kv_len, int T, int H, int Tp, float* __restrict__ ctx, unsigned short* __restrict__ ctx16,
+    int dense_nblk, int nseq) {
+    constexpr float defer_thr = kAttDefer;
+    constexpr int DH = 64, NSTG = 3, KCPR = 8, KCH = AKT * KCPR, VCH = DH * 4, STG_CH = 2 * KCH + 2 * VCH;
+    constexpr int NWI = STG_CH / 64, NDMA = (NWI + WPB - 1) / WPB, NS = 4, ND = 2;
+    extern __shared__ __attribute__((aligned(16))) u32x4 lds[];   // [NSTG][STG_CH]
+    int b, h, qblk;
+    if (dense_nblk > 0) {                                         // XCD-local order (see the v2 kernel)
+        const int within = (int)blockIdx.x % (8 * dense_nblk);
+        const int pair = ((int)blockIdx.x / (8 * dense_nblk)) * 8 + (within & 7);
+        if (pair >= nseq * H) return;
+        qblk = within >> 3;
+        b = pair / H;
+        h = pair - b * H;
+    } else {
+        b = blockIdx.z;
+        h = blockIdx.y;
+        qblk = blockIdx.x;
+    }
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, kh = lane >> 5;
+    const int D = H * DH;
+    const int Tk = kv_len ? kv_len[b] : T;
+    const int q0 = (qblk * WPB + wave) * 32;
+    const bool active = q0 < T;
+    const int nkt = (Tk + AKT - 1) / AKT;
+    const size_t seq_halfs = (size_t)T * (2 * D), vt_halfs = (size_t)DH * Tp;
+    const unsigned long long qk_bytes = std::min<unsigned long long>(0xFFFFFFFFull, (unsigned long long)qk_plane * 2ull + seq_halfs * 2ull);
+    const unsigned long long vt_bytes = std::min<unsigned long long>(0xFFFFFFFFull, (unsigned long long)vt_plane * 2ull + vt_halfs * 2ull);
+    const __amdgpu_buffer_rsrc_t rsQK = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(qk16) + (size_t)b * seq_halfs, 0, (int)(unsigned int)qk_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsVT = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(vt16) + ((size_t)b * H + h) * vt_halfs, 0, (int)(unsigned int)vt_bytes, 0x00020000);
+
+    // DMA map of a stage: the v2 kernel's (K hi | K lo | V^T hi | V^T lo, 16 wave-instructions of 1 KiB over WPB waves).  Instruction i
+    // of wave w is wave-instruction w + WPB i: with WPB in {1, 2, 4} its tensor and plane are compile-time (i < 8 / WPB: K), only the
+    // quarter of the plane it covers depends on the wave -- scalar arithmetic at issue time, no per-wave tables in SGPRs (a kernel that
+    // runs out of SGPRs keeps uniform values in VGPRs and hipcc then wraps every DMA in a readfirstlane loop).
+    static_assert(WPB == 1 || WPB == 2 || WPB == 4, "the DMA map needs WPB to divide 8");
+    constexpr int NK = 8 / WPB;                                    // K instructions per wave and bundle; the rest are V^T
+    int kvoff[NK], krow[NK], vvoff[NDMA - NK];
+#pragma unroll
+    for (int i = 0; i < NK; ++i) {
+        const int q4 = (wave + WPB * i) & 3;                       // quarter of the K plane: keys 8 q4 .. 8 q4 + 7
+        const int key = q4 * 8 + (lane >> 3);
+        krow[i] = key;
+        kvoff[i] = ((lane & 7) ^ ((key >> 1) & 7)) * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < NDMA - NK; ++i) {
+        const int q4 = (wave + WPB * (i + NK)) & 3;                // quarter of the V^T plane: dims 16 q4 .. 16 q4 + 15
+        const int g = q4 * 64 + lane, d = g >> 2, c = (g & 3) ^ ((d >> 2) & 3);
+        vvoff[i] = d * Tp * 2 + c * 16;
+    }
+    // bundle m -> stage m % 3: K tile min(m, nkt - 1) (rows clamped to the sequence's last token: finite, masked by Tk) and V^T tile
+    // clamp(m - 2) -- the clamped copies are never read, they keep the per-wave DMA count constant for the counted waits
+    auto issue_bundle = [&](int m, int stage) {
+        u32x4* base = lds + stage * STG_CH;
+        const int kk = min(m, nkt - 1), vv = min(max(m - 2, 0), nkt - 1);
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+            const int wi = wave + WPB * i, p = (WPB * i) >> 2;
+            const int vo = min(kk * AKT + krow[i], T - 1) * (2 * D) * 2 + kvoff[i];
+            const int so = (int)((unsigned int)p * (unsigned int)qk_plane * 2u + (unsigned int)(D + h * DH) * 2u);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQK, (__attribute__((address_space(3))) void*)(base + wi * 64), 16, vo, so, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NDMA - NK; ++i) {
+            const int wi = wave + WPB * (i + NK), p = (WPB * (i + NK) - 8) >> 2;
+            const int so = (int)((unsigned int)p * (unsigned int)vt_plane * 2u) + vv * ((AKT / 8) * 16);
+            const int vo = vvoff[i];       // (named locals: with an array expression written in the call hipcc 7.2 silently drops the kernel's host stub)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsVT, (__attribute__((address_space(3))) void*)(base + wi * 64), 16, vo, so, 0, 0);
+        }
+    };
+    const int last_bundle = nkt + 1;                              // V^T tile nkt - 1 travels in bundle nkt + 1
+
+    // ---- prologue: bundles 0 .. 2 into the ring, the wave's Q tile into its own 8 KB behind the ring.  The Q fragments are NOT kept
+    //      in registers (32 of them, read-only, used by 12 of a step's 24 MFMAs: with both P V and S operands and two softmax halves in
+    //      flight hipcc spilled them to scratch): every step re-reads them from LDS together with the K fragments (24 instead of 16
+    //      ds_read_b128 per step: 0.47 us of the CU's LDS read port per ~1 us step) ----
+    issue_bundle(0, 0);
+    issue_bundle(1, 1);
+    issue_bundle(2, 2);
+    const u32x4* const qbase = lds + NSTG * STG_CH + wave * (2 * KCH);
+    if (active) {
+        constexpr int NQ = 2 * KCH / 64;
+#pragma unroll
+        for (int i = 0; i < NQ; ++i) {
+            const int f = i * 64 + lane, pq = f / KCH, row = (f % KCH) / KCPR;
+            const int c = (f % KCPR) ^ ((row >> 1) & 7);
+            const int vo = (int)(((unsigned int)min(q0 + row, T - 1) * (unsigned int)(2 * D) + (unsigned int)(h * DH)) * 2u + (unsigned int)c * 16u);
+            const int so = (int)((unsigned int)pq * (unsigned int)qk_plane * 2u);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQK, (__attribute__((address_space(3))) void*)(const_cast<u32x4*>(qbase) + i * 64), 16, vo, so, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                                   // bundle 0 (K tile 0) visible to all waves; every wave's own Q tile has landed
+    asm volatile("" ::: "memory");
+
+    f32x16 om[ND], oc[ND], sm, sc;
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+        for (int v = 0; v < 16; ++v) { om[dt][v] = 0.f; oc[dt][v] = 0.f; }
+#pragma unroll
+    for (int v = 0; v < 16; ++v) { sm[v] = 0.f; sc[v] = 0.f; }
+    u32x4 ph[2], pl[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { ph[m][e] = 0u; pl[m][e] = 0u; }
+    float m_run = -INFINITY, l_run = 0.f;
+    constexpr float kInvLo = 1.0f / kLoScale;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+    // One step on the stage that holds bundle kt + 1 = {K tile kt + 1, V^T tile kt - 1}: P V of tile kt - 1, softmax of tile kt, scores
+    // of tile kt + 1.  Only TWO full steps are instantiated (with and without the key mask of the sequence's last key tile) plus the
+    // closing P V: every further variant made hipcc's register allocation worse (P and the Q fragments went to scratch with five).  The
+    // first step runs its P V on P = 0 (exact zeros added to O = 0: same bits), the last one computes scores of a clamped K tile that
+    // nobody reads.
+    // The full step, in six sub-steps separated by sched_barriers (nothing moves across them): every sub-step issues the LDS reads of
+    // the NEXT sub-step's MFMA operands (16 registers: one m of V^T, or one k16 slice s of K and Q), runs its own 6 or 3 MFMAs and its
+    // share of the vector work -- at most 32 fragment registers live at any time (loading a whole tile's operands up front needs 64 - 96
+    // and sent P and the Q fragments to scratch).
+    auto vfrag = [&](const u32x4* Vb, int m, u32x4 (&fh)[ND], u32x4 (&fl)[ND]) {
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) {
+            const int d = dt * 32 + r;
+            const int ci = d * 4 + ((2 * m + kh) ^ ((d >> 2) & 3));
+            fh[dt] = Vb[ci];
+            fl[dt] = Vb[VCH + ci];
+        }
+    };
+    auto kqfrag = [&](const u32x4* Kb, int s, u32x4& kh_, u32x4& kl_, u32x4& qh_, u32x4& ql_) {
+        const int ci = r * KCPR + ((2 * s + kh) ^ ((r >> 1) & 7));
+        kh_ = Kb[ci];
+        kl_ = Kb[KCH + ci];
+        qh_ = qbase[ci];
+        ql_ = qbase[KCH + ci];
+    };
+    auto pv = [&](int m, const u32x4 (&fh)[ND], const u32x4 (&fl)[ND]) {
+#pragma unroll
+        for (int dt = 0; dt < ND; ++dt) {
+            oc[dt] = mfma_h(fh[dt], pl[m], oc[dt]);
+            oc[dt] = mfma_h(fl[dt], ph[m], oc[dt]);
+            om[dt] = mfma_h(fh[dt], ph[m], om[dt]);
+        }
+    };
+    auto split_p = [&](const float (&st)[16], int m, int e) {        // P -> hi by truncation, lo = (p - hi) 2^11 (the v2 kernel's)
+        const float p0 = st[8 * m + 2 * e], p1 = st[8 * m + 2 * e + 1];
+        typedef __fp16 fp16x2 __attribute__((ext_vector_type(2)));
+        const fp16x2 hi2 = __builtin_amdgcn_cvt_pkrtz(p0, p1);
+        const f32x2 ps = f32x2{p0, p1} * f32x2{kLoScale, kLoScale};
+        const float l0 = fmaf((float)hi2[0], -kLoScale, ps[0]), l1 = fmaf((float)hi2[1], -kLoScale, ps[1]);
+        const fp16x2 lo2 = __builtin_amdgcn_cvt_pkrtz(l0, l1);
+        ph[m][e] = __builtin_bit_cast(unsigned int, hi2);
+        pl[m][e] = __builtin_bit_cast(unsigned int, lo2);
+    };
+    auto step = [&](int kt, const u32x4* stage) {
+        const u32x4* Kb = stage;
+        const u32x4* Vb = stage + 2 * KCH;
+        u32x4 va_h[ND], va_l[ND], vb_h[ND], vb_l[ND];
+        u32x4 k0h, k0l, q0h, q0l, k1h, k1l, q1h, q1l;
+        float st[16];
+        // ---- U0: P V (kt - 1), m = 0  |  scores of tile kt out of the accumulators, mask, row maximum, the new reference ----
+        vfrag(Vb, 0, va_h, va_l);
+        vfrag(Vb, 1, vb_h, vb_l);
+#pragma unroll
+        for (int v = 0; v < 16; ++v) st[v] = fmaf(sc[v], kInvLo, sm[v]);
+        if (kt * AKT + AKT > Tk) {                                   // the sequence's last key tile (a uniform branch, as in the v2 kernel)
+#pragma unroll
+            for (int v = 0; v < 16; ++v) {
+                const int key = kt * AKT + (v & 3) + 8 * (v >> 2) + 4 * kh;
+                if (key >= Tk) st[v] = -INFINITY;
+            }
+        }
+        float mloc = st[0];
+#pragma unroll
+        for (int v = 1; v < 16; ++v) mloc = fmaxf(mloc, st[v]);
+        {
+            const unsigned int mu = __builtin_bit_cast(unsigned int, mloc);
+            const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
+            const unsigned int s0 = sw[0], s1 = sw[1];
+            mloc = fmaxf(__builtin_bit_cast(float, s0), __builtin_bit_cast(float, s1));
+        }
+        const float m_new = fmaxf(m_run, mloc);
+        // deferred, per-row rescale (the v2 kernel's rule): alpha == 1 and the reference unchanged for a row that moved by less
+        const bool moved = m_new > m_run + defer_thr;
+        const bool rescale = !__all(m_new <= m_run + defer_thr);
+        const float alpha = moved ? __builtin_amdgcn_exp2f(m_run - m_new) : 1.0f;
+        l_run *= alpha;                                              // (x 1.0f is exact: the rows that did not move keep their bits)
+        m_run = moved ? m_new : m_run;
+        const float mb = m_run - 10.0f;
+        pv(0, va_h, va_l);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- U1: P V (kt - 1), m = 1  |  exp2 ----
+        kqfrag(Kb, 0, k0h, k0l, q0h, q0l);
+#pragma unroll
+        for (int v = 0; v < 16; v += 2) {
+            const f32x2 dlt = f32x2{st[v], st[v + 1]} - f32x2{mb, mb};
+            st[v] = __builtin_amdgcn_exp2f(dlt[0]);
+            st[v + 1] = __builtin_amdgcn_exp2f(dlt[1]);
+        }
+        pv(1, vb_h, vb_l);
+        __builtin_amdgcn_sched_barrier(0);
+        // ---- U2 .. U5: scores of tile kt + 1, one k16 slice each  |  row sum, P -> hi | lo ----
+        kqfrag(Kb, 1, k1h, k1l, q1h, q1l);
+        sc = mfma_h(k0h, q0l, zero16);
+        sc = mfma_h(k0l, q0h, sc);
+        sm = mfma_h(k0h, q0h, zero16);
+        l_run += ((st[0] + st[1]) + (st[2] + st[3])) + ((st[4] + st[5]) + (st[6] + st[7])) +
+                 (((st[8] + st[9]) + (st[10] + st[11])) + ((st[12] + st[13]) + (st[14] + st[15])));
+        split_p(st, 0, 0);
+        split_p(st, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        kqfrag(Kb, 2, k0h, k0l, q0h, q0l);
+        sc = mfma_h(k1h, q1l, sc);
+        sc = mfma_h(k1l, q1h, sc);
+        sm = mfma_h(k1h, q1h, sm);
+        split_p(st, 0, 2);
+        split_p(st, 0, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        kqfrag(Kb, 3, k1h, k1l, q1h, q1l);
+        sc = mfma_h(k0h, q0l, sc);
+        sc = mfma_h(k0l, q0h, sc);
+        sm = mfma_h(k0h, q0h, sm);
+        split_p(st, 1, 0);
+        split_p(st, 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        sc = mfma_h(k1h, q1l, sc);
+        sc = mfma_h(k1l, q1h, sc);
+        sm = mfma_h(k1h, q1h, sm);
+        split_p(st, 1, 2);
+        split_p(st, 1, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        if (rescale) {                                               // after P V (kt - 1), before P V (kt): where the v2 kernel applies it
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) { om[dt][v] *= alpha; oc[dt][v] *= alpha; }
+        }
+    };
+    auto closing_pv = [&](const u32x4* stage) {                      // P V of the last key tile
+        const u32x4* Vb = stage + 2 * KCH;
+        u32x4 va_h[ND], va_l[ND], vb_h[ND], vb_l[ND];
+        vfrag(Vb, 0, va_h, va_l);
+        vfrag(Vb, 1, vb_h, vb_l);
+        pv(0, va_h, va_l);
+        pv(1, vb_h, vb_l);
+    };
+    using T1 = std::integral_constant<bool, true>;
+    using T0 = std::integral_constant<bool, false>;
+
+    // scores of tile 0 (bundle 0 is visible since the prologue barrier)
+    if (active && nkt > 0) {
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+            const int ci = r * KCPR + ((2 * s + kh) ^ ((r >> 1) & 7));
+            const u32x4 kfh = lds[ci], kfl = lds[KCH + ci], qh = qbase[ci], ql = qbase[KCH + ci];
+            sc = mfma_h(kfh, ql, s == 0 ? zero16 : sc);
+            sc = mfma_h(kfl, qh, sc);
+            sm = mfma_h(kfh, qh, s == 0 ? zero16 : sm);
+        }
+    }
+    auto wait_bundle = [&](int younger) {
+        if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    (void)T1{}; (void)T0{};
+    int cur = 1;                                                     // stage of bundle kt + 1
+    for (int kt = 0; kt < nkt; ++kt) {
+        // bundle kt + 1 (issued two steps ago) has landed; bundle kt + 2 may stay in flight
+        wait_bundle(1);
+        __builtin_amdgcn_s_barrier();              // bundle kt + 1 visible to all waves; the stage of bundle kt (read in step kt - 1) is free
+        asm volatile("" ::: "memory");
+        if (kt + 3 <= last_bundle) issue_bundle(kt + 3, cur == 0 ? NSTG - 1 : cur - 1);
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the tail: nothing newer will be issued, let the last bundles land
+        if (active) step(kt, lds + cur * STG_CH);
+        cur = (cur == NSTG - 1) ? 0 : cur + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                  // bundle nkt + 1: the V^T tile of the last key tile
+    asm volatile("" ::: "memory");
+    if (active) closing_pv(lds + cur * STG_CH);
+
+    if (active) {
+        const float l_tot = l_run + __shfl_xor(l_run, 32);
+        const float inv = 1.0f / l_tot;
+        if (OUT == 1) {
+            const bool row_ok = q0 + r < T;
+            unsigned short* rowp = ctx16 + (size_t)(b * T + min(q0 + r, T - 1)) * (size_t)(2 * D) + (size_t)(ND * h) * 64;
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+                for (int gp = 0; gp < 2; ++gp) {
+                    unsigned int w[2][4];
+#pragma unroll
+                    for (int gi = 0; gi < 2; ++gi) {
+                        const int g = 2 * gp + gi;
+                        _Float16 hh[4], ll[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) split_act(fmaf(oc[dt][4 * g + e], kInvLo, om[dt][4 * g + e]) * inv, hh[e], ll[e]);
+                        w[gi][0] = pack_h2(hh[0], hh[1]); w[gi][1] = pack_h2(hh[2], hh[3]);
+                        w[gi][2] = pack_h2(ll[0], ll[1]); w[gi][3] = pack_h2(ll[2], ll[3]);
+                    }
+                    unsigned int first[4], second[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const auto sw = __builtin_amdgcn_permlane32_swap(w[0][k], w[1][k], false, false);
+                        first[k] = sw[0];
+                        second[k] = sw[1];
+                    }
+                    if (row_ok) {
+                        unsigned short* dst = rowp + dt * 64 + 8 * (2 * gp + kh);
+                        *reinterpret_cast<u32x4*>(dst) = u32x4{first[0], first[1], second[0], second[1]};
+                        *reinterpret_cast<u32x4*>(dst + 32) = u32x4{first[2], first[3], second[2], second[3]};
+                    }
+                }
+        } else if (q0 + r < T) {
+            const size_t off = (size_t)(b * T + q0 + r) * D + (size_t)h * DH + 4 * kh;
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float val[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) val[e] = fmaf(oc[dt][4 * g + e], kInvLo, om[dt][4 * g + e]) * inv;
+                    *reinterpret_cast<f32x4*>(ctx + off + dt * 32 + 8 * g) = f32x4{val[0], val[1], val[2], val[3]};
+                }
+        }
+    }
+}
+
+static int g_att_v3 = -1;            // -1: by shape, 0: never, 1: wherever the kernel is defined
+static bool att_v3_serves(int T, const float* conv, const float* slopes, int head_dim) {
+    (void)T;
+    return g_att_v3 != 0 && !conv && !slopes && head_dim == 64;
+}
 
 template <int OUT, int NSTG>
 static int launch_att16v2_mode(int wpb, dim3 grid, const unsigned short* qk16, size_t qk_plane,
@@ -663,13 +1014,38 @@ static int launch_att16v2_mode(int wpb, dim3 grid, const unsigned short* qk16, s
     }
 }
 
+template <int WPB, int OUT>
+static void launch_att16v3_one(dim3 grid, const unsigned short* qk16, size_t qk_plane, const unsigned short* vt16, size_t vt_plane, const int32_t* kv_len,
+                               int T, int H, int Tp, float* ctx, unsigned short* ctx16, hipStream_t s, int dense_nblk, int nseq) {
+    constexpr size_t lds_bytes = (size_t)3 * A_STAGE * 16 + (size_t)WPB * 8192;        // ring + one Q tile per wave: two 4-wave workgroups fill a CU's 160 KB
+    auto kfn = attention_f16x3_v3_kernel<WPB, OUT>;
+    if (lds_bytes > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    hipLaunchKernelGGL((attention_f16x3_v3_kernel<WPB, OUT>), grid, dim3(WPB * 64), lds_bytes, s, qk16, qk_plane, vt16, vt_plane, kv_len, T, H, Tp, ctx, ctx16,
+                       dense_nblk, nseq);
+}
+static int launch_att16v3(int out_mode, int wpb, dim3 grid, const unsigned short* qk16, size_t qk_plane, const unsigned short* vt16, size_t vt_plane,
+                          const int32_t* kv_len, int T, int H, int Tp, float* ctx, unsigned short* ctx16, hipStream_t s, int dense_nblk, int nseq) {
+#define PGMI_V3(W)                                                                                                                          \
+    do {                                                                                                                                    \
+        if (out_mode) launch_att16v3_one<W, 1>(grid, qk16, qk_plane, vt16, vt_plane, kv_len, T, H, Tp, ctx, ctx16, s, dense_nblk, nseq);   \
+        else launch_att16v3_one<W, 0>(grid, qk16, qk_plane, vt16, vt_plane, kv_len, T, H, Tp, ctx, ctx16, s, dense_nblk, nseq);            \
+    } while (0)
+    switch (wpb) {
+        case 1: PGMI_V3(1); break;
+        case 2: PGMI_V3(2); break;
+        default: PGMI_V3(4); break;
+    }
+#undef PGMI_V3
+    return PGMI_OK;
+}
+
 // Launch option (pgmi_set_option "att_xcd_local", default 1): 1 = the one-dimensional XCD-local order of the dense launches, 0 = the
 // (query block, head, sequence) grid of rounds 1-4 (kept for the interleaved A/B of scripts/att_bench.py: block order does not touch a
 // row's arithmetic, same bits).
 static int g_att_xcd_local = -1;     // -1: by shape (XCD-local from eight query blocks per sequence on: +2.5 % at T = 1024, -2 % at T = 288)
 int att_set_option(const char* name, long long value) {
     if (!strcmp(name, "att_xcd_local")) { g_att_xcd_local = (int)value; return PGMI_OK; }
-    if (!strcmp(name, "att_pp")) return att_pp_set_option(value);
+    if (!strcmp(name, "att_v3")) { g_att_v3 = (int)value; return PGMI_OK; }
     return PGMI_EINVAL;
 }
 // grid of a dense launch of nblk query blocks x H heads x B sequences, and the dense_nblk argument that goes with it
@@ -733,16 +1109,11 @@ int launch_attention_f16x3_v2(const float* qkv, const int32_t* kv_len, const flo
     else if (qkv)          // operands not prepared by the fused QKV epilogue: run the prep pass
         hipLaunchKernelGGL(qkv_prep_kernel, dim3(n32, H, B), dim3(256), 0, s, qkv, cos_t, sin_t, rotary, T, H, Tp,
                            qk16, qk_plane, vt16, vt_plane);
-    if (att_pp_serves(T, conv, slopes, head_dim)) {
-        rc = launch_att16_pp(qk16, qk_plane, vt16, vt_plane, kv_len, B, T, H, Tp, ctx, ctx16, out_mode, s);
-        if (rc) return rc;
-        PGMI_HIP(hipGetLastError());
-        return PGMI_OK;
-    }
     const int wpb = att16_waves_per_block(T), nblk = (n32 + wpb - 1) / wpb;
     int dn = 0;
     const dim3 grid = dense_grid(nblk, H, B, &dn);
-    if (out_mode == 0) rc = launch_att16v2_mode<0, 3>(wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane, s, dn, B);
+    if (att_v3_serves(T, conv, slopes, head_dim)) rc = launch_att16v3(out_mode, wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, T, H, Tp, ctx, ctx16, s, dn, B);
+    else if (out_mode == 0) rc = launch_att16v2_mode<0, 3>(wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane, s, dn, B);
     else rc = launch_att16v2_mode<1, 3>(wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane, s, dn, B);
     if (rc) return rc;
     PGMI_HIP(hipGetLastError());

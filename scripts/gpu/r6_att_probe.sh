@@ -3,5 +3,5 @@
 cd "${GRAFT_REPO_ROOT:-.}"
 export TMPDIR=/tmp
 O=gpurun_out/r6_att_probe; rm -rf $O; mkdir -p $O
-timeout 300 python -m pytest tests/test_gpu_ops.py -q -x -k "attention_pp" > $O/att_tests.log 2>&1; echo "rc $?" >> $O/att_tests.log; tail -3 $O/att_tests.log
-timeout 600 python scripts/att_bench.py --rounds 5 --shapes 286x286,90x1100 --ab ${1:-att_pp=0,att_pp=1,att_pp=17,att_pp=33,att_pp=65,att_pp=129,att_pp=97,att_pp=273,att_pp=225} > $O/att_probe.log 2>&1; grep -v "^{" $O/att_probe.log
+timeout 300 python -m pytest tests/test_gpu_ops.py -q -x -k "attention_v3" > $O/att_tests.log 2>&1; echo "rc $?" >> $O/att_tests.log; tail -3 $O/att_tests.log
+timeout 600 python scripts/att_bench.py --rounds 5 --shapes 286x286,90x1100 --ab ${1:-att_v3=0,att_v3=1} > $O/att_probe.log 2>&1; grep -v "^{" $O/att_probe.log

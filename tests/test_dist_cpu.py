@@ -1045,9 +1045,12 @@ class _FakeBenchModel(list):
 def _bench_main_entry():
     """Runs in a child process (see the test below): bench.main's N > 1 branch over gloo with the seams."""
     import bench
-    print("[Gloo] Rank chatter that a backend might print on stdout")            # must end up on stderr
-    bench.main(["--gpus", "2", "--steps", "2", "--warmup", "1"], make_model=lambda cfg, blob, dev, prec: _FakeBenchModel(),
-               make_assay=_FakeBenchAssay)
+
+    def model(cfg, blob, dev, prec):
+        print("[Gloo] Rank chatter that a backend might print on stdout")        # inside bench.main: must end up on stderr
+        os.system("echo chatter of a child process that inherits file descriptor 1")
+        return _FakeBenchModel()
+    bench.main(["--gpus", "2", "--steps", "2", "--warmup", "1"], make_model=model, make_assay=_FakeBenchAssay)
 
 
 def test_bench_n_gt_1_prints_exactly_one_json_line_on_stdout():
@@ -1071,7 +1074,7 @@ def test_bench_n_gt_1_prints_exactly_one_json_line_on_stdout():
     assert len(lines) == 1, outs[0][0]
     line = json.loads(lines[0])
     assert outs[1][0] == ""
-    assert "Rank chatter" in outs[0][1] and "Rank chatter" in outs[1][1]
+    assert "Rank chatter" in outs[0][1] and "Rank chatter" in outs[1][1] and "chatter of a child process" in outs[0][1]
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
                 "data", "config", "roofline", "strong_scaling_217", "rccl"):
         assert key in line, key

@@ -458,7 +458,7 @@ def test_esm2_beyond_1024_tokens_vs_oracle(lib):
 
 @pytest.mark.parametrize("arch", ["ESM1V_650M", "ESM2_650M"])
 def test_attention_launch_options_keep_the_bits_of_a_model(lib, arch):
-    """Split-plane attention output (the model path) under the XCD-local block order and under the two-role 8-wave kernel (att_pp) against the
+    """Split-plane attention output (the model path) under the XCD-local block order and under the software-pipelined kernel (att_v3) against the
     4-wave kernel: 4 layers at the 650M width, T = 288 and a padded batch (key masks): the same token log-probs, bit for bit."""
     from proteingym_amd import _lib
     cfg = dict(getattr(synthetic, arch), layers=4)
@@ -472,14 +472,14 @@ def test_attention_launch_options_keep_the_bits_of_a_model(lib, arch):
     tok[21, 30] = 2
     try:
         _lib.check(lib.pgmi_set_option(b"att_xcd_local", 0))
-        _lib.check(lib.pgmi_set_option(b"att_pp", 0))
+        _lib.check(lib.pgmi_set_option(b"att_v3", 0))
         base = m.token_logprobs(tok)
-        for name, value in ((b"att_xcd_local", 1), (b"att_xcd_local", -1), (b"att_pp", 1), (b"att_pp", -1)):
+        for name, value in ((b"att_xcd_local", 1), (b"att_xcd_local", -1), (b"att_v3", 1), (b"att_v3", -1)):
             _lib.check(lib.pgmi_set_option(name, value))
             got = m.token_logprobs(tok)
             keep = tok != 1
             assert np.array_equal(got[keep], base[keep]), (name, value)
     finally:
         lib.pgmi_set_option(b"att_xcd_local", -1)
-        lib.pgmi_set_option(b"att_pp", -1)
+        lib.pgmi_set_option(b"att_v3", -1)
         m.close()

@@ -319,12 +319,13 @@ def test_attention_launch_options_keep_the_bits(lib, B, T, H, kv):
 
 
 @pytest.mark.parametrize("B,T,H,kv", [(3, 288, 4, None), (2, 1000, 2, None), (1, 1024, 3, None), (5, 230, 2, [230, 197, 228, 1, 66]),
-                                      (7, 224, 1, None), (33, 290, 20, None), (2, 737, 20, [737, 700])])
-def test_attention_pp_bits_equal_v2(lib, B, T, H, kv):
-    """The barrier-locked two-role attention kernel (attention_f16x3_pp_kernel: one 8-wave workgroup per eight consecutive query tiles,
-    up to two (sequence, head) streams per workgroup, X / Y segments alternating between the two waves of a SIMD) walks every query row
-    through the 4-wave kernel's arithmetic tile by tile: context rows equal bit for bit, with and without key padding, workgroups that
-    straddle two heads / two sequences, a last workgroup with idle waves, T on and off multiples of 32."""
+                                      (7, 224, 1, None), (33, 290, 20, None), (2, 737, 20, [737, 700]), (4, 30, 2, None), (3, 64, 2, [64, 33, 5]),
+                                      (2, 5, 1, None), (3, 70, 2, None), (2, 129, 1, [100, 129])])
+def test_attention_v3_bits_equal_v2(lib, B, T, H, kv):
+    """The software-pipelined attention kernel (attention_f16x3_v3_kernel: every step runs P V of key tile kt - 1 and the scores of tile
+    kt + 1 beside the softmax of tile kt; bundles {K tile m, V^T tile m - 2} in the ring; Q fragments re-read from LDS) walks every query
+    row through the v2 kernel's arithmetic in the same order: context rows equal bit for bit, with and without key padding, one / two / four
+    waves per workgroup, T on and off multiples of 32, a single key tile."""
     rng = np.random.default_rng(T + H)
     D = H * 64
     qkv = rng.standard_normal((B, T, 3 * D)).astype(np.float32)
@@ -341,11 +342,11 @@ def test_attention_pp_bits_equal_v2(lib, B, T, H, kv):
                 ctx[b, kv[b]:] = 0
         return ctx
     try:
-        _lib.check(lib.pgmi_set_option(b"att_pp", 0))
+        _lib.check(lib.pgmi_set_option(b"att_v3", 0))
         base = run()
         assert np.isfinite(base).all()
-        _lib.check(lib.pgmi_set_option(b"att_pp", 1))
+        _lib.check(lib.pgmi_set_option(b"att_v3", 1))
         got = run()
         assert np.array_equal(got, base), float(np.nanmax(np.abs(got - base)))
     finally:
-        lib.pgmi_set_option(b"att_pp", -1)
+        lib.pgmi_set_option(b"att_v3", -1)
