@@ -819,27 +819,56 @@ __global__ __launch_bounds__(WPB * 64, 2) void attention_f16x3_v3_kernel(
         ph[m][e] = __builtin_bit_cast(unsigned int, hi2);
         pl[m][e] = __builtin_bit_cast(unsigned int, lo2);
     };
-    auto step = [&](int kt, const u32x4* stage) {
+    // The rescale of O by alpha(kt) -- decided in step kt, due after P V (kt - 1) and before P V (kt) -- is applied at the HEAD of step
+    // kt + 1 (and of the closing P V): a branch in the middle of a step would cut its straight-line block, and hipcc then sinks the exp2 /
+    // split half of the softmax below the branch, behind all 24 MFMAs (the first build of this kernel: the v2 kernel's phases again).
+    bool pend = false;
+    float pend_alpha = 1.0f;
+    auto apply_pending = [&]() {
+        if (pend) {
+#pragma unroll
+            for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+                for (int v = 0; v < 16; ++v) { om[dt][v] *= pend_alpha; oc[dt][v] *= pend_alpha; }
+        }
+    };
+    auto step = [&](auto MKc, int kt, const u32x4* stage) {
+        constexpr bool MK = decltype(MKc)::value;
+        apply_pending();
         const u32x4* Kb = stage;
         const u32x4* Vb = stage + 2 * KCH;
         u32x4 va_h[ND], va_l[ND], vb_h[ND], vb_l[ND];
         u32x4 k0h, k0l, q0h, q0l, k1h, k1l, q1h, q1l;
         float st[16];
-        // ---- U0: P V (kt - 1), m = 0  |  scores of tile kt out of the accumulators, mask, row maximum, the new reference ----
+        // The step is ONE straight-line block cut into 24 slots by sched_barriers (nothing moves across them): a slot = one MFMA + the
+        // slice of the softmax that rides in its shadow (at most ~7 single-issue instructions: a wave issues in order, so vector work
+        // overlaps a matrix instruction only if it FOLLOWS it in the stream and fits under its 32 cycles) + the LDS reads of operands
+        // three or more slots ahead.  Slots 0-11: P V (kt - 1); 12-23: scores of tile kt + 1.
+#define PGMI_SLOT() __builtin_amdgcn_sched_barrier(0)
+        // head: the V^T fragments are requested; while they travel: the scores of tile kt leave the accumulators (+ key mask)
         vfrag(Vb, 0, va_h, va_l);
         vfrag(Vb, 1, vb_h, vb_l);
 #pragma unroll
         for (int v = 0; v < 16; ++v) st[v] = fmaf(sc[v], kInvLo, sm[v]);
-        if (kt * AKT + AKT > Tk) {                                   // the sequence's last key tile (a uniform branch, as in the v2 kernel)
+        if constexpr (MK) {                                          // the sequence's last key tile
 #pragma unroll
             for (int v = 0; v < 16; ++v) {
                 const int key = kt * AKT + (v & 3) + 8 * (v >> 2) + 4 * kh;
                 if (key >= Tk) st[v] = -INFINITY;
             }
         }
-        float mloc = st[0];
+        float ma = st[0];
 #pragma unroll
-        for (int v = 1; v < 16; ++v) mloc = fmaxf(mloc, st[v]);
+        for (int v = 1; v < 8; ++v) ma = fmaxf(ma, st[v]);
+        PGMI_SLOT();
+        // ---- slots 0-5: P V (kt - 1), m = 0 ----
+        oc[0] = mfma_h(va_h[0], pl[0], oc[0]);
+        float mloc = st[8];
+#pragma unroll
+        for (int v = 9; v < 16; ++v) mloc = fmaxf(mloc, st[v]);
+        mloc = fmaxf(mloc, ma);
+        PGMI_SLOT();
+        oc[0] = mfma_h(va_l[0], ph[0], oc[0]);
         {
             const unsigned int mu = __builtin_bit_cast(unsigned int, mloc);
             const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
@@ -847,63 +876,85 @@ __global__ __launch_bounds__(WPB * 64, 2) void attention_f16x3_v3_kernel(
             mloc = fmaxf(__builtin_bit_cast(float, s0), __builtin_bit_cast(float, s1));
         }
         const float m_new = fmaxf(m_run, mloc);
+        PGMI_SLOT();
+        om[0] = mfma_h(va_h[0], ph[0], om[0]);
         // deferred, per-row rescale (the v2 kernel's rule): alpha == 1 and the reference unchanged for a row that moved by less
         const bool moved = m_new > m_run + defer_thr;
-        const bool rescale = !__all(m_new <= m_run + defer_thr);
-        const float alpha = moved ? __builtin_amdgcn_exp2f(m_run - m_new) : 1.0f;
-        l_run *= alpha;                                              // (x 1.0f is exact: the rows that did not move keep their bits)
+        pend = !__all(m_new <= m_run + defer_thr);
+        pend_alpha = moved ? __builtin_amdgcn_exp2f(m_run - m_new) : 1.0f;
+        l_run *= pend_alpha;                                         // (x 1.0f is exact)
+        asm volatile("" : "+v"(l_run));                              // NOT contracted with the row sum below: the v2 kernel's two roundings (hipcc fuses __fmul_rn too)
         m_run = moved ? m_new : m_run;
         const float mb = m_run - 10.0f;
-        pv(0, va_h, va_l);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- U1: P V (kt - 1), m = 1  |  exp2 ----
-        kqfrag(Kb, 0, k0h, k0l, q0h, q0l);
+        PGMI_SLOT();
+        auto exp_pairs = [&](int v0) {                               // two pairs: packed subtract, two exp2 each
 #pragma unroll
-        for (int v = 0; v < 16; v += 2) {
-            const f32x2 dlt = f32x2{st[v], st[v + 1]} - f32x2{mb, mb};
-            st[v] = __builtin_amdgcn_exp2f(dlt[0]);
-            st[v + 1] = __builtin_amdgcn_exp2f(dlt[1]);
-        }
-        pv(1, vb_h, vb_l);
-        __builtin_amdgcn_sched_barrier(0);
-        // ---- U2 .. U5: scores of tile kt + 1, one k16 slice each  |  row sum, P -> hi | lo ----
-        kqfrag(Kb, 1, k1h, k1l, q1h, q1l);
-        sc = mfma_h(k0h, q0l, zero16);
-        sc = mfma_h(k0l, q0h, sc);
-        sm = mfma_h(k0h, q0h, zero16);
-        l_run += ((st[0] + st[1]) + (st[2] + st[3])) + ((st[4] + st[5]) + (st[6] + st[7])) +
-                 (((st[8] + st[9]) + (st[10] + st[11])) + ((st[12] + st[13]) + (st[14] + st[15])));
-        split_p(st, 0, 0);
+            for (int v = v0; v < v0 + 4; v += 2) {
+                const f32x2 dlt = f32x2{st[v], st[v + 1]} - f32x2{mb, mb};
+                st[v] = __builtin_amdgcn_exp2f(dlt[0]);
+                st[v + 1] = __builtin_amdgcn_exp2f(dlt[1]);
+            }
+        };
+        oc[1] = mfma_h(va_h[1], pl[0], oc[1]);
+        exp_pairs(0);
+        PGMI_SLOT();
+        oc[1] = mfma_h(va_l[1], ph[0], oc[1]);
+        exp_pairs(4);
+        PGMI_SLOT();
+        om[1] = mfma_h(va_h[1], ph[0], om[1]);
+        exp_pairs(8);
+        PGMI_SLOT();
+        // ---- slots 6-11: P V (kt - 1), m = 1 ----
+        oc[0] = mfma_h(vb_h[0], pl[1], oc[0]);
+        exp_pairs(12);
+        PGMI_SLOT();
+        oc[0] = mfma_h(vb_l[0], ph[1], oc[0]);
+        const float sa = ((st[0] + st[1]) + (st[2] + st[3])) + ((st[4] + st[5]) + (st[6] + st[7]));
+        PGMI_SLOT();
+        om[0] = mfma_h(vb_h[0], ph[1], om[0]);
+        kqfrag(Kb, 0, k0h, k0l, q0h, q0l);
+        l_run += sa + (((st[8] + st[9]) + (st[10] + st[11])) + ((st[12] + st[13]) + (st[14] + st[15])));
+        PGMI_SLOT();
+        oc[1] = mfma_h(vb_h[1], pl[1], oc[1]);
+        split_p(st, 0, 0);                                           // (P of m = 0 may be overwritten: its six MFMAs have issued)
+        PGMI_SLOT();
+        oc[1] = mfma_h(vb_l[1], ph[1], oc[1]);
         split_p(st, 0, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        kqfrag(Kb, 2, k0h, k0l, q0h, q0l);
-        sc = mfma_h(k1h, q1l, sc);
-        sc = mfma_h(k1l, q1h, sc);
-        sm = mfma_h(k1h, q1h, sm);
+        PGMI_SLOT();
+        om[1] = mfma_h(vb_h[1], ph[1], om[1]);
+        kqfrag(Kb, 1, k1h, k1l, q1h, q1l);
         split_p(st, 0, 2);
+        PGMI_SLOT();
+        // ---- slots 12-23: scores of tile kt + 1, one k16 slice per three slots ----
+        sc = mfma_h(k0h, q0l, zero16);
         split_p(st, 0, 3);
-        __builtin_amdgcn_sched_barrier(0);
+        PGMI_SLOT();
+        sc = mfma_h(k0l, q0h, sc);
+        split_p(st, 1, 0);
+        PGMI_SLOT();
+        sm = mfma_h(k0h, q0h, zero16);
+        kqfrag(Kb, 2, k0h, k0l, q0h, q0l);
+        split_p(st, 1, 1);
+        PGMI_SLOT();
+        sc = mfma_h(k1h, q1l, sc);
+        split_p(st, 1, 2);
+        PGMI_SLOT();
+        sc = mfma_h(k1l, q1h, sc);
+        split_p(st, 1, 3);
+        PGMI_SLOT();
+        sm = mfma_h(k1h, q1h, sm);
         kqfrag(Kb, 3, k1h, k1l, q1h, q1l);
+        PGMI_SLOT();
         sc = mfma_h(k0h, q0l, sc);
         sc = mfma_h(k0l, q0h, sc);
         sm = mfma_h(k0h, q0h, sm);
-        split_p(st, 1, 0);
-        split_p(st, 1, 1);
-        __builtin_amdgcn_sched_barrier(0);
         sc = mfma_h(k1h, q1l, sc);
         sc = mfma_h(k1l, q1h, sc);
         sm = mfma_h(k1h, q1h, sm);
-        split_p(st, 1, 2);
-        split_p(st, 1, 3);
-        __builtin_amdgcn_sched_barrier(0);
-        if (rescale) {                                               // after P V (kt - 1), before P V (kt): where the v2 kernel applies it
-#pragma unroll
-            for (int dt = 0; dt < ND; ++dt)
-#pragma unroll
-                for (int v = 0; v < 16; ++v) { om[dt][v] *= alpha; oc[dt][v] *= alpha; }
-        }
+#undef PGMI_SLOT
     };
     auto closing_pv = [&](const u32x4* stage) {                      // P V of the last key tile
+        apply_pending();
         const u32x4* Vb = stage + 2 * KCH;
         u32x4 va_h[ND], va_l[ND], vb_h[ND], vb_l[ND];
         vfrag(Vb, 0, va_h, va_l);
@@ -929,18 +980,23 @@ __global__ __launch_bounds__(WPB * 64, 2) void attention_f16x3_v3_kernel(
         if (younger >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
-    (void)T1{}; (void)T0{};
     int cur = 1;                                                     // stage of bundle kt + 1
-    for (int kt = 0; kt < nkt; ++kt) {
+    auto step_head = [&](int kt) {
         // bundle kt + 1 (issued two steps ago) has landed; bundle kt + 2 may stay in flight
         wait_bundle(1);
         __builtin_amdgcn_s_barrier();              // bundle kt + 1 visible to all waves; the stage of bundle kt (read in step kt - 1) is free
         asm volatile("" ::: "memory");
         if (kt + 3 <= last_bundle) issue_bundle(kt + 3, cur == 0 ? NSTG - 1 : cur - 1);
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the tail: nothing newer will be issued, let the last bundles land
-        if (active) step(kt, lds + cur * STG_CH);
+    };
+    for (int kt = 0; kt < nkt - 1; ++kt) {
+        step_head(kt);
+        if (active) step(T0{}, kt, lds + cur * STG_CH);
         cur = (cur == NSTG - 1) ? 0 : cur + 1;
     }
+    step_head(nkt - 1);                                              // the sequence's last key tile: masked by Tk
+    if (active) step(T1{}, nkt - 1, lds + cur * STG_CH);
+    cur = (cur == NSTG - 1) ? 0 : cur + 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                  // bundle nkt + 1: the V^T tile of the last key tile
     asm volatile("" ::: "memory");
