@@ -716,48 +716,62 @@ __global__ __launch_bounds__(WPB * 64, 2) void attention_f16x3_v3_kernel(
     }
     // bundle m -> stage m % 3: K tile min(m, nkt - 1) (rows clamped to the sequence's last token: finite, masked by Tk) and V^T tile
     // clamp(m - 2) -- the clamped copies are never read, they keep the per-wave DMA count constant for the counted waits
-    auto issue_bundle = [&](int m, int stage) {
+    // piece i (0 .. NDMA - 1) of bundle m into `stage`; on == false: the offset is pushed out of the descriptor's range -- the
+    // instruction still counts in vmcnt (the counted waits need a constant number per step) but fetches nothing
+    auto issue_piece = [&](int i, int m, int stage, bool on) {        // (i is a constant after unrolling at every call site)
         u32x4* base = lds + stage * STG_CH;
         const int kk = min(m, nkt - 1), vv = min(max(m - 2, 0), nkt - 1);
-#pragma unroll
-        for (int i = 0; i < NK; ++i) {
+        if (i < NK) {
             const int wi = wave + WPB * i, p = (WPB * i) >> 2;
-            const int vo = min(kk * AKT + krow[i], T - 1) * (2 * D) * 2 + kvoff[i];
+            const int kr = krow[i < NK ? i : 0], ko = kvoff[i < NK ? i : 0];
+            const int vo = on ? min(kk * AKT + kr, T - 1) * (2 * D) * 2 + ko : -16;
             const int so = (int)((unsigned int)p * (unsigned int)qk_plane * 2u + (unsigned int)(D + h * DH) * 2u);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQK, (__attribute__((address_space(3))) void*)(base + wi * 64), 16, vo, so, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < NDMA - NK; ++i) {
-            const int wi = wave + WPB * (i + NK), p = (WPB * (i + NK) - 8) >> 2;
+        } else {
+            const int wi = wave + WPB * i, p = (WPB * i - 8) >> 2;
             const int so = (int)((unsigned int)p * (unsigned int)vt_plane * 2u) + vv * ((AKT / 8) * 16);
-            const int vo = vvoff[i];       // (named locals: with an array expression written in the call hipcc 7.2 silently drops the kernel's host stub)
+            const int vv0 = vvoff[i >= NK ? i - NK : 0];
+            const int vo = on ? vv0 : -16;             // (named locals: with an array expression written in the call hipcc 7.2 silently drops the kernel's host stub)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsVT, (__attribute__((address_space(3))) void*)(base + wi * 64), 16, vo, so, 0, 0);
         }
     };
+    auto issue_bundle = [&](int m, int stage, bool on) {
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i) issue_piece(i, m, stage, on);
+    };
     const int last_bundle = nkt + 1;                              // V^T tile nkt - 1 travels in bundle nkt + 1
 
-    // ---- prologue: bundles 0 .. 2 into the ring, the wave's Q tile into its own 8 KB behind the ring.  The Q fragments are NOT kept
-    //      in registers (32 of them, read-only, used by 12 of a step's 24 MFMAs: with both P V and S operands and two softmax halves in
-    //      flight hipcc spilled them to scratch): every step re-reads them from LDS together with the K fragments (24 instead of 16
-    //      ds_read_b128 per step: 0.47 us of the CU's LDS read port per ~1 us step) ----
-    issue_bundle(0, 0);
-    issue_bundle(1, 1);
-    issue_bundle(2, 2);
-    const u32x4* const qbase = lds + NSTG * STG_CH + wave * (2 * KCH);
-    if (active) {
-        constexpr int NQ = 2 * KCH / 64;
+    // ---- prologue (the v2 kernel's): bundle 0 (K tile 0) into stage 0, the Q tiles through stages 1-2, then bundles 1 and 2 ----
+    issue_bundle(0, 0, true);
+    u32x4 qh[NS], ql[NS];
+    {
+        u32x4* qbase = lds + STG_CH + wave * (2 * KCH);
+        if (active) {
+            constexpr int NQ = 2 * KCH / 64;
 #pragma unroll
-        for (int i = 0; i < NQ; ++i) {
-            const int f = i * 64 + lane, pq = f / KCH, row = (f % KCH) / KCPR;
-            const int c = (f % KCPR) ^ ((row >> 1) & 7);
-            const int vo = (int)(((unsigned int)min(q0 + row, T - 1) * (unsigned int)(2 * D) + (unsigned int)(h * DH)) * 2u + (unsigned int)c * 16u);
-            const int so = (int)((unsigned int)pq * (unsigned int)qk_plane * 2u);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQK, (__attribute__((address_space(3))) void*)(const_cast<u32x4*>(qbase) + i * 64), 16, vo, so, 0, 0);
+            for (int i = 0; i < NQ; ++i) {
+                const int f = i * 64 + lane, pq = f / KCH, row = (f % KCH) / KCPR;
+                const int c = (f % KCPR) ^ ((row >> 1) & 7);
+                const int vo = (int)(((unsigned int)min(q0 + row, T - 1) * (unsigned int)(2 * D) + (unsigned int)(h * DH)) * 2u + (unsigned int)c * 16u);
+                const int so = (int)((unsigned int)pq * (unsigned int)qk_plane * 2u);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsQK, (__attribute__((address_space(3))) void*)(qbase + i * 64), 16, vo, so, 0, 0);
+            }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (active) {
+#pragma unroll
+            for (int s = 0; s < NS; ++s) {
+                const int ci = r * KCPR + ((2 * s + kh) ^ ((r >> 1) & 7));
+                qh[s] = qbase[ci];
+                ql[s] = qbase[KCH + ci];
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                               // every wave holds its Q in registers: stages 1 and 2 are free again; bundle 0 is visible
+        asm volatile("" ::: "memory");
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();                                   // bundle 0 (K tile 0) visible to all waves; every wave's own Q tile has landed
-    asm volatile("" ::: "memory");
+    issue_bundle(1, 1, true);
+    issue_bundle(2, 2, true);
 
     f32x16 om[ND], oc[ND], sm, sc;
 #pragma unroll
@@ -794,12 +808,10 @@ __global__ __launch_bounds__(WPB * 64, 2) void attention_f16x3_v3_kernel(
             fl[dt] = Vb[VCH + ci];
         }
     };
-    auto kqfrag = [&](const u32x4* Kb, int s, u32x4& kh_, u32x4& kl_, u32x4& qh_, u32x4& ql_) {
+    auto kfrag = [&](const u32x4* Kb, int s, u32x4& kh_, u32x4& kl_) {
         const int ci = r * KCPR + ((2 * s + kh) ^ ((r >> 1) & 7));
         kh_ = Kb[ci];
         kl_ = Kb[KCH + ci];
-        qh_ = qbase[ci];
-        ql_ = qbase[KCH + ci];
     };
     auto pv = [&](int m, const u32x4 (&fh)[ND], const u32x4 (&fl)[ND]) {
 #pragma unroll
@@ -832,13 +844,13 @@ __global__ __launch_bounds__(WPB * 64, 2) void attention_f16x3_v3_kernel(
                 for (int v = 0; v < 16; ++v) { om[dt][v] *= pend_alpha; oc[dt][v] *= pend_alpha; }
         }
     };
-    auto step = [&](auto MKc, int kt, const u32x4* stage) {
+    auto step = [&](auto MKc, int kt, const u32x4* stage, int dma_stage) {
         constexpr bool MK = decltype(MKc)::value;
         apply_pending();
         const u32x4* Kb = stage;
         const u32x4* Vb = stage + 2 * KCH;
         u32x4 va_h[ND], va_l[ND], vb_h[ND], vb_l[ND];
-        u32x4 k0h, k0l, q0h, q0l, k1h, k1l, q1h, q1l;
+        u32x4 k0h, k0l, k1h, k1l;
         float st[16];
         // The step is ONE straight-line block cut into 24 slots by sched_barriers (nothing moves across them): a slot = one MFMA + the
         // slice of the softmax that rides in its shadow (at most ~7 single-issue instructions: a wave issues in order, so vector work
@@ -912,7 +924,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void attention_f16x3_v3_kernel(
         const float sa = ((st[0] + st[1]) + (st[2] + st[3])) + ((st[4] + st[5]) + (st[6] + st[7]));
         PGMI_SLOT();
         om[0] = mfma_h(vb_h[0], ph[1], om[0]);
-        kqfrag(Kb, 0, k0h, k0l, q0h, q0l);
+        kfrag(Kb, 0, k0h, k0l);
         l_run += sa + (((st[8] + st[9]) + (st[10] + st[11])) + ((st[12] + st[13]) + (st[14] + st[15])));
         PGMI_SLOT();
         oc[1] = mfma_h(vb_h[1], pl[1], oc[1]);
@@ -922,35 +934,52 @@ __global__ __launch_bounds__(WPB * 64, 2) void attention_f16x3_v3_kernel(
         split_p(st, 0, 1);
         PGMI_SLOT();
         om[1] = mfma_h(vb_h[1], ph[1], om[1]);
-        kqfrag(Kb, 1, k1h, k1l, q1h, q1l);
+        kfrag(Kb, 1, k1h, k1l);
         split_p(st, 0, 2);
         PGMI_SLOT();
-        // ---- slots 12-23: scores of tile kt + 1, one k16 slice per three slots ----
-        sc = mfma_h(k0h, q0l, zero16);
+        // ---- slots 12-23: scores of tile kt + 1, one k16 slice per three slots; the vector work ends in slot 16, the DMA of bundle
+        //      kt + 3 (into the stage of bundle kt, free since this step's barrier) rides in the slots after it ----
+        sc = mfma_h(k0h, ql[0], zero16);
         split_p(st, 0, 3);
         PGMI_SLOT();
-        sc = mfma_h(k0l, q0h, sc);
+        sc = mfma_h(k0l, qh[0], sc);
         split_p(st, 1, 0);
         PGMI_SLOT();
-        sm = mfma_h(k0h, q0h, zero16);
-        kqfrag(Kb, 2, k0h, k0l, q0h, q0l);
+        sm = mfma_h(k0h, qh[0], zero16);
+        kfrag(Kb, 2, k0h, k0l);
         split_p(st, 1, 1);
         PGMI_SLOT();
-        sc = mfma_h(k1h, q1l, sc);
+        sc = mfma_h(k1h, ql[1], sc);
         split_p(st, 1, 2);
         PGMI_SLOT();
-        sc = mfma_h(k1l, q1h, sc);
+        sc = mfma_h(k1l, qh[1], sc);
         split_p(st, 1, 3);
         PGMI_SLOT();
-        sm = mfma_h(k1h, q1h, sm);
-        kqfrag(Kb, 3, k1h, k1l, q1h, q1l);
+        sm = mfma_h(k1h, qh[1], sm);
+        kfrag(Kb, 3, k1h, k1l);
         PGMI_SLOT();
-        sc = mfma_h(k0h, q0l, sc);
-        sc = mfma_h(k0l, q0h, sc);
-        sm = mfma_h(k0h, q0h, sm);
-        sc = mfma_h(k1h, q1l, sc);
-        sc = mfma_h(k1l, q1h, sc);
-        sm = mfma_h(k1h, q1h, sm);
+        const bool dma_on = kt + 3 <= last_bundle;
+        auto dma_slot = [&](int j) {                                 // pieces j, j + 6, j + 12 ... of the bundle
+#pragma unroll
+            for (int i = j; i < NDMA; i += 6) issue_piece(i, kt + 3, dma_stage, dma_on);
+        };
+        sc = mfma_h(k0h, ql[2], sc);
+        dma_slot(0);
+        PGMI_SLOT();
+        sc = mfma_h(k0l, qh[2], sc);
+        dma_slot(1);
+        PGMI_SLOT();
+        sm = mfma_h(k0h, qh[2], sm);
+        dma_slot(2);
+        PGMI_SLOT();
+        sc = mfma_h(k1h, ql[3], sc);
+        dma_slot(3);
+        PGMI_SLOT();
+        sc = mfma_h(k1l, qh[3], sc);
+        dma_slot(4);
+        PGMI_SLOT();
+        sm = mfma_h(k1h, qh[3], sm);
+        dma_slot(5);
 #undef PGMI_SLOT
     };
     auto closing_pv = [&](const u32x4* stage) {                      // P V of the last key tile
@@ -970,10 +999,10 @@ __global__ __launch_bounds__(WPB * 64, 2) void attention_f16x3_v3_kernel(
 #pragma unroll
         for (int s = 0; s < NS; ++s) {
             const int ci = r * KCPR + ((2 * s + kh) ^ ((r >> 1) & 7));
-            const u32x4 kfh = lds[ci], kfl = lds[KCH + ci], qh = qbase[ci], ql = qbase[KCH + ci];
-            sc = mfma_h(kfh, ql, s == 0 ? zero16 : sc);
-            sc = mfma_h(kfl, qh, sc);
-            sm = mfma_h(kfh, qh, s == 0 ? zero16 : sm);
+            const u32x4 kfh = lds[ci], kfl = lds[KCH + ci];
+            sc = mfma_h(kfh, ql[s], s == 0 ? zero16 : sc);
+            sc = mfma_h(kfl, qh[s], sc);
+            sm = mfma_h(kfh, qh[s], s == 0 ? zero16 : sm);
         }
     }
     auto wait_bundle = [&](int younger) {
@@ -986,16 +1015,19 @@ __global__ __launch_bounds__(WPB * 64, 2) void attention_f16x3_v3_kernel(
         wait_bundle(1);
         __builtin_amdgcn_s_barrier();              // bundle kt + 1 visible to all waves; the stage of bundle kt (read in step kt - 1) is free
         asm volatile("" ::: "memory");
-        if (kt + 3 <= last_bundle) issue_bundle(kt + 3, cur == 0 ? NSTG - 1 : cur - 1);
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // the tail: nothing newer will be issued, let the last bundles land
+    };
+    auto idle_dma = [&](int kt) {                                    // a wave without a query tile still moves its share of the bundles
+        issue_bundle(kt + 3, cur == 0 ? NSTG - 1 : cur - 1, kt + 3 <= last_bundle);
     };
     for (int kt = 0; kt < nkt - 1; ++kt) {
         step_head(kt);
-        if (active) step(T0{}, kt, lds + cur * STG_CH);
+        if (active) step(T0{}, kt, lds + cur * STG_CH, cur == 0 ? NSTG - 1 : cur - 1);
+        else idle_dma(kt);
         cur = (cur == NSTG - 1) ? 0 : cur + 1;
     }
     step_head(nkt - 1);                                              // the sequence's last key tile: masked by Tk
-    if (active) step(T1{}, nkt - 1, lds + cur * STG_CH);
+    if (active) step(T1{}, nkt - 1, lds + cur * STG_CH, cur == 0 ? NSTG - 1 : cur - 1);
+    else idle_dma(nkt - 1);
     cur = (cur == NSTG - 1) ? 0 : cur + 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();                  // bundle nkt + 1: the V^T tile of the last key tile
@@ -1050,10 +1082,13 @@ __global__ __launch_bounds__(WPB * 64, 2) void attention_f16x3_v3_kernel(
     }
 }
 
-static int g_att_v3 = -1;            // -1: by shape, 0: never, 1: wherever the kernel is defined
+// Launch option "att_v3": -1 (default) = by shape -- from seven query tiles per sequence on, where the interleaved A/B of scripts/att_bench.py
+// has it ahead (profiles/r6/att_ab_3_*: +4.5 % at T = 288, +9 % at T = 502 / 1024, +7 % at T = 739 with key masks; +-2 % below) --, 0 = never,
+// 1 = wherever the kernel is defined (dense, head_dim 64, no causal / ALiBi flavour).  Same bits either way.
+static int g_att_v3 = -1;
 static bool att_v3_serves(int T, const float* conv, const float* slopes, int head_dim) {
-    (void)T;
-    return g_att_v3 != 0 && !conv && !slopes && head_dim == 64;
+    if (g_att_v3 == 0 || conv || slopes || head_dim != 64) return false;
+    return g_att_v3 > 0 || (T + 31) / 32 >= 7;
 }
 
 template <int OUT, int NSTG>
@@ -1073,7 +1108,7 @@ static int launch_att16v2_mode(int wpb, dim3 grid, const unsigned short* qk16, s
 template <int WPB, int OUT>
 static void launch_att16v3_one(dim3 grid, const unsigned short* qk16, size_t qk_plane, const unsigned short* vt16, size_t vt_plane, const int32_t* kv_len,
                                int T, int H, int Tp, float* ctx, unsigned short* ctx16, hipStream_t s, int dense_nblk, int nseq) {
-    constexpr size_t lds_bytes = (size_t)3 * A_STAGE * 16 + (size_t)WPB * 8192;        // ring + one Q tile per wave: two 4-wave workgroups fill a CU's 160 KB
+    constexpr size_t lds_bytes = (size_t)3 * A_STAGE * 16;
     auto kfn = attention_f16x3_v3_kernel<WPB, OUT>;
     if (lds_bytes > 65536) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
     hipLaunchKernelGGL((attention_f16x3_v3_kernel<WPB, OUT>), grid, dim3(WPB * 64), lds_bytes, s, qk16, qk_plane, vt16, vt_plane, kv_len, T, H, Tp, ctx, ctx16,
