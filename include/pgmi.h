@@ -217,9 +217,11 @@ int pgmi_synchronize(pgmi_model* m);
 /* Test hooks of the GEMM launchers (bit-neutral: they only change how a launch is cut into work items / row chunks):
  * "gemm_half_tail" (0: no half-height tail items; default 1), "gemm_max_rows" (> 0: cut every launch into row chunks of at most
  * that many rows), "att_xcd_local" (1: the dense attention launches walk their blocks in the XCD-local order; 0: the (query block,
- * head, sequence) grid; -1, default: by shape -- same bits, for interleaved timing).  The library reads PGMI_GEMM_HALF_TAIL / PGMI_GEMM_MAX_ROWS
- * when a model is created (and at the model-less pgmi_op_* / pgmi_bench_* entries); this call changes them for a live model.
- * Process-wide; returns PGMI_EINVAL for another name. */
+ * head, sequence) grid; -1, default: by shape -- same bits, for interleaved timing), "att_v3" (dense head_dim-64 attention: -1, default:
+ * the software-pipelined kernel from seven query tiles per sequence on; 0: the round-3 kernel everywhere; 1: the pipelined kernel
+ * wherever it is defined -- same bits).  The library reads PGMI_GEMM_HALF_TAIL / PGMI_GEMM_MAX_ROWS when a model is created (and at the
+ * model-less pgmi_op_* / pgmi_bench_* entries) for the options nobody has set through this call: an explicit value stays in force until
+ * -1 hands "gemm_half_tail" / "gemm_max_rows" back to the environment.  Process-wide; returns PGMI_EINVAL for another name. */
 int pgmi_set_option(const char* name, int64_t value);
 
 /* ---- single ops (numerics tests compare each against the torch op it replaces) -------------

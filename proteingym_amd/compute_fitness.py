@@ -93,7 +93,12 @@ def label_row(row, sequence, token_probs, alphabet, offset_idx):
 
 def mutated_sequences(mutants, wt_sequence, offset_idx):
     """``get_mutated_sequence`` (compute_fitness.py:252-257) for a column of SINGLE substitutions ('A25G'): wild-type copies as one
-    byte matrix, one assignment.  A string that is not letter-integer-letter fails in ``int`` as in the reference."""
+    byte matrix, one assignment.  A string that is not letter-integer-letter fails in ``int`` as in the reference.  Rows whose index
+    falls BEFORE the sequence (a wrong --offset-idx: idx < 0) go through the reference's own expression
+    ``wt[:idx] + mt + wt[idx + 1:]`` one by one -- python's negative indexing makes that a string of a different length (2 L for
+    idx = -1), which the vectorised form cannot hold -- so malformed input gives the reference's output, not a silent in-place edit.
+    (Difference kept: the whole column is parsed and validated before anything is built, so with several bad rows the FIRST error
+    raised may be another row's than in the reference's row-by-row loop.)"""
     mutants = [str(m) for m in mutants]
     wt = np.frombuffer(wt_sequence.encode("ascii"), dtype=np.uint8)
     idx = np.array([int(m[1:-1]) for m in mutants], dtype=np.int64) - int(offset_idx)
@@ -104,7 +109,11 @@ def mutated_sequences(mutants, wt_sequence, offset_idx):
     out = np.tile(wt, (len(mutants), 1))
     out[np.arange(len(mutants)), idx] = np.frombuffer("".join(m[-1] for m in mutants).encode("ascii"), dtype=np.uint8)
     flat = out.tobytes().decode("ascii")
-    return [flat[i * len(wt):(i + 1) * len(wt)] for i in range(len(mutants))]
+    seqs = [flat[i * len(wt):(i + 1) * len(wt)] for i in range(len(mutants))]
+    for i in np.flatnonzero(idx < 0):                                  # the reference's expression, verbatim semantics
+        k = int(idx[i])
+        seqs[i] = wt_sequence[:k] + mutants[i][-1] + wt_sequence[(k + 1):]
+    return seqs
 
 
 def get_mutated_sequence(row, wt_sequence, offset_idx):

@@ -241,17 +241,28 @@ constexpr int kGroupM = 4, kGroupMWide = 8, kWideTilesN = 16;
 // Test hooks (bit-neutral: both only change how a launch is cut into items / row chunks).  Read from the environment when a model is
 // created and at the op-level entries (gemm_options_from_env), changed on a live model through pgmi_set_option -- never per launch.
 //   PGMI_GEMM_HALF_TAIL / "gemm_half_tail": 0 = no half-height tail items;  PGMI_GEMM_MAX_ROWS / "gemm_max_rows": force row chunks
-struct GemmOptions { int half_tail = 1; long long max_rows = 0; };
+// An option set through pgmi_set_option stays in force: creating another model or calling an op-level entry re-reads the environment
+// only for the options nobody has set explicitly (value -1 hands an option back to the environment / its default).  Process-wide and
+// not synchronised: they are test hooks, changed between launches by the thread that launches.
+struct GemmOptions { int half_tail = 1; long long max_rows = 0; bool half_tail_set = false, max_rows_set = false; };
 static GemmOptions g_opt;
 void gemm_options_from_env() {
     const char* h = getenv("PGMI_GEMM_HALF_TAIL");
     const char* r = getenv("PGMI_GEMM_MAX_ROWS");
-    g_opt.half_tail = h ? atoi(h) : 1;
-    g_opt.max_rows = r ? atoll(r) : 0;
+    if (!g_opt.half_tail_set) g_opt.half_tail = h ? atoi(h) : 1;
+    if (!g_opt.max_rows_set) g_opt.max_rows = r ? atoll(r) : 0;
 }
 int gemm_set_option(const char* name, long long value) {
-    if (!strcmp(name, "gemm_half_tail")) { g_opt.half_tail = (int)value; return PGMI_OK; }
-    if (!strcmp(name, "gemm_max_rows")) { g_opt.max_rows = value; return PGMI_OK; }
+    if (!strcmp(name, "gemm_half_tail")) {
+        g_opt.half_tail_set = value >= 0;
+        if (value >= 0) g_opt.half_tail = (int)value; else gemm_options_from_env();
+        return PGMI_OK;
+    }
+    if (!strcmp(name, "gemm_max_rows")) {
+        g_opt.max_rows_set = value >= 0;
+        if (value >= 0) g_opt.max_rows = value; else gemm_options_from_env();
+        return PGMI_OK;
+    }
     return PGMI_EINVAL;
 }
 

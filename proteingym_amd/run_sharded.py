@@ -125,6 +125,24 @@ def planned_rows(mapping, indices, data_folder, rank, world):
     return rows, readable
 
 
+def _close_retrieval(state):
+    """Takes a retrieval state's aligner (indel scoring with retrieval: three files per assay, a temporary folder when the alignment
+    folder is read-only) away explicitly when the state is replaced."""
+    aligner = state.get("aligner") if isinstance(state, dict) else None
+    if aligner is not None and hasattr(aligner, "close"):
+        aligner.close()
+
+
+def _lock_host() -> str:
+    """Host identity for the lock files: node name + the pid namespace (two containers on one node do not share pids)."""
+    import socket
+    try:
+        ns = os.readlink("/proc/self/ns/pid")
+    except OSError:
+        ns = ""
+    return f"{socket.gethostname()}/{ns}"
+
+
 def shared_retrieval(ptr, retrieval_args, cache_dir, tag, wait_s=1800.0):
     """``tranception.build_retrieval`` computed ONCE per assay across the ranks of a job: the chunks of a large assay land on
     several ranks, each of which would otherwise re-read the alignment (and recompute sequence weights when no weight file
@@ -147,14 +165,18 @@ def shared_retrieval(ptr, retrieval_args, cache_dir, tag, wait_s=1800.0):
                     weight=float(retrieval_args.get("retrieval_inference_weight", 0.6)))
 
     def builder_alive():
+        """The lock holds 'hostname:pid'.  A pid can only be probed from its own host (and pid namespace): a waiter on another
+        node -- or in another container -- sharing the output folder cannot tell, so it keeps polling until the prior, the
+        .failed note or ``wait_s`` arrives instead of declaring the builder dead and rebuilding beside it."""
         try:
-            pid = int(open(lock).read().strip() or 0)
+            host, _, pid = open(lock).read().strip().rpartition(":")
+            pid = int(pid or 0)
         except (OSError, ValueError):
-            return True                                   # lock just created, pid not written yet (or unreadable): keep waiting
-        if pid <= 0:
+            return True                                   # lock just created, not written yet (or unreadable): keep waiting
+        if pid <= 0 or host != _lock_host():
             return True
         try:
-            os.kill(pid, 0)                               # one node: the ranks share a pid namespace
+            os.kill(pid, 0)
         except ProcessLookupError:
             return False
         except OSError:
@@ -164,7 +186,7 @@ def shared_retrieval(ptr, retrieval_args, cache_dir, tag, wait_s=1800.0):
         return from_file()
     try:
         fd = os.open(lock, os.O_CREAT | os.O_EXCL | os.O_WRONLY)
-        os.write(fd, str(os.getpid()).encode())
+        os.write(fd, f"{_lock_host()}:{os.getpid()}".encode())
         os.close(fd)
         builder = True
     except FileExistsError:
@@ -307,6 +329,7 @@ def main_tranception_mutants(own, rest, mapping, indices, rank, local_rank, worl
             if model is None:                                # one checkpoint load per rank
                 model = make_model(base.checkpoint, local_rank, base.scoring_window) if make_model is not None else \
                     ptr.from_pretrained(base.checkpoint, device=local_rank, scoring_window=base.scoring_window)
+            _close_retrieval(getattr(model, "retrieval", None))  # the previous assay's aligner files, now (not when __del__ gets to it)
             if world > 1:                                    # an assay's chunks may sit on several ranks: one of them builds the prior
                 model.retrieval = shared_retrieval(ptr, cli.retrieval_arguments(args, wild_type, msa),
                                                    os.path.join(args.output_scores_folder, ".retrieval_prior_cache"), f"{job_tag}_{dms_id}")
@@ -323,6 +346,7 @@ def main_tranception_mutants(own, rest, mapping, indices, rank, local_rank, worl
             for j in js:
                 local[j] = np.full(3 * (items[j][2] - items[j][1]), np.nan)
     if model is not None:
+        _close_retrieval(getattr(model, "retrieval", None))
         model.close()
     dev = None
     bad = np.zeros(len(indices), dtype=np.int64)

@@ -312,13 +312,14 @@ class SequenceAligner:
             raise ValueError("indel scoring with retrieval re-aligns every sequence: --clustal_omega_location <executable> is required")
         self.executable = clustal_omega_location
         folder = os.path.join(os.path.dirname(MSA_filename) or ".", "Sampled")
+        self._own_folder = None                           # a temporary folder made here is removed with the files (close())
         try:                                              # the reference's place; a read-only alignment folder gets a temporary one
             os.makedirs(folder, exist_ok=True)
             if not os.access(folder, os.W_OK):
                 raise PermissionError(folder)
         except OSError:
             import tempfile
-            folder = tempfile.mkdtemp(prefix="pgmi_sampled_")
+            folder = self._own_folder = tempfile.mkdtemp(prefix="pgmi_sampled_")
         name, tag = os.path.basename(MSA_filename), str(uuid.uuid4())
         self.sampled, self.query, self.expanded = (os.path.join(folder, f"{kind}_{tag}_{name}") for kind in ("Sampled", "Seq_to_align", "Expanded"))
         records = process_msa_data(MSA_filename)
@@ -338,6 +339,12 @@ class SequenceAligner:
                 os.remove(path)
             except OSError:
                 pass
+        if getattr(self, "_own_folder", None):
+            try:
+                os.rmdir(self._own_folder)
+            except OSError:
+                pass
+            self._own_folder = None
 
     def __del__(self):
         try:
@@ -627,13 +634,13 @@ class TranceptionModel:
                 where.setdefault(int(k), int(row))
         out_ref = ref.copy()
         new_rows, new_src = [], []
-        for u, k in enumerate(uniq):
+        root_of_key = np.full(uniq.size, -1, dtype=np.int64)           # per paying key its root row; the members are re-pointed in ONE pass below
+        for u, k in enumerate(uniq):                                    # (thousands of keys at most: no per-key scan of the multi-mutants)
             k = int(k)
             f = (k // 64) % T
             cost = f if k in where else T
             if saved[u] <= cost:
                 continue
-            rows = multi[inverse == u]
             if k in where:
                 root = where[k]
                 out_ref[root] = root                                    # forwarded in full from now on
@@ -644,7 +651,9 @@ class TranceptionModel:
                 seq[f] = k % 64
                 new_rows.append(seq)
                 new_src.append(wt_row)
-            out_ref[rows] = root
+            root_of_key[u] = root
+        pays = root_of_key[inverse] >= 0
+        out_ref[multi[pays]] = root_of_key[inverse[pays]]
         if not new_rows and (out_ref == ref).all():
             return ids, ref_local, 0
         ids_c = np.ascontiguousarray(np.concatenate([ids, np.stack(new_rows)]) if new_rows else ids, dtype=np.int32)

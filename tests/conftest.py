@@ -39,5 +39,5 @@ def gemm_option(lib):
         from proteingym_amd import _lib
         _lib.check(lib.pgmi_set_option(name.encode(), int(value)))
     yield set_
-    lib.pgmi_set_option(b"gemm_half_tail", 1)
-    lib.pgmi_set_option(b"gemm_max_rows", 0)
+    lib.pgmi_set_option(b"gemm_half_tail", -1)           # -1: back to the environment / the default (an explicit value outlives model creation)
+    lib.pgmi_set_option(b"gemm_max_rows", -1)

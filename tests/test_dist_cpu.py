@@ -364,7 +364,7 @@ def test_retrieval_waiter_takes_over_from_a_dead_builder(tmp_path):
     dead = mp.get_context("spawn").Process(target=int)
     dead.start()
     dead.join()
-    open(os.path.join(cache, "job_T2.lock"), "w").write(str(dead.pid))
+    open(os.path.join(cache, "job_T2.lock"), "w").write(f"{run_sharded._lock_host()}:{dead.pid}")
 
     class P:
         @staticmethod
@@ -373,6 +373,12 @@ def test_retrieval_waiter_takes_over_from_a_dead_builder(tmp_path):
     t0 = time.time()
     out = run_sharded.shared_retrieval(P, dict(MSA_start=1, MSA_end=3), cache, "job_T2", wait_s=600.0)
     assert time.time() - t0 < 30.0 and out["log_prior"].shape == (2, 3)
+    # a builder on ANOTHER host (or in another pid namespace) cannot be probed: the same pid number there says nothing here, so the
+    # waiter keeps polling for the prior (here: until its wait_s is over) instead of rebuilding beside a live builder at once
+    open(os.path.join(cache, "job_T3.lock"), "w").write(f"some-other-node/pid:[1]:{dead.pid}")
+    t0 = time.time()
+    out = run_sharded.shared_retrieval(P, dict(MSA_start=1, MSA_end=3), cache, "job_T3", wait_s=1.5)
+    assert 1.4 < time.time() - t0 < 30.0 and out["log_prior"].shape == (2, 3)
 
 
 def test_tranception_chunk_plan_balances_the_real_table():

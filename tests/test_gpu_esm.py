@@ -304,11 +304,16 @@ def test_esm2_15b_width_vs_oracle(lib):
     scores, table = a.run(want_table=True)
     positions = sorted(int(p) for p in a.positions)[:24]
     import torch
-    tabs = {}
-    for dt in (torch.float32, torch.float64):
-        ocfg, W = eo.from_arrays(arrays=synthetic.blob_to_arrays(cfg, blob), dtype=dt, **cfg)
-        tabs[dt] = eo.masked_marginals_table(ocfg, W, seq, positions=positions, batch=8)
-    t32, t64 = tabs[torch.float32], tabs[torch.float64]
+    import frozen
+
+    def compute():
+        tabs = {}
+        for tag, dt in (("t32", torch.float32), ("t64", torch.float64)):
+            ocfg, W = eo.from_arrays(arrays=synthetic.blob_to_arrays(cfg, blob), dtype=dt, **cfg)
+            tabs[tag] = eo.masked_marginals_table(ocfg, W, seq, positions=positions, batch=8)
+        return tabs
+    fz = frozen.cached("esm2_15b_width_2_layers", ["ESM2_15B", 2, 15, 0.075, seq, positions, blob], compute)     # (tests/frozen.py)
+    t32, t64 = fz["t32"], fz["t64"]
     noise = float(np.abs(t32[positions] - t64[positions]).max())          # the reference arithmetic's own distance to exact
     err64 = float(np.abs(table[positions] - t64[positions]).max())
     err32 = float(np.abs(table[positions] - t32[positions]).max())

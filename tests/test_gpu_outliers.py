@@ -21,10 +21,15 @@ L = 48
 def _oracle(cfg, blob, seq, positions, dtype=None):
     import torch
     from oracle import esm_oracle as eo
-    torch.set_num_threads(max(1, __import__("bench").usable_cores()))
-    kw = {} if dtype is None else {"dtype": dtype}
-    ocfg, W = eo.from_arrays(arrays=synthetic.blob_to_arrays(cfg, blob), **cfg, **kw)
-    return eo.masked_marginals_table(ocfg, W, seq, positions=list(positions), batch=16)
+    import frozen
+
+    def compute():
+        torch.set_num_threads(max(1, __import__("bench").usable_cores()))
+        kw = {} if dtype is None else {"dtype": dtype}
+        ocfg, W = eo.from_arrays(arrays=synthetic.blob_to_arrays(cfg, blob), **cfg, **kw)
+        return {"table": eo.masked_marginals_table(ocfg, W, seq, positions=list(positions), batch=16)}
+    fp = frozen.fingerprint([sorted(cfg.items()), seq, list(positions), str(dtype), blob]).hex()[:16]
+    return frozen.cached(f"outliers_{cfg['layers']}_layers_{fp}", [sorted(cfg.items()), seq, list(positions), str(dtype), blob], compute)["table"]
 
 
 @pytest.fixture(scope="module")

@@ -16,6 +16,8 @@ import pytest
 
 from proteingym_amd import esm as pesm, synthetic
 
+import frozen
+
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 L_BLAT = 286
@@ -43,9 +45,13 @@ def _oracle_table(name, embed_std, seed, seq, positions, batch):
     if key not in _ORACLE:
         _ORACLE.clear()
         cfg, blob = _weights(name, embed_std, seed)
-        torch.set_num_threads(max(1, __import__("bench").usable_cores()))
-        ocfg, W = eo.from_arrays(arrays=synthetic.blob_to_arrays(cfg, blob), **cfg)
-        _ORACLE[key] = eo.masked_marginals_table(ocfg, W, seq, positions=list(positions), batch=batch)
+
+        def compute():
+            torch.set_num_threads(max(1, __import__("bench").usable_cores()))
+            ocfg, W = eo.from_arrays(arrays=synthetic.blob_to_arrays(cfg, blob), **cfg)
+            return {"table": eo.masked_marginals_table(ocfg, W, seq, positions=list(positions), batch=batch)}
+        # (tests/frozen.py: the oracle's rows are a function of fixed seeds; the stored copy is used while everything still hashes the same)
+        _ORACLE[key] = frozen.cached(f"baseline_{name}_std{embed_std}_seed{seed}", [name, embed_std, seed, seq, list(positions), batch, blob], compute)["table"]
     return _ORACLE[key]
 
 

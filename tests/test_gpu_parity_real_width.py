@@ -22,6 +22,8 @@ import pytest
 
 from proteingym_amd import esm as pesm, synthetic
 
+import frozen  # noqa: E402  (tests/frozen.py)
+
 pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
@@ -70,9 +72,12 @@ def _long_case():
     muts.append(":".join(sub(p) for p in (510, 588)))
     positions = sorted(p + 1 for p in residues)
     cfg, blob = _blob("ESM1V_650M", 1, 0.15)
-    _threads()
-    ocfg, W = eo.from_arrays(arrays=synthetic.blob_to_arrays(cfg, blob), **cfg)
-    ref = eo.masked_marginals_table(ocfg, W, seq, positions=positions, batch=4)
+
+    def compute():
+        _threads()
+        ocfg, W = eo.from_arrays(arrays=synthetic.blob_to_arrays(cfg, blob), **cfg)
+        return {"table": eo.masked_marginals_table(ocfg, W, seq, positions=positions, batch=4)}
+    ref = frozen.cached("real_width_esm1v_650m_L1100_windows", ["ESM1V_650M", 1, 0.15, seq, positions, blob], compute)["table"]
     _LONG.update(seq=seq, muts=muts, positions=positions, ref=ref)
     return seq, muts, positions, ref
 
@@ -166,11 +171,15 @@ def test_tranception_l_full_context_vs_oracle(lib):
     seqs = [full, full[::-1]]                                              # the scorer's two reading directions
     ids, mask = to.encode_batch(seqs)
     assert ids.shape == (2, 1024)
-    with torch.no_grad():
-        ref = torch.log_softmax(to.forward_logits(ocfg, W, ids, mask), -1).numpy()
-        W64 = {k: v.double() for k, v in W.items()}
-        ref64 = torch.log_softmax(to.forward_logits(ocfg, W64, ids, mask), -1).numpy()
-        del W64
+
+    def compute_ctx():
+        with torch.no_grad():
+            r32 = torch.log_softmax(to.forward_logits(ocfg, W, ids, mask), -1).numpy()
+            W64 = {k: v.double() for k, v in W.items()}
+            r64 = torch.log_softmax(to.forward_logits(ocfg, W64, ids, mask), -1).numpy()
+        return {"ref": r32, "ref64": r64}
+    fz = frozen.cached("real_width_tranception_l_n_ctx_1024", ["TRANCEPTION_L", 3, seqs, np.asarray(ids), blob], compute_ctx)
+    ref, ref64 = fz["ref"], fz["ref64"]
     got = model.token_logprobs(ids)
     noise = float(np.abs(ref - ref64).max())
     err64 = float(np.abs(got - ref64).max())
@@ -196,12 +205,17 @@ def test_tranception_l_full_context_vs_oracle(lib):
     for p in (3, 511, 700, 1096):
         muts.append(f"{wt[p]}{p + 1}{'A' if wt[p] != 'A' else 'C'}")
     df = pd.DataFrame({"mutant": muts, "mutated_sequence": [ptr.get_mutated_sequence(wt, m) for m in muts]})   # as the real DMS files
-    with torch.no_grad():
-        want = to.score_mutants(ocfg, W, df, wt)
+    cols = ("avg_score_L_to_R", "avg_score_R_to_L", "avg_score")
+
+    def compute_scores():
+        with torch.no_grad():
+            w = to.score_mutants(ocfg, W, df, wt)
+        return {"mutated_sequence": np.array(list(w["mutated_sequence"])), **{c: w[c].to_numpy() for c in cols}}
+    want = frozen.cached("real_width_tranception_l_L1100_scores", ["TRANCEPTION_L", 3, wt, muts, blob], compute_scores)
     have = model.score_mutants(DMS_data=df, target_seq=wt)
-    assert list(have["mutated_sequence"]) == list(want["mutated_sequence"])
-    for col in ("avg_score_L_to_R", "avg_score_R_to_L", "avg_score"):
-        e = float(np.abs(have[col].to_numpy() - want[col].to_numpy()).max())
+    assert list(have["mutated_sequence"]) == [str(x) for x in want["mutated_sequence"]]
+    for col in cols:
+        e = float(np.abs(have[col].to_numpy() - want[col]).max())
         print(f"Tranception-L, L=1100 optimal windows: {col} max|err| {e:.2e}")
         assert e < TOL
     model.close()
@@ -226,7 +240,8 @@ def test_esm2_15b_width_8_layers_vs_oracle(lib):
     import torch
     from oracle import esm_oracle as eo
     layers = int(os.environ.get("PGMI_TEST_15B_LAYERS", "8"))
-    need = 3.3 * layers + 8                                              # blob + fp32 oracle (shares memory) + fp64 copy
+    need = 1.3 * layers + 4 if os.path.exists(os.path.join(frozen.FROZEN_DIR, f"real_width_esm2_15b_{layers}_layers.npz")) \
+        else 3.3 * layers + 8                                            # blob (+ fp32 oracle, which shares its memory, + fp64 copy when the oracle runs live)
     if _avail_gb() < need:
         pytest.skip(f"needs ~{need:.0f} GB of host memory for the fp64 oracle")
     _threads()
@@ -238,12 +253,16 @@ def test_esm2_15b_width_8_layers_vs_oracle(lib):
     a.close()
     m.close()
     positions = sorted(int(p) for p in a.positions)[:12]
-    tabs = {}
-    for dt in (torch.float64, torch.float32):
-        ocfg, W = eo.from_arrays(arrays=synthetic.blob_to_arrays(cfg, blob), dtype=dt, **cfg)
-        tabs[dt] = eo.masked_marginals_table(ocfg, W, seq, positions=positions, batch=6)
-        del W
-    t32, t64 = tabs[torch.float32], tabs[torch.float64]
+
+    def compute():
+        tabs = {}
+        for tag, dt in (("t64", torch.float64), ("t32", torch.float32)):
+            ocfg, W = eo.from_arrays(arrays=synthetic.blob_to_arrays(cfg, blob), dtype=dt, **cfg)
+            tabs[tag] = eo.masked_marginals_table(ocfg, W, seq, positions=positions, batch=6)
+            del W
+        return tabs
+    fz = frozen.cached(f"real_width_esm2_15b_{layers}_layers", ["ESM2_15B", 15, 0.075, layers, seq, positions, blob], compute)
+    t32, t64 = fz["t32"], fz["t64"]
     noise = float(np.abs(t32[positions] - t64[positions]).max())
     err64 = float(np.abs(table[positions] - t64[positions]).max())
     err32 = float(np.abs(table[positions] - t32[positions]).max())
