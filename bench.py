@@ -480,8 +480,53 @@ def secondary(precision, budget_note="bounded: every leg is a few seconds of GPU
                     "alignment (weights by the HIP pair-count kernel, prior fused on the device)"}
         mt.close()
 
+    def leg_tranception_217_projection():
+        # (6) config 4 AT WORKLOAD SCALE: one synthetic assay per protein-length bin of the 217-assay table (real length, single and
+        #     multi-mutant rows scored separately, both directions, prefix-shared) -> seconds per unit of the product planner's cost ->
+        #     every row of the real table (scripts/bench_projection.py)
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import bench_projection as bp
+        from proteingym_amd import tranception as ptr
+        cfgt = dict(synthetic.TRANCEPTION_L)
+        mt = ptr.TranceptionModel(cfgt, synthetic.random_tranception_weights(cfgt, seed=3), device=0)
+        shapes = synthetic.dms_shapes()
+        t0 = time.perf_counter()
+        unit, detail = bp.measure_tranception(mt, bp.tranception_sample(shapes), ptr)
+        measured_s = time.perf_counter() - t0
+        mt.close()
+        proj = bp.project_tranception(shapes, unit)
+        ref_pflop = sum(bp.tranception_flops(s["seq_len"], s["n_total"]) for s in shapes) / 1e15
+        out["tranception_217_projection"] = {
+            **proj, "reference_loop_algorithmic_pflop": ref_pflop, "reference_loop_tflops_1_gpu": ref_pflop * 1e3 / proj["seconds_1_gpu"],
+            "hours_1_gpu": proj["seconds_1_gpu"] / 3600.0, "minutes_8_gpus_planned": proj["seconds_8_gpus_planned"] / 60.0,
+            "sample": detail, "sample_seconds": round(measured_s, 1),
+            "what": "PROJECTION of config 4 (Tranception-L, the 217-assay substitution table, 2 465 767 mutants, both directions, no retrieval: "
+                    "the prior fusion is one elementwise pass) from a stratified sample: per protein-length bin the assay carrying most of the "
+                    "bin's planned cost, <= 384 single and <= 384 multi-mutant rows (depth 2-5) scored separately with the product's defaults "
+                    "(prefix sharing + intermediate roots); seconds per unit of run_sharded.chunk_cost applied to every row of the table; N = 8 "
+                    "through run_sharded.plan_mutant_chunks.  Model resident, no file I/O; SURVEY 8f estimated ~2 700 PFLOP for the reference's loop"}
+
+    def leg_indels_projection():
+        # (7) config 5 AT WORKLOAD SCALE: masked forwards per second of ESM2-650M pseudo-ppl libraries at the cost-weighted quantiles of
+        #     the 66-assay indel table's lengths -> seconds per forward (interpolated in FLOPs per forward) -> the whole table
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import bench_projection as bp
+        cfg5 = dict(synthetic.ESM2_650M)
+        m5 = pesm.EsmModel(cfg5, synthetic.random_weights(cfg5, seed=5), device=0, precision=precision)
+        shapes = synthetic.indel_shapes()
+        t0 = time.perf_counter()
+        spf, detail = bp.measure_indels(m5, bp.indel_sample_lengths(shapes), pesm)
+        measured_s = time.perf_counter() - t0
+        m5.close()
+        proj = bp.project_indels(shapes, spf)
+        out["indels_projection"] = {
+            **proj, "algorithmic_tflops_1_gpu": proj["algorithmic_pflop"] * 1e3 / proj["seconds_1_gpu"], "sample": detail, "sample_seconds": round(measured_s, 1),
+            "what": "PROJECTION of config 5 (ESM2-650M pseudo-ppl over the 66 indel assays, 287 207 mutants, one masked forward per (mutant, residue)) "
+                    "from measured forwards per second at the table's cost-weighted length quantiles, interpolated in FLOPs per forward; N = 8 through "
+                    "run_indels.partition_pool (pooled sequences, LPT).  Model resident, no file I/O; SURVEY 8f estimated ~2e5 PFLOP"}
+
     only = [x for x in os.environ.get("PGMI_BENCH_LEGS", "").split(",") if x]
-    for fn in (leg_bf16, leg_ensemble, leg_benchmark_217, leg_esm2_3b, leg_pseudo_ppl, leg_tranception):
+    for fn in (leg_bf16, leg_ensemble, leg_benchmark_217, leg_esm2_3b, leg_pseudo_ppl, leg_tranception, leg_tranception_217_projection, leg_indels_projection):
         if only and fn.__name__[4:] not in only:
             continue
         t0 = time.perf_counter()

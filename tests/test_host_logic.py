@@ -588,3 +588,40 @@ def test_pgmi_score_mutants_is_label_rows_arithmetic_on_the_host():
     bad[3] = len(seq) + 2
     with pytest.raises(_lib.PgmiError, match="reads table"):
         pesm.score_parsed(table, bad, sub_wt, sub_mt, mut_off)
+
+
+def test_workload_scale_projections_of_configs_4_and_5():
+    """bench.py's secondary.tranception_217_projection / indels_projection (scripts/bench_projection.py): the planning arithmetic on
+    the real tables -- the sample covers every protein-length bin, the projection conserves mutants and seconds, scales linearly in the
+    measured unit costs, reproduces SURVEY 8f's totals (~2 700 PFLOP for config 4's reference loop, 1.95e8 masked forwards / ~2e5 PFLOP
+    for config 5), and the N = 8 figures come from the product planners (max/mean close to 1)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts"))
+    import bench_projection as bp
+    from proteingym_amd import synthetic
+    shapes = synthetic.dms_shapes()
+    sample = bp.tranception_sample(shapes)
+    assert [e["bin"] for e in sample] == list(range(len(bp.LENGTH_BINS)))
+    assert all(bp.bin_of(e["seq_len"]) == e["bin"] and 1 <= e["singles"] <= 384 for e in sample)
+    assert sample[-1]["multis"] == 0 and all(e["multis"] == 384 for e in sample[:4])          # no multi-mutants beyond the 1 022-residue context
+    unit = {(e["bin"], kind): 2e-9 * (1 + e["bin"]) * (0.5 if kind == "multi" else 1.0) for e in sample for kind in ("single", "multi")}
+    p = bp.project_tranception(shapes, unit)
+    assert p["mutants"] == 2465767 and sum(b["mutants"] for b in p["by_length_bin"].values()) == 2465767
+    assert abs(sum(b["seconds"] for b in p["by_length_bin"].values()) - p["seconds_1_gpu"]) < 1e-9 * p["seconds_1_gpu"]
+    assert p["seconds_1_gpu"] / 8 <= p["seconds_8_gpus_planned"] < 1.1 * p["seconds_1_gpu"] / 8
+    assert 1.0 <= p["planned_load_max_over_mean_8_gpus"] < 1.1
+    p2 = bp.project_tranception(shapes, {k: 3 * v for k, v in unit.items()})
+    assert abs(p2["seconds_1_gpu"] - 3 * p["seconds_1_gpu"]) < 1e-9 * p2["seconds_1_gpu"]
+    pflop = sum(bp.tranception_flops(s["seq_len"], s["n_total"]) for s in shapes) / 1e15
+    assert 2500 < pflop < 3000                                                                  # SURVEY 8f: ~2 700 PFLOP
+    ish = synthetic.indel_shapes()
+    fw, fl = bp.indel_forwards(ish)
+    assert len(ish) == 66 and sum(s["n_total"] for s in ish) == 287207 and 1.9e8 < fw < 2.0e8 and 1.8e20 < fl < 2.2e20
+    Ls = bp.indel_sample_lengths(ish)
+    assert Ls[0] == min(s["seq_len"] for s in ish) and Ls[-1] == max(s["seq_len"] for s in ish) and 735 in Ls and len(Ls) >= 4
+    q = bp.project_indels(ish, {L: 2.0e-6 * (L + 2) for L in Ls})
+    assert q["masked_forwards"] == fw and q["largest_assay"]["DMS_id"].startswith("CAPSD_AAV2S") and q["largest_assay"]["share_of_seconds"] > 0.8
+    assert q["seconds_1_gpu"] / 8 <= q["seconds_8_gpus_planned"] < 1.01 * q["seconds_1_gpu"] / 8
+    exact = sum(max(0, s["seq_len"] - 2) * s["n_total"] * 2.0e-6 * (s["seq_len"] + 2) for s in ish)
+    assert abs(q["seconds_1_gpu"] - exact) < 0.2 * exact                                         # interpolation in FLOPs per forward between the sampled lengths
