@@ -17,11 +17,11 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libpgmi.so")
 BUILD = os.path.join(HERE, "csrc", "_build")
-SOURCES = ["api.hip", "elementwise.hip", "gemm_f32.hip", "gemm_f16.hip", "attention_f32.hip", "attention_f16.hip", "msa_weights.hip", "msa_transformer.hip"]
+SOURCES = ["api_model.hip", "api_esm.hip", "api_tranception.hip", "api_msa.hip", "api_host.hip", "api_ops.hip", "elementwise.hip", "gemm_f32.hip", "gemm_f16.hip", "attention_f32.hip", "attention_f16.hip", "attention_f16_v3.hip", "attention_f16_prep.hip", "msa_weights.hip", "msa_transformer.hip"]
 # attention_f16.hip: keep the MFMA accumulators in ArchVGPRs.  hipcc put the running O / S accumulators into AGPRs and then
 # paid 64 v_accvgpr_read + 64 v_accvgpr_write around every online-softmax rescale and around the S -> P conversion (VALU work
 # on accumulator data); the kernel fits 184 VGPRs at the same occupancy without them.
-EXTRA_FLAGS = {"attention_f16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+EXTRA_FLAGS = {"attention_f16.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "attention_f16_v3.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-value", "-Wno-unused-result"]
 
 

@@ -268,7 +268,7 @@ __global__ void rotary_kernel(float* __restrict__ qkv, const float* __restrict__
     const int t = (int)(row % T);
     float* p = qkv + row * (size_t)(3 * H * 64) + (size_t)which * H * 64 + h * 64 + d;
     const float x1 = p[0], x2 = p[32];
-    const int tr = (t * rh + (h % rh)) * 64;  // table row: one per token, or per (token, slot-group parity) for head_dim 128 (api.hip ensure_rotary)
+    const int tr = (t * rh + (h % rh)) * 64;  // table row: one per token, or per (token, slot-group parity) for head_dim 128 (api_esm.hip ensure_rotary)
     const float c1 = cos_t[tr + d], s1 = sin_t[tr + d];
     const float c2 = cos_t[tr + d + 32], s2 = sin_t[tr + d + 32];
     p[0] = x1 * c1 + (-x2) * s1;             // x*cos + rotate_half(x)*sin, first half: -x2

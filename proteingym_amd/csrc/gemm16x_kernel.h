@@ -357,7 +357,7 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
                 const int bb = m / qo.T, t = m - bb * qo.T;
                 // ESM2: the row's rotary table entries for all four column groups, loaded TOGETHER before the group loop (loads inside it
                 // were waited for one group at a time, and the wait -- vmcnt counts stores too -- included the V^T stores just issued)
-                // (a table row holds every angle twice: slots i and 32 + i are the pair (j, j + dh / 2) of one frequency -- api.hip ensure_rotary)
+                // (a table row holds every angle twice: slots i and 32 + i are the pair (j, j + dh / 2) of one frequency -- api_esm.hip ensure_rotary)
                 f32x4 rc[4], rs[4];
                 if (which < 2 && qo.rotary) {
                     const int tr = (min(t, qo.T - 1) * qo.rot_halves + (hh % qo.rot_halves)) * 64;

@@ -3,7 +3,7 @@
 Reference (under /root/reference/proteingym/baselines/esm unless noted):
   * checkpoint loading, row/column key swap        esm/pretrained.py:107-121,184-218
   * "msa_transformer" alphabet, MSABatchConverter  esm/data.py:158-164,300-334
-  * MSATransformer.forward                         esm/model/msa_transformer.py:146-205  (device: run_msa, api.hip)
+  * MSATransformer.forward                         esm/model/msa_transformer.py:146-205  (device: run_msa, csrc/api_msa.hip)
   * sample_msa / process_msa                       compute_fitness.py:26-98
   * masked-marginals over the first row            compute_fitness.py:380-399
   * MSA_processing (EVE pre-processing + weights)  proteingym/utils/msa_utils.py:24-258
