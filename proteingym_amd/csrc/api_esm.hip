@@ -74,23 +74,30 @@ int run_encoder(pgmi_model* m, int B, int T, const int32_t* keep, int n_keep, bo
         { ProfScope p(m, PGMI_K_LAYERNORM, 0, ln_bytes);
           if (prec == PGMI_PREC_FP32) launch_layernorm(m->x, L.ln1_w, L.ln1_b, M, D, 1e-5f, m->h, s);
           else launch_layernorm16(m->x, L.ln1_w, L.ln1_b, M, D, 1e-5f, m->h16, m->h16_plane, mode16, s); }
-        const bool fused_qkv = prec == PGMI_PREC_F16X3;          // attention operands straight from the QKV projection's epilogue
+        // attention operands straight from the QKV projection's epilogue -- in the bf16 mode too (round 6): the epilogue splits the fp32
+        // accumulators whatever the GEMM's operand type was, so that mode's attention runs on the 16-bit pipe as well
+        const bool fused_qkv = prec != PGMI_PREC_FP32;
         { ProfScope p(m, PGMI_K_GEMM_QKV, 2.0 * M * 3 * D * D, 0);
           if (fused_qkv)
               rc = launch_gemm16_qkv(m->h16, m->h16_plane, L.wqkv16.p, L.wqkv16.plane, L.bqkv, M, Da, D, L.wqkv16.out_scale,
                                      m->qk16, m->qk16_plane, m->vt16, m->vt16_plane, m->rot_cos, m->rot_sin,
-                                     c.arch == PGMI_ARCH_ESM2, T, m->Hs, m->gemm_variant, s, m->rot_halves);
+                                     c.arch == PGMI_ARCH_ESM2, T, m->Hs, m->gemm_variant, s, m->rot_halves, prec == PGMI_PREC_BF16);
           else
               rc = linear(m, m->h, m->h16, m->h16_plane, L.wqkv, L.wqkv16, L.bqkv, nullptr, m->qkv, nullptr, 0, M, 3 * Da, D, EPI_NONE);
           if (rc) return rc; }
         { ProfScope p(m, PGMI_K_ATTENTION, 4.0 * M * T * D, 0);
-          const bool v2 = prec == PGMI_PREC_F16X3;
+          const bool v2 = prec != PGMI_PREC_FP32;
           if (c.arch == PGMI_ARCH_ESM2 && !v2) launch_rotary(m->qkv, m->rot_cos, m->rot_sin, M, T, m->Hs, s, m->rot_halves);
-          if (v2)
+          if (prec == PGMI_PREC_F16X3)
               rc = launch_attention_f16x3_v2(fused_qkv ? nullptr : m->qkv, m->kv_len, m->rot_cos, m->rot_sin, c.arch == PGMI_ARCH_ESM2, B, T, H,
                                              m->qk16, m->qk16_plane, m->vt16, m->vt16_plane, nullptr, m->h16,
                                              m->h16_plane, 1, s, nullptr, nullptr, m->rot_halves * kHeadDim);
-          else
+          else if (v2) {       // bf16 mode: fp32 context rows (m->qkv is free: the projection went straight to the operand planes), then one bf16 plane
+              rc = launch_attention_f16x3_v2(nullptr, m->kv_len, m->rot_cos, m->rot_sin, c.arch == PGMI_ARCH_ESM2, B, T, H,
+                                             m->qk16, m->qk16_plane, m->vt16, m->vt16_plane, m->qkv, nullptr, 0, 0, s, nullptr, nullptr,
+                                             m->rot_halves * kHeadDim);
+              if (!rc) launch_split16(m->qkv, (int64_t)M * Da, 1.0f, 1, Da, m->h16, s);
+          } else
               rc = launch_attention_f32(m->qkv, m->kv_len, B, T, H, m->h, m->h16, m->h16_plane,
                                         prec == PGMI_PREC_FP32 ? 0 : mode16, s, m->rot_halves * kHeadDim);
           if (rc) return rc; }

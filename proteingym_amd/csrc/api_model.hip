@@ -291,7 +291,7 @@ int pgmi_model_create(const pgmi_config* cfg, const float* w, int64_t n_weights,
     }
     TRY(dev_alloc(m->allocs, &m->nonfinite, (size_t)1));
     PGMI_HIP(hipMemset(m->nonfinite, 0, 4));
-    if (cfg->precision == PGMI_PREC_F16X3) {
+    if (cfg->precision != PGMI_PREC_FP32) {              // (bf16 mode: its attention runs on the split-fp16 operands as well)
         m->qk16_plane = R * 2 * Da;
         m->vt16_plane = R * Da;
         TRY(dev_alloc(m->allocs, &m->qk16, m->qk16_plane * 2));

@@ -46,7 +46,11 @@ int pgmi_op_gemm(int device, int precision, const float* A, const float* W, cons
     // planes rebuilt as fp32 (tests: a row's bits through the half- and full-height items)
     const int epi = epilogue & 255;
     const bool split_planes = (epilogue & 256) != 0;
-    if (split_planes && (precision != PGMI_PREC_F16X3 || residual || (N % 32))) { for (void* p : pool) hipFree(p); set_error("split-plane GEMM op: f16x3, no residual, N %% 32 == 0"); return PGMI_EINVAL; }
+    if (split_planes && (precision == PGMI_PREC_FP32 || residual || (N % (precision == PGMI_PREC_F16X3 ? 32 : 4)))) {
+        for (void* p : pool) hipFree(p);
+        set_error("16-bit-plane GEMM op: f16x3 (N %% 32 == 0) or bf16 (N %% 4 == 0), no residual");
+        return PGMI_EINVAL;
+    }
     if (precision == PGMI_PREC_FP32) {
         rc = launch_gemm_f32(dA, dW, dB, dR, dC, M, N, K, epi, nullptr);
     } else {
@@ -68,7 +72,12 @@ int pgmi_op_gemm(int device, int precision, const float* A, const float* W, cons
                     std::vector<unsigned short> h((size_t)M * N * 2);
                     hipError_t e2 = hipMemcpy(h.data(), c16, h.size() * 2, hipMemcpyDeviceToHost);
                     if (e2 != hipSuccess) { set_error("gemm op failed: %s", hipGetErrorString(e2)); rc = PGMI_EHIP; }
-                    for (size_t m = 0; m < (size_t)M && !rc; ++m)
+                    for (size_t m = 0; m < (size_t)M && !rc && bf; ++m)           // bf16 plane, row-major
+                        for (int n = 0; n < N; ++n) {
+                            const unsigned int u = (unsigned int)h[m * N + n] << 16;
+                            memcpy(&C[m * N + n], &u, 4);
+                        }
+                    for (size_t m = 0; m < (size_t)M && !rc && !bf; ++m)
                         for (int n = 0; n < N; ++n) {
                             const size_t o = ki_off(m, n, N);
                             _Float16 hi, lo;

@@ -129,7 +129,7 @@ int launch_gemm16(const unsigned short* A, size_t a_plane, const unsigned short*
 int launch_gemm16_qkv(const unsigned short* A, size_t a_plane, const unsigned short* W, size_t w_plane,
                       const float* bias, int M, int D, int K, float out_scale, unsigned short* qk16, size_t qk_plane,
                       unsigned short* vt16, size_t vt_plane, const float* cos_t, const float* sin_t, int rotary,
-                      int T, int H, int variant, hipStream_t s, int rot_halves = 1);
+                      int T, int H, int variant, hipStream_t s, int rot_halves = 1, bool bf = false);
 struct XMap;                                       // gemm16x_kernel.h: batched / strided operand and output maps
 int launch_gemm16_ex(const unsigned short* A, const unsigned short* W, float* Cf, unsigned short* Ch, int M, int N, int K,
                      float out_scale, XMap xm, int nbatch, hipStream_t s);

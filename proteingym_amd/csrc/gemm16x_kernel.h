@@ -128,11 +128,16 @@ __device__ __forceinline__ void x_tile_coords(int wgid, int tiles_m, int tiles_n
 
 // OUT 0: fp32 [M,N] (+ residual); 1: split fp16 planes, K-interleaved (the next GEMM's operand); 2: attention operands (QkvOut).
 // XM: the batched / strided form (XMap); false = dense operands, one batch: xm is ignored (and costs nothing).
-template <int EPI, int OUT, bool XM = false>
+// BF (round 6, the un-gated bf16 throughput mode): operands are ONE bf16 plane, row-major [rows][K].  A K tile is then 64 deep -- the same 128
+// bytes per row and tile, so staging, LDS image and fragment reads are unchanged -- and a compute phase issues 16 MFMAs (k16 steps ks and
+// 2 + ks of the tile: the chunks the f16x3 form reads as the hi and the lo half of one step) instead of the 24 of the three split products.
+template <int EPI, int OUT, bool XM = false, bool BF = false>
 __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
     const unsigned short* __restrict__ A, const unsigned short* __restrict__ W, const float* __restrict__ bias,
     const float* residual, float* Cf, unsigned short* Ch, size_t c_plane, int M, int N, int K, float out_scale,
     TilePlan tp, QkvOut qo, XMap xm_arg) {
+    static_assert(!(XM && BF), "the batched / strided form is f16x3 only");
+    constexpr unsigned int EB = BF ? 2u : 4u;                     // operand bytes per k element: one bf16, or the hi and the lo half
     const XMap xm = XM ? xm_arg : XMap{};                         // dense instantiations: every xm test below folds away
     constexpr int WN = 4, TMX = 4, TN = 2, LD = 4;               // TMX: 32-row MFMA tiles per wave of a full item (a half item: 2)
     extern __shared__ __attribute__((aligned(16))) u32x4 lds[];  // [2][X_STAGE] + patches
@@ -152,15 +157,15 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
     const int csrc = c8 ^ sw8;
     // buffer descriptors built from kernel arguments only (provably wave-uniform): loads take a 32-bit per-lane byte offset
     // and the K-tile offset as an SGPR -- no 64-bit address arithmetic in the memory phases
-    const unsigned int a_row_bytes = xm.a_row_bytes ? xm.a_row_bytes : (unsigned int)K * 4u;
-    const unsigned int w_row_bytes = xm.w_row_bytes ? xm.w_row_bytes : (unsigned int)K * 4u;
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(A), 0, (int)(xm.a_bytes ? xm.a_bytes : (unsigned int)M * (unsigned int)K * 4u), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(W), 0, (int)(xm.w_bytes ? xm.w_bytes : (unsigned int)N * (unsigned int)K * 4u), 0x00020000);
+    const unsigned int a_row_bytes = xm.a_row_bytes ? xm.a_row_bytes : (unsigned int)K * EB;
+    const unsigned int w_row_bytes = xm.w_row_bytes ? xm.w_row_bytes : (unsigned int)K * EB;
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(A), 0, (int)(xm.a_bytes ? xm.a_bytes : (unsigned int)M * (unsigned int)K * EB), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(W), 0, (int)(xm.w_bytes ? xm.w_bytes : (unsigned int)N * (unsigned int)K * EB), 0x00020000);
     unsigned int a_off[LD], w_off[LD];
     int m0 = 0, n0 = 0, a_ld = LD, batch = 0;
     unsigned int a_base = 0, w_base = 0;                          // the batch's operand offsets (SGPRs)
     bool half_item = false;                                       // a 128-row item: half of a tile (tail of the item list), or every item (half == 2)
-    const int nk = K / 32;
+    const int nk = BF ? K / 64 : K / 32;                          // K tiles of 128 bytes per row
     const int n_items = tp.n_main + tp.n_tail;
     auto decode = [&](int item) {                                 // sets m0, n0, half_item, batch and the source offsets
         const bool all_half = tp.half == 2;
@@ -254,6 +259,15 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
     };
     auto mfmas = [&](auto tmc) {
         constexpr int TM = decltype(tmc)::value;
+        if constexpr (BF) {                                       // two k16 steps of plain bf16 products
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) acc[j][i] = mfma16<true>(wf[p][j], af[p][i], acc[j][i]);
+            return;
+        }
         scale_whi();
 #pragma unroll
         for (int j = 0; j < TN; ++j)
@@ -520,6 +534,64 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
             // no bank conflicts: FC1 -0.8 % -- and did not keep it: the full- and the half-height instantiations then disagreed in the
             // last bits on rows holding values below fp16's normal range (tests/test_gpu_tranception.py::test_token_logprobs_do_not_…),
             // although every op-level comparison on random data was bit-identical.)
+            if constexpr (BF) {
+                // bf16 plane out, row-major [M][N] (the next GEMM's operand): the wave's 64 columns are 128 contiguous bytes per row;
+                // through a per-wave LDS patch (32 rows x 128 B + 16 B pad) so that 8 lanes store one full line
+                constexpr int SPB = 144;
+                const bool staged = (N % 8 == 0) && (en0 + (wn * TN + TN) * 32 <= N);
+                unsigned char* patch = patches + wave * (32 * SPB);
+                f32x4 bvs[TN][4];
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int n = en0 + (wn * TN + j) * 32 + 8 * g + 4 * kh;
+                        bvs[j][g] = (bias && n < N) ? *reinterpret_cast<const f32x4*>(bias + n) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) asm volatile("" :: "v"(bvs[j][g]));
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int m = em0 + (wm * TM + i) * 32 + r;
+                    const bool row_ok = m < M;
+                    if (!staged && !row_ok) continue;
+                    if (row_ok)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int n = en0 + (wn * TN + j) * 32 + 8 * g + 4 * kh;
+                            if (n >= N) continue;
+                            const f32x4 bv = bvs[j][g];
+                            f32x4 val;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) val[e] = fmaf(acc[j][i][4 * g + e], out_scale, bv[e]);
+                            if (EPI == EPI_GELU) val = gelu_erf16(val);
+                            if (EPI == EPI_SQRELU)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { const float t = fmaxf(val[e], 0.0f); val[e] = t * t; }
+                            u32x2 pk;
+                            pk[0] = (unsigned int)f32_to_bf16_rne(val[0]) | ((unsigned int)f32_to_bf16_rne(val[1]) << 16);
+                            pk[1] = (unsigned int)f32_to_bf16_rne(val[2]) | ((unsigned int)f32_to_bf16_rne(val[3]) << 16);
+                            if (staged) *reinterpret_cast<u32x2*>(patch + r * SPB + j * 64 + (8 * g + 4 * kh) * 2) = pk;
+                            else *reinterpret_cast<u32x2*>(Ch + (size_t)m * (size_t)N + n) = pk;
+                        }
+                    if (staged) {
+                        __builtin_amdgcn_wave_barrier();
+                        const int m_base = em0 + (wm * TM + i) * 32;
+                        const size_t ncol0 = (size_t)en0 + (size_t)wn * TN * 32;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const int q = lane + 64 * k, row = q >> 3, cc = q & 7;
+                            const u32x4 v = *reinterpret_cast<const u32x4*>(patch + row * SPB + cc * 16);
+                            if (m_base + row < M) *reinterpret_cast<u32x4*>(Ch + (size_t)(m_base + row) * (size_t)N + ncol0 + cc * 8) = v;
+                        }
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
+            } else {
             // per-wave LDS patch: 32 rows x (256 B in OUTPUT order: group 0 hi | group 0 lo | group 1 hi | group 1 lo) + 16 B pad
             constexpr int SP = 272;
             const bool staged = (N % 8 == 0) && (en0 + (wn * TN + TN) * 32 <= N);
@@ -599,6 +671,7 @@ __global__ __launch_bounds__(XNT, 2) void gemm16x_kernel(
                     }
                     __builtin_amdgcn_wave_barrier();
                 }
+            }
             }
         }
         return more;

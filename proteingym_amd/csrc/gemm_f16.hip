@@ -273,7 +273,8 @@ static thread_local GemmTune g_tune;
 
 static int launch_gemm16x_one(const unsigned short* A, const unsigned short* W,
                               const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
-                              int M, int N, int K, int epilogue, float out_scale, hipStream_t s, const QkvOut* qkv) {
+                              int M, int N, int K, int epilogue, float out_scale, hipStream_t s, const QkvOut* qkv, bool bf = false) {
+    const unsigned long long eb = bf ? 2ull : 4ull;                  // operand bytes per k element (gemm16x_kernel.h: BF)
     const GemmTune tune = g_tune;
     TilePlan tp{};
     tp.group_m = tune.group_m > 0 ? tune.group_m : ((N + XBN - 1) / XBN >= kWideTilesN ? kGroupMWide : kGroupM);
@@ -281,7 +282,7 @@ static int launch_gemm16x_one(const unsigned short* A, const unsigned short* W,
     tp.tiles_n = (N + XBN - 1) / XBN;
     const int T = tp.tiles_m * tp.tiles_n, G = x_num_cus();
     tp.n_main = T;
-    if ((unsigned long long)std::max(M, N) * (unsigned long long)K * 4ull >= (1ull << 32) ||
+    if ((unsigned long long)std::max(M, N) * (unsigned long long)K * eb >= (1ull << 32) ||
         (Cf && (unsigned long long)M * (unsigned long long)N * 4ull >= (1ull << 31))) {      // launch_gemm16x chunks M below this
         set_error("gemm16x: operand of %d x %d split elements (or %d x %d outputs) exceeds the 32-bit offset range", std::max(M, N), K, M, N);
         return PGMI_EINVAL;
@@ -303,7 +304,7 @@ static int launch_gemm16x_one(const unsigned short* A, const unsigned short* W,
     const XMap xmap{};
 #define PGMI_LAUNCH16X(EPI_, OUT_)                                                                        \
     do {                                                                                                 \
-        auto kfn = gemm16x_kernel<EPI_, OUT_>;                                                            \
+        auto kfn = bf ? gemm16x_kernel<EPI_, OUT_, false, true> : gemm16x_kernel<EPI_, OUT_>;             \
         const size_t lds_bytes = X_LDS_BYTES;                                                            \
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kfn),                           \
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);  \
@@ -368,32 +369,33 @@ int launch_gemm16_ex(const unsigned short* A, const unsigned short* W, float* Cf
 // stream.  Fused QKV output: chunks are whole sequences (the V^T scatter is per (sequence, head)).
 static int launch_gemm16x(const unsigned short* A, const unsigned short* W,
                           const float* bias, const float* residual, float* Cf, unsigned short* Ch, size_t c_plane,
-                          int M, int N, int K, int epilogue, float out_scale, hipStream_t s, const QkvOut* qkv = nullptr) {
+                          int M, int N, int K, int epilogue, float out_scale, hipStream_t s, const QkvOut* qkv = nullptr, bool bf = false) {
     const unsigned long long lim = (1ull << 32) - 1;
-    if ((unsigned long long)N * (unsigned long long)K * 4ull > lim) {
+    const unsigned long long eb = bf ? 2ull : 4ull;
+    if ((unsigned long long)N * (unsigned long long)K * eb > lim) {
         set_error("gemm16x: weight of %d x %d split elements exceeds the 32-bit offset range", N, K);
         return PGMI_EINVAL;
     }
     const long long test_rows = g_opt.max_rows;                          // tests: force chunking at small shapes
-    long long max_rows = (long long)(lim / ((unsigned long long)K * 4ull));
+    long long max_rows = (long long)(lim / ((unsigned long long)K * eb));
     if (Cf) max_rows = std::min(max_rows, (long long)(((1ull << 31) - 1) / ((unsigned long long)N * 4ull)));   // the fp32 epilogue's buffer offsets
     if (test_rows > 0) max_rows = std::min(max_rows, test_rows);
-    if (M <= max_rows) return launch_gemm16x_one(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s, qkv);
+    if (M <= max_rows) return launch_gemm16x_one(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, out_scale, s, qkv, bf);
     long long per = qkv ? (max_rows / qkv->T) * qkv->T : (max_rows / XBM) * XBM;
     if (per <= 0) per = qkv ? 0 : max_rows;
     if (per <= 0) { set_error("gemm16x: one sequence of %d tokens x K = %d exceeds the 32-bit offset range", qkv->T, K); return PGMI_EINVAL; }
     for (long long m0 = 0; m0 < M; m0 += per) {
         const int mc = (int)std::min<long long>(per, M - m0);
-        const unsigned short* Ac = A + (size_t)m0 * (size_t)K * 2;                     // K-interleaved rows: 2 K halfs each
+        const unsigned short* Ac = A + (size_t)m0 * (size_t)K * (bf ? 1 : 2);          // K-interleaved rows: 2 K halfs each (bf16: K)
         int rc;
         if (qkv) {
             QkvOut q = *qkv;                                                           // rows m0.. are sequences m0 / T ..
             q.vt16 = qkv->vt16 + (size_t)(m0 / qkv->T) * (size_t)qkv->H * kHeadDim * (size_t)qkv->Tp;
             rc = launch_gemm16x_one(Ac, W, bias, nullptr, nullptr, Ch + (size_t)m0 * (size_t)(2 * (N / 3)), c_plane, mc, N, K, epilogue,
-                                    out_scale, s, &q);
+                                    out_scale, s, &q, bf);
         } else {
             rc = launch_gemm16x_one(Ac, W, bias, residual ? residual + (size_t)m0 * N : nullptr, Cf ? Cf + (size_t)m0 * N : nullptr,
-                                    Ch ? Ch + (size_t)m0 * (size_t)(2 * N) : nullptr, c_plane, mc, N, K, epilogue, out_scale, s, nullptr);
+                                    Ch ? Ch + (size_t)m0 * (size_t)((bf ? 1 : 2) * N) : nullptr, c_plane, mc, N, K, epilogue, out_scale, s, nullptr, bf);
         }
         if (rc) return rc;
     }
@@ -431,6 +433,15 @@ int launch_gemm16(const unsigned short* A, size_t a_plane, const unsigned short*
     }
     if (planes == 1 && bf) {
         if (out_scale != 1.0f) { set_error("gemm16: bf16 weights are not pre-scaled"); return PGMI_EINVAL; }
+        if (Ch && (N % 4) != 0) { set_error("gemm16: bf16 plane output needs N %% 4 == 0, got %d", N); return PGMI_EINVAL; }
+        // round 6: the persistent ping-pong kernel in its one-plane form (gemm16x_kernel.h BF); the round-1 kernel is kept for the A/B
+        // (variant 2000: scripts/gemm_ab.py)
+        if (variant != 2000) {
+            set_tune(variant);
+            const int rc = launch_gemm16x(A, W, bias, residual, Cf, Ch, c_plane, M, N, K, epilogue, 1.0f, s, nullptr, true);
+            g_tune = GemmTune{};
+            return rc;
+        }
         if ((long long)M * N >= 1 << 22) return launch_bf16_cfg<2, 4, 4, 2>(A, W, bias, residual, Cf, Ch, M, N, K, epilogue, s);
         return launch_bf16_cfg<2, 2, 2, 2>(A, W, bias, residual, Cf, Ch, M, N, K, epilogue, s);
     }
@@ -443,15 +454,15 @@ int launch_gemm16(const unsigned short* A, size_t a_plane, const unsigned short*
 int launch_gemm16_qkv(const unsigned short* A, size_t a_plane, const unsigned short* W, size_t w_plane,
                       const float* bias, int M, int D, int K, float out_scale, unsigned short* qk16, size_t qk_plane,
                       unsigned short* vt16, size_t vt_plane, const float* cos_t, const float* sin_t, int rotary,
-                      int T, int H, int variant, hipStream_t s, int rot_halves) {
+                      int T, int H, int variant, hipStream_t s, int rot_halves, bool bf) {
     (void)a_plane; (void)w_plane;
-    if (M <= 0 || D <= 0 || (K % 32) || (D % 64) || M % T || rot_halves < 1) {
+    if (M <= 0 || D <= 0 || (K % (bf ? 64 : 32)) || (D % 64) || M % T || rot_halves < 1) {
         set_error("gemm16_qkv: unsupported shape M=%d D=%d K=%d T=%d", M, D, K, T);
         return PGMI_EINVAL;
     }
     QkvOut qo{vt16, vt_plane, cos_t, sin_t, T, H, (T + 31) / 32 * 32, rotary, rot_halves};
     set_tune(variant);
-    const int rc = launch_gemm16x(A, W, bias, nullptr, nullptr, qk16, qk_plane, M, 3 * D, K, EPI_NONE, out_scale, s, &qo);
+    const int rc = launch_gemm16x(A, W, bias, nullptr, nullptr, qk16, qk_plane, M, 3 * D, K, EPI_NONE, out_scale, s, &qo, bf);
     g_tune = GemmTune{};
     return rc;
 }

@@ -228,9 +228,15 @@ def test_gemm_f16x3_launch_parameters_bit_identical(lib, monkeypatch, M, N, K, e
         assert np.array_equal(out[0], C)
 
 
+@pytest.mark.parametrize("variant", [0, 2000])                   # the persistent ping-pong kernel in its one-plane form / the round-1 kernel
 @pytest.mark.parametrize("M,N,K,epi,res", [(300, 384, 256, 0, False), (3600, 384, 128, 0, False),
-                                            (3600, 256, 128, 1, False), (3600, 128, 256, 0, True), (70, 128, 128, 1, True)])
-def test_gemm_bf16(lib, M, N, K, epi, res):
+                                            (3600, 256, 128, 1, False), (3600, 128, 256, 0, True), (70, 128, 128, 1, True),
+                                            (2300, 1280, 1280, 0, True),        # half-height tail items, 20 K tiles of 64
+                                            (4200, 5120, 1280, 1, False),       # FC1's shape class: a second item per workgroup, GELU
+                                            (700, 1280, 5120, 0, True),         # FC2's: 80 K tiles
+                                            (513, 1284, 192, 0, False)])        # ragged last column tile, an odd number of K tiles
+def test_gemm_bf16(lib, monkeypatch, variant, M, N, K, epi, res):
+    monkeypatch.setenv("PGMI_GEMM_VARIANT", str(variant))
     rng = np.random.default_rng(5)
     A = rng.standard_normal((M, K)).astype(np.float32)
     W = (rng.standard_normal((N, K)) / np.sqrt(K)).astype(np.float32)
@@ -244,7 +250,12 @@ def test_gemm_bf16(lib, M, N, K, epi, res):
         ref = ref * 0.5 * (1.0 + torch.erf(ref / np.sqrt(2.0)))
     if res:
         ref = ref + torch.from_numpy(R).double()
-    assert np.abs(Cc - ref.numpy()).max() < 1e-4       # exact bf16 inputs, fp32 accumulate
+    assert np.abs(Cc - ref.numpy()).max() < 1e-4 * max(1.0, np.sqrt(K / 256))       # exact bf16 inputs, fp32 accumulate
+    if not res and N % 4 == 0 and variant == 0:        # the bf16-plane epilogue (the next GEMM's operand): the same values rounded to bf16
+        Cp = np.empty((M, N), np.float32)
+        _lib.check(lib.pgmi_op_gemm(0, _lib.PREC_BF16, _p(A), _p(W), _p(bias), None, M, N, K, epi | 256, _p(Cp)))
+        want = torch.from_numpy(Cc).bfloat16().float().numpy()
+        assert np.array_equal(Cp, want)
 
 
 def test_gemm16x_row_chunks_are_bit_identical(lib, monkeypatch):
