@@ -306,7 +306,9 @@ def secondary(precision, budget_note="bounded: every leg is a few seconds of GPU
                                        "max_abs_score_difference_vs_f16x3": err, "score_range": float(np.ptp(scores["f16x3"])),
                                        "spearman_bf16_vs_f16x3": round(float(spearmanr(scores["bf16"], scores["f16x3"])[0]), 4),
                                        "parity_gated": False,
-                                       "what": "BASELINE configs[1] in plain bf16 (--precision bf16): NOT parity-gated -- its distance to the parity-gated f16x3 "
+                                       "what": "BASELINE configs[1] in plain bf16 (--precision bf16; round 6: the persistent ping-pong GEMM kernel in its one-plane "
+                                               "form -- 64-deep K tiles, one v_mfma_f32_32x32x16_bf16 per product block --, the attention on the split-fp16 pipe from the "
+                                               "fused QKV epilogue, context rows as one bf16 plane): NOT parity-gated -- its distance to the parity-gated f16x3 "
                                                "scores of the same checkpoint is measured here; the headline runs f16x3, which holds the 1e-4 bar"}
 
     def leg_benchmark_217():

@@ -92,12 +92,11 @@ int run_encoder(pgmi_model* m, int B, int T, const int32_t* keep, int n_keep, bo
               rc = launch_attention_f16x3_v2(fused_qkv ? nullptr : m->qkv, m->kv_len, m->rot_cos, m->rot_sin, c.arch == PGMI_ARCH_ESM2, B, T, H,
                                              m->qk16, m->qk16_plane, m->vt16, m->vt16_plane, nullptr, m->h16,
                                              m->h16_plane, 1, s, nullptr, nullptr, m->rot_halves * kHeadDim);
-          else if (v2) {       // bf16 mode: fp32 context rows (m->qkv is free: the projection went straight to the operand planes), then one bf16 plane
+          else if (v2)         // bf16 mode: the context rows leave as one bf16 plane (the out-projection's operand)
               rc = launch_attention_f16x3_v2(nullptr, m->kv_len, m->rot_cos, m->rot_sin, c.arch == PGMI_ARCH_ESM2, B, T, H,
-                                             m->qk16, m->qk16_plane, m->vt16, m->vt16_plane, m->qkv, nullptr, 0, 0, s, nullptr, nullptr,
+                                             m->qk16, m->qk16_plane, m->vt16, m->vt16_plane, nullptr, m->h16, m->h16_plane, 2, s, nullptr, nullptr,
                                              m->rot_halves * kHeadDim);
-              if (!rc) launch_split16(m->qkv, (int64_t)M * Da, 1.0f, 1, Da, m->h16, s);
-          } else
+          else
               rc = launch_attention_f32(m->qkv, m->kv_len, B, T, H, m->h, m->h16, m->h16_plane,
                                         prec == PGMI_PREC_FP32 ? 0 : mode16, s, m->rot_halves * kHeadDim);
           if (rc) return rc; }

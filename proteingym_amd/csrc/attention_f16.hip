@@ -335,7 +335,10 @@ __global__ __launch_bounds__(WPB * 64) void attention_f16x3_v2_kernel(
 
     if (active) {
         const float l_tot = l_run + __shfl_xor(l_run, 32);
-        if (OUT == 1) {
+        if (OUT == 3) {          // one bf16 plane, row-major (attention_f16_common.h)
+            store_ctx_bf16<ND>(om, oc, 1.0f / l_tot, kInvLo, q0 + r < T && q0 + r >= p0,
+                               ctx16 + (size_t)(orow0 + max(min(q0 + r, T - 1), p0)) * (size_t)D + (size_t)h * DH, kh);
+        } else if (OUT == 1) {
             // Split-plane output, 16-byte stores: lane (r, kh) holds columns 8g + 4kh .. + 3 of its query row for g = 0 .. 3; one
             // v_permlane32_swap per dword hands lane (r, 0) its partner's half of an even g and lane (r, 1) its partner's half of
             // the following odd g, so every lane owns 8 consecutive columns = one dwordx4 per plane: 8 store instructions per
@@ -465,7 +468,7 @@ int launch_attention_f16x3_v2(const float* qkv, const int32_t* kv_len, const flo
                               int rotary, int B, int T, int H, unsigned short* qk16, size_t qk_plane,
                               unsigned short* vt16, size_t vt_plane, float* ctx, unsigned short* ctx16, size_t plane,
                               int out_mode, hipStream_t s, const float* conv, const float* slopes, int head_dim) {
-    if (B <= 0 || T <= 0 || H <= 0 || out_mode < 0 || out_mode > 1 || (head_dim != 64 && head_dim != 128)) {
+    if (B <= 0 || T <= 0 || H <= 0 || out_mode < 0 || out_mode > 2 || (head_dim != 64 && head_dim != 128)) {      // out_mode 2: one bf16 plane
         set_error("attention_f16x3_v2: bad arguments B=%d T=%d H=%d out=%d head_dim=%d", B, T, H, out_mode, head_dim);
         return PGMI_EINVAL;
     }
@@ -492,6 +495,7 @@ int launch_attention_f16x3_v2(const float* qkv, const int32_t* kv_len, const flo
         int dn = 0;
         const dim3 grid = dense_grid(nblk, H, B, &dn);
         if (out_mode == 0) rc = launch_att16v2_one<4, 0, 3, 128>(grid, qk16, qk_plane, vt16, vt_plane, kv_len, nullptr, T, H, Tp, ctx, ctx16, plane, s, RagMap{}, dn, B);
+        else if (out_mode == 2) rc = launch_att16v2_one<4, 3, 3, 128>(grid, qk16, qk_plane, vt16, vt_plane, kv_len, nullptr, T, H, Tp, ctx, ctx16, plane, s, RagMap{}, dn, B);
         else rc = launch_att16v2_one<4, 1, 3, 128>(grid, qk16, qk_plane, vt16, vt_plane, kv_len, nullptr, T, H, Tp, ctx, ctx16, plane, s, RagMap{}, dn, B);
         if (rc) return rc;
         PGMI_HIP(hipGetLastError());
@@ -507,6 +511,7 @@ int launch_attention_f16x3_v2(const float* qkv, const int32_t* kv_len, const flo
     const dim3 grid = dense_grid(nblk, H, B, &dn);
     if (att_v3_serves(T, conv, slopes, head_dim)) rc = launch_att16v3(out_mode, wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, T, H, Tp, ctx, ctx16, s, dn, B);
     else if (out_mode == 0) rc = launch_att16v2_mode<0, 3>(wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane, s, dn, B);
+    else if (out_mode == 2) rc = launch_att16v2_mode<3, 3>(wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane, s, dn, B);
     else rc = launch_att16v2_mode<1, 3>(wpb, grid, qk16, qk_plane, vt16, vt_plane, kv_len, slopes, T, H, Tp, ctx, ctx16, plane, s, dn, B);
     if (rc) return rc;
     PGMI_HIP(hipGetLastError());

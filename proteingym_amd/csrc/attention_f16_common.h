@@ -49,6 +49,42 @@ struct RagMap {
     const int32_t* ent_j;
 };
 
+// Context rows as ONE bf16 plane, row-major [rows][H * DH] (OUT 3: the bf16 throughput mode's out-projection operand).  The split-plane
+// epilogue's lane exchange with two dwords per (lane, column group): lane (r, kh) holds columns 8 g + 4 kh .. + 3 of its row; one
+// v_permlane32_swap per dword gives every lane 8 consecutive columns = one 16-byte store.  All 64 lanes take part in the swaps.
+template <int ND>
+__device__ __forceinline__ void store_ctx_bf16(const f32x16 (&om)[ND], const f32x16 (&oc)[ND], float inv, float inv_lo, bool row_ok,
+                                               unsigned short* row_head, int kh) {
+    auto rne = [](float f) -> unsigned int {
+        unsigned int u = __builtin_bit_cast(unsigned int, f);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        return u >> 16;
+    };
+#pragma unroll
+    for (int dt = 0; dt < ND; ++dt)
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+            unsigned int w[2][2];
+#pragma unroll
+            for (int gi = 0; gi < 2; ++gi) {
+                const int g = 2 * gp + gi;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaf(oc[dt][4 * g + e], inv_lo, om[dt][4 * g + e]) * inv;
+                w[gi][0] = rne(v[0]) | (rne(v[1]) << 16);
+                w[gi][1] = rne(v[2]) | (rne(v[3]) << 16);
+            }
+            unsigned int first[2], second[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(w[0][k], w[1][k], false, false);
+                first[k] = sw[0];
+                second[k] = sw[1];
+            }
+            if (row_ok) *reinterpret_cast<u32x4*>(row_head + dt * 32 + 8 * (2 * gp + kh)) = u32x4{first[0], first[1], second[0], second[1]};
+        }
+}
+
 // attention_f16_prep.hip: operands for launches that do not come from the fused QKV projection
 void launch_qkv_prep(dim3 grid, hipStream_t s, const float* qkv, const float* cos_t, const float* sin_t, int rotary, int T, int H, int Tp,
                      unsigned short* qk16, size_t qk_plane, unsigned short* vt16, size_t vt_plane);

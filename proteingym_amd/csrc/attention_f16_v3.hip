@@ -402,7 +402,9 @@ __global__ __launch_bounds__(WPB * 64, 2) void attention_f16x3_v3_kernel(
     if (active) {
         const float l_tot = l_run + __shfl_xor(l_run, 32);
         const float inv = 1.0f / l_tot;
-        if (OUT == 1) {
+        if (OUT == 3) {
+            store_ctx_bf16<ND>(om, oc, inv, kInvLo, q0 + r < T, ctx16 + (size_t)(b * T + min(q0 + r, T - 1)) * (size_t)D + (size_t)h * DH, kh);
+        } else if (OUT == 1) {
             const bool row_ok = q0 + r < T;
             unsigned short* rowp = ctx16 + (size_t)(b * T + min(q0 + r, T - 1)) * (size_t)(2 * D) + (size_t)(ND * h) * 64;
 #pragma unroll
@@ -470,7 +472,8 @@ int launch_att16v3(int out_mode, int wpb, dim3 grid, const unsigned short* qk16,
                           const int32_t* kv_len, int T, int H, int Tp, float* ctx, unsigned short* ctx16, hipStream_t s, int dense_nblk, int nseq) {
 #define PGMI_V3(W)                                                                                                                          \
     do {                                                                                                                                    \
-        if (out_mode) launch_att16v3_one<W, 1>(grid, qk16, qk_plane, vt16, vt_plane, kv_len, T, H, Tp, ctx, ctx16, s, dense_nblk, nseq);   \
+        if (out_mode == 2) launch_att16v3_one<W, 3>(grid, qk16, qk_plane, vt16, vt_plane, kv_len, T, H, Tp, ctx, ctx16, s, dense_nblk, nseq); \
+        else if (out_mode) launch_att16v3_one<W, 1>(grid, qk16, qk_plane, vt16, vt_plane, kv_len, T, H, Tp, ctx, ctx16, s, dense_nblk, nseq);   \
         else launch_att16v3_one<W, 0>(grid, qk16, qk_plane, vt16, vt_plane, kv_len, T, H, Tp, ctx, ctx16, s, dense_nblk, nseq);            \
     } while (0)
     switch (wpb) {
