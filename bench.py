@@ -35,7 +35,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "f16x3": 2500.0}   # MI355X_MICROARCH.md, dense
 L_BLAT, N_MUT_BLAT = 286, 4996
-PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r5", "pmc_traffic.json")
+PMC_TRAFFIC = os.path.join(ROOT, "profiles", "r6", "pmc_traffic.json")
 
 
 def ffn_traffic(precision, M, D, F, live=None):

@@ -154,6 +154,7 @@ __global__ __launch_bounds__(WPB * 64, 2) void attention_f16x3_v3_kernel(
     constexpr float kInvLo = 1.0f / kLoScale;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 
     // One step on the stage that holds bundle kt + 1 = {K tile kt + 1, V^T tile kt - 1}: P V of tile kt - 1, softmax of tile kt, scores
     // of tile kt + 1.  Only TWO full steps are instantiated (with and without the key mask of the sequence's last key tile) plus the
@@ -238,7 +239,8 @@ __global__ __launch_bounds__(WPB * 64, 2) void attention_f16x3_v3_kernel(
 #pragma unroll
         for (int v = 1; v < 8; ++v) ma = fmaxf(ma, st[v]);
         PGMI_SLOT();
-        // ---- slots 0-5: P V (kt - 1), m = 0 ----
+        // ---- slots 0-5: P V (kt - 1), m = 0 ----  (measured and not kept: the whole row maximum before the first MFMA, which waits for
+        //      the V^T fragments anyway: +2.7 % / +5.6 % over v2 at T = 288 / 1024 instead of +4.5 % / +9 %)
         oc[0] = mfma_h(va_h[0], pl[0], oc[0]);
         float mloc = st[8];
 #pragma unroll
@@ -399,6 +401,8 @@ __global__ __launch_bounds__(WPB * 64, 2) void attention_f16x3_v3_kernel(
     asm volatile("" ::: "memory");
     if (active) closing_pv(lds + cur * STG_CH);
 
+    // (Measured and not kept, profiles/r6/att_ab_4_*: the split-plane rows through a per-wave LDS transpose -- 16 lanes per 256-byte row, 8 lines
+    // per store instruction instead of 32 partial ones, the GEMM's OUT 1 epilogue -- is within 0.5 % of the lane-exchange stores at every shape.)
     if (active) {
         const float l_tot = l_run + __shfl_xor(l_run, 32);
         const float inv = 1.0f / l_tot;
