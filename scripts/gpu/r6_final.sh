@@ -18,6 +18,13 @@ if [ "$1" != "quick" ]; then
   bash scripts/pmc_profile.sh r6 --steps 1 --warmup 0 --cpu-seconds 0 --layers 4 --no-box-state --no-live-traffic > $O/pmc.log 2>&1; cp gpurun_out/pmc_r6/summary.txt $O/pmc_summary.txt; cp gpurun_out/pmc_r6/pmc_traffic.json $O/pmc_traffic.json
 fi
 timeout 400 python scripts/att_bench.py --rounds 7 --shapes 286x286,90x1100,150x150,600x120,200x230,120x500,60x737 --ab att_v3=0,att_v3=-1 > $O/att_bench.log 2>&1
+# attention under the counters: the round-3 kernel and the software-pipelined one in the same process (separate passes per counter group)
+mkdir -p $O/pmc_att
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU_MFMA_MOPS_F32 --output-format csv -d $O/pmc_att/sq -o p -- python scripts/att_bench.py --rounds 2 --layers 2 --shapes 286x286,90x1100 --ab att_v3=0,att_v3=1 > $O/pmc_att/sq.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_att/fetch -o p -- python scripts/att_bench.py --rounds 2 --layers 2 --shapes 286x286,90x1100 --ab att_v3=0,att_v3=1 > $O/pmc_att/fetch.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS --output-format csv -d $O/pmc_att/valu -o p -- python scripts/att_bench.py --rounds 2 --layers 2 --shapes 286x286,90x1100 --ab att_v3=0,att_v3=1 > $O/pmc_att/valu.log 2>&1
+python scripts/pmc_summarize.py $O/pmc_att 2>&1 | grep -A16 "attention_f16x3" > $O/pmc_attention_summary.txt; head -60 $O/pmc_attention_summary.txt
+find $O/pmc_att -name "*.csv" -delete; find $O/pmc_att -name "*.db" -delete
 timeout 300 python scripts/bench_tranception.py > $O/bench_tranception.json 2> $O/bench_tranception.err
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_tranception -o p -- python scripts/bench_tranception.py > $O/prof_tranception.log 2>&1
 timeout 300 python scripts/bench_msa_transformer.py > $O/bench_msa_transformer.json 2> $O/bench_msa.err
