@@ -32,6 +32,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# RCCL / device-tensor sharing between the ranks of one node needs dmabuf IPC handles on this driver (without it:
+# `hipIpcGetMemHandle: invalid argument`); exported on the pool's boxes already -- kept here for any other launcher
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 PEAK_TFLOPS = {"fp32": 157.3, "bf16": 2500.0, "f16x3": 2500.0}   # MI355X_MICROARCH.md, dense
 L_BLAT, N_MUT_BLAT = 286, 4996

@@ -129,6 +129,7 @@ def init_from_env(backend: str = None):
     """Initialise torch.distributed from the torchrun environment (RANK/LOCAL_RANK/WORLD_SIZE/
     MASTER_*).  Returns (rank, local_rank, world)."""
     import os
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # dmabuf IPC handles: what RCCL needs between the ranks of a node on this driver
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
