@@ -406,6 +406,9 @@ int pgmi_pppl_run(pgmi_model* m, pgmi_pppl* q, int64_t first, int64_t count, dou
         q->last_chunks += 1;
         q->last_padded += (int64_t)bc * T;
         g0 += bc;
+        // a call can hold hours of forwards (CAPSD_AAV2S: 1.6e8 rows): the fp16 range flag is read every 64 chunks
+        // (~20 s at T = 737), not only at the end, so that the caller's fp32 re-run starts when the overflow happens
+        if ((q->last_chunks & 63) == 0 && g0 < R && (rc = check_nonfinite(m)) != PGMI_OK) { cleanup(); return rc; }
     }
     for (int j = 0; j < J; ++j) q->last_tokens += (rp[j + 1] - rp[j]) * len_of(sid[j]);
     {

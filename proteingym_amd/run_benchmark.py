@@ -592,7 +592,7 @@ def main_position_shards(args, mapping, todo, cols, ens_cols, rank, local_rank, 
         try:
             mutant_col = row["DMS_mutant_column"] if "DMS_mutant_column" in mapping.columns else args.mutation_col
             f["df"] = pd.read_csv(os.path.join(args.dms_input, row["DMS_filename"]))
-            f["offset"] = int(row["start_idx"]) if "start_idx" in mapping.columns and row["start_idx"] != "" else 1
+            f["offset"] = int(row["start_idx"]) if "start_idx" in mapping.columns and row["start_idx"] != "" else int(args.offset_idx)
             f["mutants"] = [str(m) for m in f["df"][mutant_col]]
             f["positions"] = np.arange(len(seq) + 2, dtype=np.int32) if args.all_positions else \
                 pesm.positions_read(f["mutants"], seq, f["offset"])

@@ -151,3 +151,60 @@ def test_run_benchmark_retries_an_overflowing_checkpoint_in_fp32_and_survives_a_
     assert err < 5 * TOL                                   # the bar of the fp32 re-run above (a 1e5 activation)
     m16.close()
     m32.close()
+
+
+def test_run_indels_redoes_an_overflowing_library_in_fp32(lib, tmp_path):
+    """Config 5's runner on the same kind of checkpoint: two indel libraries, a clean and a hot ESM2 checkpoint; the hot one
+    leaves the fp16 range in f16x3, so both libraries are re-scored in fp32 for THAT checkpoint -- bit-equal to an fp32
+    model's pseudo-ppl --, the clean one stays f16x3, scores_summary.csv says which; a library without the sequence column is
+    dropped (no CSV, rc != 0) and the others are written."""
+    import pandas as pd
+    from proteingym_amd import run_indels as ri
+    cfg = dict(synthetic.ESM2_650M, layers=3)
+    clean = synthetic.random_weights(cfg, seed=19, embed_std=0.15)
+    hot = clean.copy()
+    synthetic.blob_to_arrays(cfg, hot)["layers.1.fc1.bias"][301] = 1.0e5
+    synthetic.save_fair_esm_checkpoint(str(tmp_path / "clean_ck.pt"), cfg, clean)
+    synthetic.save_fair_esm_checkpoint(str(tmp_path / "hot_ck.pt"), cfg, hot)
+    libs = {}
+    for k, (Lk, n) in enumerate(((37, 9), (52, 7))):
+        _, seqs = synthetic.random_indel_library(seed=70 + k, L=Lk, n=n)
+        libs[f"I{k}"] = list(seqs)
+        pd.DataFrame({"mutant": [f"m{j}" for j in range(len(seqs))], "mutated_sequence": seqs, "DMS_score": np.arange(len(seqs)) * 0.5}
+                     ).to_csv(tmp_path / f"I{k}.csv", index=False)
+    pd.DataFrame({"mutant": ["m0"], "DMS_score": [0.0]}).to_csv(tmp_path / "I2.csv", index=False)           # no mutated_sequence column
+    pd.DataFrame({"DMS_id": ["I0", "I1", "I2"], "DMS_filename": ["I0.csv", "I1.csv", "I2.csv"], "target_seq": ["M"] * 3}
+                 ).to_csv(tmp_path / "map.csv", index=False)
+    out = tmp_path / "out"
+    with pytest.raises(SystemExit, match="1 assay.s. failed"):
+        ri.main(ri.create_parser().parse_args(["--model-location", str(tmp_path / "clean_ck.pt"), str(tmp_path / "hot_ck.pt"), "--model_type", "ESM2",
+                                               "--dms_mapping", str(tmp_path / "map.csv"), "--dms-input", str(tmp_path), "--dms-output", str(out)]))
+    assert not (out / "I2.csv").exists()
+    summary = pd.read_csv(out / "scores_summary.csv", keep_default_na=False).set_index("DMS_id")
+    assert list(summary["status"]) == ["ok", "ok", "failed"] and "mutated_sequence" in summary.loc["I2", "error"]
+    m16, alphabet = pesm.load_model_and_alphabet(str(tmp_path / "clean_ck.pt"), precision="f16x3")
+    m32, _ = pesm.load_model_and_alphabet(str(tmp_path / "hot_ck.pt"), precision="fp32")
+    mhot16, _ = pesm.load_model_and_alphabet(str(tmp_path / "hot_ck.pt"), precision="f16x3")
+    for name, seqs in libs.items():
+        got = pd.read_csv(out / f"{name}.csv", float_precision="round_trip")
+        assert summary.loc[name, "precision_hot_ck"] == "fp32" and summary.loc[name, "precision_clean_ck"] == ""
+        for col, model in (("clean_ck", m16), ("hot_ck", m32)):
+            sl = pesm.SequenceLibrary(model, seqs, alphabet)
+            want = sl.score()
+            sl.close()
+            assert np.array_equal(got[col].to_numpy(), want), (name, col)
+        assert list(got.columns) == ["mutant", "mutated_sequence", "DMS_score", "clean_ck", "hot_ck"]        # ESM2: no ensemble column
+    sl = pesm.SequenceLibrary(mhot16, libs["I0"], alphabet)
+    with pytest.raises(pesm.PgmiError) as info:                                                             # what the runner caught
+        sl.score()
+    assert info.value.code == _lib.EOVERFLOW
+    sl.close()
+    # a call can hold hours of forwards: the range flag is read every 64 chunks, not only at the end of the call
+    msmall, _ = pesm.load_model_and_alphabet(str(tmp_path / "hot_ck.pt"), precision="f16x3", max_rows=2048)     # 32 rows of <= 64 tokens per chunk
+    sl = pesm.SequenceLibrary(msmall, synthetic.random_indel_library(seed=90, L=40, n=64)[1], alphabet)             # ~2 400 rows: 76 chunks
+    with pytest.raises(pesm.PgmiError) as info:
+        sl.score()
+    assert info.value.code == _lib.EOVERFLOW and sl.stats()["batches"] == 64, sl.stats()
+    sl.close()
+    for m in (m16, m32, mhot16, msmall):
+        m.close()
