@@ -1,0 +1,125 @@
+"""A seeded sweep over shapes nobody picked by hand: architecture (ESM-1b/1v with and without the LayerNorm before the stack,
+with and without token dropout; ESM2), depth, heads x head dimension, feed-forward width, protein length (1 residue ... beyond
+the 1 024-token window), residue numbering offset, mutant libraries (singles, multi-mutants that repeat positions), the three
+strategies of compute_fitness.py (masked-marginals :486-504, wt-marginals :433-475 with both window modes, pseudo-ppl :258-279)
+and both parity-gated precisions -- every case through the C ABI against the CPU oracle (oracle/esm_oracle.py, pinned to the
+reference by tests/test_oracle_pinning.py) at the flat 1e-4.  Widths are narrow (the oracle runs live, a few seconds in all);
+what the sweep varies is everything that does not depend on the width: tile edges (T % 32, T < 32, one tile, many), the window
+logic, the ragged batches of the pseudo-ppl packer, the parser.
+
+PGMI_SWEEP_CASES (default 36) and PGMI_SWEEP_SEED (default 2026) widen or move the sweep:
+    PGMI_SWEEP_CASES=400 PGMI_SWEEP_SEED=7 python -m pytest tests/test_gpu_random_shapes.py -m gpu -q -s"""
+import os
+
+import numpy as np
+import pytest
+
+from proteingym_amd import _lib, compute_fitness as pcf, esm as pesm, synthetic
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+CASES = int(os.environ.get("PGMI_SWEEP_CASES", "36"))
+SEED = int(os.environ.get("PGMI_SWEEP_SEED", "2026"))
+
+
+def _draw(rng):
+    arch = rng.choice(["esm1b", "esm1b_lnb", "esm1b_nodrop", "esm2"])
+    heads = int(rng.choice([1, 2, 3, 4, 5]))
+    head_dim = int(rng.choice([16, 32, 64, 64]))
+    if arch == "esm2" and rng.random() < 0.2:
+        head_dim = 24                                                    # ESM2-35M's
+    precision = str(rng.choice(["f16x3", "f16x3", "fp32"]))
+    if precision == "f16x3" and (heads * head_dim) % 32:                 # the split-fp16 GEMM wants K % 32 (esm.py says so too)
+        heads = heads * 2 if head_dim == 16 else 4
+    D = heads * head_dim
+    ffn = int(rng.choice([2, 3, 4])) * D
+    if precision == "f16x3" and ffn % 32:
+        ffn = 4 * D
+    base = synthetic.ESM2_650M if arch == "esm2" else synthetic.ESM1V_650M
+    cfg = dict(base, layers=int(rng.integers(1, 4)), embed_dim=D, heads=heads, ffn_dim=ffn)
+    if arch == "esm1b_lnb":
+        cfg["emb_layer_norm_before"] = 1
+    if arch == "esm1b_nodrop":
+        cfg["token_dropout"] = 0
+    kind = rng.choice(["tiny", "short", "tile_edge", "medium", "window"], p=[0.12, 0.3, 0.25, 0.25, 0.08])
+    L = {"tiny": lambda: int(rng.integers(1, 6)), "short": lambda: int(rng.integers(6, 62)),
+         "tile_edge": lambda: int(rng.choice([30, 62, 94, 126, 222, 254])) + int(rng.integers(-1, 2)),
+         "medium": lambda: int(rng.integers(62, 420)), "window": lambda: int(rng.integers(1023, 1100))}[kind]()
+    return dict(arch=arch, cfg=cfg, precision=precision, L=L, offset=int(rng.choice([1, 1, 2, 17, 290])),
+                strategy=str(rng.choice(["masked-marginals", "masked-marginals", "wt-marginals", "pseudo-ppl"])),
+                window=str(rng.choice(["optimal", "overlapping"])), seed=int(rng.integers(1 << 30)))
+
+
+def _library(rng, seq, offset, n):
+    """Singles and multi-mutants (depth 2-5, positions may repeat inside a mutant: label_row adds every listed substitution)."""
+    aa = synthetic.AA
+    out = []
+    for _ in range(n):
+        depth = 1 if rng.random() < 0.6 else int(rng.integers(2, 6))
+        subs = []
+        for _ in range(depth):
+            p = int(rng.integers(0, len(seq)))
+            subs.append(f"{seq[p]}{p + offset}{rng.choice([a for a in aa if a != seq[p]])}")
+        out.append(":".join(subs))
+    return out
+
+
+@pytest.mark.parametrize("case", range(CASES))
+def test_random_shape_vs_oracle(lib, case):
+    from oracle import esm_oracle as eo
+    rng = np.random.default_rng([SEED, case])
+    c = _draw(rng)
+    cfg, L = c["cfg"], c["L"]
+    if c["strategy"] == "pseudo-ppl":
+        L = min(max(L, 3), 90)                                           # (L - 2) forwards per sequence on the CPU
+    blob = synthetic.random_weights(cfg, seed=c["seed"] % 100000, embed_std=0.3)
+    ocfg, W = eo.from_arrays(arrays=synthetic.blob_to_arrays(cfg, blob), **cfg)
+    model = pesm.EsmModel(cfg, blob, device=0, precision=c["precision"])
+    alphabet = pesm.Alphabet()
+    seq = synthetic.random_sequence(rng, L)
+    what = f"case {case}: {c['arch']} {cfg['layers']}x{cfg['embed_dim']} ({cfg['heads']} heads) ffn {cfg['ffn_dim']} {c['precision']} " \
+           f"L={L} offset={c['offset']} {c['strategy']}"
+    try:
+        if c["strategy"] == "masked-marginals":
+            muts = _library(rng, seq, c["offset"], int(rng.integers(1, 40)))
+            assay = pesm.Assay(model, seq, muts, offset_idx=c["offset"], alphabet=alphabet)
+            scores, table = assay.run(want_table=True)
+            positions = [int(p) for p in assay.positions]
+            assay.close()
+            assert positions == sorted({int(s[1:-1]) - c["offset"] + 1 for m in muts for s in m.split(":")}), what
+            ref = eo.masked_marginals_table(ocfg, W, seq, positions=positions, batch=8 if L + 2 <= 1024 else 1)
+            err_t = float(np.abs(table[positions] - ref[positions]).max())
+            ref_s = np.array([eo.label_row(m, seq, ref, c["offset"]) for m in muts])
+        elif c["strategy"] == "wt-marginals":
+            if cfg["arch"] == _lib.ARCH_ESM1B and L + 2 > 1024 and c["window"] == "optimal":
+                with pytest.raises(pesm.PgmiError, match="maximum sequence length"):     # modules.py:256-260: the reference raises too
+                    pcf.wt_marginals_table(model, alphabet, seq, "optimal")
+                return
+            muts = _library(rng, seq, c["offset"], int(rng.integers(1, 40)))
+            table = pcf.wt_marginals_table(model, alphabet, seq, c["window"])[0]
+            scores = pesm.score_from_table(table, muts, seq, c["offset"])
+            ref = eo.wt_marginals_table(ocfg, W, seq, c["window"])
+            err_t = float(np.abs(table - ref).max())
+            ref_s = np.array([eo.label_row(m, seq, ref, c["offset"]) for m in muts])
+            what += f" window={c['window']}"
+        else:
+            _, seqs = synthetic.random_indel_library(seed=c["seed"] % 9973, L=L, n=int(rng.integers(1, 6)), max_edit=min(3, max(1, L - 3)))
+            seqs = [s for s in seqs if len(s) >= 1]
+            sl = pesm.SequenceLibrary(model, seqs, alphabet)
+            scores, terms = sl.score(want_terms=True)
+            sl.close()
+            ref_s = np.array([eo.compute_pppl(ocfg, W, s) for s in seqs])
+            err_t = 0.0
+            for s, t in zip(seqs, terms):
+                assert len(t) == max(0, len(s) - 2), what
+            scores = np.asarray(scores)
+            # a sum of up to 90 terms: each term at the flat bar
+            assert np.all(np.abs(scores - ref_s) <= TOL * np.maximum(1, [len(s) - 2 for s in seqs])), (what, scores, ref_s)
+            print(what, f"{len(seqs)} sequences, sums max|err| {float(np.abs(scores - ref_s).max()):.2e}")
+            return
+        err_s = float(np.abs(np.asarray(scores) - ref_s).max())
+        print(what, f"rows max|err| {err_t:.2e}, scores max|err| {err_s:.2e} ({len(muts)} mutants)")
+        assert err_t < TOL, what
+        assert err_s < TOL, what
+    finally:
+        model.close()
