@@ -123,3 +123,68 @@ def test_random_shape_vs_oracle(lib, case):
         assert err_s < TOL, what
     finally:
         model.close()
+
+
+def _draw_tranception(rng):
+    heads = int(rng.choice([4, 8, 12]))                                  # grouped ALiBi / convolutions: heads in four groups, 64 wide
+    D = heads * 64
+    cfg = dict(synthetic.TRANCEPTION_L, layers=int(rng.integers(1, 4)), embed_dim=D, heads=heads, ffn_dim=int(rng.choice([2, 4])) * D)
+    kind = rng.choice(["tiny", "short", "tile_edge", "medium", "window"], p=[0.1, 0.3, 0.3, 0.22, 0.08])
+    L = {"tiny": lambda: int(rng.integers(2, 8)), "short": lambda: int(rng.integers(8, 62)),
+         "tile_edge": lambda: int(rng.choice([30, 62, 94, 126, 190, 254])) + int(rng.integers(-1, 2)),
+         "medium": lambda: int(rng.integers(62, 330)), "window": lambda: int(rng.integers(1023, 1060))}[kind]()
+    mode = str(rng.choice(["substitutions", "substitutions", "indels", "sliding"]))
+    return dict(cfg=cfg, L=L, mode=mode, mirror=bool(rng.random() < 0.7), share=bool(rng.random() < 0.7), seed=int(rng.integers(1 << 30)))
+
+
+@pytest.mark.parametrize("case", range(max(1, CASES // 3)))
+def test_random_tranception_shape_vs_oracle(lib, case):
+    """The same for Tranception (model_pytorch.py:878-928, scoring_utils.py:77-203): heads x 64, depth, protein length up to and
+    beyond the 1 024-token context, substitutions (prefix-shared or every sequence in full) / indel libraries / sliding windows,
+    one or both reading directions, with the wild type among the rows or not."""
+    import pandas as pd
+    import torch
+    from oracle import tranception_oracle as to
+    from proteingym_amd import tranception as ptr
+    rng = np.random.default_rng([SEED, 1000 + case])
+    c = _draw_tranception(rng)
+    cfg, L = c["cfg"], c["L"]
+    blob = synthetic.random_tranception_weights(cfg, seed=c["seed"] % 100000)
+    ocfg, W = to.from_arrays(arrays=synthetic.tranception_blob_to_arrays(cfg, blob), **cfg)
+    wt = synthetic.random_sequence(rng, L)
+    n = int(rng.integers(1, 24))
+    if c["mode"] == "indels":
+        _, seqs = synthetic.random_indel_library(seed=c["seed"] % 9973, L=L, n=n, max_edit=min(3, max(1, L - 5)))
+        seqs = list(dict.fromkeys(s for s in seqs if len(s) >= 2 and s != wt))
+        if rng.random() < 0.5:
+            seqs.insert(int(rng.integers(0, len(seqs) + 1)), wt)
+        df = pd.DataFrame({"mutant": seqs, "mutated_sequence": seqs})        # the indel files carry the sequence in both (model_pytorch.py:890-893)
+    else:
+        muts = list(dict.fromkeys(_library(rng, wt, 1, n)))
+        df = pd.DataFrame({"mutant": muts, "mutated_sequence": [ptr.get_mutated_sequence(wt, m) for m in muts]})
+        df = df[df["mutated_sequence"] != wt].drop_duplicates("mutated_sequence")      # (a multi-mutant may undo itself)
+        if rng.random() < 0.3:
+            df = pd.concat([df, pd.DataFrame({"mutant": [wt[0] + "1" + wt[0]], "mutated_sequence": [wt]})], ignore_index=True)
+    window = "sliding" if c["mode"] == "sliding" else "optimal"
+    what = f"case {case}: Tranception {cfg['layers']}x{cfg['embed_dim']} ({cfg['heads']} heads) ffn {cfg['ffn_dim']} L={L} {c['mode']} " \
+           f"mirror={c['mirror']} share_prefix={c['share']} rows={len(df)}"
+    if len(df) == 0:
+        pytest.skip(what + ": empty library")
+    model = ptr.TranceptionModel(cfg, blob, device=0, scoring_window=window)
+    model.share_prefix = c["share"]
+    try:
+        with torch.no_grad():
+            want = to.score_mutants(ocfg, W, df, wt, scoring_mirror=c["mirror"], scoring_window=window, indel_mode=c["mode"] == "indels")
+        have = model.score_mutants(DMS_data=df, target_seq=wt, scoring_mirror=c["mirror"], indel_mode=c["mode"] == "indels")
+        assert sorted(have.columns) == sorted(want.columns), (what, list(have.columns), list(want.columns))
+        key = "mutated_sequence"
+        h = have[have[key].notna()].set_index(key)
+        w = want[want[key].notna()].set_index(key)
+        assert sorted(h.index) == sorted(w.index), what
+        cols = [x for x in ("avg_score_L_to_R", "avg_score_R_to_L", "avg_score") if x in w.columns]
+        worst = max(float(np.abs(h.loc[w.index, x].to_numpy(dtype=np.float64) - w[x].to_numpy(dtype=np.float64)).max()) for x in cols)
+        assert len(have) == len(want), what                               # the zero row of the wild type, when it is among the inputs
+        print(what, f"avg scores max|err| {worst:.2e}")
+        assert worst < TOL, what
+    finally:
+        model.close()
