@@ -188,3 +188,42 @@ def test_random_tranception_shape_vs_oracle(lib, case):
         assert worst < TOL, what
     finally:
         model.close()
+
+
+@pytest.mark.parametrize("case", range(max(1, CASES // 4)))
+def test_random_msa_transformer_grid_vs_oracle(lib, case):
+    """The same for the MSA Transformer (esm/model/msa_transformer.py:146-205, esm/axial_attention.py): heads x 64, depth, R rows x
+    C columns on both sides of every tile edge (one row -- an alignment of the query alone --, R < 32, C % 32, the split of the tied
+    scores over the rows): the whole grid's log-probabilities and the masked-marginals rows (compute_fitness.py:380-394; the last
+    layer runs for the kept column only) against the oracle."""
+    import torch
+    from oracle import msa_transformer_oracle as mo
+    from proteingym_amd import msa_transformer as pmsa
+    rng = np.random.default_rng([SEED, 2000 + case])
+    heads = int(rng.choice([1, 2, 4, 12]))
+    cfg = dict(arch=4, layers=int(rng.integers(1, 4)), embed_dim=64 * heads, heads=heads, ffn_dim=int(rng.choice([2, 4])) * 64 * heads,
+               max_positions=1024, embed_positions_msa=True)
+    R = int(rng.choice([1, 2, int(rng.integers(3, 31)), int(rng.choice([31, 32, 33])), int(rng.integers(34, 130))]))
+    C = int(rng.choice([int(rng.integers(3, 31)), int(rng.choice([31, 32, 33, 63, 64, 65])), int(rng.integers(66, 200))]))
+    arrays = synthetic.random_msa_transformer_arrays(cfg, seed=int(rng.integers(100000)))
+    blob = pmsa.pack_state_dict(cfg, arrays)
+    tok = rng.integers(4, 30, size=(R, C)).astype(np.int64)
+    tok[:, 0] = 0                                                        # <cls>
+    tok[1:][rng.random((R - 1, C)) < 0.05] = 30                          # gaps in the members
+    tok[:, 0] = 0
+    what = f"case {case}: MSA Transformer {cfg['layers']}x{cfg['embed_dim']} ({heads} heads) ffn {cfg['ffn_dim']} grid {R} x {C}"
+    m = pmsa.MsaTransformerModel(cfg, blob, max_rows=max(2048, ((R + 31) // 32 * 32) * ((C + 31) // 32 * 32)))
+    try:
+        ocfg, W = mo.from_arrays(arrays=arrays, **cfg)
+        with torch.no_grad():
+            ref = torch.log_softmax(mo.forward_logits(ocfg, W, tok), -1).numpy()
+        lp = m.token_logprobs(tok)
+        err = float(np.abs(lp - ref).max())
+        positions = sorted({int(p) for p in rng.integers(1, C, size=min(4, C - 1))})
+        rows = m.masked_logprobs(tok, positions, seq_len=C - 1)
+        table = mo.masked_marginals_table(ocfg, W, tok, C - 1, positions=positions)
+        err_m = float(np.abs(rows - table[positions]).max())
+        print(what, f"grid max|err| {err:.2e}, masked rows max|err| {err_m:.2e}")
+        assert err < TOL and err_m < TOL, what
+    finally:
+        m.close()
