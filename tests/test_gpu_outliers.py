@@ -164,8 +164,8 @@ def test_run_indels_redoes_an_overflowing_library_in_fp32(lib, tmp_path):
     clean = synthetic.random_weights(cfg, seed=19, embed_std=0.15)
     hot = clean.copy()
     synthetic.blob_to_arrays(cfg, hot)["layers.1.fc1.bias"][301] = 1.0e5
-    synthetic.save_fair_esm_checkpoint(str(tmp_path / "clean_ck.pt"), cfg, clean)
-    synthetic.save_fair_esm_checkpoint(str(tmp_path / "hot_ck.pt"), cfg, hot)
+    synthetic.save_fair_esm_checkpoint(str(tmp_path / "esm2_clean_ck.pt"), cfg, clean)
+    synthetic.save_fair_esm_checkpoint(str(tmp_path / "esm2_hot_ck.pt"), cfg, hot)
     libs = {}
     for k, (Lk, n) in enumerate(((37, 9), (52, 7))):
         _, seqs = synthetic.random_indel_library(seed=70 + k, L=Lk, n=n)
@@ -177,30 +177,30 @@ def test_run_indels_redoes_an_overflowing_library_in_fp32(lib, tmp_path):
                  ).to_csv(tmp_path / "map.csv", index=False)
     out = tmp_path / "out"
     with pytest.raises(SystemExit, match="1 assay.s. failed"):
-        ri.main(ri.create_parser().parse_args(["--model-location", str(tmp_path / "clean_ck.pt"), str(tmp_path / "hot_ck.pt"), "--model_type", "ESM2",
+        ri.main(ri.create_parser().parse_args(["--model-location", str(tmp_path / "esm2_clean_ck.pt"), str(tmp_path / "esm2_hot_ck.pt"), "--model_type", "ESM2",
                                                "--dms_mapping", str(tmp_path / "map.csv"), "--dms-input", str(tmp_path), "--dms-output", str(out)]))
     assert not (out / "I2.csv").exists()
     summary = pd.read_csv(out / "scores_summary.csv", keep_default_na=False).set_index("DMS_id")
     assert list(summary["status"]) == ["ok", "ok", "failed"] and "mutated_sequence" in summary.loc["I2", "error"]
-    m16, alphabet = pesm.load_model_and_alphabet(str(tmp_path / "clean_ck.pt"), precision="f16x3")
-    m32, _ = pesm.load_model_and_alphabet(str(tmp_path / "hot_ck.pt"), precision="fp32")
-    mhot16, _ = pesm.load_model_and_alphabet(str(tmp_path / "hot_ck.pt"), precision="f16x3")
+    m16, alphabet = pesm.load_model_and_alphabet(str(tmp_path / "esm2_clean_ck.pt"), precision="f16x3")
+    m32, _ = pesm.load_model_and_alphabet(str(tmp_path / "esm2_hot_ck.pt"), precision="fp32")
+    mhot16, _ = pesm.load_model_and_alphabet(str(tmp_path / "esm2_hot_ck.pt"), precision="f16x3")
     for name, seqs in libs.items():
         got = pd.read_csv(out / f"{name}.csv", float_precision="round_trip")
-        assert summary.loc[name, "precision_hot_ck"] == "fp32" and summary.loc[name, "precision_clean_ck"] == ""
-        for col, model in (("clean_ck", m16), ("hot_ck", m32)):
+        assert summary.loc[name, "precision_esm2_hot_ck"] == "fp32" and summary.loc[name, "precision_esm2_clean_ck"] == ""
+        for col, model in (("esm2_clean_ck", m16), ("esm2_hot_ck", m32)):
             sl = pesm.SequenceLibrary(model, seqs, alphabet)
             want = sl.score()
             sl.close()
             assert np.array_equal(got[col].to_numpy(), want), (name, col)
-        assert list(got.columns) == ["mutant", "mutated_sequence", "DMS_score", "clean_ck", "hot_ck"]        # ESM2: no ensemble column
+        assert list(got.columns) == ["mutant", "mutated_sequence", "DMS_score", "esm2_clean_ck", "esm2_hot_ck"]        # ESM2: no ensemble column
     sl = pesm.SequenceLibrary(mhot16, libs["I0"], alphabet)
     with pytest.raises(pesm.PgmiError) as info:                                                             # what the runner caught
         sl.score()
     assert info.value.code == _lib.EOVERFLOW
     sl.close()
     # a call can hold hours of forwards: the range flag is read every 64 chunks, not only at the end of the call
-    msmall, _ = pesm.load_model_and_alphabet(str(tmp_path / "hot_ck.pt"), precision="f16x3", max_rows=2048)     # 32 rows of <= 64 tokens per chunk
+    msmall, _ = pesm.load_model_and_alphabet(str(tmp_path / "esm2_hot_ck.pt"), precision="f16x3", max_rows=2048)     # 32 rows of <= 64 tokens per chunk
     sl = pesm.SequenceLibrary(msmall, synthetic.random_indel_library(seed=90, L=40, n=64)[1], alphabet)             # ~2 400 rows: 76 chunks
     with pytest.raises(pesm.PgmiError) as info:
         sl.score()

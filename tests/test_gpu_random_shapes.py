@@ -29,12 +29,10 @@ def _draw(rng):
     if arch == "esm2" and rng.random() < 0.2:
         head_dim = 24                                                    # ESM2-35M's
     precision = str(rng.choice(["f16x3", "f16x3", "fp32"]))
-    if precision == "f16x3" and (heads * head_dim) % 32:                 # the split-fp16 GEMM wants K % 32 (esm.py says so too)
-        heads = heads * 2 if head_dim == 16 else 4
+    if (heads * head_dim) % 32:                                          # pgmi_model_create: embed_dim and ffn_dim are multiples of 32 (every
+        heads = heads * 2 if head_dim == 16 else 4                       # released width is: 320 / 480 / 640 / 768 / 1280 / 2560 / 5120)
     D = heads * head_dim
     ffn = int(rng.choice([2, 3, 4])) * D
-    if precision == "f16x3" and ffn % 32:
-        ffn = 4 * D
     base = synthetic.ESM2_650M if arch == "esm2" else synthetic.ESM1V_650M
     cfg = dict(base, layers=int(rng.integers(1, 4)), embed_dim=D, heads=heads, ffn_dim=ffn)
     if arch == "esm1b_lnb":
