@@ -625,3 +625,31 @@ def test_workload_scale_projections_of_configs_4_and_5():
     assert q["seconds_1_gpu"] / 8 <= q["seconds_8_gpus_planned"] < 1.01 * q["seconds_1_gpu"] / 8
     exact = sum(max(0, s["seq_len"] - 2) * s["n_total"] * 2.0e-6 * (s["seq_len"] + 2) for s in ish)
     assert abs(q["seconds_1_gpu"] - exact) < 0.2 * exact                                         # interpolation in FLOPs per forward between the sampled lengths
+
+
+def test_parser_agrees_with_label_row_on_arbitrary_strings(lib):
+    """pgmi_parse_mutants against the parsing of label_row (compute_fitness.py:240-250: ``row.split(":")``, ``mutation[0]``,
+    ``int(mutation[1:-1]) - offset_idx``, ``mutation[-1]``, the wild-type assertion) on strings drawn from the characters that
+    matter: whenever the C parser accepts a string, python's own parsing accepts it too and gives the same (position, wt, mt)
+    triples; everything python would mis-read silently (a negative index wraps around the sequence) or cannot index is refused."""
+    from hypothesis import given, settings, strategies as st
+    seq = "MKTAYIAKQRQISFVKSHFSRQ"
+    offset = 3
+
+    @settings(max_examples=600, deadline=None)
+    @given(st.lists(st.text(alphabet="MKTAYIQRSFVHGC:0123456789-+ _x", min_size=0, max_size=12), min_size=1, max_size=4))
+    def check(muts):
+        try:
+            sub_pos, sub_wt, sub_mt, off = pesm.parse_mutants(muts, seq, offset)
+        except (ValueError, AssertionError):
+            return
+        k = 0
+        for i, m in enumerate(muts):
+            assert off[i] == k
+            for s in m.split(":"):
+                idx = int(s[1:-1]) - offset                              # python accepts what the C parser accepted ...
+                assert 0 <= idx < len(seq) and seq[idx] == s[0]          # ... inside the sequence, at the listed wild type
+                assert (sub_pos[k], sub_wt[k], sub_mt[k]) == (1 + idx, eo.get_idx(s[0]), eo.get_idx(s[-1]))
+                k += 1
+        assert off[-1] == k
+    check()
