@@ -225,3 +225,46 @@ def test_random_msa_transformer_grid_vs_oracle(lib, case):
         assert err < TOL and err_m < TOL, what
     finally:
         m.close()
+
+
+@pytest.mark.parametrize("case", range(max(1, CASES // 9)))
+def test_random_assay_tables_through_the_runner(lib, tmp_path, case):
+    """run_benchmark over a drawn table of assays (lengths 8 ... 420, rows 1 ... 300, offsets, a second checkpoint or not) in its three
+    work-unit forms -- whole assays one at a time, short assays grouped behind key masks, chunks of masked positions -- writes the scores of
+    ``Assay.run()`` on each assay alone, bit for bit, and the same files in all three."""
+    import pandas as pd
+    from proteingym_amd import run_benchmark as rb
+    rng = np.random.default_rng([SEED, 3000 + case])
+    arch = synthetic.ESM2_650M if rng.random() < 0.4 else synthetic.ESM1V_650M
+    heads = int(rng.choice([2, 4]))
+    cfg = dict(arch, layers=int(rng.integers(1, 3)), embed_dim=64 * heads, heads=heads, ffn_dim=128 * heads)
+    stems = (["esm2_t_a"] if arch is synthetic.ESM2_650M else ["esm1v_a", "esm1v_b"][: int(rng.integers(1, 3))])
+    for k, stem in enumerate(stems):
+        synthetic.save_fair_esm_checkpoint(str(tmp_path / f"{stem}.pt"), cfg, synthetic.random_weights(cfg, seed=int(rng.integers(100000)), embed_std=0.3))
+    rows, assays = [], {}
+    for k in range(int(rng.integers(2, 7))):
+        L = int(rng.choice([int(rng.integers(8, 60)), int(rng.integers(60, 200)), int(rng.integers(200, 420))]))
+        offset = int(rng.choice([1, 1, 5, 120]))
+        seq = synthetic.random_sequence(rng, L)
+        muts = _library(rng, seq, offset, int(rng.integers(1, 300)))
+        pd.DataFrame({"mutant": muts, "DMS_score": rng.standard_normal(len(muts))}).to_csv(tmp_path / f"A{k}.csv", index=False)
+        rows.append({"DMS_id": f"A{k}", "DMS_filename": f"A{k}.csv", "target_seq": seq, "DMS_total_number_mutants": len(muts), "start_idx": offset})
+        assays[f"A{k}"] = (seq, muts, offset)
+    pd.DataFrame(rows).to_csv(tmp_path / "map.csv", index=False)
+    common = ["--model-location"] + [str(tmp_path / f"{s}.pt") for s in stems] + ["--model_type", "ESM2" if arch is synthetic.ESM2_650M else "ESM1v",
+              "--dms_mapping", str(tmp_path / "map.csv"), "--dms-input", str(tmp_path)]
+    modes = {"one": ["--batch-short-tokens", "0"], "groups": ["--batch-short-tokens", "250", "--batch-short-rows", "400"],
+             "positions": ["--shard", "positions", "--chunk-forwards", str(int(rng.integers(3, 40)))]}
+    for name, extra in modes.items():
+        rb.main(rb.create_parser().parse_args(common + ["--dms-output", str(tmp_path / name)] + extra))
+    models = [pesm.load_model_and_alphabet(str(tmp_path / f"{s}.pt"))[0] for s in stems]
+    try:
+        for a, (seq, muts, offset) in assays.items():
+            ref = open(tmp_path / "one" / f"{a}.csv").read()
+            assert open(tmp_path / "groups" / f"{a}.csv").read() == ref and open(tmp_path / "positions" / f"{a}.csv").read() == ref, (case, a)
+            got = pd.read_csv(tmp_path / "one" / f"{a}.csv", float_precision="round_trip")
+            for s, m in zip(stems, models):
+                assert np.array_equal(got[s].to_numpy(), pesm.Assay(m, seq, muts, offset_idx=offset).run()), (case, a, s)
+    finally:
+        for m in models:
+            m.close()
