@@ -264,7 +264,11 @@ def test_random_assay_tables_through_the_runner(lib, tmp_path, case):
             assert open(tmp_path / "groups" / f"{a}.csv").read() == ref and open(tmp_path / "positions" / f"{a}.csv").read() == ref, (case, a)
             got = pd.read_csv(tmp_path / "one" / f"{a}.csv", float_precision="round_trip")
             for s, m in zip(stems, models):
-                assert np.array_equal(got[s].to_numpy(), pesm.Assay(m, seq, muts, offset_idx=offset).run()), (case, a, s)
+                alone = pesm.Assay(m, seq, muts, offset_idx=offset)
+                try:
+                    assert np.array_equal(got[s].to_numpy(), alone.run()), (case, a, s)
+                finally:
+                    alone.close()
     finally:
         for m in models:
             m.close()
