@@ -237,7 +237,7 @@ def test_random_assay_tables_through_the_runner(lib, tmp_path, case):
     rng = np.random.default_rng([SEED, 3000 + case])
     arch = synthetic.ESM2_650M if rng.random() < 0.4 else synthetic.ESM1V_650M
     heads = int(rng.choice([2, 4]))
-    cfg = dict(arch, layers=int(rng.integers(1, 3)), embed_dim=64 * heads, heads=heads, ffn_dim=128 * heads)
+    cfg = dict(arch, layers=int(rng.integers(1, 3)), embed_dim=64 * heads, heads=heads, ffn_dim=256 * heads)     # (an ESM2 file says 4 x embed_dim)
     stems = (["esm2_t_a"] if arch is synthetic.ESM2_650M else ["esm1v_a", "esm1v_b"][: int(rng.integers(1, 3))])
     for k, stem in enumerate(stems):
         synthetic.save_fair_esm_checkpoint(str(tmp_path / f"{stem}.pt"), cfg, synthetic.random_weights(cfg, seed=int(rng.integers(100000)), embed_std=0.3))
