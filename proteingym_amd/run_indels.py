@@ -12,7 +12,8 @@ mutants, 735 residues), so assays are not the unit of work here: the ``mutated_s
 form one pool, every sequence is priced by its algorithmic FLOPs ((L-2) forwards of L+2 tokens), the pool is
 LPT-balanced over the ranks (one process per GPU, weights replicated), each rank uploads only its share as a
 device-resident library (esm.SequenceLibrary -> pgmi_pppl_*: rows enumerated on the device, mixed lengths packed per
-batch) and ONE fixed-stride all_gather (RCCL over xGMI; 8 bytes per mutant) returns the score vector to every rank;
+batch), slice by slice with the scores so far saved after each (--save-every-forwards: a re-run takes up where it ended), and ONE
+fixed-stride all_gather (RCCL over xGMI; 8 bytes per mutant) returns the score vector to every rank;
 rank 0 writes one ``<DMS_id>.csv`` per assay with the reference's columns.
 """
 from __future__ import annotations
@@ -41,6 +42,11 @@ def create_parser():
     p.add_argument("--sequence-col", type=str, default="mutated_sequence")
     p.add_argument("--precision", type=str, default="f16x3", choices=sorted(pesm._lib.PRECISIONS))
     p.add_argument("--backend", type=str, default=None, help="torch.distributed backend (default nccl)")
+    p.add_argument("--save-every-forwards", type=int, default=250000,
+                   help="a rank scores its share in slices of about this many masked forwards (~10 min of one GPU at 735 residues) and "
+                        "saves the scores it has after each slice under <dms-output>/.partial; a re-run of the same command (same files, "
+                        "checkpoints, precision, number of ranks) takes up where the slices ended -- the table is days of GPU time, a job "
+                        "that dies at hour 17 must not start over.  A sequence's score does not depend on its slice: same bits.  0 = off")
     return p
 
 
@@ -79,6 +85,47 @@ class _DevicePppl:
 
     def close(self):
         self.model.close()
+
+
+def share_digest(sequences, location: str, precision: str) -> str:
+    """What a saved slice file must match to be taken up: this rank's sequences in order, the checkpoint (name, size) and the precision."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(("\n".join(sequences)).encode())
+    h.update(f"|{os.path.basename(str(location))}|{os.path.getsize(location) if os.path.exists(str(location)) else -1}|{precision}".encode())
+    return h.hexdigest()
+
+
+def score_in_slices(model, sequences, path, forwards_per_save: int, digest: str, log=None):
+    """``model.score`` over ``sequences`` in slices of about ``forwards_per_save`` masked forwards; after every slice the scores so far go
+    to ``path`` (atomic replace).  A file left there by an earlier run of the same share (``digest``) is taken up: its sequences are not
+    scored again.  Returns the float64 scores."""
+    n = len(sequences)
+    out = np.full(n, np.nan, dtype=np.float64)
+    done = 0
+    if path and os.path.exists(path):
+        try:
+            with np.load(path, allow_pickle=False) as z:
+                if str(z["digest"]) == digest and z["scores"].shape == (n,):
+                    done = int(z["done"])
+                    out[:done] = z["scores"][:done]
+        except Exception:                                       # noqa: BLE001 -- a torn or foreign file: start over
+            done = 0
+        if done and log:
+            log(f"taking up {done} of {n} sequences from {path}")
+    forwards = [max(0, len(s) - 2) for s in sequences]
+    while done < n:
+        end, acc = done, 0
+        while end < n and (end == done or acc + forwards[end] <= forwards_per_save):
+            acc += forwards[end]
+            end += 1
+        out[done:end] = np.asarray(model.score(sequences[done:end]), dtype=np.float64)
+        done = end
+        if path and done < n:
+            tmp = path + ".tmp.npz"
+            np.savez(tmp, digest=np.asarray(digest), done=np.asarray(done), scores=out)
+            os.replace(tmp, path)
+    return out
 
 
 def main(args, make_model=None):
@@ -152,6 +199,7 @@ def main(args, make_model=None):
         return bad, over
 
     vectors = []
+    partial_dir, partials = os.path.join(args.dms_output, ".partial"), []
     for ci, loc in enumerate(args.model_location):
         local = np.full(len(mine), np.nan, dtype=np.float64)
         live = [i for i, _, _ in frames if i not in failed]
@@ -162,7 +210,15 @@ def main(args, make_model=None):
             try:
                 if len(live) < len(frames):
                     raise RuntimeError("an assay of the pool failed on an earlier checkpoint")
-                local[:] = np.asarray(model.score([pool[k] for k in mine]), dtype=np.float64)
+                share = [pool[k] for k in mine]
+                if args.save_every_forwards > 0 and share:
+                    os.makedirs(partial_dir, exist_ok=True)
+                    partial = os.path.join(partial_dir, f"{cols[ci]}_rank{rank}of{world}.npz")
+                    local[:] = score_in_slices(model, share, partial, args.save_every_forwards, share_digest(share, loc, args.precision),
+                                               log=lambda m: print(f"[rank {rank}] {cols[ci]}: {m}", flush=True))
+                    partials.append(partial)
+                else:
+                    local[:] = np.asarray(model.score(share), dtype=np.float64)
             except BaseException as e:                          # noqa: BLE001 -- which assay it was shows one at a time
                 if isinstance(e, KeyboardInterrupt):
                     raise
@@ -218,8 +274,16 @@ def main(args, make_model=None):
               f"{loads.max() / max(loads.mean(), 1e-30):.4f}")
     if world > 1:
         import torch.distributed as tdist
-        tdist.barrier()
+        tdist.barrier()                                         # rank 0 has written the CSVs: the saved slices are no longer needed
         tdist.destroy_process_group()
+    if not failed:                                              # (a failed run keeps them: its re-run scores the failed assays again, and
+        for f in partials:                                      # takes the shares up only if the pool -- hence the digest -- is unchanged)
+            if os.path.exists(f):
+                os.remove(f)
+        try:
+            os.rmdir(partial_dir)
+        except OSError:
+            pass
     _exit_on_failures(mapping, failed, rank, who="run_indels")
     return vectors
 

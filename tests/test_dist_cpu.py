@@ -1086,3 +1086,65 @@ def test_bench_n_gt_1_prints_exactly_one_json_line_on_stdout():
         assert key in line, key
     assert line["n_gpus"] == 2 and line["scaling"] == "weak" and line["steps"] == 2 and line["rccl"]["world_size"] == 2
     assert line["strong_scaling_217"]["assays"] == 24 and line["value"] > 0
+
+
+# ---- run_indels: a job that dies is taken up where its saved slices ended -------------------------------------------------------
+class _CountingPppl(_FakePppl):
+    """_FakePppl that counts the sequences it is asked for and can be told to die (the way a node does: no exception handler
+    gets to run the failure-isolation path) after a number of score() calls."""
+    scored, calls, die_after = [], 0, None
+
+    def score(self, sequences):
+        cls = type(self)
+        if cls.die_after is not None and cls.calls >= cls.die_after:
+            raise KeyboardInterrupt("the node went away")
+        cls.calls += 1
+        cls.scored += list(sequences)
+        return super().score(sequences)
+
+
+def test_run_indels_takes_up_a_dead_job_where_its_slices_ended(tmp_path):
+    """Config 5 is days of GPU time: a rank scores its share in slices and saves the scores it has after each; the same command run
+    again scores only what is missing (per checkpoint), writes the files of a run that never died -- byte for byte --, and removes the
+    slice files; another pool (a different digest) does not take them up."""
+    import pandas as pd
+    from proteingym_amd import run_indels as ri, synthetic
+    rng = np.random.default_rng(9)
+    rows = []
+    for k, (L, n) in enumerate(((50, 30), (90, 40))):
+        _, seqs = synthetic.random_indel_library(seed=30 + k, L=L, n=n)
+        pd.DataFrame({"mutant": seqs, "mutated_sequence": seqs, "DMS_score": rng.standard_normal(n)}).to_csv(tmp_path / f"I{k}.csv", index=False)
+        rows.append({"DMS_id": f"I{k}", "DMS_filename": f"I{k}.csv", "target_seq": "M"})
+    pd.DataFrame(rows).to_csv(tmp_path / "map.csv", index=False)
+    for name in ("esm2_a.pt", "esm2_b.pt"):
+        (tmp_path / name).write_bytes(b"not read by the seam; its size is part of the digest")
+
+    def args(out, every):
+        return ri.create_parser().parse_args(["--model-location", str(tmp_path / "esm2_a.pt"), str(tmp_path / "esm2_b.pt"), "--model_type", "ESM2",
+                                              "--dms_mapping", str(tmp_path / "map.csv"), "--dms-input", str(tmp_path), "--dms-output", str(tmp_path / out),
+                                              "--save-every-forwards", str(every)])
+    _CountingPppl.scored, _CountingPppl.calls, _CountingPppl.die_after = [], 0, None
+    ri.main(args("clean", 0), make_model=_CountingPppl)                                  # one piece, nothing saved
+    assert _CountingPppl.calls == 2 and not (tmp_path / "clean" / ".partial").exists()
+    total = len(_CountingPppl.scored)                                                    # 70 sequences x 2 checkpoints
+    _CountingPppl.scored, _CountingPppl.calls, _CountingPppl.die_after = [], 0, 3
+    with pytest.raises(KeyboardInterrupt):
+        ri.main(args("out", 900), make_model=_CountingPppl)                              # ~12 sequences of 90 residues per slice
+    first = len(_CountingPppl.scored)
+    saved = sorted(os.listdir(tmp_path / "out" / ".partial"))
+    assert saved == ["esm2_a_rank0of1.npz"] and 0 < first < total // 2 and not (tmp_path / "out" / "I0.csv").exists()
+    _CountingPppl.scored, _CountingPppl.calls, _CountingPppl.die_after = [], 0, None
+    ri.main(args("out", 900), make_model=_CountingPppl)
+    # the slice in flight when the job died was not saved: it is scored again; nothing that was saved is
+    assert len(_CountingPppl.scored) < total - (first - 14) and len(_CountingPppl.scored) >= total - first
+    for k in range(2):
+        assert open(tmp_path / "out" / f"I{k}.csv").read() == open(tmp_path / "clean" / f"I{k}.csv").read()
+    assert not (tmp_path / "out" / ".partial").exists()
+    # a slice file of another share is not taken up: same name, other digest
+    _CountingPppl.scored, _CountingPppl.calls, _CountingPppl.die_after = [], 0, 2
+    with pytest.raises(KeyboardInterrupt):
+        ri.main(args("other", 900), make_model=_CountingPppl)
+    pd.read_csv(tmp_path / "I1.csv").iloc[::-1].to_csv(tmp_path / "I1.csv", index=False)         # the pool changes
+    _CountingPppl.scored, _CountingPppl.calls, _CountingPppl.die_after = [], 0, None
+    ri.main(args("other", 900), make_model=_CountingPppl)
+    assert len(_CountingPppl.scored) == total

@@ -94,3 +94,20 @@ def test_cli_pseudo_ppl_on_indel_file(lib, gp, golden_dir, tmp_path):
     assert (np.abs(df["esm1v_toy_1"].to_numpy() - g["cli/esm1v_toy_1"]) < TERM_TOL).all()
     assert np.array_equal(df["Ensemble_ESM1v"].to_numpy(), df["esm1v_toy_1"].to_numpy())
     assert df[list(src.columns)].equals(src)
+
+
+def test_run_indels_in_saved_slices_writes_the_one_piece_files(lib, golden_dir, tmp_path):
+    """run_indels --save-every-forwards: the rank's share scored in slices of ~60 masked forwards (a saved file after each) against the
+    share in one piece: the same CSV bytes (a sequence's score does not depend on what shares its library), no slice file left."""
+    from proteingym_amd import run_indels as ri
+    src = pd.read_csv(os.path.join(golden_dir, "TOY_INDELS.csv"))
+    src.to_csv(tmp_path / "I0.csv", index=False)
+    src.iloc[::-2].to_csv(tmp_path / "I1.csv", index=False)
+    pd.DataFrame({"DMS_id": ["I0", "I1"], "DMS_filename": ["I0.csv", "I1.csv"], "target_seq": ["M"] * 2}).to_csv(tmp_path / "map.csv", index=False)
+    common = ["--model-location", os.path.join(golden_dir, "esm2_toy.pt"), "--model_type", "ESM2", "--dms_mapping", str(tmp_path / "map.csv"),
+              "--dms-input", str(tmp_path)]
+    ri.main(ri.create_parser().parse_args(common + ["--dms-output", str(tmp_path / "one"), "--save-every-forwards", "0"]))
+    ri.main(ri.create_parser().parse_args(common + ["--dms-output", str(tmp_path / "sliced"), "--save-every-forwards", "60"]))
+    for name in ("I0.csv", "I1.csv"):
+        assert open(tmp_path / "sliced" / name).read() == open(tmp_path / "one" / name).read()
+    assert not (tmp_path / "sliced" / ".partial").exists()
