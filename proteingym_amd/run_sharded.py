@@ -404,6 +404,37 @@ def _value_after(argv, flag):
     raise SystemExit(f"run_sharded: the single-assay arguments must contain {flag}")
 
 
+OUTPUT_FLAG = {"tranception": ("--output_scores_folder", "avg_score"), "msa_transformer": ("--dms-output", None)}
+
+
+def _without_existing(baseline, rest, mapping, indices, rank, world):
+    """--skip-existing: the assays still to do, decided by rank 0's view of the output folder and broadcast (the plan and every
+    collective are shaped by this list).  Tranception: a CSV with an ``avg_score`` column; MSA Transformer: a CSV that holds the
+    ``<checkpoint>_ensemble`` column its CLI writes after the last seed (seeds already on disk are skipped by the CLI itself)."""
+    flag, column = OUTPUT_FLAG[baseline]
+    todo = []
+    if rank == 0:
+        folder = _value_after(rest, flag)
+        for i in indices:
+            path = os.path.join(folder, str(mapping.iloc[i]["DMS_id"]) + ".csv")
+            done = False
+            if os.path.exists(path):
+                try:
+                    have = list(pd.read_csv(path, nrows=0).columns)
+                    done = (column in have) if column else any(str(c).endswith("_ensemble") for c in have)
+                except Exception:                      # noqa: BLE001 -- a torn file is not a finished assay
+                    done = False
+            if not done:
+                todo.append(i)
+        print(f"run_sharded: --skip-existing leaves {len(todo)} of {len(indices)} assays to do", flush=True)
+    if world > 1:
+        import torch.distributed as tdist
+        box = [todo]
+        tdist.broadcast_object_list(box, src=0)
+        todo = box[0]
+    return todo
+
+
 def plan(baseline: str, mapping: pd.DataFrame, indices, world: int):
     costs = [assay_cost(baseline, mapping.iloc[i]) for i in indices]
     assignment = pdist.lpt_partition(costs, world)
@@ -428,6 +459,9 @@ def main(argv=None, make_model=None):
                          "assays cannot balance a handful of them)")
     ap.add_argument("--max-chunk-rows", type=int, default=0, help="--shard mutants: cap on the rows of one work item (default: planned from the cost)")
     ap.add_argument("--backend", type=str, default=None)
+    ap.add_argument("--skip-existing", action="store_true",
+                    help="leave out the assays whose <output folder>/<DMS_id>.csv already exists with a score column (a re-run after a "
+                         "job that died or failed in some assays takes up the missing ones; decided on rank 0, the same list on every rank)")
     own = ap.parse_args(argv[:cut])
     rest = argv[cut + 1:]
     module, index_flag, ref_flag, device_flag = BASELINES[own.baseline]
@@ -442,6 +476,8 @@ def main(argv=None, make_model=None):
     rank, local_rank, world = pdist.init_from_env(own.backend)
     mapping = pd.read_csv(_value_after(rest, ref_flag))
     indices = list(range(len(mapping))) if own.indices is None else list(own.indices)
+    if own.skip_existing:
+        indices = _without_existing(own.baseline, rest, mapping, indices, rank, world)
     if own.shard == "mutants":
         return main_tranception_mutants(own, rest, mapping, indices, rank, local_rank, world, make_model=make_model)
     by_position = own.shard == "positions"

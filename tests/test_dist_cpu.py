@@ -1148,3 +1148,26 @@ def test_run_indels_takes_up_a_dead_job_where_its_slices_ended(tmp_path):
     _CountingPppl.scored, _CountingPppl.calls, _CountingPppl.die_after = [], 0, None
     ri.main(args("other", 900), make_model=_CountingPppl)
     assert len(_CountingPppl.scored) == total
+
+
+def test_run_sharded_skip_existing_takes_up_the_missing_assays(tmp_path):
+    """run_sharded tranception --skip-existing: after a run that lost two of four CSVs (a dead job, failed assays) the same command
+    scores exactly those two, leaves the others' files alone and writes what the first run wrote."""
+    from proteingym_amd import run_sharded
+    workdir = str(tmp_path)
+    rows = _make_tranception_assays(workdir, False)
+    argv = _tranception_args(workdir, "optimal", False)
+    cli_part = argv[argv.index("--") + 1:]
+    run_sharded.main(["tranception", "--", *cli_part], make_model=_fake_tranception)
+    out = os.path.join(workdir, "out")
+    first = {r["DMS_id"]: open(os.path.join(out, r["DMS_id"] + ".csv")).read() for r in rows}
+    stamp = {r["DMS_id"]: os.stat(os.path.join(out, r["DMS_id"] + ".csv")).st_mtime_ns for r in rows}
+    os.remove(os.path.join(out, "T1.csv"))
+    open(os.path.join(out, "T3.csv"), "w").write("mutated_sequence\n")                # a torn file: no score column
+    items = run_sharded.main(["tranception", "--skip-existing", "--", *cli_part], make_model=_fake_tranception)
+    assert [n for _, _, n in items] == [rows[1]["DMS_total_number_mutants"], rows[3]["DMS_total_number_mutants"]]
+    for r in rows:
+        path = os.path.join(out, r["DMS_id"] + ".csv")
+        assert open(path).read() == first[r["DMS_id"]]
+        assert (os.stat(path).st_mtime_ns == stamp[r["DMS_id"]]) == (r["DMS_id"] in ("T0", "T2"))
+    assert run_sharded.main(["tranception", "--skip-existing", "--", *cli_part], make_model=_fake_tranception) == []      # nothing left
