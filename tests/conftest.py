@@ -1,8 +1,14 @@
 import os
 import sys
 
-import numpy as np
-import pytest
+# The CPU suite shares its cores with whatever else runs on the box: OpenMP workers that spin while they wait turn contention into
+# minutes.  Measured here with eight busy processes beside the suite: 1 087 s spinning (the 1 020 s of round 5's review), 310 s with
+# passive waiting; on idle cores 115 - 140 s against 180 s.  (bench.py's cpu_baseline runs in its own process with the defaults.)
+for _k, _v in (("OMP_WAIT_POLICY", "PASSIVE"), ("GOMP_SPINCOUNT", "0"), ("KMP_BLOCKTIME", "0")):
+    os.environ.setdefault(_k, _v)
+
+import numpy as np  # noqa: E402
+import pytest  # noqa: E402
 
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 if ROOT not in sys.path:
