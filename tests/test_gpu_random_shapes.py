@@ -272,3 +272,57 @@ def test_random_assay_tables_through_the_runner(lib, tmp_path, case):
     finally:
         for m in models:
             m.close()
+
+
+@pytest.mark.parametrize("case", range(max(1, CASES // 6)))
+def test_random_tranception_retrieval_vs_oracle(lib, tmp_path, case):
+    """Tranception with inference-time retrieval (model_pytorch.py:806-830, msa_utils.py:63-138) on a drawn alignment: members 5 - 60 %
+    away from the query with gaps, covering residues [MSA_start, MSA_end) of a protein that may be longer than the alignment (and, now and
+    then, than the context: every scoring window overlaps the prior differently, in both reading directions), a drawn fusion weight."""
+    import pandas as pd
+    import torch
+    from oracle import tranception_oracle as to
+    from proteingym_amd import tranception as ptr
+    rng = np.random.default_rng([SEED, 4000 + case])
+    heads = int(rng.choice([4, 8]))
+    cfg = dict(synthetic.TRANCEPTION_L, layers=int(rng.integers(1, 3)), embed_dim=64 * heads, heads=heads, ffn_dim=128 * heads)
+    L = int(rng.choice([int(rng.integers(12, 60)), int(rng.integers(60, 260)), int(rng.integers(1023, 1050))], p=[0.4, 0.5, 0.1]))
+    wt = synthetic.random_sequence(rng, L)
+    ms = int(rng.integers(0, max(1, L // 3)))
+    me = int(rng.integers(min(L, ms + 6), L + 1)) if rng.random() < 0.7 else L
+    span = np.array(list(wt[ms:me]))
+    lines = [f">query/{ms + 1}-{me}", "".join(span)]
+    for k in range(int(rng.integers(3, 50))):
+        row = span.copy()
+        flip = rng.random(row.size) < rng.uniform(0.05, 0.6)
+        row[flip] = rng.choice(list(synthetic.AA), size=int(flip.sum()))
+        row[rng.random(row.size) < 0.05] = "-"
+        lines += [f">member{k}/{ms + 1}-{me}", "".join(row)]
+    a2m = tmp_path / "drawn.a2m"
+    a2m.write_text("\n".join(lines) + "\n")
+    weight = float(rng.choice([0.6, 0.3, 0.9]))
+    blob = synthetic.random_tranception_weights(cfg, seed=int(rng.integers(100000)))
+    ocfg, W = to.from_arrays(arrays=synthetic.tranception_blob_to_arrays(cfg, blob), **cfg)
+    muts = list(dict.fromkeys(_library(rng, wt, 1, int(rng.integers(2, 20)))))
+    df = pd.DataFrame({"mutant": muts, "mutated_sequence": [ptr.get_mutated_sequence(wt, m) for m in muts]})
+    df = df[df["mutated_sequence"] != wt].drop_duplicates("mutated_sequence")
+    what = f"case {case}: Tranception + retrieval {cfg['layers']}x{cfg['embed_dim']} L={L} alignment [{ms}, {me}) weight {weight} rows={len(df)}"
+    if len(df) == 0:
+        pytest.skip(what + ": empty library")
+    prior = to.get_msa_prior(str(a2m), ms, me, L)
+    retrieval = dict(log_prior=torch.log(torch.tensor(prior).float()).numpy(), MSA_start=ms, MSA_end=me, weight=weight)
+    model = ptr.TranceptionModel(cfg, blob, device=0)
+    try:
+        model.retrieval = ptr.build_retrieval(dict(MSA_filename=str(a2m), MSA_start=ms, MSA_end=me, full_protein_length=L,
+                                                   retrieval_inference_weight=weight))
+        assert np.abs(np.exp(model.retrieval["log_prior"]) - prior).max() < 1e-6, what
+        with torch.no_grad():
+            want = to.score_mutants(ocfg, W, df, wt, retrieval=retrieval)
+        have = model.score_mutants(DMS_data=df, target_seq=wt)
+        h, w = have.set_index("mutated_sequence"), want.set_index("mutated_sequence")
+        worst = max(float(np.abs(h.loc[w.index, x].to_numpy(dtype=np.float64) - w[x].to_numpy(dtype=np.float64)).max())
+                    for x in ("avg_score_L_to_R", "avg_score_R_to_L", "avg_score"))
+        print(what, f"avg scores max|err| {worst:.2e}")
+        assert worst < TOL, what
+    finally:
+        model.close()
