@@ -653,3 +653,46 @@ def test_parser_agrees_with_label_row_on_arbitrary_strings(lib):
                 k += 1
         assert off[-1] == k
     check()
+
+
+def test_tranception_slices_agree_with_the_oracle_on_drawn_libraries():
+    """tranception.get_sequence_slices (scoring_utils.py:152-203 on plain lists) against the oracle's pandas restatement on drawn inputs:
+    protein lengths on both sides of a small context, barycentres of multi-mutants at the window edges, duplicated rows, the wild type
+    among the rows, 'optimal' / 'sliding', indel libraries of mixed lengths -- the same frame, row for row, in the same order."""
+    import pandas as pd
+    from hypothesis import given, settings, strategies as st
+    from oracle import tranception_oracle as to
+    from proteingym_amd import tranception as ptr
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.integers(0, 2 ** 31 - 1))
+    def check(seed):
+        rng = np.random.default_rng(seed)
+        ctx = int(rng.choice([8, 10, 16, 33]))
+        L = int(rng.integers(2, 4 * ctx))
+        wt = synthetic.random_sequence(rng, L)
+        mode = str(rng.choice(["optimal", "sliding", "indel"]))
+        start_idx = int(rng.choice([1, 1, 4]))
+        n = int(rng.integers(1, 12))
+        if mode == "indel":
+            _, seqs = synthetic.random_indel_library(seed=seed % 9973, L=L, n=n, max_edit=min(3, max(1, L - 1)))
+            seqs = [s for s in seqs if s] + ([wt] if rng.random() < 0.4 else [])
+            df = pd.DataFrame({"mutated_sequence": seqs, "mutant": seqs})
+        else:
+            muts = []
+            for _ in range(n):
+                subs = []
+                for _ in range(1 if rng.random() < 0.5 else int(rng.integers(2, 5))):
+                    p = int(rng.integers(0, L))
+                    subs.append(f"{wt[p]}{p + start_idx}{rng.choice([a for a in synthetic.AA if a != wt[p]])}")
+                muts.append(":".join(subs))
+            if rng.random() < 0.3:
+                muts.append(muts[0])                                      # a duplicated row
+            df = pd.DataFrame({"mutant": muts, "mutated_sequence": [ptr.get_mutated_sequence(wt, m, start_idx) for m in muts]})
+        kw = dict(start_idx=start_idx, scoring_window="sliding" if mode == "sliding" else "optimal", indel_mode=mode == "indel")
+        a = ptr.get_sequence_slices(df.copy(), wt, ctx, **kw).reset_index(drop=True)
+        b = to.get_sequence_slices(df.copy(), wt, ctx, **kw).reset_index(drop=True)
+        cols = ["mutated_sequence", "sliced_mutated_sequence", "window_start", "window_end"]
+        assert list(a.columns) == list(b.columns), (mode, list(a.columns), list(b.columns))
+        assert len(a) == len(b) and all(list(a[c]) == list(b[c]) for c in cols), (seed, mode, L, ctx)
+    check()

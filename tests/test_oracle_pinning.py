@@ -1376,3 +1376,48 @@ def test_accept_real_weights_script_on_the_toy_goldens(tmp_path, monkeypatch, go
     err = capsys.readouterr().err
     assert "absent.pt" in err and "NOT_AN_ASSAY" in err and "no_such_folder" in err and not os.path.exists(tmp_path / "run3")
     assert accept.main(["--proteingym", str(tmp_path / "nowhere"), "--dms-folder", str(dms), "--esm1v", str(ck / "esm1v_toy_1.pt")]) == 2
+
+
+@pytest.mark.skipif(not rh.reference_available(), reason="/root/reference not present (GPU box)")
+def test_tranception_slices_vs_live_reference_on_drawn_libraries():
+    """tranception.get_sequence_slices and the oracle's restatement against the reference's own function (scoring_utils.py:152-203) on
+    drawn inputs: lengths on both sides of a small context, multi-mutant barycentres at the window edges, duplicated rows, the wild type
+    among the rows, 'optimal' / 'sliding', indel libraries of mixed lengths -- the same rows in the same order from all three."""
+    from hypothesis import given, settings, strategies as st
+    from oracle import tranception_oracle as to
+    from proteingym_amd import synthetic, tranception as ptr
+    rh.load_reference_tranception()
+    from tranception.utils import scoring_utils as ref
+
+    @settings(max_examples=120, deadline=None)
+    @given(st.integers(0, 2 ** 31 - 1))
+    def check(seed):
+        rng = np.random.default_rng(seed)
+        ctx = int(rng.choice([8, 10, 16, 33]))
+        L = int(rng.integers(2, 4 * ctx))
+        wt = synthetic.random_sequence(rng, L)
+        mode = str(rng.choice(["optimal", "sliding", "indel"]))
+        start_idx = int(rng.choice([1, 1, 4]))
+        n = int(rng.integers(1, 12))
+        if mode == "indel":
+            _, seqs = synthetic.random_indel_library(seed=seed % 9973, L=L, n=n, max_edit=min(3, max(1, L - 1)))
+            seqs = [s for s in seqs if s] + ([wt] if rng.random() < 0.4 else [])
+            df = pd.DataFrame({"mutated_sequence": seqs, "mutant": seqs})
+        else:
+            muts = []
+            for _ in range(n):
+                subs = []
+                for _ in range(1 if rng.random() < 0.5 else int(rng.integers(2, 5))):
+                    p = int(rng.integers(0, L))
+                    subs.append(f"{wt[p]}{p + start_idx}{rng.choice([a for a in synthetic.AA if a != wt[p]])}")
+                muts.append(":".join(subs))
+            if rng.random() < 0.3:
+                muts.append(muts[0])
+            df = pd.DataFrame({"mutant": muts, "mutated_sequence": [ref.get_mutated_sequence(wt, m, start_idx) for m in muts]})
+        kw = dict(start_idx=start_idx, scoring_window="sliding" if mode == "sliding" else "optimal", indel_mode=mode == "indel")
+        want = ref.get_sequence_slices(df.copy(), wt, ctx, **kw).reset_index(drop=True)
+        cols = ["mutated_sequence", "sliced_mutated_sequence", "window_start", "window_end"]
+        for name, fn in (("product", ptr.get_sequence_slices), ("oracle", to.get_sequence_slices)):
+            got = fn(df.copy(), wt, ctx, **kw).reset_index(drop=True)
+            assert len(got) == len(want) and all(list(got[c]) == list(want[c]) for c in cols), (name, seed, mode, L, ctx)
+    check()
