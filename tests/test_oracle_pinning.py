@@ -1421,3 +1421,32 @@ def test_tranception_slices_vs_live_reference_on_drawn_libraries():
             got = fn(df.copy(), wt, ctx, **kw).reset_index(drop=True)
             assert len(got) == len(want) and all(list(got[c]) == list(want[c]) for c in cols), (name, seed, mode, L, ctx)
     check()
+
+
+@pytest.mark.skipif(not rh.reference_available(), reason="/root/reference not present (GPU box)")
+def test_tokenizer_vs_live_reference_on_arbitrary_text():
+    """The same comparison (esm/data.py:178-254) on text drawn from the characters that matter -- residues in both cases, the rare letters,
+    gap symbols, angle brackets and the special tokens' spellings, blanks and newlines: the same ids, the same token lists, or the same
+    KeyError."""
+    from hypothesis import given, settings, strategies as st
+    from proteingym_amd import esm as pesm
+    rh.load_reference()
+    from esm import data as ref_data
+    ref = ref_data.Alphabet.from_architecture("ESM-1b")
+    mine = pesm.Alphabet()
+    piece = st.one_of(st.sampled_from(["<mask>", "<cls>", "<eos>", "<pad>", "<unk>", "<null_1>", "<", ">", "<m", "mask>", " ", "\n", "\t"]),
+                      st.text(alphabet="ACDEFGHIKLMNPQRSTVWYXBUZOJ.-*acdxj", min_size=1, max_size=6))
+
+    @settings(max_examples=500, deadline=None)
+    @given(st.lists(piece, min_size=0, max_size=8).map("".join))
+    def check(text):
+        try:
+            want = ref.encode(text)
+        except KeyError as e:
+            with pytest.raises(KeyError) as got:
+                mine.encode(text)
+            assert got.value.args == e.args, repr(text)
+            return
+        assert mine.encode(text) == want, repr(text)
+        assert mine.tokenize(text) == ref.tokenize(text), repr(text)
+    check()
