@@ -440,7 +440,9 @@ static int launch_att16v2_mode(int wpb, dim3 grid, const unsigned short* qk16, s
 // Launch option (pgmi_set_option "att_xcd_local", default 1): 1 = the one-dimensional XCD-local order of the dense launches, 0 = the
 // (query block, head, sequence) grid of rounds 1-4 (kept for the interleaved A/B of scripts/att_bench.py: block order does not touch a
 // row's arithmetic, same bits).
-static int g_att_xcd_local = -1;     // -1: by shape (XCD-local from eight query blocks per sequence on: +2.5 % at T = 1024, -2 % at T = 288)
+static int g_att_xcd_local = -1;     // -1: by shape -- XCD-local from two query blocks per sequence on.  (Round 5, v2 kernel: +2.5 % at T = 1024, -2 % at
+                                     // T = 288, so it was used from eight blocks on; with the pipelined kernel, round 6: +5 % at T = 152, +3.5 % at 230 / 256, 0 at 288,
+                                     // +1.6 / +0.7 / +3 % at 322 / 352 / 382, +3 % at 502, +2 % at 739, +6 % at 902; causal: -1 ... +3 %: profiles/r6/att_ab_6_*)
 int att_set_option(const char* name, long long value) {
     if (!strcmp(name, "att_xcd_local")) { g_att_xcd_local = (int)value; return PGMI_OK; }
     if (!strcmp(name, "att_v3")) { att_v3_set_option((int)value); return PGMI_OK; }
@@ -448,7 +450,7 @@ int att_set_option(const char* name, long long value) {
 }
 // grid of a dense launch of nblk query blocks x H heads x B sequences, and the dense_nblk argument that goes with it
 static dim3 dense_grid(int nblk, int H, int B, int* dense_nblk) {
-    if (g_att_xcd_local == 0 || (g_att_xcd_local < 0 && nblk < 8)) { *dense_nblk = 0; return dim3(nblk, H, B); }
+    if (g_att_xcd_local == 0 || (g_att_xcd_local < 0 && nblk < 2)) { *dense_nblk = 0; return dim3(nblk, H, B); }
     *dense_nblk = nblk;
     const long long pairs = (long long)H * B, groups = (pairs + 7) / 8;
     return dim3((unsigned)(groups * 8 * nblk), 1, 1);
